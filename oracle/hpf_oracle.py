@@ -1,0 +1,256 @@
+"""CPU oracle for the hpfrec full-batch CAVI path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; nothing under hpfrec_amd/ does.  It restates the reference's driver
+(/root/reference/hpfrec/cython_loops.pxi, "PXI" below) on top of the C loops in
+hpf_oracle.c, using numpy for the rate updates exactly where the reference uses
+numpy (PXI:236-259), so reduction orders (naive row adds for axis=0, numpy's
+pairwise blocks for axis=1) are the reference's own.
+
+Parity status: PINNED.  tests/golden/*.npz were produced by the real reference,
+compiled and imported in the build container (tests/golden/make_golden.py); the
+eight variational arrays of this oracle match those fixtures bit-for-bit
+(tests/test_oracle.py).  llk scalars go through BLAS sdot in the reference, whose
+accumulation order depends on OpenBLAS' CPU dispatch, so they are compared at 1e-6
+relative ("BLAS order unpinned").
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_real_t = ctypes.c_float          # hpfrec/cython_float.pxi:9
+obj_ind_type = ctypes.c_size_t     # hpfrec/cython_float_nonwindows.pyx:10
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libhpf_oracle.so")
+    src = os.path.join(_HERE, "hpf_oracle.c")
+    if force or (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libhpf_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(build())
+        vp, i64, u64, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_int
+        L.hpf_oracle_digamma_vec.argtypes = [vp, vp, i64]
+        L.hpf_oracle_update_phi_f32.argtypes = [vp, vp, vp, vp, vp, vp, u64, ci, vp, vp, u64, ci]
+        L.hpf_oracle_scatter_f32.argtypes = [vp, vp, vp, u64, vp, vp, u64]
+        L.hpf_oracle_llk_f32_d.argtypes = [vp, vp, vp, vp, vp, u64, u64, vp, vp, ci, ci, ci]
+        L.hpf_oracle_sum_prediction_f32_d.argtypes = [vp, vp, vp, vp, u64, ci, ci, vp, vp]
+        L.hpf_oracle_predict_f32.argtypes = [vp, vp, vp, vp, vp, u64, ci, ci]
+        L.hpf_oracle_update_phi_csr_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, u64, ci]
+        L.hpf_oracle_scatter_csr_f32.argtypes = [vp, vp, vp, u64, u64, vp, vp, vp]
+        L.hpf_oracle_max_threads.restype = ci
+        for f in (L.hpf_oracle_digamma_vec, L.hpf_oracle_update_phi_f32, L.hpf_oracle_scatter_f32,
+                  L.hpf_oracle_llk_f32_d, L.hpf_oracle_sum_prediction_f32_d, L.hpf_oracle_predict_f32,
+                  L.hpf_oracle_update_phi_csr_f32, L.hpf_oracle_scatter_csr_f32):
+            f.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data
+
+
+def _f32(a):
+    return np.require(a, dtype=np.float32, requirements=["C_CONTIGUOUS", "ALIGNED"])
+
+
+def _ind(a):
+    return np.require(a, dtype=np.uint64, requirements=["C_CONTIGUOUS", "ALIGNED"])
+
+
+def digamma(x):
+    x = np.require(x, dtype=np.float64, requirements=["C_CONTIGUOUS"])
+    out = np.empty_like(x)
+    lib().hpf_oracle_digamma_vec(_p(x), _p(out), x.size)
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# PXI:117-143
+# --------------------------------------------------------------------------- #
+def initialize_parameters(Theta, Beta, random_seed, a, a_prime, b_prime, c, c_prime, d_prime):
+    nU, k = Theta.shape
+    nI = Beta.shape[0]
+    bitgen = np.random.MT19937(seed=random_seed if random_seed > 0 else None)
+    rng = np.random.Generator(bitgen)
+    # draw order is part of the contract: user rate, item rate, user shape, item shape
+    u_rate = rng.random(size=(nU, k), dtype=np.float32)
+    i_rate = rng.random(size=(nI, k), dtype=np.float32)
+    u_shape = rng.random(size=(nU, k), dtype=np.float32)
+    i_shape = rng.random(size=(nI, k), dtype=np.float32)
+    Gamma_rte = a_prime + 0.01 * u_rate
+    Lambda_rte = c_prime + 0.01 * i_rate
+    Gamma_shp = a_prime + 0.01 * u_shape
+    Lambda_shp = c_prime + 0.01 * i_shape
+    k_rte = np.full((nU, 1), b_prime, dtype=np.float32)
+    t_rte = np.full((nI, 1), d_prime, dtype=np.float32)
+    Theta[:, :] = Gamma_shp / Gamma_rte
+    Beta[:, :] = Lambda_shp / Lambda_rte
+    return Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte
+
+
+class Hyper:
+    """float32-rounded hyper-parameters and the derived constants of PXI:173-174,209-210."""
+
+    def __init__(self, k, a, a_prime, b_prime, c, c_prime, d_prime):
+        f = np.float32
+        self.k = int(k)
+        self.a, self.a_prime, self.b_prime = f(a), f(a_prime), f(b_prime)
+        self.c, self.c_prime, self.d_prime = f(c), f(c_prime), f(d_prime)
+        self.k_shp = f(self.a_prime + f(self.k) * self.a)
+        self.t_shp = f(self.c_prime + f(self.k) * self.c)
+        self.add_k_rte = f(self.a_prime / self.b_prime)
+        self.add_t_rte = f(self.c_prime / self.d_prime)
+
+
+class State:
+    """The eight arrays of the variational state, laid out as in the reference."""
+
+    names = ("Theta", "Beta", "Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "k_rte", "t_rte")
+
+    def __init__(self, nU, nI, hyper, random_seed):
+        self.Theta = np.empty((nU, hyper.k), dtype=np.float32)
+        self.Beta = np.empty((nI, hyper.k), dtype=np.float32)
+        (self.Gamma_shp, self.Gamma_rte, self.Lambda_shp, self.Lambda_rte, self.k_rte,
+         self.t_rte) = initialize_parameters(self.Theta, self.Beta, random_seed, float(hyper.a),
+                                             float(hyper.a_prime), float(hyper.b_prime), float(hyper.c),
+                                             float(hyper.c_prime), float(hyper.d_prime))
+
+    def as_dict(self):
+        return {n: getattr(self, n).copy() for n in self.names}
+
+
+def cavi_iteration(st, hy, Y, ix_u, ix_i, phi, sum_exp_trick=0, nthreads=1):
+    """One full-batch sweep, PXI:232-259, in the reference's statement order."""
+    L = lib()
+    k = hy.k
+    nY = Y.shape[0]
+    L.hpf_oracle_update_phi_f32(_p(st.Gamma_shp), _p(st.Gamma_rte), _p(st.Lambda_shp), _p(st.Lambda_rte),
+                                _p(phi), _p(Y), k, int(sum_exp_trick), _p(ix_u), _p(ix_i), nY, int(nthreads))
+    st.Gamma_rte = float(hy.k_shp) / st.k_rte + st.Beta.sum(axis=0, keepdims=True)
+    st.Gamma_shp[:, :] = float(hy.a)
+    st.Lambda_shp[:, :] = float(hy.c)
+    L.hpf_oracle_scatter_f32(_p(st.Gamma_shp), _p(st.Lambda_shp), _p(phi), k, _p(ix_u), _p(ix_i), nY)
+    st.Theta[:, :] = st.Gamma_shp / st.Gamma_rte
+    st.Lambda_rte = float(hy.t_shp) / st.t_rte + st.Theta.sum(axis=0, keepdims=True)
+    st.Beta[:, :] = st.Lambda_shp / st.Lambda_rte
+    st.k_rte = float(hy.add_k_rte) + st.Theta.sum(axis=1, keepdims=True)
+    st.t_rte = float(hy.add_t_rte) + st.Beta.sum(axis=1, keepdims=True)
+
+
+def llk_plus_rmse(Theta, Beta, Y, ix_u, ix_i, nthreads=1, add_mse=1, full_llk=0):
+    """PXI:627-658 -> (sum Y log(yhat) [- lgamma], sum sq err) as np.longdouble."""
+    hi = np.zeros(2)
+    lo = np.zeros(2)
+    lib().hpf_oracle_llk_f32_d(_p(Theta), _p(Beta), _p(Y), _p(ix_u), _p(ix_i), Y.shape[0], Theta.shape[1],
+                               _p(hi), _p(lo), int(nthreads), int(add_mse), int(full_llk))
+    return np.longdouble(hi) + np.longdouble(lo)
+
+
+def sum_prediction(Theta, Beta, ix_u, ix_i, nthreads=1):
+    hi = np.zeros(1)
+    lo = np.zeros(1)
+    lib().hpf_oracle_sum_prediction_f32_d(_p(Theta), _p(Beta), _p(ix_u), _p(ix_i), ix_u.shape[0],
+                                          Theta.shape[1], int(nthreads), _p(hi), _p(lo))
+    return np.longdouble(hi[0]) + np.longdouble(lo[0])
+
+
+def train_llk(st, Y, ix_u, ix_i, nthreads=1, full_llk=0):
+    """PXI:75-79: nnz term minus (sum_u Theta).(sum_i Beta); returns (llk, rmse)."""
+    e = llk_plus_rmse(st.Theta, st.Beta, Y, ix_u, ix_i, nthreads, 1, full_llk)
+    llk = e[0] - st.Theta.sum(axis=0).dot(st.Beta.sum(axis=0))
+    return llk, np.sqrt(e[1] / Y.shape[0])
+
+
+def calc_llk(Y, ix_u, ix_i, Theta, Beta, k, nthreads, full_llk):
+    """PXI:525-534 (HPF.eval_llk): nnz term minus the sum of predictions over listed pairs."""
+    Y, ix_u, ix_i = _f32(Y), _ind(ix_u), _ind(ix_i)
+    e = llk_plus_rmse(Theta, Beta, Y, ix_u, ix_i, nthreads, 0, full_llk)
+    return e[0] - sum_prediction(Theta, Beta, ix_u, ix_i, nthreads)
+
+
+def predict_arr(M1, M2, ix_u, ix_i, nthreads=1):
+    """PXI:538-543"""
+    ix_u, ix_i = _ind(ix_u), _ind(ix_i)
+    out = np.zeros(ix_u.shape[0], dtype=np.float32)
+    lib().hpf_oracle_predict_f32(_p(out), _p(M1), _p(M2), _p(ix_u), _p(ix_i), ix_u.shape[0], M1.shape[1],
+                                 int(nthreads))
+    return out
+
+
+def fit_full_batch(Y, ix_u, ix_i, nU, nI, k, maxiter, random_seed, a=0.3, a_prime=0.3, b_prime=1.0,
+                   c=0.3, c_prime=0.3, d_prime=1.0, sum_exp_trick=0, nthreads=1, capture_at=(),
+                   state=None):
+    """Run `maxiter` full-batch iterations (PXI:227-259) from the reference's initialisation.
+
+    Returns (state, captures) where captures[it] is a dict of the eight arrays after
+    `it` iterations (1-based count) for every it in capture_at.
+    """
+    Y, ix_u, ix_i = _f32(Y), _ind(ix_u), _ind(ix_i)
+    hy = Hyper(k, a, a_prime, b_prime, c, c_prime, d_prime)
+    st = state if state is not None else State(nU, nI, hy, random_seed)
+    phi = np.empty((Y.shape[0], k), dtype=np.float32)
+    caps = {}
+    for it in range(maxiter):
+        cavi_iteration(st, hy, Y, ix_u, ix_i, phi, sum_exp_trick, nthreads)
+        if (it + 1) in capture_at:
+            caps[it + 1] = st.as_dict()
+    return st, caps
+
+
+def partial_fit_step(st, hy, Y_batch, ix_u_batch, ix_i_batch, users_this_batch, items_this_batch,
+                     step_size_batch, multiplier_batch, user_batch, nthreads=1):
+    """PXI:423-473 (cython partial_fit): one SVI step on caller-supplied triplets."""
+    L = lib()
+    f = np.float32
+    Y_batch, ix_u_batch, ix_i_batch = _f32(Y_batch), _ind(ix_u_batch), _ind(ix_i_batch)
+    k = hy.k
+    n = Y_batch.shape[0]
+    step = float(f(step_size_batch))
+    mult = float(f(multiplier_batch))
+    step_prev = float(f(1) - f(step_size_batch))
+    phi = np.empty((n, k), dtype=np.float32)
+    L.hpf_oracle_update_phi_f32(_p(st.Gamma_shp), _p(st.Gamma_rte), _p(st.Lambda_shp), _p(st.Lambda_rte),
+                                _p(phi), _p(Y_batch), k, 1, _p(ix_u_batch), _p(ix_i_batch), n, int(nthreads))
+    if user_batch:
+        st.Gamma_rte[:, :] = float(hy.k_shp) / st.k_rte + st.Beta.sum(axis=0, keepdims=True)
+        Lambda_shp_prev = st.Lambda_shp[items_this_batch, :].copy()
+    else:
+        st.Lambda_rte[:, :] = float(hy.t_shp) / st.t_rte + st.Theta.sum(axis=0, keepdims=True)
+        Gamma_shp_prev = st.Gamma_shp[users_this_batch, :].copy()
+    st.Gamma_shp[users_this_batch, :] = float(hy.a)
+    st.Lambda_shp[items_this_batch, :] = float(hy.c)
+    L.hpf_oracle_scatter_f32(_p(st.Gamma_shp), _p(st.Lambda_shp), _p(phi), k, _p(ix_u_batch), _p(ix_i_batch), n)
+    if user_batch:
+        st.Lambda_shp[items_this_batch, :] = (step * mult * st.Lambda_shp[items_this_batch, :]
+                                              + step_prev * Lambda_shp_prev)
+        st.Theta[:, :] = st.Gamma_shp / st.Gamma_rte
+        st.Lambda_rte[items_this_batch, :] = (
+            step * (float(hy.t_shp) / st.t_rte[items_this_batch] + st.Theta.sum(axis=0, keepdims=False))
+            + step_prev * st.Lambda_rte[items_this_batch, :])
+        st.Beta[:, :] = st.Lambda_shp / st.Lambda_rte
+    else:
+        st.Gamma_shp[users_this_batch, :] = (step * mult * st.Gamma_shp[users_this_batch, :]
+                                             + step_prev * Gamma_shp_prev)
+        st.Beta[:, :] = st.Lambda_shp / st.Lambda_rte
+        st.Gamma_rte[users_this_batch, :] = (
+            step * (float(hy.k_shp) / st.k_rte[users_this_batch] + st.Beta.sum(axis=0, keepdims=False))
+            + step_prev * st.Gamma_rte[users_this_batch, :])
+        st.Theta[:, :] = st.Gamma_shp / st.Gamma_rte
+    st.k_rte[:, :] = step * (float(hy.add_k_rte) + st.Theta.sum(axis=1, keepdims=True)) + step_prev * st.k_rte
+    st.t_rte[:, :] = step * (float(hy.add_t_rte) + st.Beta.sum(axis=1, keepdims=True)) + step_prev * st.t_rte
+
+
+def max_threads():
+    return int(lib().hpf_oracle_max_threads())

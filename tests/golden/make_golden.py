@@ -1,0 +1,177 @@
+"""Generate the golden vectors under tests/golden/ from the REAL reference.
+
+Runs only in the build container, where the reference has been compiled in a scratch
+copy OUTSIDE this repo:
+
+    cp -r /root/reference /tmp/hpfrec_oracle && chmod -R u+w /tmp/hpfrec_oracle
+    cd /tmp/hpfrec_oracle && python3 setup.py build_ext --inplace
+    cd /root/repo && python tests/golden/make_golden.py
+
+Only outputs (arrays/scalars the reference computed) are written; inputs are
+regenerated from seeds by tests/datagen.py wherever the tests run.  All captures use
+use_float=True, ncores=1, allow_inconsistent_math=False, reindex=False -- the
+reference's deterministic path.
+"""
+import contextlib
+import io
+import os
+import sys
+import warnings
+
+import numpy as np
+import pandas as pd
+
+REF = os.environ.get("HPFREC_REF_BUILD", "/tmp/hpfrec_oracle")
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from hpfrec import HPF  # noqa: E402  (the reference, imported from the scratch build)
+import datagen  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+NAMES = ("Theta", "Beta", "Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "k_rte", "t_rte")
+
+
+def quiet(fn, *a, **kw):
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return fn(*a, **kw)
+
+
+def grab(m):
+    return {n: np.array(getattr(m, n)) for n in NAMES}
+
+
+def fit_ref(df, k, maxiter, seed=123, **kw):
+    args = dict(k=k, maxiter=maxiter, random_seed=seed, ncores=1, reindex=False, verbose=False,
+                stop_crit="maxiter", check_every=None, keep_all_objs=True, allow_inconsistent_math=False,
+                use_float=True)
+    args.update(kw)
+    m = HPF(**args)
+    quiet(m.fit, df.copy())
+    return m
+
+
+def c1_full():
+    df, nU, nI = datagen.readme_counts()
+    out = {}
+    for it in (1, 2, 5, 10, 20):
+        m = fit_ref(df, 30, it)
+        assert m.niter == it - 1
+        for n, v in grab(m).items():
+            out["it%d_%s" % (it, n)] = v
+    for it in (10, 20):
+        m = fit_ref(df, 30, it, verbose=True, check_every=it)
+        out["train_llk_it%d" % it] = np.float64(m.train_llk)
+    m = fit_ref(df, 30, 20)
+    out["eval_llk_it20"] = np.float64(quiet(m.eval_llk, df.copy())["llk"])
+    out["eval_llk_full_it20"] = np.float64(quiet(m.eval_llk, df.copy(), full_llk=True)["llk"])
+    m = fit_ref(df, 30, 10, verbose=True, check_every=10, full_llk=True)
+    out["train_llk_full_it10"] = np.float64(m.train_llk)
+    # stopping rule: train-llk criterion, record where it stops
+    m = fit_ref(df, 30, 200, stop_crit="train-llk", check_every=5, stop_thr=1e-3)
+    out["trainllk_stop_niter"] = np.int64(m.niter)
+    m = fit_ref(df, 30, 200, stop_crit="diff-norm", check_every=5, stop_thr=1e-1)
+    out["diffnorm_stop_niter"] = np.int64(m.niter)
+    np.savez_compressed(os.path.join(OUT, "c1_full.npz"), **out)
+    print("c1_full", len(out))
+
+
+def c1_trick():
+    df, nU, nI = datagen.readme_counts()
+    out = {}
+    for it in (1, 10):
+        m = fit_ref(df, 30, it, sum_exp_trick=True)
+        for n, v in grab(m).items():
+            out["it%d_%s" % (it, n)] = v
+    np.savez_compressed(os.path.join(OUT, "c1_trick.npz"), **out)
+    print("c1_trick", len(out))
+
+
+def c1_hyper():
+    """non-default hyper-parameters, small a/c (stress for the digamma recurrence) and k=7"""
+    df, nU, nI = datagen.readme_counts()
+    out = {}
+    m = fit_ref(df, 7, 5, a=0.05, a_prime=0.7, b_prime=2.0, c=0.02, c_prime=1.3, d_prime=0.5, seed=5)
+    for n, v in grab(m).items():
+        out["it5_%s" % n] = v
+    np.savez_compressed(os.path.join(OUT, "c1_hyper.npz"), **out)
+    print("c1_hyper", len(out))
+
+
+def mid_full():
+    df, nU, nI = datagen.mid_counts()
+    out = {"nnz": np.int64(df.shape[0])}
+    for it in (1, 5, 10):
+        m = fit_ref(df, 50, it)
+        for n, v in grab(m).items():
+            out["it%d_%s_rows" % (it, n)] = v[::10].copy()
+            out["it%d_%s_colsum64" % (it, n)] = v.astype(np.float64).sum(axis=0)
+    m = fit_ref(df, 50, 10, verbose=True, check_every=10)
+    out["train_llk_it10"] = np.float64(m.train_llk)
+    np.savez_compressed(os.path.join(OUT, "mid_full.npz"), **out)
+    print("mid_full", len(out))
+
+
+def c1_partial_fit():
+    batches, nU, nI = datagen.partial_fit_batches()
+    m = HPF(k=30, reindex=False, keep_data=False, random_seed=123, ncores=1, use_float=True)
+    out = {}
+    for b, (kind, bdf) in enumerate(batches):
+        if b == 0:
+            quiet(m.partial_fit, bdf.copy(), batch_type=kind, nusers=nU, nitems=nI)
+        else:
+            quiet(m.partial_fit, bdf.copy(), batch_type=kind)
+        for n, v in grab(m).items():
+            out["call%d_%s" % (b + 1, n)] = v
+        out["call%d_niter" % (b + 1)] = np.int64(m.niter)
+    np.savez_compressed(os.path.join(OUT, "c1_partial_fit.npz"), **out)
+    print("c1_partial_fit", len(out))
+
+
+def c1_svi():
+    df, nU, nI = datagen.readme_counts()
+    out = {}
+    for tag, kw in (("both", dict(users_per_batch=20, items_per_batch=25)),
+                    ("users", dict(users_per_batch=30)),
+                    ("items", dict(items_per_batch=40)),
+                    ("both_fullphi", dict(users_per_batch=20, items_per_batch=25, alloc_full_phi=True))):
+        m = fit_ref(df, 30, 4, **kw)
+        for n, v in grab(m).items():
+            out["%s_%s" % (tag, n)] = v
+    np.savez_compressed(os.path.join(OUT, "c1_svi.npz"), **out)
+    print("c1_svi", len(out))
+
+
+def c1_predict():
+    df, nU, nI = datagen.readme_counts()
+    m = fit_ref(df, 30, 20, keep_data=True)
+    out = {}
+    rs = np.random.RandomState(3)
+    pu, pi = rs.randint(nU, size=500), rs.randint(nI, size=500)
+    out["pairs_u"], out["pairs_i"] = pu, pi
+    out["predict_pairs"] = m.predict(user=pu, item=pi)
+    out["predict_scalar_10_11"] = np.float32(m.predict(user=10, item=11))
+    for u in (0, 10, 57):
+        out["topN_u%d_seen_excluded" % u] = np.array(m.topN(user=u, n=10, exclude_seen=True))
+        out["topN_u%d_all" % u] = np.array(m.topN(user=u, n=10, exclude_seen=False))
+    out["topN_u10_pool"] = np.array(m.topN(user=10, n=3, exclude_seen=False, items_pool=np.arange(5, 40)))
+    # fold-in for a new user (README.md:131-139)
+    rs2 = np.random.RandomState(2)
+    new = pd.DataFrame({"ItemId": rs2.choice(np.arange(nI), size=20, replace=False),
+                        "Count": rs2.gamma(1, 1, size=20).astype("int32")})
+    new = new.loc[new.Count > 0].reset_index(drop=True)
+    out["new_user_items"] = new.ItemId.to_numpy()
+    out["new_user_counts"] = new.Count.to_numpy()
+    out["predict_factors"] = quiet(m.predict_factors, new.copy(), random_seed=1)
+    np.savez_compressed(os.path.join(OUT, "c1_predict.npz"), **out)
+    print("c1_predict", len(out))
+
+
+if __name__ == "__main__":
+    c1_full()
+    c1_trick()
+    c1_hyper()
+    mid_full()
+    c1_partial_fit()
+    c1_svi()
+    c1_predict()
