@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Benchmark of the HPF full-batch CAVI sweep on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full CAVI iteration (phi -> shape accumulation -> all rate updates -> the
+per-iteration all-reduce when N>1; cython_loops.pxi:232-259 of the reference) over the synthetic
+MillionSong-shaped matrix of BASELINE config C3 (1M x 380k, ~48M nnz, k=50, fp32), data resident in
+HBM before the timed region.  With N>1 the SAME matrix is sharded by users (strong scaling).
+
+Prints ONE JSON line on rank 0 (see the bench contract in the task): metric/value/unit ... plus
+  "roofline":     the dominant kernel (sweep_kernel) priced against HBM peak, timed with HIP events
+                  on the launch stream inside the timed region;
+  "cpu_baseline": the CPU oracle (oracle/, a port of the reference's Cython loops) timed on this
+                  node's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from hpfrec_amd import cavi, cython_loops_float as backend  # noqa: E402
+from hpfrec_amd.ops_hip import HipOps  # noqa: E402
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (nU, nI, target nnz, k, label)
+    "c3": (1_000_000, 380_000, 48_000_000, 50, "C3 MillionSong-shaped synthetic 1M x 380k, 48M nnz, k=50, full batch"),
+    "c2": (138_000, 27_000, 20_000_000, 50, "C2 MovieLens-20M-shaped synthetic 138k x 27k, 20M nnz, k=50, full batch"),
+    "c4": (1_000_000, 380_000, 48_000_000, 100, "C4 MillionSong-shaped synthetic 1M x 380k, 48M nnz, k=100, full batch"),
+    "small": (100_000, 30_000, 2_000_000, 50, "small synthetic 100k x 30k, 2M nnz, k=50 (debug)"),
+}
+
+
+def synth_on_device(nU, nI, nnz_target, device, seed=1, item_power=2.5, sigma=1.0):
+    """SURVEY.md section 8d generator, on the GPU: log-normal user degrees, power-law item popularity
+    (i = floor(nI * U^2.5)), unique (u,i) pairs, Y = 1 + floor(Gamma(1,1)).  Deterministic per seed."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    deg = torch.exp(sigma * torch.randn(nU, generator=g, device=device, dtype=torch.float64))
+    deg = torch.clamp(torch.round(deg * (nnz_target * 1.012 / deg.sum())), min=1).to(torch.int64)
+    total = int(deg.sum().item())
+    u = torch.repeat_interleave(torch.arange(nU, device=device, dtype=torch.int64), deg, output_size=total)
+    r = torch.rand(total, generator=g, device=device, dtype=torch.float64)
+    i = torch.clamp((nI * r.pow(item_power)).to(torch.int64), max=nI - 1)
+    key = torch.unique(u * nI + i)
+    del u, i, r
+    u = key // nI
+    i = key - u * nI
+    e = torch.rand(key.shape[0], generator=g, device=device, dtype=torch.float32)
+    y = 1.0 + torch.floor(-torch.log1p(-e))
+    perm = torch.randperm(key.shape[0], generator=g, device=device)  # the reference takes unsorted COO
+    return u[perm], i[perm], y[perm]
+
+
+class TimedOps(HipOps):
+    """HipOps that brackets every launch with HIP events on the launch stream (torch's current
+    stream is the stream the C ABI launches on)."""
+
+    def __init__(self, device):
+        super().__init__(device)
+        self.recording = False
+        self.events = {}
+
+    def _timed(self, name, fn, *a, **kw):
+        if not self.recording:
+            return fn(*a, **kw)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*a, **kw)
+        e1.record()
+        self.events.setdefault(name, []).append((e0, e1))
+        return out
+
+    def sweep(self, *a, **kw):
+        return self._timed("sweep", super().sweep, *a, **kw)
+
+    def row_finalize(self, *a, **kw):
+        return self._timed("row_finalize", super().row_finalize, *a, **kw)
+
+    def colsum_reduce(self, *a, **kw):
+        return self._timed("colsum_reduce", super().colsum_reduce, *a, **kw)
+
+    def segsum(self, *a, **kw):
+        return self._timed("segsum", super().segsum, *a, **kw)
+
+    def summary(self):
+        out = {}
+        for name, evs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = {"calls": len(ms), "avg_ms": float(np.mean(ms)), "total_ms": float(np.sum(ms))}
+        return out
+
+
+def cpu_baseline(nU, nI, k, nnz_full, sample_users=40_000, iters=2):
+    """The CPU oracle (port of the reference's loops: materialised phi, per-nonzero double
+    psi/log/exp, serial scatter, numpy rate updates) on this node's host cores, on a bounded sample:
+    the first `sample_users` users of a same-shaped matrix (all items kept).  Extrapolated linearly
+    in nnz to the full workload (the reference's cost is per nonzero)."""
+    from oracle import hpf_oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import datagen
+    nnz_s = int(nnz_full * (sample_users / nU))
+    iu, ii, Y = datagen.synthetic_hpf_shaped(sample_users, nI, nnz_s, seed=1)
+    cores = O.max_threads()
+    hy = O.Hyper(k, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
+    st = O.State(sample_users, nI, hy, 123)
+    phi = np.empty((Y.shape[0], k), dtype=np.float32)
+    Yc, iuc, iic = O._f32(Y), O._ind(iu), O._ind(ii)
+    O.cavi_iteration(st, hy, Yc, iuc, iic, phi, 0, cores)  # warm (page-in phi)
+    t0 = time.time()
+    for _ in range(iters):
+        O.cavi_iteration(st, hy, Yc, iuc, iic, phi, 0, cores)
+    dt = (time.time() - t0) / iters
+    per_full = dt * (nnz_full / Y.shape[0])
+    return {"value": 1.0 / per_full, "unit": "iters/s", "cores": cores, "kind": "port",
+            "sample": "%d users x %d items, %d nnz, k=%d, %d timed iterations at %.2f s/iter; scaled by nnz to %d nnz"
+                      % (sample_users, nI, Y.shape[0], k, iters, dt, nnz_full)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--llk", action="store_true", help="also time one train-llk evaluation (reported separately)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N>1)"
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+
+    nU, nI, nnz_target, k, label = WORKLOADS[args.workload]
+    iu, ii, y = synth_on_device(nU, nI, nnz_target, device)
+    nnz = int(iu.shape[0])
+
+    ops = TimedOps(device)
+    hy = cavi.Hyper(k, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
+    lu, li, ly, (u0, u1) = cavi.shard_users(iu, ii, y, nU, rank, world)
+    del iu, ii, y
+    model = cavi.FullBatchCavi(ops, device, lu, li, ly, u1 - u0, nI, hy)
+    del lu, li, ly
+    Theta = np.empty((nU, k), np.float32)
+    Beta = np.empty((nI, k), np.float32)
+    init = backend.initialize_parameters(Theta, Beta, 123, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
+    s = slice(u0, u1)
+    model.load_state(init[0][s], init[1][s], init[2], init[3], init[4][s], init[5], Theta[s], Beta)
+    del init, Theta, Beta
+    torch.cuda.empty_cache()
+
+    def fence():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.iterate()
+    fence()
+    ops.recording = not args.no_events
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.iterate()
+    fence()
+    dt = time.perf_counter() - t0
+    ops.recording = False
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    llk_ms = None
+    if args.llk:
+        fence()
+        t1 = time.perf_counter()
+        terms = model.llk_terms(False)
+        sub = model.colsum_dot()
+        fence()
+        llk_ms = (time.perf_counter() - t1) * 1e3
+        llk_val = float(terms[0] - sub)
+
+    # sanity: the state must be finite after the run (a NaN run would be a meaningless number)
+    finite = bool(torch.isfinite(model.Beta).all().item() and torch.isfinite(model.Theta).all().item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        ksum = ops.summary()
+        # algorithmic bytes, SURVEY.md section 8d: whole iteration, and per sweep launch
+        b_iter = nnz * (8 + 8 * k) + nU * (12 + 20 * k) + nI * (4 + 24 * k)
+        n_loc = model.nnz
+        b_sweep = n_loc * (4 + 4 * k) + ((model.nU + model.nI) / 2.0) * (8 + 4 * k)
+        roof = None
+        if "sweep" in ksum:
+            t_sweep = ksum["sweep"]["avg_ms"] * 1e-3
+            ach = b_sweep / t_sweep
+            roof = {"bound": "hbm", "kernel": "sweep_kernel", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
+                    "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": _pmc_traffic(args.workload, world),
+                    "algorithmic_bytes_per_launch": b_sweep, "avg_launch_ms": ksum["sweep"]["avg_ms"],
+                    "launches": ksum["sweep"]["calls"],
+                    "iteration": {"algorithmic_bytes": b_iter, "frac_of_hbm_peak": (b_iter / world) / (ms * 1e-3) / HBM_PEAK
+                                  if world == 1 else None},
+                    "kernels_ms_per_step": {n: v["total_ms"] / args.steps for n, v in ksum.items()}}
+        line = {
+            "metric": "full-batch CAVI iters/sec (48M nnz, k=50)" if args.workload == "c3" else
+                      "full-batch CAVI iters/sec (%s)" % args.workload,
+            "value": args.steps / dt, "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": label, "users": nU, "items": nI, "nnz": nnz, "k": k, "ld": model.ld,
+                       "parallelism": "users sharded x%d, 1 all-reduce/iter" % world if world > 1 else "1 GPU",
+                       "seg_cap": cavi.layout.SEG_CAP, "state_finite": finite},
+            "roofline": roof,
+        }
+        if llk_ms is not None:
+            line["llk_pass_ms"] = llk_ms
+            line["train_llk"] = llk_val
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(nU, nI, k, nnz)
+            except Exception as e:  # the bench line must survive a broken host toolchain
+                line["cpu_baseline"] = {"value": None, "error": repr(e)}
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if dist:
+        dist.destroy_process_group()
+
+
+def _pmc_traffic(workload, world):
+    """HBM bytes per sweep launch from the rocprofv3 --pmc passes committed under profiles/
+    (collected separately, never in the timed run); None when no such summary exists."""
+    p = os.path.join(ROOT, "profiles", "pmc_%s_n%d.json" % (workload, world))
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get("sweep_kernel_hbm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+if __name__ == "__main__":
+    main()

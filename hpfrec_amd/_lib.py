@@ -1,0 +1,106 @@
+"""ctypes binding of libhpf_hip.so (C ABI declared in include/hpf_hip.h).
+
+The library is the product: there is no CPU fallback.  If it is missing or cannot be
+loaded, every compute entry point raises -- loudly -- instead of degrading.
+
+torch is imported first on purpose: the PyTorch ROCm wheel bundles its own
+libamdhip64.so (SONAME libamdhip64.so.7); loading it before libhpf_hip.so makes the
+dynamic linker resolve our NEEDED libamdhip64.so.7 to that same runtime, so streams and
+device pointers are shared between torch and the kernels.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+SO_PATH = os.path.join(_PKG, "libhpf_hip.so")
+SRC_PATH = os.path.join(_PKG, "csrc", "hpf_hip.hip")
+INC_PATH = os.path.join(_ROOT, "include")
+
+HPF_HIP_ABI_VERSION = 1
+
+#: every symbol include/hpf_hip.h declares (tests check the .so exports all of them)
+SYMBOLS = (
+    "hpf_hip_abi_version", "hpf_hip_ld_for_k", "hpf_hip_device_info", "hpf_hip_sweep_f32",
+    "hpf_hip_row_finalize_f32", "hpf_hip_colsum_reduce_f32", "hpf_hip_colsum_f32", "hpf_hip_expect_f32",
+    "hpf_hip_segsum_f32", "hpf_hip_pair_llk_f32", "hpf_hip_pair_dot_f32",
+)
+
+_lib = None
+
+
+class HpfHipError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    if (not force) and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= max(
+            os.path.getmtime(SRC_PATH), os.path.getmtime(os.path.join(INC_PATH, "hpf_hip.h"))):
+        return SO_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I" + INC_PATH,
+           "-o", SO_PATH, SRC_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise HpfHipError(
+            "hpfrec_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH)
+    try:
+        L = ctypes.CDLL(SO_PATH)
+    except OSError as e:  # pragma: no cover
+        raise HpfHipError("hpfrec_amd: cannot load %s: %s" % (SO_PATH, e))
+    vp, i64, ci, cf = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+    L.hpf_hip_abi_version.argtypes = []
+    L.hpf_hip_ld_for_k.argtypes = [ci]
+    L.hpf_hip_device_info.argtypes = [ctypes.POINTER(ci), ctypes.c_char_p, ci]
+    L.hpf_hip_sweep_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]
+    L.hpf_hip_row_finalize_f32.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, ci, ci, ci, vp]
+    L.hpf_hip_colsum_reduce_f32.argtypes = [vp, ci, vp, ci, vp]
+    L.hpf_hip_colsum_f32.argtypes = [vp, i64, ci, vp, ci, vp]
+    L.hpf_hip_expect_f32.argtypes = [vp, vp, vp, i64, ci, ci, vp]
+    L.hpf_hip_segsum_f32.argtypes = [vp, vp, i64, vp, ci, vp]
+    L.hpf_hip_pair_llk_f32.argtypes = [vp, vp, vp, vp, vp, i64, vp, ci, ci, ci, ci, vp]
+    L.hpf_hip_pair_dot_f32.argtypes = [vp, vp, vp, vp, i64, vp, ci, ci, vp]
+    for s in SYMBOLS:
+        getattr(L, s).restype = ci
+    if L.hpf_hip_abi_version() != HPF_HIP_ABI_VERSION:
+        raise HpfHipError("hpfrec_amd: ABI version mismatch, rebuild libhpf_hip.so")
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HpfHipError("hpfrec_amd: %s failed with code %d" % (what, rc))
+
+
+def ld_for_k(k):
+    """Padded leading dimension of a factor table for k latent factors (pure function of k;
+    mirrors hpf_hip_ld_for_k so host-only code paths do not need the .so)."""
+    if k <= 0:
+        raise ValueError("k must be positive")
+    ld = 32
+    while ld < k:
+        ld <<= 1
+    if ld > 1024:
+        raise ValueError("k=%d is larger than the kernels are instantiated for (max 1024)" % k)
+    return ld
+
+
+def device_info():
+    cu = ctypes.c_int(0)
+    buf = ctypes.create_string_buffer(256)
+    check(lib().hpf_hip_device_info(ctypes.byref(cu), buf, 256), "hpf_hip_device_info")
+    return cu.value, buf.value.decode()

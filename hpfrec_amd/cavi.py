@@ -1,0 +1,183 @@
+"""Full-batch CAVI driver: the device-side counterpart of the loop body of fit_hpf
+(/root/reference/hpfrec/cython_loops.pxi:227-259, "PXI").
+
+Statement order of the reference iteration, which this driver preserves:
+  (1) phi from the *old* shapes/rates                       PXI:232   -> both sweeps read eT/eB of the previous iteration
+  (2) Gamma_rte = k_shp/k_rte + colsum(Beta_old)            PXI:236   -> user row_finalize (cs_other = csB)
+  (3) Gamma_shp = a + sum phi ; Lambda_shp = c + sum phi    PXI:239-249
+  (4) Theta = Gamma_shp/Gamma_rte                           PXI:251
+  (5) Lambda_rte = t_shp/t_rte + colsum(Theta_new)          PXI:255   -> item row_finalize (cs_other = csT) runs after the user side
+  (6) Beta = Lambda_shp/Lambda_rte                          PXI:256
+  (7) k_rte = a'/b' + rowsum(Theta); t_rte = c'/d' + rowsum(Beta)   PXI:258-259
+
+Multi-GPU (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm): users are
+sharded in contiguous nnz-balanced ranges, item tables are replicated, and the only exchange is
+one sum all-reduce per iteration of [item accumulators (nI*ld) || colsum(Theta) (ld)].
+
+The kernels are reached through an `ops` object (hpfrec_amd.ops_hip.HipOps).  There is no CPU
+implementation in this package.
+"""
+import numpy as np
+import torch
+
+from . import _lib, layout
+
+
+class Hyper:
+    """Hyper-parameters rounded to float32 as the reference's `real_t` arguments are
+    (PXI:147-148) and the derived constants of PXI:173-174 and PXI:209-210."""
+
+    def __init__(self, k, a, a_prime, b_prime, c, c_prime, d_prime):
+        f = np.float32
+        self.k = int(k)
+        self.a, self.a_prime, self.b_prime = f(a), f(a_prime), f(b_prime)
+        self.c, self.c_prime, self.d_prime = f(c), f(c_prime), f(d_prime)
+        self.k_shp = f(self.a_prime + f(self.k) * self.a)
+        self.t_shp = f(self.c_prime + f(self.k) * self.c)
+        self.add_k_rte = f(self.a_prime / self.b_prime)
+        self.add_t_rte = f(self.c_prime / self.d_prime)
+
+
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist
+    return None
+
+
+def shard_users(ix_u, ix_i, y, nU, rank, world):
+    """Keep the nonzeros of this rank's contiguous, nnz-balanced user range.
+    Returns (local ix_u, ix_i, y, (u0, u1))."""
+    if world <= 1:
+        return ix_u, ix_i, y, (0, int(nU))
+    counts = torch.bincount(ix_u.to(torch.int64), minlength=int(nU))
+    indptr = torch.zeros(int(nU) + 1, dtype=torch.int64, device=ix_u.device)
+    torch.cumsum(counts, 0, out=indptr[1:])
+    u0, u1 = layout.nnz_balanced_ranges(indptr, world)[rank]
+    keep = (ix_u >= u0) & (ix_u < u1)
+    return ix_u[keep] - u0, ix_i[keep], y[keep], (u0, u1)
+
+
+class FullBatchCavi:
+    """Device-resident state + one-iteration step for (a shard of) the HPF model."""
+
+    def __init__(self, ops, device, ix_u, ix_i, y, nU, nI, hyper, seg_cap=layout.SEG_CAP):
+        """ix_u/ix_i/y: COO triplets of THIS rank (user ids local to the shard), torch tensors."""
+        self.ops = ops
+        self.device = torch.device(device)
+        self.hy = hyper
+        self.k = hyper.k
+        self.ld = _lib.ld_for_k(self.k)
+        self.nU, self.nI = int(nU), int(nI)
+        dev = self.device
+        self.users, self.items, self.u_sorted = layout.build_sides(ix_u.to(dev), ix_i.to(dev), y.to(dev),
+                                                                   self.nU, self.nI, seg_cap)
+        self.nnz = self.users.nnz
+        self.dist = _dist()
+        ld = self.ld
+        f32 = dict(dtype=torch.float32, device=dev)
+        z = lambda n: torch.zeros((n, ld), **f32)
+        self.Gamma_shp, self.Gamma_rte, self.Theta = z(self.nU), z(self.nU), z(self.nU)
+        self.Lambda_shp, self.Lambda_rte, self.Beta = z(self.nI), z(self.nI), z(self.nI)
+        self.k_rte = torch.zeros(self.nU, **f32)
+        self.t_rte = torch.zeros(self.nI, **f32)
+        self.eT, self.eT_next, self.eB = z(self.nU), z(self.nU), z(self.nI)
+        self.part_u = torch.empty((max(1, self.users.nseg), ld), **f32)
+        self.part_i = torch.empty((max(1, self.items.nseg), ld), **f32)
+        self.gu = ops.finalize_grid(self.nU)
+        self.gi = ops.finalize_grid(self.nI)
+        self.csT_part = torch.zeros((self.gu, ld), **f32)
+        self.csB_part = torch.zeros((self.gi, ld), **f32)
+        self.csB = torch.zeros(ld, **f32)
+        # [item accumulators || colsum(Theta)]: one flat buffer so that one all-reduce moves both
+        self.xbuf = torch.zeros(self.nI * ld + ld, **f32) if self.dist else None
+        self.csT = self.xbuf[self.nI * ld:] if self.dist else torch.zeros(ld, **f32)
+        self.acc_i = self.xbuf[: self.nI * ld].view(self.nI, ld) if self.dist else None
+        self.niter_done = 0
+
+    # ------------------------------------------------------------------------------------
+    def _pad(self, host_arr, out):
+        t = torch.from_numpy(np.ascontiguousarray(host_arr, dtype=np.float32)).to(self.device)
+        out.zero_()
+        out[:, : self.k] = t.view(out.shape[0], self.k)
+
+    def load_state(self, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta):
+        """Upload host arrays ([n,k] / [n,1], this rank's user rows) and derive eT, eB and colsum(Beta)."""
+        self._pad(Gamma_shp, self.Gamma_shp)
+        self._pad(Gamma_rte, self.Gamma_rte)
+        self._pad(Lambda_shp, self.Lambda_shp)
+        self._pad(Lambda_rte, self.Lambda_rte)
+        self._pad(Theta, self.Theta)
+        self._pad(Beta, self.Beta)
+        self.k_rte.copy_(torch.from_numpy(np.ascontiguousarray(k_rte, dtype=np.float32).reshape(-1)))
+        self.t_rte.copy_(torch.from_numpy(np.ascontiguousarray(t_rte, dtype=np.float32).reshape(-1)))
+        self.refresh_expectations()
+
+    def refresh_expectations(self):
+        ops, k, ld = self.ops, self.k, self.ld
+        ops.expect(self.Gamma_shp, self.Gamma_rte, self.eT, self.nU, k, ld)
+        ops.expect(self.Lambda_shp, self.Lambda_rte, self.eB, self.nI, k, ld)
+        ops.colsum(self.Beta, self.nI, ld, self.csB_part)
+        ops.colsum_reduce(self.csB_part, self.csB, ld)
+
+    # ------------------------------------------------------------------------------------
+    def iterate(self):
+        ops, hy, k, ld = self.ops, self.hy, self.k, self.ld
+        # user side: phi-weighted gather over CSR rows, then the closed-form user updates
+        ops.sweep(self.users, self.eT, self.eB, self.part_u, k, ld)
+        ops.row_finalize(self.part_u, self.users.row_seg_ptr, self.nU, self.eT, self.eT_next, self.Gamma_shp,
+                         self.Gamma_rte, self.Theta, self.k_rte, self.csB, self.csT_part, hy.a, hy.k_shp,
+                         hy.add_k_rte, k, ld)
+        ops.colsum_reduce(self.csT_part, self.csT, ld)
+        # item side: same kernel over CSC rows; still reads the OLD eT (double-buffered)
+        ops.sweep(self.items, self.eB, self.eT, self.part_i, k, ld)
+        if self.dist:
+            ops.segsum(self.part_i, self.items.row_seg_ptr, self.nI, self.acc_i, ld)
+            self.dist.all_reduce(self.xbuf)
+            part, rsp = self.acc_i, None
+        else:
+            part, rsp = self.part_i, self.items.row_seg_ptr
+        ops.row_finalize(part, rsp, self.nI, self.eB, self.eB, self.Lambda_shp, self.Lambda_rte, self.Beta,
+                         self.t_rte, self.csT, self.csB_part, hy.c, hy.t_shp, hy.add_t_rte, k, ld)
+        ops.colsum_reduce(self.csB_part, self.csB, ld)
+        self.eT, self.eT_next = self.eT_next, self.eT
+        self.niter_done += 1
+
+    # ------------------------------------------------------------------------------------
+    def llk_terms(self, full_llk=False):
+        """Global (all-reduced) float64 [sum y*log(yhat)(-lgamma), sum sq.err, sum yhat, nnz] over the training nonzeros."""
+        t = self.ops.pair_llk(self.Theta, self.Beta, self.u_sorted, self.users.idx, self.users.y, self.k, self.ld,
+                              full_llk)
+        out = torch.cat([t.to(torch.float64), torch.tensor([float(self.nnz)], dtype=torch.float64,
+                                                           device=t.device)])
+        if self.dist:
+            self.dist.all_reduce(out)
+        return out.cpu().numpy()
+
+    def pair_llk_terms(self, ix_u, ix_i, y, full_llk=False):
+        """Same terms over caller-listed pairs (validation set); ix_u must be local to this shard."""
+        t = self.ops.pair_llk(self.Theta, self.Beta, ix_u, ix_i, y, self.k, self.ld, full_llk)
+        out = torch.cat([t.to(torch.float64), torch.tensor([float(ix_u.shape[0])], dtype=torch.float64,
+                                                           device=t.device)])
+        if self.dist:
+            self.dist.all_reduce(out)
+        return out.cpu().numpy()
+
+    def colsum_dot(self):
+        """(sum_u Theta) . (sum_i Beta) in float32, the subtrahend of the train llk (PXI:78)."""
+        if self.niter_done == 0:
+            self.ops.colsum(self.Theta, self.nU, self.ld, self.csT_part)
+            self.ops.colsum_reduce(self.csT_part, self.csT, self.ld)
+            if self.dist:
+                self.dist.all_reduce(self.csT)
+        a = self.csT[: self.k].cpu().numpy()
+        b = self.csB[: self.k].cpu().numpy()
+        return np.dot(a, b)
+
+    # ------------------------------------------------------------------------------------
+    def fetch(self, name):
+        """Unpadded host copy of one state array (this rank's rows)."""
+        t = getattr(self, name)
+        if t.dim() == 1:
+            return t.cpu().numpy().reshape(-1, 1).copy()
+        return t[:, : self.k].contiguous().cpu().numpy()

@@ -1,0 +1,636 @@
+// hpf_hip.hip -- gfx950 (MI355X, CDNA4) kernels + C ABI for the HPF full-batch CAVI sweep.
+//
+// What is replaced (reference: /root/reference/hpfrec/cython_loops.pxi = "PXI"):
+//   sweep_kernel        <- update_phi PXI:551-591 fused with update_G_n_L_sh PXI:613-621
+//   row_finalize_kernel <- numpy rate/shape statements of fit_hpf PXI:236-259 + the psi/log/exp
+//                          hoisted out of update_phi (PXI:588: they only depend on the row)
+//   pair_llk_kernel     <- llk_plus_rmse PXI:627-658, sum_prediction PXI:816-825
+//   pair_dot_kernel     <- predict_multiple PXI:803-810
+//
+// Design: the reference evaluates, per nonzero and factor,
+//   exp(psi(Gs_uk) - log(Gr_uk) + psi(Ls_ik) - log(Lr_ik)) = eT_uk * eB_ik
+// with eT/eB depending on one row only.  We keep eT (users) and eB (items) as padded fp32
+// tables and never materialise phi: per nonzero s = <eT_u, eB_i>, w = y/s and
+//   Gamma_shp_u = a + eT_u (*) sum_i w eB_i        (CSR pass, rows = users)
+//   Lambda_shp_i = c + eB_i (*) sum_u w eT_u       (CSC pass, rows = items)
+// Both passes are the same kernel: HBM/L2-bound gathers of 4*ld-byte rows, no atomics,
+// bit-reproducible.  Wave64 layout: a row of ld floats is held by LPR = ld/4 lanes as one
+// float4 each (VPL float4 per lane when ld > 256), so a wavefront processes 64/LPR nonzeros
+// per step; the k-reduction is 4 DPP adds inside a 16-lane DPP row.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "hpf_hip.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256;
+constexpr int WPB = BLOCK / WAVE;
+
+// ----------------------------------------------------------------------------------------
+// cross-lane helpers
+// ----------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// all-reduce (sum) over aligned groups of W lanes; every lane of the group gets the total
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {
+    v += dpp_f<0xB1>(v);                         // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);                         // quad_perm [2,3,0,1]
+    if constexpr (W >= 8) v += dpp_f<0x141>(v);  // row_half_mirror
+    if constexpr (W >= 16) v += dpp_f<0x140>(v); // row_mirror
+    if constexpr (W >= 32) v += __shfl_xor(v, 16);
+    if constexpr (W >= 64) v += __shfl_xor(v, 32);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+    for (int m = 1; m < WAVE; m <<= 1) v = fmax(v, __shfl_xor(v, m));
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int m = 1; m < WAVE; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) {
+    return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
+}
+
+// ----------------------------------------------------------------------------------------
+// exp(psi(x)) / r for x > 0, r > 0, in double.
+//   psi(x) = psi(x+6) - sum_{i<6} 1/(x+i)           (recurrence, only when x < 6)
+//   psi(s) = log s - 1/(2s) - sum_n B_2n/(2n s^2n)   (asymptotic, s >= 6: truncation < 2e-13)
+// so exp(psi(x))/r = (s/r) * exp(-(1/(2s) + series + recurrence sum)) with no log at all.
+// Same series as the Cephes psi the reference calls through scipy (PXI:5,588).
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ double expect_ratio(float shp, float rte) {
+    double x = (double)shp;
+    double s = x, w = 0.0;
+    if (x < 6.0) {
+        const double p01 = x * (x + 1.0), p23 = (x + 2.0) * (x + 3.0), p45 = (x + 4.0) * (x + 5.0);
+        const double n01 = 2.0 * x + 1.0, n23 = 2.0 * x + 5.0, n45 = 2.0 * x + 9.0;
+        w = (n01 * p23 * p45 + n23 * p01 * p45 + n45 * p01 * p23) / (p01 * p23 * p45);
+        s = x + 6.0;
+    }
+    const double r = 1.0 / s;
+    const double z = r * r;
+    double poly = 8.33333333333333333333E-2;
+    poly = fma(poly, z, -2.10927960927960927961E-2);
+    poly = fma(poly, z, 7.57575757575757575758E-3);
+    poly = fma(poly, z, -4.16666666666666666667E-3);
+    poly = fma(poly, z, 3.96825396825396825397E-3);
+    poly = fma(poly, z, -8.33333333333333333333E-3);
+    poly = fma(poly, z, 8.33333333333333333333E-2);
+    const double v = fma(poly, z, 0.5 * r) + w;
+    return (s / (double)rte) * exp(-v);
+}
+
+// ----------------------------------------------------------------------------------------
+// sweep: one wavefront per segment
+// ----------------------------------------------------------------------------------------
+template <int LPR, int VPL, bool SCATTER>
+__global__ __launch_bounds__(BLOCK) void sweep_kernel(const hpf_segment *__restrict__ segs, int64_t nseg,
+                                                      const int32_t *__restrict__ idx,
+                                                      const float *__restrict__ y,
+                                                      const float *__restrict__ tab_self,
+                                                      const float *__restrict__ tab_other,
+                                                      float *__restrict__ part, float *scatter_acc) {
+    constexpr int LD = 4 * LPR * VPL;
+    constexpr int NG = WAVE / LPR;  // nonzeros per step
+    constexpr int U = 4;            // gathers in flight per wavefront (WAVE/NG = LPR >= 8 is a multiple)
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int g = lane / LPR;
+    const int j = lane % LPR;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WPB;
+
+    for (int64_t sg = (int64_t)blockIdx.x * WPB + wid; sg < nseg; sg += nwaves) {
+        const hpf_segment sgm = segs[sg];
+        const int len = sgm.len;
+        const float4 *selfp = reinterpret_cast<const float4 *>(tab_self + (size_t)sgm.row * LD);
+        float4 rv[VPL], acc[VPL];
+#pragma unroll
+        for (int v = 0; v < VPL; v++) {
+            rv[v] = selfp[v * LPR + j];
+            acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int32_t *ip = idx + sgm.begin;
+        const float *yp = y + sgm.begin;
+
+        for (int base = 0; base < len; base += WAVE) {
+            const int n = min(WAVE, len - base);
+            int myc = 0;
+            float myy = 0.f;
+            if (lane < n) {
+                myc = ip[base + lane];
+                myy = yp[base + lane];
+            }
+            int nsteps = (n + NG - 1) / NG;
+            nsteps = (nsteps + U - 1) & ~(U - 1);
+            for (int t0 = 0; t0 < nsteps; t0 += U) {
+                float4 o[U][VPL];
+                float yy[U];
+                int cc[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int src = (t0 + u) * NG + g;
+                    cc[u] = __shfl(myc, src);
+                    yy[u] = __shfl(myy, src);
+                    const float4 *op = reinterpret_cast<const float4 *>(tab_other + (size_t)cc[u] * LD);
+#pragma unroll
+                    for (int v = 0; v < VPL; v++) o[u][v] = op[v * LPR + j];
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    float p = 0.f;
+#pragma unroll
+                    for (int v = 0; v < VPL; v++) p += dot4(rv[v], o[u][v]);
+                    const float s = group_sum<LPR>(p);
+                    const float w = (yy[u] > 0.f) ? yy[u] * __builtin_amdgcn_rcpf(s) : 0.f;
+#pragma unroll
+                    for (int v = 0; v < VPL; v++) {
+                        acc[v].x = fmaf(w, o[u][v].x, acc[v].x);
+                        acc[v].y = fmaf(w, o[u][v].y, acc[v].y);
+                        acc[v].z = fmaf(w, o[u][v].z, acc[v].z);
+                        acc[v].w = fmaf(w, o[u][v].w, acc[v].w);
+                    }
+                    if constexpr (SCATTER) {
+                        if (yy[u] > 0.f) {
+                            float *sp = scatter_acc + (size_t)cc[u] * LD;
+#pragma unroll
+                            for (int v = 0; v < VPL; v++) {
+                                float *q = sp + (v * LPR + j) * 4;
+                                unsafeAtomicAdd(q + 0, w * rv[v].x);
+                                unsafeAtomicAdd(q + 1, w * rv[v].y);
+                                unsafeAtomicAdd(q + 2, w * rv[v].z);
+                                unsafeAtomicAdd(q + 3, w * rv[v].w);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // fold the NG sub-wave groups (fixed order: deterministic)
+#pragma unroll
+        for (int v = 0; v < VPL; v++) {
+#pragma unroll
+            for (int m = LPR; m < WAVE; m <<= 1) {
+                acc[v].x += __shfl_xor(acc[v].x, m);
+                acc[v].y += __shfl_xor(acc[v].y, m);
+                acc[v].z += __shfl_xor(acc[v].z, m);
+                acc[v].w += __shfl_xor(acc[v].w, m);
+            }
+        }
+        if (g == 0) {
+            float4 *pp = reinterpret_cast<float4 *>(part + (size_t)sg * LD);
+#pragma unroll
+            for (int v = 0; v < VPL; v++) pp[v * LPR + j] = acc[v];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// row finalize: one wavefront per table row, lane <-> factor
+// ----------------------------------------------------------------------------------------
+template <int LD>
+__global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
+    const float *__restrict__ part, const int64_t *__restrict__ row_seg_ptr, int64_t nrows, const float *e_old,
+    float *e_new, float *__restrict__ shp, float *__restrict__ rte, float *__restrict__ fac, float *rs,
+    const float *__restrict__ cs_other, float *__restrict__ cs_partial, float prior_shp, float top_shp,
+    float add_rte, int k) {
+    constexpr int CPL = (LD + WAVE - 1) / WAVE;  // factors per lane
+    __shared__ float red[WPB][LD];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WPB;
+
+    float csl[CPL], csacc[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; q++) {
+        const int c = lane + WAVE * q;
+        csl[q] = (c < k) ? cs_other[c] : 0.f;
+        csacc[q] = 0.f;
+    }
+
+    for (int64_t r = (int64_t)blockIdx.x * WPB + wid; r < nrows; r += nwaves) {
+        int64_t s0 = r, s1 = r + 1;
+        if (row_seg_ptr) {
+            s0 = row_seg_ptr[r];
+            s1 = row_seg_ptr[r + 1];
+        }
+        const float base_rte = top_shp / rs[r];
+        float sh[CPL], rt[CPL], fc[CPL];
+        double ev[CPL];
+        float fsum = 0.f;
+        double emax = 0.0;
+#pragma unroll
+        for (int q = 0; q < CPL; q++) {
+            const int c = lane + WAVE * q;
+            const bool valid = c < k;
+            float a = 0.f;
+            if (c < LD) {
+                for (int64_t sg = s0; sg < s1; sg++) a += part[(size_t)sg * LD + c];
+            }
+            const float eo = (c < LD) ? e_old[(size_t)r * LD + c] : 0.f;
+            sh[q] = fmaf(eo, a, prior_shp);
+            rt[q] = base_rte + csl[q];
+            fc[q] = valid ? sh[q] / rt[q] : 0.f;
+            ev[q] = valid ? expect_ratio(sh[q], rt[q]) : 0.0;
+            fsum += fc[q];
+            emax = fmax(emax, ev[q]);
+            csacc[q] += fc[q];
+        }
+        fsum = wave_sum(fsum);
+        emax = wave_max_d(emax);
+        const double inv = 1.0 / emax;
+#pragma unroll
+        for (int q = 0; q < CPL; q++) {
+            const int c = lane + WAVE * q;
+            if (c < LD) {
+                const size_t o = (size_t)r * LD + c;
+                const bool valid = c < k;
+                e_new[o] = valid ? (float)(ev[q] * inv) : 0.f;
+                if (shp) shp[o] = valid ? sh[q] : 0.f;
+                if (rte) rte[o] = valid ? rt[q] : 0.f;
+                if (fac) fac[o] = fc[q];
+            }
+        }
+        if (lane == 0) rs[r] = add_rte + fsum;
+    }
+
+    // per-block column sums of fac (fixed order -> reproducible for a fixed grid)
+#pragma unroll
+    for (int q = 0; q < CPL; q++) {
+        const int c = lane + WAVE * q;
+        if (c < LD) red[wid][c] = csacc[q];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < LD; c += BLOCK) {
+        float t = red[0][c];
+#pragma unroll
+        for (int w2 = 1; w2 < WPB; w2++) t += red[w2][c];
+        cs_partial[(size_t)blockIdx.x * LD + c] = t;
+    }
+}
+
+template <int LD>
+__global__ __launch_bounds__(BLOCK) void colsum_kernel(const float *__restrict__ tab, int64_t nrows,
+                                                       float *__restrict__ cs_partial) {
+    constexpr int CPL = (LD + WAVE - 1) / WAVE;
+    __shared__ float red[WPB][LD];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WPB;
+    float csacc[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; q++) csacc[q] = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * WPB + wid; r < nrows; r += nwaves) {
+#pragma unroll
+        for (int q = 0; q < CPL; q++) {
+            const int c = lane + WAVE * q;
+            if (c < LD) csacc[q] += tab[(size_t)r * LD + c];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < CPL; q++) {
+        const int c = lane + WAVE * q;
+        if (c < LD) red[wid][c] = csacc[q];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < LD; c += BLOCK) {
+        float t = red[0][c];
+#pragma unroll
+        for (int w2 = 1; w2 < WPB; w2++) t += red[w2][c];
+        cs_partial[(size_t)blockIdx.x * LD + c] = t;
+    }
+}
+
+// cs_out[c] = sum_b cs_partial[b][c]; 16 interleaved double chains per column, folded in order
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float *__restrict__ cs_partial, int nblk,
+                                                             float *__restrict__ cs_out, int ld) {
+    __shared__ double red[16][WAVE];
+    const int cl = threadIdx.x & (WAVE - 1);
+    const int chunk = threadIdx.x >> 6;
+    const int c = blockIdx.x * WAVE + cl;
+    double s = 0.0;
+    if (c < ld) {
+        for (int b = chunk; b < nblk; b += 16) s += (double)cs_partial[(size_t)b * ld + c];
+    }
+    red[chunk][cl] = s;
+    __syncthreads();
+    if (chunk == 0 && c < ld) {
+        double t = red[0][cl];
+#pragma unroll
+        for (int q = 1; q < 16; q++) t += red[q][cl];
+        cs_out[c] = (float)t;
+    }
+}
+
+template <int LD>
+__global__ __launch_bounds__(BLOCK) void expect_kernel(const float *__restrict__ shp, const float *__restrict__ rte,
+                                                       float *__restrict__ e, int64_t nrows, int k) {
+    constexpr int CPL = (LD + WAVE - 1) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WPB;
+    for (int64_t r = (int64_t)blockIdx.x * WPB + wid; r < nrows; r += nwaves) {
+        double ev[CPL];
+        double emax = 0.0;
+#pragma unroll
+        for (int q = 0; q < CPL; q++) {
+            const int c = lane + WAVE * q;
+            ev[q] = (c < k) ? expect_ratio(shp[(size_t)r * LD + c], rte[(size_t)r * LD + c]) : 0.0;
+            emax = fmax(emax, ev[q]);
+        }
+        emax = wave_max_d(emax);
+        const double inv = 1.0 / emax;
+#pragma unroll
+        for (int q = 0; q < CPL; q++) {
+            const int c = lane + WAVE * q;
+            if (c < LD) e[(size_t)r * LD + c] = (c < k) ? (float)(ev[q] * inv) : 0.f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void segsum_kernel(const float *__restrict__ part,
+                                                       const int64_t *__restrict__ row_seg_ptr, int64_t nrows,
+                                                       float *__restrict__ acc, int ld) {
+    const int64_t total = nrows * (int64_t)ld;
+    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLOCK) {
+        const int64_t r = t / ld;
+        const int c = (int)(t - r * ld);
+        float a = 0.f;
+        for (int64_t sg = row_seg_ptr[r]; sg < row_seg_ptr[r + 1]; sg++) a += part[(size_t)sg * ld + c];
+        acc[t] = a;
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// listed-pair kernels: LPR lanes per (user,item) pair
+// ----------------------------------------------------------------------------------------
+template <int LPR, int VPL>
+__device__ __forceinline__ float pair_dot(const float *__restrict__ T, const float *__restrict__ B, int u, int i,
+                                          int j) {
+    constexpr int LD = 4 * LPR * VPL;
+    const float4 *tp = reinterpret_cast<const float4 *>(T + (size_t)u * LD);
+    const float4 *bp = reinterpret_cast<const float4 *>(B + (size_t)i * LD);
+    float p = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; v++) p += dot4(tp[v * LPR + j], bp[v * LPR + j]);
+    return group_sum<LPR>(p);
+}
+
+template <int LPR, int VPL, bool FULL>
+__global__ __launch_bounds__(BLOCK) void pair_llk_kernel(const float *__restrict__ T, const float *__restrict__ B,
+                                                         const int32_t *__restrict__ ix_u,
+                                                         const int32_t *__restrict__ ix_i,
+                                                         const float *__restrict__ y, int64_t n,
+                                                         double *__restrict__ partial) {
+    constexpr int NG = WAVE / LPR;
+    __shared__ double red[WPB][3];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int g = lane / LPR, j = lane % LPR;
+    const int wid = threadIdx.x >> 6;
+    const int64_t ngroups = (int64_t)gridDim.x * WPB * NG;
+    const int64_t gid = ((int64_t)blockIdx.x * WPB + wid) * NG + g;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    // wave-uniform trip count (cross-lane reductions need whole groups; tails are masked by y = 0)
+    const int64_t iters = (n + ngroups - 1) / ngroups;
+    for (int64_t it = 0; it < iters; it++) {
+        const int64_t p = it * ngroups + gid;
+        const bool live = p < n;
+        const int u = live ? ix_u[p] : 0;
+        const int i = live ? ix_i[p] : 0;
+        const float yy = live ? y[p] : 0.f;
+        const float yhat = pair_dot<LPR, VPL>(T, B, u, i, j);
+        if (live && j == 0) {
+            if constexpr (FULL)
+                a0 += (double)yy * log((double)yhat) - lgamma((double)yy + 1.0);
+            else
+                a0 += (double)(yy * logf(yhat));
+            const float d = yy - yhat;
+            a1 += (double)(d * d);
+            a2 += (double)yhat;
+        }
+    }
+    a0 = wave_sum_d(a0);
+    a1 = wave_sum_d(a1);
+    a2 = wave_sum_d(a2);
+    if (lane == 0) {
+        red[wid][0] = a0;
+        red[wid][1] = a1;
+        red[wid][2] = a2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double t = red[0][threadIdx.x];
+#pragma unroll
+        for (int w2 = 1; w2 < WPB; w2++) t += red[w2][threadIdx.x];
+        partial[(size_t)blockIdx.x * 4 + threadIdx.x] = t;
+    }
+    if (threadIdx.x == 3) partial[(size_t)blockIdx.x * 4 + 3] = 0.0;
+}
+
+template <int LPR, int VPL>
+__global__ __launch_bounds__(BLOCK) void pair_dot_kernel(const float *__restrict__ T, const float *__restrict__ B,
+                                                         const int32_t *__restrict__ ix_u,
+                                                         const int32_t *__restrict__ ix_i, int64_t n,
+                                                         float *__restrict__ out) {
+    constexpr int NG = WAVE / LPR;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int g = lane / LPR, j = lane % LPR;
+    const int wid = threadIdx.x >> 6;
+    const int64_t ngroups = (int64_t)gridDim.x * WPB * NG;
+    const int64_t gid = ((int64_t)blockIdx.x * WPB + wid) * NG + g;
+    const int64_t iters = (n + ngroups - 1) / ngroups;
+    for (int64_t it = 0; it < iters; it++) {
+        const int64_t p = it * ngroups + gid;
+        const bool live = p < n;
+        const int u = live ? ix_u[p] : 0;
+        const int i = live ? ix_i[p] : 0;
+        const float yhat = pair_dot<LPR, VPL>(T, B, u, i, j);
+        if (live && j == 0) out[p] = yhat;
+    }
+}
+
+inline int clamp_grid(int64_t want, int grid_blocks) {
+    int64_t g = grid_blocks > 0 ? grid_blocks : 2048;
+    if (want < g) g = want;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+inline int last_error() { return (int)hipGetLastError(); }
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------
+// C ABI
+// ----------------------------------------------------------------------------------------
+#define HPF_DISPATCH_LD(ld, CALL)                    \
+    switch (ld) {                                    \
+        case 32: { CALL(8, 1); break; }              \
+        case 64: { CALL(16, 1); break; }             \
+        case 128: { CALL(32, 1); break; }            \
+        case 256: { CALL(64, 1); break; }            \
+        case 512: { CALL(64, 2); break; }            \
+        case 1024: { CALL(64, 4); break; }           \
+        default: return HPF_EUNSUPPORTED;            \
+    }
+
+#define HPF_DISPATCH_LD1(ld, CALL)                   \
+    switch (ld) {                                    \
+        case 32: { CALL(32); break; }                \
+        case 64: { CALL(64); break; }                \
+        case 128: { CALL(128); break; }              \
+        case 256: { CALL(256); break; }              \
+        case 512: { CALL(512); break; }              \
+        case 1024: { CALL(1024); break; }            \
+        default: return HPF_EUNSUPPORTED;            \
+    }
+
+extern "C" {
+
+int hpf_hip_abi_version(void) { return HPF_HIP_ABI_VERSION; }
+
+int hpf_hip_ld_for_k(int k) {
+    if (k <= 0) return HPF_EINVAL;
+    int ld = 32;
+    while (ld < k) ld <<= 1;
+    if (ld > 1024) return HPF_EUNSUPPORTED;
+    return ld;
+}
+
+int hpf_hip_device_info(int *cu_count, char *arch, int arch_len) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return (int)e;
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (arch && arch_len > 0) {
+        strncpy(arch, prop.gcnArchName, (size_t)arch_len - 1);
+        arch[arch_len - 1] = 0;
+    }
+    return 0;
+}
+
+int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
+                      const float *tab_self, const float *tab_other, float *part, float *scatter_acc, int k, int ld,
+                      int grid_blocks, void *stream) {
+    if (nseg == 0) return 0;
+    if (!segs || !idx || !y || !tab_self || !tab_other || !part || nseg < 0 || k <= 0 || ld != hpf_hip_ld_for_k(k))
+        return HPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = clamp_grid((nseg + WPB - 1) / WPB, grid_blocks);
+#define CALL(LPR, VPL)                                                                                            \
+    if (scatter_acc)                                                                                              \
+        hipLaunchKernelGGL((sweep_kernel<LPR, VPL, true>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg, idx, y,   \
+                           tab_self, tab_other, part, scatter_acc);                                               \
+    else                                                                                                          \
+        hipLaunchKernelGGL((sweep_kernel<LPR, VPL, false>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg, idx, y,  \
+                           tab_self, tab_other, part, scatter_acc);
+    HPF_DISPATCH_LD(ld, CALL)
+#undef CALL
+    return last_error();
+}
+
+int hpf_hip_row_finalize_f32(const float *part, const int64_t *row_seg_ptr, int64_t nrows, const float *e_old,
+                             float *e_new, float *shp, float *rte, float *fac, float *rs, const float *cs_other,
+                             float *cs_partial, float prior_shp, float top_shp, float add_rte, int k, int ld,
+                             int grid_blocks, void *stream) {
+    if (!part || !e_old || !e_new || !rs || !cs_other || !cs_partial || nrows <= 0 || k <= 0 ||
+        ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0)
+        return HPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    // the grid is NOT clamped: cs_partial has exactly grid_blocks rows and all are written
+#define CALL(LD)                                                                                                  \
+    hipLaunchKernelGGL((row_finalize_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, part, row_seg_ptr, nrows, \
+                       e_old, e_new, shp, rte, fac, rs, cs_other, cs_partial, prior_shp, top_shp, add_rte, k);
+    HPF_DISPATCH_LD1(ld, CALL)
+#undef CALL
+    return last_error();
+}
+
+int hpf_hip_colsum_reduce_f32(const float *cs_partial, int nblk, float *cs_out, int ld, void *stream) {
+    if (!cs_partial || !cs_out || nblk <= 0 || ld < 32) return HPF_EINVAL;
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((ld + WAVE - 1) / WAVE), dim3(1024), 0, (hipStream_t)stream,
+                       cs_partial, nblk, cs_out, ld);
+    return last_error();
+}
+
+int hpf_hip_colsum_f32(const float *tab, int64_t nrows, int ld, float *cs_partial, int grid_blocks, void *stream) {
+    if (!tab || !cs_partial || nrows <= 0 || grid_blocks <= 0) return HPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(LD) \
+    hipLaunchKernelGGL((colsum_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, tab, nrows, cs_partial);
+    HPF_DISPATCH_LD1(ld, CALL)
+#undef CALL
+    return last_error();
+}
+
+int hpf_hip_expect_f32(const float *shp, const float *rte, float *e, int64_t nrows, int k, int ld, void *stream) {
+    if (!shp || !rte || !e || nrows <= 0 || k <= 0 || ld != hpf_hip_ld_for_k(k)) return HPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = clamp_grid((nrows + WPB - 1) / WPB, 2048);
+#define CALL(LD) hipLaunchKernelGGL((expect_kernel<LD>), dim3(grid), dim3(BLOCK), 0, st, shp, rte, e, nrows, k);
+    HPF_DISPATCH_LD1(ld, CALL)
+#undef CALL
+    return last_error();
+}
+
+int hpf_hip_segsum_f32(const float *part, const int64_t *row_seg_ptr, int64_t nrows, float *acc, int ld,
+                       void *stream) {
+    if (!part || !row_seg_ptr || !acc || nrows <= 0 || ld < 32) return HPF_EINVAL;
+    const int grid = clamp_grid((nrows * ld + BLOCK - 1) / BLOCK, 4096);
+    hipLaunchKernelGGL(segsum_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, part, row_seg_ptr, nrows, acc,
+                       ld);
+    return last_error();
+}
+
+int hpf_hip_pair_llk_f32(const float *T, const float *B, const int32_t *ix_u, const int32_t *ix_i, const float *y,
+                         int64_t n, double *partial, int k, int ld, int full_llk, int grid_blocks, void *stream) {
+    if (!T || !B || !partial || n < 0 || k <= 0 || ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0) return HPF_EINVAL;
+    if (n > 0 && (!ix_u || !ix_i || !y)) return HPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    // grid not clamped: partial has 4*grid_blocks entries and all are written
+#define CALL(LPR, VPL)                                                                                              \
+    if (full_llk)                                                                                                   \
+        hipLaunchKernelGGL((pair_llk_kernel<LPR, VPL, true>), dim3(grid_blocks), dim3(BLOCK), 0, st, T, B, ix_u,   \
+                           ix_i, y, n, partial);                                                                    \
+    else                                                                                                            \
+        hipLaunchKernelGGL((pair_llk_kernel<LPR, VPL, false>), dim3(grid_blocks), dim3(BLOCK), 0, st, T, B, ix_u,  \
+                           ix_i, y, n, partial);
+    HPF_DISPATCH_LD(ld, CALL)
+#undef CALL
+    return last_error();
+}
+
+int hpf_hip_pair_dot_f32(const float *T, const float *B, const int32_t *ix_u, const int32_t *ix_i, int64_t n,
+                         float *out, int k, int ld, void *stream) {
+    if (n == 0) return 0;
+    if (!T || !B || !ix_u || !ix_i || !out || n < 0 || k <= 0 || ld != hpf_hip_ld_for_k(k)) return HPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(LPR, VPL)                                                                                          \
+    {                                                                                                           \
+        const int grid = clamp_grid((n + (WPB * (WAVE / LPR)) - 1) / (WPB * (WAVE / LPR)), 2048);              \
+        hipLaunchKernelGGL((pair_dot_kernel<LPR, VPL>), dim3(grid), dim3(BLOCK), 0, st, T, B, ix_u, ix_i, n, out); \
+    }
+    HPF_DISPATCH_LD(ld, CALL)
+#undef CALL
+    return last_error();
+}
+
+}  // extern "C"

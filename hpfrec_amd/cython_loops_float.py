@@ -1,0 +1,324 @@
+"""Drop-in for the reference's compiled extension module `hpfrec.cython_loops_float`.
+
+The reference's `hpfrec/__init__.py` talks to its Cython extension only through module-level
+functions and three type attributes (cython_loops.pxi, "PXI": fit_hpf PXI:147, partial_fit
+PXI:423, calc_user_factors PXI:476, calc_llk PXI:525, predict_arr PXI:538,
+initialize_parameters PXI:117, cast_* PXI:11-18; c_real_t / obj_ind_type from
+cython_float.pxi:9 and cython_float_nonwindows.pyx:10).  This module exports the same names with
+the same arity, argument meaning, in-place semantics and return values, but runs the numerics on
+an MI355X through libhpf_hip.so.  A maintainer of the reference can therefore swap
+`from . import cython_loops_float` for `from hpfrec_amd import cython_loops_float`
+(INTEGRATION.md shows the stub).
+
+Host side here: argument checking, RNG initialisation (numpy, bit-identical to the reference),
+upload/download, the outer loop and stopping rule.  No numerics run on the CPU.
+"""
+import ctypes
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import cavi, svi
+from .ops_hip import HipOps
+
+c_real_t = ctypes.c_float          # hpfrec/cython_float.pxi:9
+obj_ind_type = ctypes.c_size_t     # hpfrec/cython_float_nonwindows.pyx:10
+obj_long_double_type = ctypes.c_longdouble
+
+#: test seam: tests/ may install a CPU stand-in for HipOps here to exercise host logic without a
+#: GPU.  It is None in the product, in which case HipOps is required and fails loudly without a GPU.
+_OPS_FACTORY = None
+_DEVICE = None
+
+
+def _make_ops():
+    if _OPS_FACTORY is not None:
+        return _OPS_FACTORY()
+    return HipOps(_DEVICE)
+
+
+# -- helper functions (PXI:11-18) ---------------------------------------------------------
+def cast_real_t(n):
+    return float(np.float32(n))
+
+
+def cast_int(n):
+    return int(ctypes.c_int(int(n)).value)
+
+
+def cast_ind_type(n):
+    return int(ctypes.c_size_t(int(n)).value)
+
+
+# -- PXI:117-143 --------------------------------------------------------------------------
+def initialize_parameters(Theta, Beta, random_seed, a, a_prime, b_prime, c, c_prime, d_prime):
+    """Random initialisation, on the host with numpy so that the MT19937 stream -- four
+    `random(dtype=float32)` draws in the order user-rate, item-rate, user-shape, item-shape -- is
+    the reference's.  All four use a'/c' (not a/c), as the reference does.  Fills Theta/Beta in
+    place and returns (Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte)."""
+    nU, k = Theta.shape
+    nI = Beta.shape[0]
+    rng = np.random.Generator(np.random.MT19937(seed=random_seed if random_seed > 0 else None))
+    draws = [rng.random(size=(n, k), dtype=np.float32) for n in (nU, nI, nU, nI)]
+    Gamma_rte = a_prime + 0.01 * draws[0]
+    Lambda_rte = c_prime + 0.01 * draws[1]
+    Gamma_shp = a_prime + 0.01 * draws[2]
+    Lambda_shp = c_prime + 0.01 * draws[3]
+    k_rte = np.full((nU, 1), b_prime, dtype=np.float32)
+    t_rte = np.full((nI, 1), d_prime, dtype=np.float32)
+    np.divide(Gamma_shp, Gamma_rte, out=Theta)
+    np.divide(Lambda_shp, Lambda_rte, out=Beta)
+    return Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte
+
+
+def _print_norm_diff(it, check_every, normdiff):
+    print("Iteration %d | Norm(Theta_{%d} - Theta_{%d}): %.5f" % (it, it, it - check_every, normdiff))
+
+
+def _print_llk_iter(it, llk, rmse, has_valset):
+    tag = "val" if has_valset else "train"
+    print(("Iteration %d | " + tag + " llk: %d | " + tag + " rmse: %.4f") % (it, int(llk), rmse))
+
+
+def _print_final_msg(it, llk, rmse, minutes):
+    print("\n\nOptimization finished")
+    print("Final log-likelihood: %d" % int(llk))
+    print("Final RMSE: %.4f" % rmse)
+    print("Minutes taken (optimization part): %.1f" % minutes)
+    print("")
+
+
+def save_parameters(verbose, save_folder, file_names, obj_list):
+    """PXI:44-49"""
+    if verbose:
+        print("Saving final parameters to .csv files...")
+    for name, obj in zip(file_names, obj_list):
+        np.savetxt(os.path.join(save_folder, name), obj, fmt="%.10f", delimiter=",")
+
+
+def _as_index_tensor(a, n_max, what):
+    a = np.ascontiguousarray(a)
+    if a.size and (int(a.max()) >= n_max):
+        raise ValueError("%s contains an id >= %d" % (what, n_max))
+    return torch.from_numpy(a.astype(np.int64, copy=False))
+
+
+class _Engine:
+    """Glue between the reference-shaped host arrays and cavi.FullBatchCavi (handles sharding)."""
+
+    def __init__(self, hyper, Y, ix_u, ix_i, nU, nI, Yval=None, ix_u_val=None, ix_i_val=None):
+        self.ops = _make_ops()
+        self.device = self.ops.device
+        dist = cavi._dist()
+        self.dist = dist
+        self.rank = dist.get_rank() if dist else 0
+        self.world = dist.get_world_size() if dist else 1
+        dev = self.device
+        tu = _as_index_tensor(ix_u, nU, "UserId").to(dev)
+        ti = _as_index_tensor(ix_i, nI, "ItemId").to(dev)
+        ty = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(dev)
+        lu, li, ly, (self.u0, self.u1) = cavi.shard_users(tu, ti, ty, nU, self.rank, self.world)
+        self.nU_global, self.nI = int(nU), int(nI)
+        self.model = cavi.FullBatchCavi(self.ops, dev, lu, li, ly, self.u1 - self.u0, nI, hyper)
+        self.nnz_global = int(Y.shape[0])
+        self.val = None
+        if Yval is not None and Yval.shape[0] > 0:
+            vu = _as_index_tensor(ix_u_val, nU, "val UserId").to(dev)
+            vi = _as_index_tensor(ix_i_val, nI, "val ItemId").to(dev)
+            vy = torch.from_numpy(np.ascontiguousarray(Yval, dtype=np.float32)).to(dev)
+            keep = (vu >= self.u0) & (vu < self.u1)
+            self.val = ((vu[keep] - self.u0).to(torch.int32), vi[keep].to(torch.int32), vy[keep])
+            self.nval_global = int(Yval.shape[0])
+
+    def upload(self, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta):
+        s = slice(self.u0, self.u1)
+        self.model.load_state(Gamma_shp[s], Gamma_rte[s], Lambda_shp, Lambda_rte, k_rte[s], t_rte, Theta[s], Beta)
+
+    def gather_users(self, name):
+        """Full (all users) host copy of a user-side array."""
+        local = self.model.fetch(name)
+        if not self.dist:
+            return local
+        full = torch.zeros((self.nU_global, local.shape[1]), dtype=torch.float32, device=self.device)
+        full[self.u0: self.u1] = torch.from_numpy(local).to(self.device)
+        self.dist.all_reduce(full)
+        return full.cpu().numpy()
+
+    def theta_norm_diff(self, prev):
+        d = self.model.Theta - prev
+        sq = (d.double() * d.double()).sum().reshape(1)
+        if self.dist:
+            self.dist.all_reduce(sq)
+        return float(np.sqrt(sq.item()))
+
+
+# -- PXI:147-418 --------------------------------------------------------------------------
+def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta, maxiter, stop_crit,
+            check_every, stop_thr, users_per_batch, items_per_batch, step_size, sum_exp_trick, st_ix_u,
+            save_folder, random_seed, verbose, nthreads, par_sh, has_valset, Yval, ix_u_val, ix_i_val,
+            full_llk, keep_all_objs, alloc_full_phi):
+    """Same contract as the reference's fit_hpf (PXI:147-162, returns PXI:413-418):
+    fills Theta/Beta in place, returns (i, (Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte,
+    t_rte) or None, last_llk) with i the 0-based index of the last iteration run.
+
+    `nthreads`, `par_sh` (allow_inconsistent_math) and `alloc_full_phi` are accepted and ignored:
+    the device path is always parallel, always reproducible and never materialises phi.
+    `sum_exp_trick` is honoured implicitly: E rows are max-normalised in every mode.
+    """
+    nU, k = Theta.shape
+    nI = Beta.shape[0]
+    hy = cavi.Hyper(k, a, a_prime, b_prime, c, c_prime, d_prime)
+    if verbose > 0:
+        print("Initializing parameters...")
+    Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte = initialize_parameters(
+        Theta, Beta, random_seed, float(hy.a), float(hy.a_prime), float(hy.b_prime), float(hy.c),
+        float(hy.c_prime), float(hy.d_prime))
+
+    full_updates = (users_per_batch == 0) and (items_per_batch == 0)
+    if not full_updates:
+        return svi.fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte,
+                               t_rte, maxiter, stop_crit, check_every, stop_thr, users_per_batch, items_per_batch,
+                               step_size, save_folder, random_seed, verbose, has_valset, Yval, ix_u_val, ix_i_val,
+                               full_llk, keep_all_objs, _make_ops)
+
+    eng = _Engine(hy, Y, ix_u, ix_i, nU, nI, Yval if has_valset else None, ix_u_val, ix_i_val)
+    eng.upload(Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta)
+    model = eng.model
+    errs = np.zeros(2, dtype=np.longdouble)
+    last_crit = -np.inf
+    Theta_prev = model.Theta.clone() if stop_crit == "diff-norm" else None
+
+    def evaluate(final=False):
+        """llk + rmse the way assess_convergence / eval_after_term compute them (PXI:66-79, 99-112)."""
+        if has_valset and eng.val is not None:
+            t = model.pair_llk_terms(eng.val[0], eng.val[1], eng.val[2], full_llk)
+            if final:
+                # PXI:105 subtracts Theta[ix_u_val].sum(0).Beta[ix_i_val].sum(0) here (sic)
+                sub = _val_colsum_dot(eng)
+            else:
+                sub = t[2]
+            errs[0] = np.longdouble(t[0]) - np.longdouble(sub)
+            errs[1] = np.sqrt(np.longdouble(t[1]) / eng.nval_global)
+        else:
+            t = model.llk_terms(full_llk)
+            errs[0] = np.longdouble(t[0]) - np.longdouble(model.colsum_dot())
+            errs[1] = np.sqrt(np.longdouble(t[1]) / eng.nnz_global)
+
+    if verbose > 0:
+        print("Initializing optimization procedure...")
+    st_time = time.time()
+    i = -1
+    for i in range(maxiter):
+        model.iterate()
+        if check_every > 0 and ((i + 1) % check_every) == 0:
+            if stop_crit == "diff-norm":
+                last_crit = eng.theta_norm_diff(Theta_prev)
+                if verbose:
+                    _print_norm_diff(i + 1, check_every, last_crit)
+                if last_crit < stop_thr:
+                    break
+                Theta_prev.copy_(model.Theta)
+            else:
+                evaluate()
+                if verbose:
+                    _print_llk_iter(i + 1, errs[0], float(errs[1]), has_valset)
+                if stop_crit != "maxiter":
+                    if (i + 1) == check_every:
+                        last_crit = errs[0]
+                    else:
+                        if (1.0 - errs[0] / last_crit) <= stop_thr:
+                            break
+                        last_crit = errs[0]
+
+    last_llk = None
+    if stop_crit in ("diff-norm", "maxiter") and verbose > 0:
+        evaluate(final=True)
+        last_llk = errs[0]
+    minutes = (time.time() - st_time) / 60.0
+    if verbose:
+        _print_final_msg(i + 1, errs[0], float(errs[1]), minutes)
+
+    Theta[:, :] = eng.gather_users("Theta")
+    Beta[:, :] = model.fetch("Beta")
+    temp = None
+    if keep_all_objs or save_folder != "":
+        temp = (eng.gather_users("Gamma_shp"), eng.gather_users("Gamma_rte"), model.fetch("Lambda_shp"),
+                model.fetch("Lambda_rte"), eng.gather_users("k_rte"), model.fetch("t_rte"))
+    if save_folder != "" and eng.rank == 0:
+        save_parameters(verbose, save_folder,
+                        ["Theta", "Beta", "Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "kappa_rte", "tau_rte"],
+                        [Theta, Beta] + list(temp))
+    if not keep_all_objs:
+        temp = None
+    return i, temp, last_llk
+
+
+def _val_colsum_dot(eng):
+    m = eng.model
+    vu, vi, _ = eng.val
+    a = m.Theta[vu.long()].sum(dim=0)
+    if eng.dist:
+        eng.dist.all_reduce(a)
+    b = m.Beta[vi.long()].sum(dim=0)
+    if eng.dist:
+        eng.dist.all_reduce(b)
+    return float(np.dot(a[: m.k].cpu().numpy(), b[: m.k].cpu().numpy()))
+
+
+# -- PXI:423-473 --------------------------------------------------------------------------
+def partial_fit(Y_batch, ix_u_batch, ix_i_batch, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte,
+                t_rte, add_k_rte, add_t_rte, a, c, k_shp, t_shp, k, users_this_batch, items_this_batch, par_sh,
+                step_size_batch, multiplier_batch, nthreads, user_batch):
+    """One SVI step on caller-supplied triplets; mutates all eight arrays in place (PXI:443-473)."""
+    svi.partial_fit_step(_make_ops(), Y_batch, ix_u_batch, ix_i_batch, Theta, Beta, Gamma_shp, Gamma_rte,
+                         Lambda_shp, Lambda_rte, k_rte, t_rte, add_k_rte, add_t_rte, a, c, k_shp, t_shp, int(k),
+                         users_this_batch, items_this_batch, step_size_batch, multiplier_batch, bool(user_batch))
+
+
+# -- PXI:525-534 --------------------------------------------------------------------------
+def calc_llk(Y, ix_u, ix_i, Theta, Beta, k, nthreads, full_llk):
+    """sum_n Y_n log(yhat_n) [- lgamma(Y_n+1)] - sum_n yhat_n over the listed pairs (HPF.eval_llk)."""
+    ops = _make_ops()
+    dev = ops.device
+    k = int(k)
+    ld = cavi._lib.ld_for_k(k)
+    T = _padded(Theta, ld, dev)
+    B = _padded(Beta, ld, dev)
+    iu = _as_index_tensor(ix_u, Theta.shape[0], "UserId").to(dev).to(torch.int32)
+    ii = _as_index_tensor(ix_i, Beta.shape[0], "ItemId").to(dev).to(torch.int32)
+    y = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(dev)
+    t = ops.pair_llk(T, B, iu, ii, y, k, ld, bool(full_llk)).cpu().numpy()
+    return np.longdouble(t[0]) - np.longdouble(t[2])
+
+
+# -- PXI:538-543 --------------------------------------------------------------------------
+def predict_arr(M1, M2, ix_u, ix_i, nthreads):
+    ops = _make_ops()
+    dev = ops.device
+    k = int(M1.shape[1])
+    ld = cavi._lib.ld_for_k(k)
+    T = _padded(M1, ld, dev)
+    B = _padded(M2, ld, dev)
+    iu = _as_index_tensor(ix_u, M1.shape[0], "UserId").to(dev).to(torch.int32)
+    ii = _as_index_tensor(ix_i, M2.shape[0], "ItemId").to(dev).to(torch.int32)
+    out = torch.zeros(iu.shape[0], dtype=torch.float32, device=dev)
+    ops.pair_dot(T, B, iu, ii, out, k, ld)
+    return out.cpu().numpy()
+
+
+def _padded(host_arr, ld, dev):
+    n, k = host_arr.shape
+    t = torch.zeros((n, ld), dtype=torch.float32, device=dev)
+    t[:, :k] = torch.from_numpy(np.ascontiguousarray(host_arr, dtype=np.float32)).to(dev)
+    return t
+
+
+# -- PXI:476-520 --------------------------------------------------------------------------
+def calc_user_factors(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_i, Theta, Beta, Lambda_shp, Lambda_rte, nY, k,
+                      maxiter, nthreads, random_seed, stop_thr, return_all):
+    """Fold-in of one new user with item parameters fixed (HPF.predict_factors / add_user)."""
+    return svi.calc_user_factors(_make_ops(), a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_i, Theta, Beta,
+                                 Lambda_shp, Lambda_rte, int(nY), int(k), int(maxiter), int(random_seed),
+                                 float(stop_thr), bool(return_all))

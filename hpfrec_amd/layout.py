@@ -1,0 +1,93 @@
+"""COO triplets -> the sparse layouts the sweep kernel consumes.
+
+The reference keeps the data as unsorted COO triplets (fit_hpf signature, cython_loops.pxi:147-151)
+and, for SVI only, a CSR start-index vector (hpfrec/__init__.py:587-606) and a scipy CSC copy
+(cython_loops.pxi:22-25).  The HIP path wants, per side, the nonzeros grouped by row and cut into
+bounded *segments* (include/hpf_hip.h: hpf_segment) so that one wavefront never owns more than
+SEG_CAP nonzeros.  Duplicate (user,item) pairs stay separate observations, exactly as the
+reference treats them in full-batch mode (scipy's tocsr() would merge them; we never call it).
+
+Everything here is index plumbing on torch tensors (any device, incl. CPU for the tests).
+"""
+import torch
+
+SEG_CAP = 256  # nonzeros per segment: 64 steps of 4 nonzeros at ld=64
+
+
+class SparseSide:
+    """Nonzeros grouped by the rows of one side (users -> CSR, items -> CSC)."""
+
+    def __init__(self, nrows, indptr, idx, y, seg_cap=SEG_CAP):
+        self.nrows = int(nrows)
+        self.indptr = indptr            # int64 [nrows+1]
+        self.idx = idx                  # int32 [nnz] row ids of the *other* side
+        self.y = y                      # float32 [nnz]
+        self.nnz = int(idx.shape[0])
+        self.segs, self.row_seg_ptr = build_segments(indptr, seg_cap)
+        self.nseg = int(self.segs.shape[0])
+
+
+def build_segments(indptr, seg_cap=SEG_CAP):
+    """Cut rows into segments of at most seg_cap nonzeros.
+
+    Returns (segs, row_seg_ptr): segs is an int64 [nseg,2] tensor whose memory image is an array
+    of hpf_segment {int64 begin; int32 len; int32 row} (little endian: len | row<<32), and
+    row_seg_ptr [nrows+1] lists each row's segment range (empty rows have no segment).
+    """
+    dev = indptr.device
+    deg = indptr[1:] - indptr[:-1]
+    nseg_row = (deg + (seg_cap - 1)) // seg_cap
+    row_seg_ptr = torch.zeros(deg.shape[0] + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(nseg_row, 0, out=row_seg_ptr[1:])
+    nseg = int(row_seg_ptr[-1].item()) if deg.shape[0] > 0 else 0
+    rows = torch.repeat_interleave(torch.arange(deg.shape[0], dtype=torch.int64, device=dev), nseg_row,
+                                   output_size=nseg)
+    within = torch.arange(nseg, dtype=torch.int64, device=dev) - row_seg_ptr[rows]
+    begin = indptr[rows] + within * seg_cap
+    length = torch.clamp(deg[rows] - within * seg_cap, max=seg_cap)
+    segs = torch.stack([begin, length | (rows << 32)], dim=1).contiguous()
+    return segs, row_seg_ptr
+
+
+def _indptr(sorted_rows, nrows):
+    counts = torch.bincount(sorted_rows, minlength=nrows)
+    indptr = torch.zeros(nrows + 1, dtype=torch.int64, device=sorted_rows.device)
+    torch.cumsum(counts, 0, out=indptr[1:])
+    return indptr
+
+
+def build_sides(ix_u, ix_i, y, nU, nI, seg_cap=SEG_CAP):
+    """(user side, item side, ix_u sorted) from COO triplets (int64 ids, float32 counts).
+
+    User side: sorted by (user, item).  Item side: a stable re-sort of that order by item, so users
+    ascend within every item column (gathers walk the user table in address order).
+    """
+    ix_u = ix_u.to(torch.int64)
+    ix_i = ix_i.to(torch.int64)
+    y = y.to(torch.float32)
+    if ix_u.numel() > 0:
+        if int(ix_u.max()) >= nU or int(ix_i.max()) >= nI or int(ix_u.min()) < 0 or int(ix_i.min()) < 0:
+            raise ValueError("user/item index out of range")
+    key = ix_u * int(nI) + ix_i
+    order = torch.argsort(key, stable=True)
+    u_s, i_s, y_s = ix_u[order], ix_i[order], y[order]
+    users = SparseSide(nU, _indptr(u_s, nU), i_s.to(torch.int32), y_s, seg_cap)
+    order2 = torch.argsort(i_s, stable=True)
+    items = SparseSide(nI, _indptr(i_s[order2], nI), u_s[order2].to(torch.int32), y_s[order2], seg_cap)
+    return users, items, u_s.to(torch.int32)
+
+
+def nnz_balanced_ranges(indptr, nparts):
+    """Contiguous row ranges with (nearly) equal nonzero counts: list of (row_begin, row_end).
+    Used to shard users over GPUs (balance nnz, not user counts)."""
+    nrows = indptr.shape[0] - 1
+    total = int(indptr[-1].item())
+    bounds = [0]
+    for p in range(1, nparts):
+        target = (total * p) // nparts
+        r = int(torch.searchsorted(indptr, torch.tensor([target], dtype=indptr.dtype, device=indptr.device),
+                                   right=False).item())
+        r = max(bounds[-1], min(r, nrows))
+        bounds.append(r)
+    bounds.append(nrows)
+    return [(bounds[p], bounds[p + 1]) for p in range(nparts)]

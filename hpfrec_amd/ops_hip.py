@@ -1,0 +1,81 @@
+"""HipOps: the kernel launchers of include/hpf_hip.h on torch device tensors.
+
+This is the only implementation of the op set that ships.  (tests/cpu_ops.py holds a
+numpy stand-in with the same method names so that host logic -- layouts, sharding, the
+driver loop, the HPF class -- can be exercised on machines without a GPU; it is never
+importable from this package.)
+"""
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class HipOps:
+    name = "hip"
+
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise _lib.HpfHipError("hpfrec_amd: no ROCm device visible (torch.cuda.is_available() is False); "
+                                   "the HIP path has no CPU fallback")
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.L = _lib.lib()
+        with torch.cuda.device(self.device):
+            self.cu_count, self.arch = _lib.device_info()
+        # memory-bound grid: a few blocks per CU, grid-stride over the rest (CDNA guide, guideline 11)
+        self.sweep_blocks = max(1, self.cu_count) * 8
+        self.finalize_blocks = max(1, self.cu_count) * 4
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    # -- every method mirrors one C entry point ------------------------------------------
+    def sweep(self, side, tab_self, tab_other, part, k, ld, scatter_acc=None):
+        _lib.check(self.L.hpf_hip_sweep_f32(_ptr(side.segs), side.nseg, _ptr(side.idx), _ptr(side.y),
+                                            _ptr(tab_self), _ptr(tab_other), _ptr(part), _ptr(scatter_acc),
+                                            k, ld, self.sweep_blocks, self._stream()), "hpf_hip_sweep_f32")
+
+    def finalize_grid(self, nrows):
+        return int(max(1, min(self.finalize_blocks, (nrows + 3) // 4)))
+
+    def row_finalize(self, part, row_seg_ptr, nrows, e_old, e_new, shp, rte, fac, rs, cs_other, cs_partial,
+                     prior_shp, top_shp, add_rte, k, ld):
+        grid = cs_partial.shape[0]
+        _lib.check(self.L.hpf_hip_row_finalize_f32(_ptr(part), _ptr(row_seg_ptr), nrows, _ptr(e_old), _ptr(e_new),
+                                                   _ptr(shp), _ptr(rte), _ptr(fac), _ptr(rs), _ptr(cs_other),
+                                                   _ptr(cs_partial), float(prior_shp), float(top_shp),
+                                                   float(add_rte), k, ld, grid, self._stream()),
+                   "hpf_hip_row_finalize_f32")
+
+    def colsum_reduce(self, cs_partial, cs_out, ld):
+        _lib.check(self.L.hpf_hip_colsum_reduce_f32(_ptr(cs_partial), cs_partial.shape[0], _ptr(cs_out), ld,
+                                                    self._stream()), "hpf_hip_colsum_reduce_f32")
+
+    def colsum(self, tab, nrows, ld, cs_partial):
+        _lib.check(self.L.hpf_hip_colsum_f32(_ptr(tab), nrows, ld, _ptr(cs_partial), cs_partial.shape[0],
+                                             self._stream()), "hpf_hip_colsum_f32")
+
+    def expect(self, shp, rte, e, nrows, k, ld):
+        _lib.check(self.L.hpf_hip_expect_f32(_ptr(shp), _ptr(rte), _ptr(e), nrows, k, ld, self._stream()),
+                   "hpf_hip_expect_f32")
+
+    def segsum(self, part, row_seg_ptr, nrows, acc, ld):
+        _lib.check(self.L.hpf_hip_segsum_f32(_ptr(part), _ptr(row_seg_ptr), nrows, _ptr(acc), ld, self._stream()),
+                   "hpf_hip_segsum_f32")
+
+    def pair_llk(self, T, B, ix_u, ix_i, y, k, ld, full_llk):
+        """-> float64 tensor [3]: sum y*log(yhat) [- lgamma(y+1)], sum (y-yhat)^2, sum yhat."""
+        n = int(ix_u.shape[0])
+        grid = int(max(1, min(self.sweep_blocks, (n + 15) // 16)))
+        partial = torch.empty((grid, 4), dtype=torch.float64, device=self.device)
+        _lib.check(self.L.hpf_hip_pair_llk_f32(_ptr(T), _ptr(B), _ptr(ix_u), _ptr(ix_i), _ptr(y), n, _ptr(partial),
+                                               k, ld, int(bool(full_llk)), grid, self._stream()),
+                   "hpf_hip_pair_llk_f32")
+        return partial.sum(dim=0)[:3]
+
+    def pair_dot(self, T, B, ix_u, ix_i, out, k, ld):
+        _lib.check(self.L.hpf_hip_pair_dot_f32(_ptr(T), _ptr(B), _ptr(ix_u), _ptr(ix_i), int(ix_u.shape[0]),
+                                               _ptr(out), k, ld, self._stream()), "hpf_hip_pair_dot_f32")

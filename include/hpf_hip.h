@@ -1,0 +1,125 @@
+/*
+ * hpf_hip.h -- C ABI of libhpf_hip.so, the MI355X (gfx950) replacement for the
+ * Cython/OpenMP loops of david-cortes/hpfrec (hpfrec/cython_loops.pxi, "PXI").
+ *
+ * The reference has no FFI of its own: hpfrec/__init__.py calls module-level Python
+ * functions of the compiled extension hpfrec.cython_loops_float, which in turn call
+ * `cdef ... nogil` loops.  Those cdef loops are the functions replaced here; each
+ * entry point below cites the loop(s) it stands in for.  The Python-level drop-in
+ * (same names/arity as the extension module) lives in hpfrec_amd/cython_loops_float.py
+ * and binds this ABI through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (e.g. torch.Tensor.data_ptr()); nothing is
+ *     allocated, retained or freed by the library; all launches are asynchronous on
+ *     `stream` (a hipStream_t passed as void*; NULL = the default stream);
+ *   - return value: 0 on success, otherwise the hipError_t of the failed launch or a
+ *     negative HPF_E* code for argument errors; no exception crosses the ABI;
+ *   - factor tables are row-major float32 [nrows][ld] with ld = hpf_hip_ld_for_k(k)
+ *     (>= k, power of two >= 32, rows 128-byte aligned); columns k..ld-1 of the
+ *     e_* / fac tables are zero and must stay zero;
+ *   - index arrays are int32 (row ids of the *other* side), segment descriptors are
+ *     hpf_segment.  The reference uses size_t indices (cython_float_nonwindows.pyx:8);
+ *     the Python layer narrows them after a range check.
+ */
+#ifndef HPF_HIP_H
+#define HPF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPF_HIP_ABI_VERSION 1
+
+#define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
+#define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
+
+/* A contiguous run of nonzeros belonging to one sparse row (CSR row of a user, or CSC
+ * column of an item).  Rows longer than the segment cap are split into several
+ * segments so that no wavefront owns an unbounded amount of work. */
+typedef struct hpf_segment {
+    int64_t begin; /* offset of the first nonzero in idx[] / y[]          */
+    int32_t len;   /* number of nonzeros (> 0)                            */
+    int32_t row;   /* row of tab_self this segment belongs to             */
+} hpf_segment;
+
+int hpf_hip_abi_version(void);
+
+/* Padded leading dimension for k latent factors, or HPF_EUNSUPPORTED. */
+int hpf_hip_ld_for_k(int k);
+
+/* Device name ("gfx950...") and compute-unit count of the current device. */
+int hpf_hip_device_info(int *cu_count, char *arch, int arch_len);
+
+/*
+ * Fused phi + shape accumulation for one side of the bipartite graph.
+ * Replaces update_phi (PXI:551-591) + update_G_n_L_sh (PXI:613-621) for the rows of
+ * tab_self, without materialising phi (reference: np.empty((nY,k)), PXI:187):
+ *
+ *   for every segment g, nonzero n in g (other-side row c = idx[n], count y[n]):
+ *       s = <tab_self[row(g)], tab_other[c]>;   w = y[n] / s
+ *       part[g][:] += w * tab_other[c][:]
+ *       (optional) scatter_acc[c][:] += w * tab_self[row(g)][:]   -- atomicAdd
+ *
+ * with tab_self/tab_other holding E = exp(psi(shape) - log(rate)) rows (row-scaled,
+ * see hpf_hip_row_finalize_f32), so that shape_row = prior + tab_self[row] (*) sum of
+ * that row's part[] entries.  One wavefront per segment, 64/(ld/4) nonzeros per step.
+ * scatter_acc may be NULL (the deterministic two-pass scheme: call once per side).
+ */
+int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
+                      const float *tab_self, const float *tab_other, float *part, float *scatter_acc,
+                      int k, int ld, int grid_blocks, void *stream);
+
+/*
+ * Closed-form updates for the rows of one side.  Replaces the numpy statements of
+ * fit_hpf PXI:236-259 (and the psi/log/exp hoisted out of update_phi, PXI:588):
+ *
+ *   acc      = sum of part[g] over the row's segments g in [row_seg_ptr[r], row_seg_ptr[r+1])
+ *              (row_seg_ptr == NULL: part is already one accumulator row per table row)
+ *   shp[r]   = prior_shp + e_old[r] (*) acc              Gamma_shp / Lambda_shp
+ *   rte[r]   = top_shp / rs[r] + cs_other                 Gamma_rte (PXI:236) / Lambda_rte (PXI:255)
+ *   fac[r]   = shp[r] / rte[r]                            Theta (PXI:251) / Beta (PXI:256)
+ *   rs[r]    = add_rte + sum_k fac[r]                     k_rte (PXI:258) / t_rte (PXI:259)
+ *   e_new[r] = exp(psi(shp[r]) - log(rte[r])) / max_k(.)  input of the next sweep
+ *   cs_partial[block] = per-block column sums of fac      -> hpf_hip_colsum_reduce_f32
+ *
+ * e_new may alias e_old.  rs is updated in place.  shp/rte/fac may be NULL (skip store).
+ */
+int hpf_hip_row_finalize_f32(const float *part, const int64_t *row_seg_ptr, int64_t nrows, const float *e_old,
+                             float *e_new, float *shp, float *rte, float *fac, float *rs,
+                             const float *cs_other, float *cs_partial, float prior_shp, float top_shp,
+                             float add_rte, int k, int ld, int grid_blocks, void *stream);
+
+/* cs_out[c] = sum_b cs_partial[b][c], fixed order, double accumulation (Beta.sum(axis=0), PXI:236,255). */
+int hpf_hip_colsum_reduce_f32(const float *cs_partial, int nblk, float *cs_out, int ld, void *stream);
+
+/* Per-block column sums of a table (first iteration / partial_fit: Beta.sum(axis=0) from host-initialised Beta). */
+int hpf_hip_colsum_f32(const float *tab, int64_t nrows, int ld, float *cs_partial, int grid_blocks, void *stream);
+
+/* e[r] = exp(psi(shp[r]) - log(rte[r])) / rowmax, pads zeroed: the hoisted transcendental part of
+ * update_phi (PXI:570,588) for rows whose shape/rate came from the host (initialisation, PXI:134-138). */
+int hpf_hip_expect_f32(const float *shp, const float *rte, float *e, int64_t nrows, int k, int ld, void *stream);
+
+/* acc[r] = sum of the row's part[] segments (multi-GPU item side, before the all-reduce). */
+int hpf_hip_segsum_f32(const float *part, const int64_t *row_seg_ptr, int64_t nrows, float *acc, int ld,
+                       void *stream);
+
+/*
+ * Poisson log-likelihood terms over listed pairs.  Replaces llk_plus_rmse (PXI:627-658)
+ * and sum_prediction (PXI:816-825): per block b, partial[4b+0] = sum y*log(yhat)
+ * [- lgamma(y+1) when full_llk], partial[4b+1] = sum (y-yhat)^2, partial[4b+2] = sum yhat,
+ * accumulated in double (reference: long double).  The caller adds the blocks.
+ */
+int hpf_hip_pair_llk_f32(const float *T, const float *B, const int32_t *ix_u, const int32_t *ix_i, const float *y,
+                         int64_t n, double *partial, int k, int ld, int full_llk, int grid_blocks, void *stream);
+
+/* out[n] = <T[ix_u[n]], B[ix_i[n]]>.  Replaces predict_multiple (PXI:803-810). */
+int hpf_hip_pair_dot_f32(const float *T, const float *B, const int32_t *ix_u, const int32_t *ix_i, int64_t n,
+                         float *out, int k, int ld, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPF_HIP_H */

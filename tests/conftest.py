@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture
+def cpu_ops_backend():
+    """Install the numpy stand-in ops (tests/cpu_ops.py) for host-logic tests; restore afterwards."""
+    import cpu_ops
+    from hpfrec_amd import cython_loops_float as backend
+    old = backend._OPS_FACTORY
+    backend._OPS_FACTORY = cpu_ops.CpuOps
+    yield backend
+    backend._OPS_FACTORY = old
+
+
+@pytest.fixture
+def hip_backend():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from hpfrec_amd import cython_loops_float as backend
+    assert backend._OPS_FACTORY is None
+    return backend

@@ -1,0 +1,132 @@
+"""CpuOps: numpy stand-in for hpfrec_amd.ops_hip.HipOps -- TEST INFRASTRUCTURE ONLY.
+
+Same method names and argument meaning as HipOps, float64 arithmetic on CPU torch tensors.
+Two uses:
+  * `-m "not gpu"` tests exercise the host logic (layout, driver loop, sharding over gloo,
+    the HPF class) on machines without a GPU by installing it in
+    hpfrec_amd.cython_loops_float._OPS_FACTORY;
+  * `-m gpu` tests use it as the op-by-op reference of each HIP kernel (alongside the
+    end-to-end comparison with the oracle / golden vectors).
+It lives under tests/ so that nothing in the package can route through it.
+"""
+import numpy as np
+import scipy.special as sp
+import torch
+
+
+def _np(t):
+    return t.numpy()
+
+
+def _decode_segs(side):
+    s = _np(side.segs)
+    begin = s[:, 0].copy()
+    meta = s[:, 1]
+    length = (meta & 0xFFFFFFFF).astype(np.int64)
+    row = (meta >> 32).astype(np.int64)
+    return begin, length, row
+
+
+class CpuOps:
+    name = "cpu-standin"
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self.sweep_blocks = 8
+        self.finalize_blocks = 4
+
+    def finalize_grid(self, nrows):
+        return int(max(1, min(self.finalize_blocks, (nrows + 3) // 4)))
+
+    def sweep(self, side, tab_self, tab_other, part, k, ld, scatter_acc=None):
+        if side.nseg == 0:
+            return
+        begin, length, row = _decode_segs(side)
+        seg_of_nnz = np.repeat(np.arange(side.nseg), length)
+        offs = np.concatenate([[0], np.cumsum(length)[:-1]])
+        # positions of every segment's nonzeros (segments may be any subset of the rows)
+        pos = np.repeat(begin, length) + (np.arange(length.sum()) - np.repeat(offs, length))
+        idx = _np(side.idx).astype(np.int64)[pos]
+        y = _np(side.y).astype(np.float64)[pos]
+        S = _np(tab_self).astype(np.float64)[row[seg_of_nnz]]
+        O = _np(tab_other).astype(np.float64)[idx]
+        s = (S * O).sum(axis=1)
+        w = np.where(y > 0, y / s, 0.0)
+        contrib = w[:, None] * O
+        out = np.add.reduceat(contrib, offs, axis=0)
+        _np(part)[: side.nseg] = out.astype(np.float32)
+        if scatter_acc is not None:
+            acc = _np(scatter_acc).astype(np.float64)
+            np.add.at(acc, idx, w[:, None] * S)
+            _np(scatter_acc)[:] = acc.astype(np.float32)
+
+    def row_finalize(self, part, row_seg_ptr, nrows, e_old, e_new, shp, rte, fac, rs, cs_other, cs_partial,
+                     prior_shp, top_shp, add_rte, k, ld):
+        P = _np(part).astype(np.float64)
+        if row_seg_ptr is None:
+            acc = P[:nrows]
+        else:
+            rsp = _np(row_seg_ptr)
+            acc = np.zeros((nrows, ld))
+            nz = rsp[1:] > rsp[:-1]
+            if nz.any():
+                acc[nz] = np.add.reduceat(P[: rsp[-1]], rsp[:-1][nz], axis=0)
+        f = np.float32
+        sh = (f(prior_shp) + (_np(e_old).astype(np.float64) * acc)).astype(np.float32)
+        rt = (f(top_shp) / _np(rs)[:, None] + _np(cs_other)[None, :]).astype(np.float32)
+        valid = np.arange(ld) < k
+        fc = np.where(valid[None, :], sh / rt, 0).astype(np.float32)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            E = sp.psi(sh.astype(np.float64)) - np.log(rt.astype(np.float64))
+        E = np.where(valid[None, :], E, -np.inf)
+        E = E - E.max(axis=1, keepdims=True)
+        _np(e_new)[:] = np.exp(E).astype(np.float32)
+        if shp is not None:
+            _np(shp)[:] = np.where(valid[None, :], sh, 0)
+        if rte is not None:
+            _np(rte)[:] = np.where(valid[None, :], rt, 0)
+        if fac is not None:
+            _np(fac)[:] = fc
+        _np(rs)[:] = (f(add_rte) + fc.astype(np.float64).sum(axis=1)).astype(np.float32)
+        cp = _np(cs_partial)
+        cp[:] = 0
+        cp[0] = fc.astype(np.float64).sum(axis=0).astype(np.float32)
+
+    def colsum_reduce(self, cs_partial, cs_out, ld):
+        _np(cs_out)[:] = _np(cs_partial).astype(np.float64).sum(axis=0).astype(np.float32)
+
+    def colsum(self, tab, nrows, ld, cs_partial):
+        cp = _np(cs_partial)
+        cp[:] = 0
+        cp[0] = _np(tab)[:nrows].astype(np.float64).sum(axis=0).astype(np.float32)
+
+    def expect(self, shp, rte, e, nrows, k, ld):
+        valid = np.arange(ld) < k
+        with np.errstate(divide="ignore", invalid="ignore"):
+            E = sp.psi(_np(shp).astype(np.float64)) - np.log(_np(rte).astype(np.float64))
+        E = np.where(valid[None, :], E, -np.inf)
+        E = E - E.max(axis=1, keepdims=True)
+        _np(e)[:] = np.exp(E).astype(np.float32)
+
+    def segsum(self, part, row_seg_ptr, nrows, acc, ld):
+        rsp = _np(row_seg_ptr)
+        out = np.zeros((nrows, ld))
+        nz = rsp[1:] > rsp[:-1]
+        if nz.any():
+            out[nz] = np.add.reduceat(_np(part).astype(np.float64)[: rsp[-1]], rsp[:-1][nz], axis=0)
+        _np(acc)[:] = out.astype(np.float32)
+
+    def pair_llk(self, T, B, ix_u, ix_i, y, k, ld, full_llk):
+        Tn = _np(T).astype(np.float64)[_np(ix_u).astype(np.int64)]
+        Bn = _np(B).astype(np.float64)[_np(ix_i).astype(np.int64)]
+        yy = _np(y).astype(np.float64)
+        yhat = (Tn * Bn).sum(axis=1)
+        a0 = (yy * np.log(yhat)).sum()
+        if full_llk:
+            a0 -= sp.gammaln(yy + 1.0).sum()
+        return torch.tensor([a0, ((yy - yhat) ** 2).sum(), yhat.sum()], dtype=torch.float64)
+
+    def pair_dot(self, T, B, ix_u, ix_i, out, k, ld):
+        Tn = _np(T).astype(np.float64)[_np(ix_u).astype(np.int64)]
+        Bn = _np(B).astype(np.float64)[_np(ix_i).astype(np.int64)]
+        _np(out)[:] = (Tn * Bn).sum(axis=1).astype(np.float32)

