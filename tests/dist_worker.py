@@ -1,0 +1,35 @@
+"""Worker for tests/test_dist_gloo.py: one rank of a world_size-N gloo job running the sharded
+driver on the numpy stand-in ops."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.dirname(HERE), HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def run(rank, world, port, out_dir, k, its, case):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cpu_ops
+    import datagen
+    from hpfrec_amd import cython_loops_float as be
+    be._OPS_FACTORY = cpu_ops.CpuOps
+    if case == "c1":
+        df, nU, nI = datagen.readme_counts()
+    else:
+        df, nU, nI = datagen.mid_counts(nusers=600, nitems=400, nobs=20000)
+    Y, iu, ii = datagen.triplets(df)
+    Theta = np.empty((nU, k), np.float32)
+    Beta = np.empty((nI, k), np.float32)
+    i, temp, llk = be.fit_hpf(0.3, 0.3, 1.0, 0.3, 0.3, 1.0, Y, iu, ii, Theta, Beta, its, "maxiter", its, 1e-3, 0, 0, None,
+                              0, np.zeros(1, np.uint64), "", 123, 1, 1, 0, 0, np.empty(0, np.float32),
+                              np.empty(0, np.uint64), np.empty(0, np.uint64), 0, 1, 0)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), Theta=Theta, Beta=Beta, Gamma_shp=temp[0], Gamma_rte=temp[1],
+             Lambda_shp=temp[2], Lambda_rte=temp[3], k_rte=temp[4], t_rte=temp[5], llk=np.float64(llk), niter=i)
+    dist.destroy_process_group()

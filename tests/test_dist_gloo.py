@@ -1,0 +1,48 @@
+"""The N>1 path on CPU: world_size 2 and 3 over gloo (user-sharded driver, one all-reduce of
+[item accumulators || colsum(Theta)] per iteration), numpy stand-in ops.  Every rank must end with
+the full, identical model, equal (to rounding: the sum order changes) to the single-process run."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+import datagen
+import dist_worker
+
+NAMES = ("Theta", "Beta", "Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "k_rte", "t_rte")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,case", [(2, "c1"), (3, "mid")])
+def test_sharded_equals_single(tmp_path, cpu_ops_backend, world, case, capsys):
+    k, its = 20, 5
+    if case == "c1":
+        df, nU, nI = datagen.readme_counts()
+    else:
+        df, nU, nI = datagen.mid_counts(nusers=600, nitems=400, nobs=20000)
+    Y, iu, ii = datagen.triplets(df)
+    Theta = np.empty((nU, k), np.float32)
+    Beta = np.empty((nI, k), np.float32)
+    i, temp, llk = cpu_ops_backend.fit_hpf(0.3, 0.3, 1.0, 0.3, 0.3, 1.0, Y, iu, ii, Theta, Beta, its, "maxiter", its, 1e-3,
+                                           0, 0, None, 0, np.zeros(1, np.uint64), "", 123, 1, 1, 0, 0,
+                                           np.empty(0, np.float32), np.empty(0, np.uint64), np.empty(0, np.uint64), 0, 1, 0)
+    single = dict(zip(NAMES, (Theta, Beta) + tuple(temp)))
+    mp.spawn(dist_worker.run, args=(world, _free_port(), str(tmp_path), k, its, case), nprocs=world, join=True)
+    outs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    for r in range(world):
+        assert int(outs[r]["niter"]) == i
+        assert abs(float(outs[r]["llk"]) / float(llk) - 1) < 1e-6
+        for n in NAMES:
+            assert outs[r][n].shape == single[n].shape
+            assert np.max(np.abs(outs[r][n] - single[n]) / np.abs(single[n])) < 1e-5, (r, n)
+            assert np.array_equal(outs[r][n], outs[0][n]), (r, n)  # replicas agree bit for bit

@@ -1,0 +1,126 @@
+"""The drop-in HPF class: README sample flow (/root/reference/README.md:72-150) on the CPU stand-in
+ops (host logic only), and on the GPU against the reference's golden outputs."""
+import os
+import warnings
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+from scipy.sparse import coo_array
+
+import datagen
+from conftest import GOLDEN
+from hpfrec_amd import HPF
+
+NAMES = ("Theta", "Beta", "Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "k_rte", "t_rte")
+
+
+def _maxrel(a, b):
+    return float(np.max(np.abs(a - b) / np.abs(b)))
+
+
+def _check_fit_against_golden(tol):
+    df, nU, nI = datagen.readme_counts()
+    g = np.load(os.path.join(GOLDEN, "c1_full.npz"))
+    m = HPF(k=30, maxiter=10, random_seed=123, reindex=False, verbose=False, check_every=None, keep_all_objs=True)
+    assert m.fit(df.copy()) is m
+    assert m.is_fitted and m.niter == 9 and m.train_llk is None
+    for n in NAMES:
+        assert _maxrel(getattr(m, n), g["it10_%s" % n]) < tol, n
+    return m, df, nU, nI, g
+
+
+def test_constructor_validation():
+    with pytest.raises(AssertionError):
+        HPF(k=0)
+    with pytest.raises(AssertionError):
+        HPF(a=-1.0)
+    with pytest.raises(ValueError):
+        HPF(maxiter=None)
+    with pytest.raises(ValueError):
+        HPF(stop_crit="train-llk", check_every=None)
+    with pytest.raises(ValueError):
+        HPF(step_size=3)
+    with pytest.raises(AssertionError):
+        HPF(stop_crit="bogus")
+    m = HPF(a=1, verbose=False)
+    assert m.a == 1.0 and m.check_every == 0 and m.users_per_batch == 0
+    assert HPF(reindex=False).produce_dicts is False
+
+
+def test_fit_flow_on_standin(cpu_ops_backend, capsys):
+    m, df, nU, nI, g = _check_fit_against_golden(5e-5)
+    assert m.Theta.shape == (nU, 30) and m.Beta.shape == (nI, 30) and m.Theta.dtype == np.float32
+    assert not hasattr(m, "input_df") and not hasattr(m, "val_set")
+    # reindex=True: ids renumbered by first appearance; dicts built; predictions go through the mapping
+    df2 = df.copy()
+    df2["UserId"] = "u" + df2["UserId"].astype(str)
+    df2["ItemId"] = df2["ItemId"] + 1000
+    m2 = HPF(k=30, maxiter=10, random_seed=123, verbose=True, stop_crit="train-llk", check_every=5).fit(df2)
+    out = capsys.readouterr().out
+    assert "Hierarchical Poisson Factorization" in out and "Number of users: 100" in out and "train llk" in out
+    first_u = pd.unique(df2["UserId"])
+    assert list(m2.user_mapping_[:5]) == list(first_u[:5]) and m2.user_dict_[first_u[3]] == 3
+    p = m2.predict(user=first_u[3], item=m2.item_mapping_[7])
+    assert np.isclose(p, m2.Theta[3].dot(m2.Beta[7]), rtol=1e-6)
+    assert np.isnan(m2.predict(user="nobody", item=m2.item_mapping_[7]))
+    arr = m2.predict(user=[first_u[0], "nobody", first_u[2]], item=[1001, 1002, 999999])
+    assert np.isfinite(arr[0]) and np.isnan(arr[1]) and np.isnan(arr[2])
+    top = m2.topN(user=first_u[0], n=10, exclude_seen=True)
+    seen = set(df2.loc[df2.UserId == first_u[0], "ItemId"])
+    assert len(top) == 10 and not (set(top) & seen)
+    top_all = m2.topN(user=first_u[0], n=5, exclude_seen=False)
+    scores = m2.Theta[0].dot(m2.Beta.T)
+    assert list(top_all) == list(m2.item_mapping_[np.argsort(-scores)[:5]])
+    with pytest.raises(ValueError):
+        m2.topN(user="nobody")
+    ll = m2.eval_llk(df2.copy())
+    assert ll["nobs"] == df2.shape[0] and np.isfinite(float(ll["llk"]))
+
+
+def test_fit_inputs_coo_array_and_zero_filter(cpu_ops_backend):
+    df, nU, nI = datagen.readme_counts()
+    m_df = HPF(k=8, maxiter=3, random_seed=1, reindex=False, verbose=False, check_every=None).fit(df.copy())
+    X = coo_array((df.Count.to_numpy(), (df.UserId.to_numpy(), df.ItemId.to_numpy())), shape=(nU, nI))
+    m_coo = HPF(k=8, maxiter=3, random_seed=1, verbose=False, check_every=None).fit(X)
+    assert m_coo.reindex is False and np.array_equal(m_df.Theta, m_coo.Theta)
+    m_arr = HPF(k=8, maxiter=3, random_seed=1, reindex=False, verbose=False, check_every=None).fit(df[["UserId", "ItemId", "Count"]].to_numpy())
+    assert np.allclose(m_df.Theta, m_arr.Theta, rtol=1e-6)
+    dfz = pd.concat([df, pd.DataFrame({"UserId": [1], "ItemId": [2], "Count": [0]})], ignore_index=True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m_z = HPF(k=8, maxiter=3, random_seed=1, reindex=False, verbose=False, check_every=None).fit(dfz)
+    assert any("less than 1" in str(x.message) for x in w)
+    assert np.array_equal(m_z.Theta, m_df.Theta)
+    with pytest.raises(ValueError):
+        HPF(verbose=False).fit([1, 2, 3])
+    with pytest.raises(ValueError):
+        HPF(stop_crit="val-llk", verbose=False).fit(df.copy())
+
+
+def test_valset_stopping(cpu_ops_backend):
+    df, nU, nI = datagen.readme_counts()
+    val = df.sample(200, random_state=1)
+    m = HPF(k=10, maxiter=60, stop_crit="val-llk", check_every=5, stop_thr=1e-2, random_seed=2, verbose=False,
+            reindex=False).fit(df.copy(), val_set=val.copy())
+    assert m.niter < 59 and (m.niter + 1) % 5 == 0
+
+
+@pytest.mark.gpu
+def test_fit_predict_topn_vs_golden_on_gpu(hip_backend):
+    m, df, nU, nI, g = _check_fit_against_golden(5e-5)
+    gp = np.load(os.path.join(GOLDEN, "c1_predict.npz"))
+    m20 = HPF(k=30, maxiter=20, random_seed=123, reindex=False, verbose=False, check_every=None).fit(df.copy())
+    got = m20.predict(user=gp["pairs_u"], item=gp["pairs_i"])
+    assert _maxrel(got, gp["predict_pairs"]) < 1e-4
+    assert abs(m20.predict(user=10, item=11) / gp["predict_scalar_10_11"] - 1) < 1e-4
+    for u in (0, 10, 57):
+        # same ids; order may differ only where the reference's own scores tie within rounding
+        assert set(m20.topN(user=u, n=10, exclude_seen=True)) == set(gp["topN_u%d_seen_excluded" % u])
+        assert list(m20.topN(user=u, n=10, exclude_seen=False))[:3] == list(gp["topN_u%d_all" % u])[:3]
+    assert list(m20.topN(user=10, n=3, exclude_seen=False, items_pool=np.arange(5, 40))) == list(gp["topN_u10_pool"])
+    gl = np.load(os.path.join(GOLDEN, "c1_full.npz"))
+    assert abs(float(m20.eval_llk(df.copy())["llk"]) / gl["eval_llk_it20"] - 1) < 1e-4
+    mv = HPF(k=30, maxiter=10, random_seed=123, reindex=False, verbose=True, check_every=10).fit(df.copy())
+    assert abs(float(mv.train_llk) / gl["train_llk_it10"] - 1) < 1e-4
