@@ -86,6 +86,9 @@ class TimedOps(HipOps):
     def sweep(self, *a, **kw):
         return self._timed("sweep", super().sweep, *a, **kw)
 
+    def sweep_finalize(self, *a, **kw):
+        return self._timed("sweep_finalize", super().sweep_finalize, *a, **kw)
+
     def row_finalize(self, *a, **kw):
         return self._timed("row_finalize", super().row_finalize, *a, **kw)
 
@@ -138,6 +141,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not bracket launches with HIP events")
     ap.add_argument("--llk", action="store_true", help="also time one train-llk evaluation (reported separately)")
+    ap.add_argument("--no-fuse", action="store_true", help="separate sweep and row-finalize launches")
+    ap.add_argument("--lean", action="store_true",
+                    help="skip the Gamma/Lambda shape+rate table stores (outputs only) in the timed iterations")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -172,18 +178,22 @@ def main():
     del init, Theta, Beta
     torch.cuda.empty_cache()
 
+    if args.no_fuse:
+        model.set_fused(False)
+    store = not args.lean
+
     def fence():
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        model.iterate()
+        model.iterate(store)
     fence()
     ops.recording = not args.no_events
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        model.iterate()
+        model.iterate(store)
     fence()
     dt = time.perf_counter() - t0
     ops.recording = False
@@ -211,17 +221,26 @@ def main():
         # algorithmic bytes, SURVEY.md section 8d: whole iteration, and per sweep launch
         b_iter = nnz * (8 + 8 * k) + nU * (12 + 20 * k) + nI * (4 + 24 * k)
         n_loc = model.nnz
-        b_sweep = n_loc * (4 + 4 * k) + ((model.nU + model.nI) / 2.0) * (8 + 4 * k)
         roof = None
-        if "sweep" in ksum:
-            t_sweep = ksum["sweep"]["avg_ms"] * 1e-3
-            ach = b_sweep / t_sweep
-            roof = {"bound": "hbm", "kernel": "sweep_kernel", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
+        # dominant kernel: the sweep.  Fused mode: sweep_kernel<..,FUSE=true> also finishes the rows it
+        # swept, so one launch owns half an iteration's algorithmic bytes (nnz term + that side's row
+        # term).  Unfused: nnz*(4+4k) + rows*(8+4k) (segment descriptor + own row) per launch.
+        dom = "sweep_finalize" if "sweep_finalize" in ksum else ("sweep" if "sweep" in ksum else None)
+        if dom:
+            if dom == "sweep_finalize":
+                b_launch = (n_loc * (8 + 8 * k) + model.nU * (12 + 20 * k) + model.nI * (4 + 24 * k)) / 2.0
+            else:
+                b_launch = n_loc * (4 + 4 * k) + ((model.nU + model.nI) / 2.0) * (8 + 4 * k)
+            t_k = ksum[dom]["avg_ms"] * 1e-3
+            ach = b_launch / t_k
+            roof = {"bound": "hbm", "kernel": "sweep_kernel (%s)" % ("fused with row finalize" if dom == "sweep_finalize"
+                                                                     else "unfused"),
+                    "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": _pmc_traffic(args.workload, world),
-                    "algorithmic_bytes_per_launch": b_sweep, "avg_launch_ms": ksum["sweep"]["avg_ms"],
-                    "launches": ksum["sweep"]["calls"],
-                    "iteration": {"algorithmic_bytes": b_iter, "frac_of_hbm_peak": (b_iter / world) / (ms * 1e-3) / HBM_PEAK
-                                  if world == 1 else None},
+                    "algorithmic_bytes_per_launch": b_launch, "avg_launch_ms": ksum[dom]["avg_ms"],
+                    "launches": ksum[dom]["calls"],
+                    "iteration": {"algorithmic_bytes": b_iter,
+                                  "frac_of_hbm_peak": b_iter / (ms * 1e-3) / HBM_PEAK if world == 1 else None},
                     "kernels_ms_per_step": {n: v["total_ms"] / args.steps for n, v in ksum.items()}}
         line = {
             "metric": "full-batch CAVI iters/sec (48M nnz, k=50)" if args.workload == "c3" else
@@ -231,7 +250,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": label, "users": nU, "items": nI, "nnz": nnz, "k": k, "ld": model.ld,
                        "parallelism": "users sharded x%d, 1 all-reduce/iter" % world if world > 1 else "1 GPU",
-                       "seg_cap": cavi.layout.SEG_CAP, "state_finite": finite},
+                       "seg_cap": cavi.layout.SEG_CAP, "fused_finalize": model.fused and world == 1,
+                       "stores_all_state_tables": store, "state_finite": finite},
             "roofline": roof,
         }
         if llk_ms is not None:

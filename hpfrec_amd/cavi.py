@@ -84,10 +84,13 @@ class FullBatchCavi:
         self.eT, self.eT_next, self.eB = z(self.nU), z(self.nU), z(self.nI)
         self.part_u = torch.empty((max(1, self.users.nseg), ld), **f32)
         self.part_i = torch.empty((max(1, self.items.nseg), ld), **f32)
-        self.gu = ops.finalize_grid(self.nU)
-        self.gi = ops.finalize_grid(self.nI)
-        self.csT_part = torch.zeros((self.gu, ld), **f32)
-        self.csB_part = torch.zeros((self.gi, ld), **f32)
+        # column-sum partials: [fused-sweep blocks | finalize blocks of the rows the sweep cannot finish]
+        self.fused = True
+        self.gsu, self.gsi = ops.sweep_grid(self.users.nseg), ops.sweep_grid(self.items.nseg)
+        self.gu, self.gi = ops.finalize_grid(self.nU), ops.finalize_grid(self.nI)
+        self.csT_part = torch.zeros((self.gsu + self.gu, ld), **f32)
+        self.csB_part = torch.zeros((self.gsi + self.gi, ld), **f32)
+        self.cs_scratch = torch.zeros((max(self.gu, self.gi), ld), **f32)  # for whole-table column sums
         self.csB = torch.zeros(ld, **f32)
         # [item accumulators || colsum(Theta)]: one flat buffer so that one all-reduce moves both
         self.xbuf = torch.zeros(self.nI * ld + ld, **f32) if self.dist else None
@@ -117,28 +120,57 @@ class FullBatchCavi:
         ops, k, ld = self.ops, self.k, self.ld
         ops.expect(self.Gamma_shp, self.Gamma_rte, self.eT, self.nU, k, ld)
         ops.expect(self.Lambda_shp, self.Lambda_rte, self.eB, self.nI, k, ld)
-        ops.colsum(self.Beta, self.nI, ld, self.csB_part)
-        ops.colsum_reduce(self.csB_part, self.csB, ld)
+        ops.colsum(self.Beta, self.nI, ld, self.cs_scratch)
+        ops.colsum_reduce(self.cs_scratch, self.csB, ld)
+
+    def set_fused(self, flag):
+        """Choose between the fused sweep+finalize launches and separate launches.  Each mode writes
+        a fixed subset of the column-sum partial rows, so they are cleared on a switch."""
+        self.fused = bool(flag)
+        self.csT_part.zero_()
+        self.csB_part.zero_()
 
     # ------------------------------------------------------------------------------------
-    def iterate(self):
+    def _side_update(self, side, nrows, e_self, e_other, e_new, part, shp, rte, fac, rs, cs_other, cs_part, gs, gf,
+                     prior, top, add, store):
+        """sweep one side and apply its closed-form updates.  Fused mode: the wavefront that swept a
+        single-segment row finishes it (fp64 work overlaps other waves' gathers); split and empty rows
+        are finished by a small follow-up launch over side.multi_rows."""
+        ops, k, ld = self.ops, self.k, self.ld
+        shp, rte, fac = (shp, rte, fac) if store else (None, None, fac)
+        if self.fused and side.nseg > 0:
+            ops.sweep_finalize(side, e_self, e_other, part, e_new, shp, rte, fac, rs, cs_other, cs_part[:gs],
+                               prior, top, add, k, ld)
+            nm = side.nmulti
+            gm = max(1, min(gf, (nm + 3) // 4))
+            ops.row_finalize(part, side.row_seg_ptr, nm, e_self, e_new, shp, rte, fac, rs, cs_other,
+                             cs_part[gs: gs + gm], prior, top, add, k, ld, row_list=side.multi_rows)
+        else:
+            ops.sweep(side, e_self, e_other, part, k, ld)
+            ops.row_finalize(part, side.row_seg_ptr, nrows, e_self, e_new, shp, rte, fac, rs, cs_other,
+                             cs_part[gs:], prior, top, add, k, ld)
+
+    def iterate(self, store=True):
+        """One CAVI iteration.  store=False skips writing Gamma/Lambda shape and rate tables (they are
+        outputs only; Theta/Beta, the scalar rates and the E tables are always kept current)."""
         ops, hy, k, ld = self.ops, self.hy, self.k, self.ld
         # user side: phi-weighted gather over CSR rows, then the closed-form user updates
-        ops.sweep(self.users, self.eT, self.eB, self.part_u, k, ld)
-        ops.row_finalize(self.part_u, self.users.row_seg_ptr, self.nU, self.eT, self.eT_next, self.Gamma_shp,
-                         self.Gamma_rte, self.Theta, self.k_rte, self.csB, self.csT_part, hy.a, hy.k_shp,
-                         hy.add_k_rte, k, ld)
+        self._side_update(self.users, self.nU, self.eT, self.eB, self.eT_next, self.part_u, self.Gamma_shp,
+                          self.Gamma_rte, self.Theta, self.k_rte, self.csB, self.csT_part, self.gsu, self.gu,
+                          hy.a, hy.k_shp, hy.add_k_rte, store)
         ops.colsum_reduce(self.csT_part, self.csT, ld)
         # item side: same kernel over CSC rows; still reads the OLD eT (double-buffered)
-        ops.sweep(self.items, self.eB, self.eT, self.part_i, k, ld)
         if self.dist:
+            ops.sweep(self.items, self.eB, self.eT, self.part_i, k, ld)
             ops.segsum(self.part_i, self.items.row_seg_ptr, self.nI, self.acc_i, ld)
             self.dist.all_reduce(self.xbuf)
-            part, rsp = self.acc_i, None
+            ops.row_finalize(self.acc_i, None, self.nI, self.eB, self.eB, self.Lambda_shp if store else None,
+                             self.Lambda_rte if store else None, self.Beta, self.t_rte, self.csT,
+                             self.csB_part[self.gsi:], hy.c, hy.t_shp, hy.add_t_rte, k, ld)
         else:
-            part, rsp = self.part_i, self.items.row_seg_ptr
-        ops.row_finalize(part, rsp, self.nI, self.eB, self.eB, self.Lambda_shp, self.Lambda_rte, self.Beta,
-                         self.t_rte, self.csT, self.csB_part, hy.c, hy.t_shp, hy.add_t_rte, k, ld)
+            self._side_update(self.items, self.nI, self.eB, self.eT, self.eB, self.part_i, self.Lambda_shp,
+                              self.Lambda_rte, self.Beta, self.t_rte, self.csT, self.csB_part, self.gsi, self.gi,
+                              hy.c, hy.t_shp, hy.add_t_rte, store)
         ops.colsum_reduce(self.csB_part, self.csB, ld)
         self.eT, self.eT_next = self.eT_next, self.eT
         self.niter_done += 1
@@ -166,8 +198,8 @@ class FullBatchCavi:
     def colsum_dot(self):
         """(sum_u Theta) . (sum_i Beta) in float32, the subtrahend of the train llk (PXI:78)."""
         if self.niter_done == 0:
-            self.ops.colsum(self.Theta, self.nU, self.ld, self.csT_part)
-            self.ops.colsum_reduce(self.csT_part, self.csT, self.ld)
+            self.ops.colsum(self.Theta, self.nU, self.ld, self.cs_scratch)
+            self.ops.colsum_reduce(self.cs_scratch, self.csT, self.ld)
             if self.dist:
                 self.dist.all_reduce(self.csT)
         a = self.csT[: self.k].cpu().numpy()

@@ -99,25 +99,50 @@ __device__ __forceinline__ double expect_ratio(float shp, float rte) {
 // ----------------------------------------------------------------------------------------
 // sweep: one wavefront per segment
 // ----------------------------------------------------------------------------------------
-template <int LPR, int VPL, bool SCATTER>
+struct FinalizeArgs {  // the row-finalize operands when it is fused into the sweep (FUSE = true)
+    const float *cs_other;
+    float *cs_partial, *e_new, *shp, *rte, *fac, *rs;
+    float prior_shp, top_shp, add_rte;
+    int k;
+};
+
+template <int LPR, int VPL, bool SCATTER, bool FUSE>
 __global__ __launch_bounds__(BLOCK) void sweep_kernel(const hpf_segment *__restrict__ segs, int64_t nseg,
                                                       const int32_t *__restrict__ idx,
                                                       const float *__restrict__ y,
-                                                      const float *__restrict__ tab_self,
+                                                      const float *tab_self,  // may alias fa.e_new
                                                       const float *__restrict__ tab_other,
-                                                      float *__restrict__ part, float *scatter_acc) {
+                                                      float *__restrict__ part, float *scatter_acc,
+                                                      const FinalizeArgs fa) {
     constexpr int LD = 4 * LPR * VPL;
     constexpr int NG = WAVE / LPR;  // nonzeros per step
     constexpr int U = 4;            // gathers in flight per wavefront (WAVE/NG = LPR >= 8 is a multiple)
+    constexpr int NQ = 4 * VPL;     // factors held per lane during the sweep
     const int lane = threadIdx.x & (WAVE - 1);
     const int g = lane / LPR;
     const int j = lane % LPR;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * WPB;
 
+    // FUSE: after the cross-group fold every group holds the whole accumulator row, so the
+    // finalize work is dealt out over ALL 64 lanes: lane (g,j) owns the NC factors q = g + t*NG of
+    // its float4s (q = 4v + e  ->  column (v*LPR + j)*4 + e); with NG = 8 > NQ only groups 0-3 work.
+    constexpr int NC = (NQ >= NG) ? NQ / NG : 1;
+    float csl[NC], csacc[NC];
+    int colq[NC];
+    if constexpr (FUSE) {
+#pragma unroll
+        for (int t = 0; t < NC; t++) {
+            const int q = g + t * NG;
+            colq[t] = (q < NQ) ? ((q >> 2) * LPR + j) * 4 + (q & 3) : LD;  // LD = "no column"
+            csl[t] = (colq[t] < fa.k) ? fa.cs_other[colq[t]] : 0.f;
+            csacc[t] = 0.f;
+        }
+    }
+
     for (int64_t sg = (int64_t)blockIdx.x * WPB + wid; sg < nseg; sg += nwaves) {
         const hpf_segment sgm = segs[sg];
-        const int len = sgm.len;
+        const int len = sgm.len & HPF_SEG_LEN_MASK;
         const float4 *selfp = reinterpret_cast<const float4 *>(tab_self + (size_t)sgm.row * LD);
         float4 rv[VPL], acc[VPL];
 #pragma unroll
@@ -192,23 +217,85 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(const hpf_segment *__restr
                 acc[v].w += __shfl_xor(acc[v].w, m);
             }
         }
-        if (g == 0) {
-            float4 *pp = reinterpret_cast<float4 *>(part + (size_t)sg * LD);
+        bool whole_row = false;
+        if constexpr (FUSE) whole_row = (sgm.len & HPF_SEG_WHOLE_ROW) != 0;
+        if (!whole_row) {
+            if (g == 0) {
+                float4 *pp = reinterpret_cast<float4 *>(part + (size_t)sg * LD);
 #pragma unroll
-            for (int v = 0; v < VPL; v++) pp[v * LPR + j] = acc[v];
+                for (int v = 0; v < VPL; v++) pp[v * LPR + j] = acc[v];
+            }
+        } else if constexpr (FUSE) {
+            // this segment is its row's only one: finish the row here (same math as
+            // row_finalize_kernel), overlapping the fp64 work with other waves' gathers
+            const int row = sgm.row;
+            const float base_rte = fa.top_shp / fa.rs[row];
+            float sh[NC], rt[NC], fc[NC];
+            double ev[NC];
+            float fsum = 0.f;
+            double emax = 0.0;
+#pragma unroll
+            for (int t = 0; t < NC; t++) {
+                const int q = g + t * NG;
+                float a = 0.f, eo = 0.f;
+#pragma unroll
+                for (int qq = 0; qq < NQ; qq++) {  // pick float4 component q (q is lane-dependent)
+                    const int v = qq >> 2, e = qq & 3;
+                    const float av = (e == 0) ? acc[v].x : (e == 1) ? acc[v].y : (e == 2) ? acc[v].z : acc[v].w;
+                    const float ov = (e == 0) ? rv[v].x : (e == 1) ? rv[v].y : (e == 2) ? rv[v].z : rv[v].w;
+                    a = (qq == q) ? av : a;
+                    eo = (qq == q) ? ov : eo;
+                }
+                const bool valid = colq[t] < fa.k;
+                sh[t] = fmaf(eo, a, fa.prior_shp);
+                rt[t] = base_rte + csl[t];
+                fc[t] = valid ? sh[t] / rt[t] : 0.f;
+                ev[t] = valid ? expect_ratio(sh[t], rt[t]) : 0.0;
+                fsum += fc[t];
+                emax = fmax(emax, ev[t]);
+                csacc[t] += fc[t];
+            }
+            fsum = wave_sum(fsum);
+            emax = wave_max_d(emax);
+            const double inv = 1.0 / emax;
+#pragma unroll
+            for (int t = 0; t < NC; t++) {
+                if (colq[t] < LD) {
+                    const size_t o = (size_t)row * LD + colq[t];
+                    const bool valid = colq[t] < fa.k;
+                    fa.e_new[o] = valid ? (float)(ev[t] * inv) : 0.f;
+                    if (fa.shp) fa.shp[o] = valid ? sh[t] : 0.f;
+                    if (fa.rte) fa.rte[o] = valid ? rt[t] : 0.f;
+                    if (fa.fac) fa.fac[o] = fc[t];
+                }
+            }
+            if (lane == 0) fa.rs[row] = fa.add_rte + fsum;
+        }
+    }
+
+    if constexpr (FUSE) {
+        // per-block column sums of fac over the rows finished here
+        __shared__ float red[WPB][LD];
+#pragma unroll
+        for (int t = 0; t < NC; t++) {
+            if (colq[t] < LD) red[wid][colq[t]] = csacc[t];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < LD; c += BLOCK) {
+            float t = red[0][c];
+#pragma unroll
+            for (int w2 = 1; w2 < WPB; w2++) t += red[w2][c];
+            fa.cs_partial[(size_t)blockIdx.x * LD + c] = t;
         }
     }
 }
 
-// ----------------------------------------------------------------------------------------
-// row finalize: one wavefront per table row, lane <-> factor
-// ----------------------------------------------------------------------------------------
 template <int LD>
 __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
-    const float *__restrict__ part, const int64_t *__restrict__ row_seg_ptr, int64_t nrows, const float *e_old,
-    float *e_new, float *__restrict__ shp, float *__restrict__ rte, float *__restrict__ fac, float *rs,
-    const float *__restrict__ cs_other, float *__restrict__ cs_partial, float prior_shp, float top_shp,
-    float add_rte, int k) {
+    const float *__restrict__ part, const int64_t *__restrict__ row_seg_ptr, const int64_t *__restrict__ row_list,
+    int64_t nrows, const float *e_old, float *e_new, float *__restrict__ shp, float *__restrict__ rte,
+    float *__restrict__ fac, float *rs, const float *__restrict__ cs_other, float *__restrict__ cs_partial,
+    float prior_shp, float top_shp, float add_rte, int k) {
     constexpr int CPL = (LD + WAVE - 1) / WAVE;  // factors per lane
     __shared__ float red[WPB][LD];
     const int lane = threadIdx.x & (WAVE - 1);
@@ -223,7 +310,8 @@ __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
         csacc[q] = 0.f;
     }
 
-    for (int64_t r = (int64_t)blockIdx.x * WPB + wid; r < nrows; r += nwaves) {
+    for (int64_t t = (int64_t)blockIdx.x * WPB + wid; t < nrows; t += nwaves) {
+        const int64_t r = row_list ? row_list[t] : t;
         int64_t s0 = r, s1 = r + 1;
         if (row_seg_ptr) {
             s0 = row_seg_ptr[r];
@@ -240,7 +328,15 @@ __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
             const bool valid = c < k;
             float a = 0.f;
             if (c < LD) {
-                for (int64_t sg = s0; sg < s1; sg++) a += part[(size_t)sg * LD + c];
+                // popular rows have up to ~1e3 segments: 8 independent loads in flight, fixed fold order
+                int64_t sg = s0;
+                for (; sg + 8 <= s1; sg += 8) {
+                    float p[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) p[u] = part[(size_t)(sg + u) * LD + c];
+                    a += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+                }
+                for (; sg < s1; sg++) a += part[(size_t)sg * LD + c];
             }
             const float eo = (c < LD) ? e_old[(size_t)r * LD + c] : 0.f;
             sh[q] = fmaf(eo, a, prior_shp);
@@ -325,7 +421,15 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float *__rest
     const int c = blockIdx.x * WAVE + cl;
     double s = 0.0;
     if (c < ld) {
-        for (int b = chunk; b < nblk; b += 16) s += (double)cs_partial[(size_t)b * ld + c];
+        int b = chunk;
+        for (; b + 16 * 7 < nblk; b += 16 * 8) {
+            float p[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) p[u] = cs_partial[(size_t)(b + 16 * u) * ld + c];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += (double)p[u];
+        }
+        for (; b < nblk; b += 16) s += (double)cs_partial[(size_t)b * ld + c];
     }
     red[chunk][cl] = s;
     __syncthreads();
@@ -535,30 +639,50 @@ int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx,
         return HPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int grid = clamp_grid((nseg + WPB - 1) / WPB, grid_blocks);
-#define CALL(LPR, VPL)                                                                                            \
-    if (scatter_acc)                                                                                              \
-        hipLaunchKernelGGL((sweep_kernel<LPR, VPL, true>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg, idx, y,   \
-                           tab_self, tab_other, part, scatter_acc);                                               \
-    else                                                                                                          \
-        hipLaunchKernelGGL((sweep_kernel<LPR, VPL, false>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg, idx, y,  \
-                           tab_self, tab_other, part, scatter_acc);
+    const FinalizeArgs fa = {};
+#define CALL(LPR, VPL)                                                                                              \
+    if (scatter_acc)                                                                                                \
+        hipLaunchKernelGGL((sweep_kernel<LPR, VPL, true, false>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg, idx, \
+                           y, tab_self, tab_other, part, scatter_acc, fa);                                          \
+    else                                                                                                            \
+        hipLaunchKernelGGL((sweep_kernel<LPR, VPL, false, false>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg,     \
+                           idx, y, tab_self, tab_other, part, scatter_acc, fa);
     HPF_DISPATCH_LD(ld, CALL)
 #undef CALL
     return last_error();
 }
 
-int hpf_hip_row_finalize_f32(const float *part, const int64_t *row_seg_ptr, int64_t nrows, const float *e_old,
-                             float *e_new, float *shp, float *rte, float *fac, float *rs, const float *cs_other,
-                             float *cs_partial, float prior_shp, float top_shp, float add_rte, int k, int ld,
-                             int grid_blocks, void *stream) {
-    if (!part || !e_old || !e_new || !rs || !cs_other || !cs_partial || nrows <= 0 || k <= 0 ||
+int hpf_hip_sweep_finalize_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
+                               const float *tab_self, const float *tab_other, float *part, float *e_new, float *shp,
+                               float *rte, float *fac, float *rs, const float *cs_other, float *cs_partial,
+                               float prior_shp, float top_shp, float add_rte, int k, int ld, int grid_blocks,
+                               void *stream) {
+    if (!segs || !idx || !y || !tab_self || !tab_other || !part || !e_new || !rs || !cs_other || !cs_partial ||
+        nseg <= 0 || k <= 0 || ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0)
+        return HPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    // grid NOT clamped: every block writes its cs_partial row
+    const FinalizeArgs fa = {cs_other, cs_partial, e_new, shp, rte, fac, rs, prior_shp, top_shp, add_rte, k};
+#define CALL(LPR, VPL)                                                                                            \
+    hipLaunchKernelGGL((sweep_kernel<LPR, VPL, false, true>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg, \
+                       idx, y, tab_self, tab_other, part, (float *)nullptr, fa);
+    HPF_DISPATCH_LD(ld, CALL)
+#undef CALL
+    return last_error();
+}
+
+int hpf_hip_row_finalize_f32(const float *part, const int64_t *row_seg_ptr, const int64_t *row_list, int64_t nrows,
+                             const float *e_old, float *e_new, float *shp, float *rte, float *fac, float *rs,
+                             const float *cs_other, float *cs_partial, float prior_shp, float top_shp, float add_rte,
+                             int k, int ld, int grid_blocks, void *stream) {
+    if (!part || !e_old || !e_new || !rs || !cs_other || !cs_partial || nrows < 0 || k <= 0 ||
         ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0)
         return HPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     // the grid is NOT clamped: cs_partial has exactly grid_blocks rows and all are written
 #define CALL(LD)                                                                                                  \
-    hipLaunchKernelGGL((row_finalize_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, part, row_seg_ptr, nrows, \
-                       e_old, e_new, shp, rte, fac, rs, cs_other, cs_partial, prior_shp, top_shp, add_rte, k);
+    hipLaunchKernelGGL((row_finalize_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, part, row_seg_ptr, row_list, \
+                       nrows, e_old, e_new, shp, rte, fac, rs, cs_other, cs_partial, prior_shp, top_shp, add_rte, k);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
     return last_error();

@@ -12,6 +12,8 @@ Everything here is index plumbing on torch tensors (any device, incl. CPU for th
 import torch
 
 SEG_CAP = 256  # nonzeros per segment: 64 steps of 4 nonzeros at ld=64
+SEG_LEN_MASK = 0x00FFFFFF    # include/hpf_hip.h: HPF_SEG_LEN_MASK
+SEG_WHOLE_ROW = 0x40000000   # include/hpf_hip.h: HPF_SEG_WHOLE_ROW
 
 
 class SparseSide:
@@ -25,13 +27,17 @@ class SparseSide:
         self.nnz = int(idx.shape[0])
         self.segs, self.row_seg_ptr = build_segments(indptr, seg_cap)
         self.nseg = int(self.segs.shape[0])
+        # rows the fused sweep cannot finish on its own: split rows and rows without any nonzero
+        nseg_row = self.row_seg_ptr[1:] - self.row_seg_ptr[:-1]
+        self.multi_rows = torch.nonzero(nseg_row != 1).reshape(-1).contiguous()
+        self.nmulti = int(self.multi_rows.shape[0])
 
 
 def build_segments(indptr, seg_cap=SEG_CAP):
     """Cut rows into segments of at most seg_cap nonzeros.
 
     Returns (segs, row_seg_ptr): segs is an int64 [nseg,2] tensor whose memory image is an array
-    of hpf_segment {int64 begin; int32 len; int32 row} (little endian: len | row<<32), and
+    of hpf_segment {int64 begin; int32 len|flags; int32 row} (little endian: len | flags | row<<32), and
     row_seg_ptr [nrows+1] lists each row's segment range (empty rows have no segment).
     """
     dev = indptr.device
@@ -45,7 +51,8 @@ def build_segments(indptr, seg_cap=SEG_CAP):
     within = torch.arange(nseg, dtype=torch.int64, device=dev) - row_seg_ptr[rows]
     begin = indptr[rows] + within * seg_cap
     length = torch.clamp(deg[rows] - within * seg_cap, max=seg_cap)
-    segs = torch.stack([begin, length | (rows << 32)], dim=1).contiguous()
+    flags = torch.where(nseg_row[rows] == 1, SEG_WHOLE_ROW, 0)
+    segs = torch.stack([begin, length | flags | (rows << 32)], dim=1).contiguous()
     return segs, row_seg_ptr
 
 

@@ -38,13 +38,27 @@ class HipOps:
                                             _ptr(tab_self), _ptr(tab_other), _ptr(part), _ptr(scatter_acc),
                                             k, ld, self.sweep_blocks, self._stream()), "hpf_hip_sweep_f32")
 
+    def sweep_grid(self, nseg):
+        return int(max(1, min(self.sweep_blocks, (nseg + 3) // 4)))
+
+    def sweep_finalize(self, side, tab_self, tab_other, part, e_new, shp, rte, fac, rs, cs_other, cs_partial,
+                       prior_shp, top_shp, add_rte, k, ld):
+        """sweep + fused row finalize of single-segment rows; cs_partial must have sweep_grid(nseg) rows."""
+        _lib.check(self.L.hpf_hip_sweep_finalize_f32(_ptr(side.segs), side.nseg, _ptr(side.idx), _ptr(side.y),
+                                                     _ptr(tab_self), _ptr(tab_other), _ptr(part), _ptr(e_new),
+                                                     _ptr(shp), _ptr(rte), _ptr(fac), _ptr(rs), _ptr(cs_other),
+                                                     _ptr(cs_partial), float(prior_shp), float(top_shp),
+                                                     float(add_rte), k, ld, cs_partial.shape[0], self._stream()),
+                   "hpf_hip_sweep_finalize_f32")
+
     def finalize_grid(self, nrows):
         return int(max(1, min(self.finalize_blocks, (nrows + 3) // 4)))
 
     def row_finalize(self, part, row_seg_ptr, nrows, e_old, e_new, shp, rte, fac, rs, cs_other, cs_partial,
-                     prior_shp, top_shp, add_rte, k, ld):
+                     prior_shp, top_shp, add_rte, k, ld, row_list=None):
         grid = cs_partial.shape[0]
-        _lib.check(self.L.hpf_hip_row_finalize_f32(_ptr(part), _ptr(row_seg_ptr), nrows, _ptr(e_old), _ptr(e_new),
+        _lib.check(self.L.hpf_hip_row_finalize_f32(_ptr(part), _ptr(row_seg_ptr), _ptr(row_list), nrows, _ptr(e_old),
+                                                   _ptr(e_new),
                                                    _ptr(shp), _ptr(rte), _ptr(fac), _ptr(rs), _ptr(cs_other),
                                                    _ptr(cs_partial), float(prior_shp), float(top_shp),
                                                    float(add_rte), k, ld, grid, self._stream()),

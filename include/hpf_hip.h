@@ -40,10 +40,13 @@ extern "C" {
  * column of an item).  Rows longer than the segment cap are split into several
  * segments so that no wavefront owns an unbounded amount of work. */
 typedef struct hpf_segment {
-    int64_t begin; /* offset of the first nonzero in idx[] / y[]          */
-    int32_t len;   /* number of nonzeros (> 0)                            */
-    int32_t row;   /* row of tab_self this segment belongs to             */
+    int64_t begin; /* offset of the first nonzero in idx[] / y[]                          */
+    int32_t len;   /* number of nonzeros (> 0) in the low 24 bits, HPF_SEG_* flags above  */
+    int32_t row;   /* row of tab_self this segment belongs to                             */
 } hpf_segment;
+
+#define HPF_SEG_LEN_MASK 0x00FFFFFF
+#define HPF_SEG_WHOLE_ROW 0x40000000 /* the segment is the only one of its row */
 
 int hpf_hip_abi_version(void);
 
@@ -73,9 +76,24 @@ int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx,
                       int k, int ld, int grid_blocks, void *stream);
 
 /*
+ * hpf_hip_sweep_f32 with the row finalizer (next entry) fused in: a segment flagged
+ * HPF_SEG_WHOLE_ROW is finished by the wavefront that swept it -- shp/rte/fac/rs/e_new of its row are
+ * written directly (e_old = tab_self; e_new may alias tab_self) and nothing goes to part[]; other
+ * segments write part[] as usual and their rows (and rows without any nonzero) are finished by a
+ * following hpf_hip_row_finalize_f32 call with a row_list.  cs_partial must have grid_blocks rows;
+ * all are written.  This overlaps the fp64 transcendental work with the gathers of other waves.
+ */
+int hpf_hip_sweep_finalize_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
+                               const float *tab_self, const float *tab_other, float *part, float *e_new, float *shp,
+                               float *rte, float *fac, float *rs, const float *cs_other, float *cs_partial,
+                               float prior_shp, float top_shp, float add_rte, int k, int ld, int grid_blocks,
+                               void *stream);
+
+/*
  * Closed-form updates for the rows of one side.  Replaces the numpy statements of
  * fit_hpf PXI:236-259 (and the psi/log/exp hoisted out of update_phi, PXI:588):
  *
+ *   r        = row_list ? row_list[t] : t,   t = 0 .. nrows-1   (row_list: finish only the listed rows)
  *   acc      = sum of part[g] over the row's segments g in [row_seg_ptr[r], row_seg_ptr[r+1])
  *              (row_seg_ptr == NULL: part is already one accumulator row per table row)
  *   shp[r]   = prior_shp + e_old[r] (*) acc              Gamma_shp / Lambda_shp
@@ -87,8 +105,8 @@ int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx,
  *
  * e_new may alias e_old.  rs is updated in place.  shp/rte/fac may be NULL (skip store).
  */
-int hpf_hip_row_finalize_f32(const float *part, const int64_t *row_seg_ptr, int64_t nrows, const float *e_old,
-                             float *e_new, float *shp, float *rte, float *fac, float *rs,
+int hpf_hip_row_finalize_f32(const float *part, const int64_t *row_seg_ptr, const int64_t *row_list, int64_t nrows,
+                             const float *e_old, float *e_new, float *shp, float *rte, float *fac, float *rs,
                              const float *cs_other, float *cs_partial, float prior_shp, float top_shp,
                              float add_rte, int k, int ld, int grid_blocks, void *stream);
 

@@ -22,7 +22,7 @@ def _decode_segs(side):
     s = _np(side.segs)
     begin = s[:, 0].copy()
     meta = s[:, 1]
-    length = (meta & 0xFFFFFFFF).astype(np.int64)
+    length = (meta & 0x00FFFFFF).astype(np.int64)
     row = (meta >> 32).astype(np.int64)
     return begin, length, row
 
@@ -37,6 +37,19 @@ class CpuOps:
 
     def finalize_grid(self, nrows):
         return int(max(1, min(self.finalize_blocks, (nrows + 3) // 4)))
+
+    def sweep_grid(self, nseg):
+        return int(max(1, min(self.sweep_blocks, (nseg + 3) // 4)))
+
+    def sweep_finalize(self, side, tab_self, tab_other, part, e_new, shp, rte, fac, rs, cs_other, cs_partial,
+                       prior_shp, top_shp, add_rte, k, ld):
+        """sweep, then finish exactly the rows that consist of one segment (HPF_SEG_WHOLE_ROW)."""
+        e_old = tab_self.clone()
+        self.sweep(side, tab_self, tab_other, part, k, ld)
+        rsp = _np(side.row_seg_ptr)
+        single = torch.from_numpy(np.nonzero((rsp[1:] - rsp[:-1]) == 1)[0].astype(np.int64))
+        self.row_finalize(part, side.row_seg_ptr, int(single.shape[0]), e_old, e_new, shp, rte, fac, rs, cs_other,
+                          cs_partial, prior_shp, top_shp, add_rte, k, ld, row_list=single)
 
     def sweep(self, side, tab_self, tab_other, part, k, ld, scatter_acc=None):
         if side.nseg == 0:
@@ -61,35 +74,38 @@ class CpuOps:
             _np(scatter_acc)[:] = acc.astype(np.float32)
 
     def row_finalize(self, part, row_seg_ptr, nrows, e_old, e_new, shp, rte, fac, rs, cs_other, cs_partial,
-                     prior_shp, top_shp, add_rte, k, ld):
+                     prior_shp, top_shp, add_rte, k, ld, row_list=None):
         P = _np(part).astype(np.float64)
+        rows = np.arange(nrows) if row_list is None else _np(row_list)[:nrows].astype(np.int64)
+        cp = _np(cs_partial)
+        cp[:] = 0
+        if rows.shape[0] == 0:
+            return
         if row_seg_ptr is None:
-            acc = P[:nrows]
+            acc = P[rows]
         else:
             rsp = _np(row_seg_ptr)
-            acc = np.zeros((nrows, ld))
-            nz = rsp[1:] > rsp[:-1]
-            if nz.any():
-                acc[nz] = np.add.reduceat(P[: rsp[-1]], rsp[:-1][nz], axis=0)
+            acc = np.zeros((rows.shape[0], ld))
+            for t, r in enumerate(rows):  # rows may be any subset; plain loop keeps this obviously right
+                if rsp[r + 1] > rsp[r]:
+                    acc[t] = P[rsp[r]: rsp[r + 1]].sum(axis=0)
         f = np.float32
-        sh = (f(prior_shp) + (_np(e_old).astype(np.float64) * acc)).astype(np.float32)
-        rt = (f(top_shp) / _np(rs)[:, None] + _np(cs_other)[None, :]).astype(np.float32)
+        sh = (f(prior_shp) + (_np(e_old).astype(np.float64)[rows] * acc)).astype(np.float32)
+        rt = (f(top_shp) / _np(rs)[rows][:, None] + _np(cs_other)[None, :]).astype(np.float32)
         valid = np.arange(ld) < k
         fc = np.where(valid[None, :], sh / rt, 0).astype(np.float32)
         with np.errstate(divide="ignore", invalid="ignore"):
             E = sp.psi(sh.astype(np.float64)) - np.log(rt.astype(np.float64))
         E = np.where(valid[None, :], E, -np.inf)
         E = E - E.max(axis=1, keepdims=True)
-        _np(e_new)[:] = np.exp(E).astype(np.float32)
+        _np(e_new)[rows] = np.exp(E).astype(np.float32)
         if shp is not None:
-            _np(shp)[:] = np.where(valid[None, :], sh, 0)
+            _np(shp)[rows] = np.where(valid[None, :], sh, 0)
         if rte is not None:
-            _np(rte)[:] = np.where(valid[None, :], rt, 0)
+            _np(rte)[rows] = np.where(valid[None, :], rt, 0)
         if fac is not None:
-            _np(fac)[:] = fc
-        _np(rs)[:] = (f(add_rte) + fc.astype(np.float64).sum(axis=1)).astype(np.float32)
-        cp = _np(cs_partial)
-        cp[:] = 0
+            _np(fac)[rows] = fc
+        _np(rs)[rows] = (f(add_rte) + fc.astype(np.float64).sum(axis=1)).astype(np.float32)
         cp[0] = fc.astype(np.float64).sum(axis=0).astype(np.float32)
 
     def colsum_reduce(self, cs_partial, cs_out, ld):

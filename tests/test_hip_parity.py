@@ -287,3 +287,79 @@ def test_invariants_at_2m_nnz(hip_backend):
     assert _maxrel(arrs["Theta"], arrs["Gamma_shp"] / arrs["Gamma_rte"]) < 1e-6
     assert _maxrel(arrs["k_rte"][:, 0], np.float32(0.3) + arrs["Theta"].sum(axis=1)) < 1e-5
     assert np.isfinite(arrs["Beta"]).all() and (arrs["Beta"] > 0).all()
+
+
+@pytest.mark.parametrize("k", [30, 50, 100, 300])
+def test_fused_sweep_finalize_op(ops, k):
+    """sweep_kernel<FUSE=true> + row_finalize(row_list) == separate sweep + row_finalize over all rows."""
+    rs = np.random.RandomState(k + 7)
+    ld = _lib.ld_for_k(k)
+    nU, nI, n = 400, 120, 30000
+    iu = torch.from_numpy((nU * rs.random_sample(n) ** 2).astype(np.int64) + 0)
+    iu = torch.clamp(iu + 3, max=nU - 1)                      # users 0-2 have no data
+    ii = torch.from_numpy((nI * rs.random_sample(n) ** 3).astype(np.int64))
+    y = torch.from_numpy((rs.gamma(1, 1, size=n) + 1).astype(np.float32))
+    eT, eB = _rand_tables(rs, nU, k, ld), _rand_tables(rs, nI, k, ld)
+    users, items, _ = layout.build_sides(iu, ii, y, nU, nI)
+    assert items.nmulti > 0 and users.nmulti >= 3
+    for side, ts, to, nrows in ((users, eT, eB, nU), (items, eB, eT, nI)):
+        dside = layout.SparseSide.__new__(layout.SparseSide)
+        dside.__dict__.update({a: (v.cuda() if torch.is_tensor(v) else v) for a, v in side.__dict__.items()})
+        rs0 = torch.from_numpy(rs.uniform(0.5, 30, size=nrows).astype(np.float32))
+        cs = torch.zeros(ld)
+        cs[:k] = torch.from_numpy(rs.uniform(5, 50, size=k).astype(np.float32))
+        res = {}
+        for mode in ("fused", "split"):
+            part = torch.zeros((side.nseg, ld), device="cuda")
+            outs = [torch.full((nrows, ld), -1.0, device="cuda") for _ in range(4)]
+            rsg = rs0.cuda()
+            gs, gf = ops.sweep_grid(side.nseg), ops.finalize_grid(nrows)
+            csp = torch.zeros((gs + gf, ld), device="cuda")
+            if mode == "fused":
+                ops.sweep_finalize(dside, ts.cuda(), to.cuda(), part, outs[0], outs[1], outs[2], outs[3], rsg, cs.cuda(),
+                                   csp[:gs], 0.3, 15.3, 0.3, k, ld)
+                gm = max(1, min(gf, (side.nmulti + 3) // 4))
+                ops.row_finalize(part, dside.row_seg_ptr, side.nmulti, ts.cuda(), outs[0], outs[1], outs[2], outs[3],
+                                 rsg, cs.cuda(), csp[gs:gs + gm], 0.3, 15.3, 0.3, k, ld, row_list=dside.multi_rows)
+            else:
+                ops.sweep(dside, ts.cuda(), to.cuda(), part, k, ld)
+                ops.row_finalize(part, dside.row_seg_ptr, nrows, ts.cuda(), outs[0], outs[1], outs[2], outs[3], rsg,
+                                 cs.cuda(), csp[gs:], 0.3, 15.3, 0.3, k, ld)
+            cso = torch.zeros(ld, device="cuda")
+            ops.colsum_reduce(csp, cso, ld)
+            torch.cuda.synchronize()
+            res[mode] = [o.cpu() for o in outs] + [rsg.cpu(), cso.cpu()]
+        for a, b in zip(res["fused"][:4], res["split"][:4]):
+            assert torch.equal(a, b)          # same arithmetic in the same order: bit-identical tables
+        # the k-sum runs over a different lane<->factor map in the fused kernel: equal to rounding
+        assert float(((res["fused"][4] - res["split"][4]).abs() / res["split"][4].abs()).max()) < 1e-6
+        assert float(((res["fused"][5] - res["split"][5]).abs() / res["split"][5].abs().clamp_min(1e-30))[:k].max()) < 1e-6
+        # and against the numpy reference
+        ref = cpu_ops.CpuOps()
+        want = [torch.zeros((nrows, ld)) for _ in range(4)]
+        rsw = rs0.clone()
+        wpart = torch.zeros((side.nseg, ld))
+        ref.sweep(side, ts, to, wpart, k, ld)
+        ref.row_finalize(wpart, side.row_seg_ptr, nrows, ts, want[0], want[1], want[2], want[3], rsw, cs,
+                         torch.zeros((1, ld)), 0.3, 15.3, 0.3, k, ld)
+        for name, a, b in zip(("e_new", "shp", "rte", "fac"), res["fused"][:4], want):
+            assert float(((a - b).abs() / b.abs().clamp_min(1e-30))[:, :k].max()) < 3e-5, name
+
+
+def test_fused_and_split_drivers_agree(hip_backend):
+    from hpfrec_amd import cavi
+    df, nU, nI = datagen.mid_counts()
+    Y, iu, ii = datagen.triplets(df)
+    a = _fit(hip_backend, Y, iu, ii, nU, nI, 50, 4)[1]
+    orig = cavi.FullBatchCavi.__init__
+
+    def unfused_init(self, *args, **kw):
+        orig(self, *args, **kw)
+        self.set_fused(False)
+    cavi.FullBatchCavi.__init__ = unfused_init
+    try:
+        b = _fit(hip_backend, Y, iu, ii, nU, nI, 50, 4)[1]
+    finally:
+        cavi.FullBatchCavi.__init__ = orig
+    for n in NAMES:
+        assert _maxrel(a[n], b[n]) < 2e-6, n

@@ -49,7 +49,8 @@ def test_missing_gpu_fails_loudly():
 
 def _segments_cover(side):
     s = side.segs.numpy()
-    begin, length, row = s[:, 0], s[:, 1] & 0xFFFFFFFF, s[:, 1] >> 32
+    begin, length, row = s[:, 0], s[:, 1] & layout.SEG_LEN_MASK, s[:, 1] >> 32
+    whole = (s[:, 1] & layout.SEG_WHOLE_ROW) != 0
     indptr = side.indptr.numpy()
     cover = np.zeros(side.nnz, dtype=np.int64)
     for b, l, r in zip(begin, length, row):
@@ -59,7 +60,9 @@ def _segments_cover(side):
     rsp = side.row_seg_ptr.numpy()
     for r in range(side.nrows):
         assert (row[rsp[r]:rsp[r + 1]] == r).all()
-        assert rsp[r + 1] - rsp[r] == -(-(indptr[r + 1] - indptr[r]) // layout.SEG_CAP) or True
+        assert whole[rsp[r]:rsp[r + 1]].all() == (rsp[r + 1] - rsp[r] == 1) or rsp[r + 1] == rsp[r]
+    nseg_row = rsp[1:] - rsp[:-1]
+    assert np.array_equal(side.multi_rows.numpy(), np.nonzero(nseg_row != 1)[0])
 
 
 @pytest.mark.parametrize("seg_cap", [4, 256])
@@ -74,7 +77,7 @@ def test_layout_keeps_duplicates_and_covers(seg_cap):
     assert users.nnz == n and items.nnz == n  # duplicates stay separate observations
     for side in (users, items):
         _segments_cover(side)
-        assert int(side.segs[:, 1].bitwise_and(0xFFFFFFFF).max()) <= seg_cap
+        assert int(side.segs[:, 1].bitwise_and(layout.SEG_LEN_MASK).max()) <= seg_cap
     # same multiset of (u,i,y) on both sides
     a = sorted(zip(u_sorted.tolist(), users.idx.tolist(), users.y.tolist()))
     rows_i = torch.repeat_interleave(torch.arange(nI), items.indptr[1:] - items.indptr[:-1])
