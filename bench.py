@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="do not bracket launches with HIP events")
     ap.add_argument("--llk", action="store_true", help="also time one train-llk evaluation (reported separately)")
     ap.add_argument("--no-fuse", action="store_true", help="separate sweep and row-finalize launches")
+    ap.add_argument("--atomic", action="store_true", help="experimental one-pass variant with fp32 atomics")
     ap.add_argument("--lean", action="store_true",
                     help="skip the Gamma/Lambda shape+rate table stores (outputs only) in the timed iterations")
     args = ap.parse_args()
@@ -181,6 +182,9 @@ def main():
     if args.no_fuse:
         model.set_fused(False)
     store = not args.lean
+    if args.atomic:
+        model.set_fused(False)
+        model.iterate = model.iterate_one_pass_atomic
 
     def fence():
         if dist:

@@ -16,7 +16,8 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-SO_PATH = os.path.join(_PKG, "libhpf_hip.so")
+# HPF_HIP_SO: load a differently-tuned build of the same source (kernel A/B runs); default in-tree build
+SO_PATH = os.environ.get("HPF_HIP_SO") or os.path.join(_PKG, "libhpf_hip.so")
 SRC_PATH = os.path.join(_PKG, "csrc", "hpf_hip.hip")
 INC_PATH = os.path.join(_ROOT, "include")
 

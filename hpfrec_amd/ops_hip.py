@@ -5,6 +5,8 @@ numpy stand-in with the same method names so that host logic -- layouts, shardin
 driver loop, the HPF class -- can be exercised on machines without a GPU; it is never
 importable from this package.)
 """
+import os
+
 import torch
 
 from . import _lib
@@ -26,7 +28,7 @@ class HipOps:
         with torch.cuda.device(self.device):
             self.cu_count, self.arch = _lib.device_info()
         # memory-bound grid: a few blocks per CU, grid-stride over the rest (CDNA guide, guideline 11)
-        self.sweep_blocks = max(1, self.cu_count) * 8
+        self.sweep_blocks = max(1, self.cu_count) * int(os.environ.get("HPF_SWEEP_BPC", "8"))
         self.finalize_blocks = max(1, self.cu_count) * 4
 
     def _stream(self):
