@@ -704,8 +704,9 @@ class HPF:
         return out
 
     def _seen_by(self, user):
-        st = self._st_ix_user[user]
-        return self.seen[st: st + self._n_seen_by_user[user]]
+        # int(): after an SVI fit the start index is a size_t array, and uint64 + int32 is float64 in numpy
+        st = int(self._st_ix_user[user])
+        return self.seen[st: st + int(self._n_seen_by_user[user])]
 
     def topN(self, user, n=10, exclude_seen=True, items_pool=None):
         """The n items with the highest predicted count for `user`, best first; optionally without

@@ -472,12 +472,14 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float *__rest
 
 template <int LD>
 __global__ __launch_bounds__(BLOCK) void expect_kernel(const float *__restrict__ shp, const float *__restrict__ rte,
-                                                       float *__restrict__ e, int64_t nrows, int k) {
+                                                       float *__restrict__ e, const int64_t *__restrict__ row_list,
+                                                       int64_t nrows, int k) {
     constexpr int CPL = (LD + WAVE - 1) / WAVE;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * WPB;
-    for (int64_t r = (int64_t)blockIdx.x * WPB + wid; r < nrows; r += nwaves) {
+    for (int64_t t = (int64_t)blockIdx.x * WPB + wid; t < nrows; t += nwaves) {
+        const int64_t r = row_list ? row_list[t] : t;
         double ev[CPL];
         double emax = 0.0;
 #pragma unroll
@@ -497,12 +499,14 @@ __global__ __launch_bounds__(BLOCK) void expect_kernel(const float *__restrict__
 }
 
 __global__ __launch_bounds__(BLOCK) void segsum_kernel(const float *__restrict__ part,
-                                                       const int64_t *__restrict__ row_seg_ptr, int64_t nrows,
+                                                       const int64_t *__restrict__ row_seg_ptr,
+                                                       const int64_t *__restrict__ row_list, int64_t nrows,
                                                        float *__restrict__ acc, int ld) {
     const int64_t total = nrows * (int64_t)ld;
     for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLOCK) {
-        const int64_t r = t / ld;
-        const int c = (int)(t - r * ld);
+        const int64_t rr = t / ld;
+        const int c = (int)(t - rr * ld);
+        const int64_t r = row_list ? row_list[rr] : rr;
         float a = 0.f;
         for (int64_t sg = row_seg_ptr[r]; sg < row_seg_ptr[r + 1]; sg++) a += part[(size_t)sg * ld + c];
         acc[t] = a;
@@ -734,22 +738,26 @@ int hpf_hip_colsum_f32(const float *tab, int64_t nrows, int ld, float *cs_partia
     return last_error();
 }
 
-int hpf_hip_expect_f32(const float *shp, const float *rte, float *e, int64_t nrows, int k, int ld, void *stream) {
-    if (!shp || !rte || !e || nrows <= 0 || k <= 0 || ld != hpf_hip_ld_for_k(k)) return HPF_EINVAL;
+int hpf_hip_expect_f32(const float *shp, const float *rte, float *e, const int64_t *row_list, int64_t nrows, int k,
+                       int ld, void *stream) {
+    if (nrows == 0) return 0;
+    if (!shp || !rte || !e || nrows < 0 || k <= 0 || ld != hpf_hip_ld_for_k(k)) return HPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int grid = clamp_grid((nrows + WPB - 1) / WPB, 2048);
-#define CALL(LD) hipLaunchKernelGGL((expect_kernel<LD>), dim3(grid), dim3(BLOCK), 0, st, shp, rte, e, nrows, k);
+#define CALL(LD) \
+    hipLaunchKernelGGL((expect_kernel<LD>), dim3(grid), dim3(BLOCK), 0, st, shp, rte, e, row_list, nrows, k);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
     return last_error();
 }
 
-int hpf_hip_segsum_f32(const float *part, const int64_t *row_seg_ptr, int64_t nrows, float *acc, int ld,
-                       void *stream) {
-    if (!part || !row_seg_ptr || !acc || nrows <= 0 || ld < 32) return HPF_EINVAL;
+int hpf_hip_segsum_f32(const float *part, const int64_t *row_seg_ptr, const int64_t *row_list, int64_t nrows,
+                       float *acc, int ld, void *stream) {
+    if (nrows == 0) return 0;
+    if (!part || !row_seg_ptr || !acc || nrows < 0 || ld < 32) return HPF_EINVAL;
     const int grid = clamp_grid((nrows * ld + BLOCK - 1) / BLOCK, 4096);
-    hipLaunchKernelGGL(segsum_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, part, row_seg_ptr, nrows, acc,
-                       ld);
+    hipLaunchKernelGGL(segsum_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, part, row_seg_ptr, row_list,
+                       nrows, acc, ld);
     return last_error();
 }
 

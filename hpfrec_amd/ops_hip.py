@@ -74,13 +74,13 @@ class HipOps:
         _lib.check(self.L.hpf_hip_colsum_f32(_ptr(tab), nrows, ld, _ptr(cs_partial), cs_partial.shape[0],
                                              self._stream()), "hpf_hip_colsum_f32")
 
-    def expect(self, shp, rte, e, nrows, k, ld):
-        _lib.check(self.L.hpf_hip_expect_f32(_ptr(shp), _ptr(rte), _ptr(e), nrows, k, ld, self._stream()),
-                   "hpf_hip_expect_f32")
+    def expect(self, shp, rte, e, nrows, k, ld, row_list=None):
+        _lib.check(self.L.hpf_hip_expect_f32(_ptr(shp), _ptr(rte), _ptr(e), _ptr(row_list), nrows, k, ld,
+                                             self._stream()), "hpf_hip_expect_f32")
 
-    def segsum(self, part, row_seg_ptr, nrows, acc, ld):
-        _lib.check(self.L.hpf_hip_segsum_f32(_ptr(part), _ptr(row_seg_ptr), nrows, _ptr(acc), ld, self._stream()),
-                   "hpf_hip_segsum_f32")
+    def segsum(self, part, row_seg_ptr, nrows, acc, ld, row_list=None):
+        _lib.check(self.L.hpf_hip_segsum_f32(_ptr(part), _ptr(row_seg_ptr), _ptr(row_list), nrows, _ptr(acc), ld,
+                                             self._stream()), "hpf_hip_segsum_f32")
 
     def pair_llk(self, T, B, ix_u, ix_i, y, k, ld, full_llk):
         """-> float64 tensor [3]: sum y*log(yhat) [- lgamma(y+1)], sum (y-yhat)^2, sum yhat."""

@@ -1,25 +1,360 @@
-"""Stochastic (mini-batch) paths: SVI epochs of fit_hpf (cython_loops.pxi:262-377), the Cython
-partial_fit (cython_loops.pxi:423-473) and the single-user fold-in (cython_loops.pxi:476-520).
+"""Stochastic (mini-batch) paths on the device: the SVI epochs of fit_hpf
+(/root/reference/hpfrec/cython_loops.pxi:262-377, "PXI"), the Cython partial_fit (PXI:423-473) and the
+single-user fold-in calc_user_factors (PXI:476-520) -- the "next" rows f1/f4 of SURVEY.md section 8.
 
-These are the "next" rows of SURVEY.md section 8f-1/8f-4; they reuse the sweep kernel with a
-row-list of segments and the atomic scatter variant.  Not implemented yet in this round: the
-functions raise instead of silently computing on the CPU.
+Division of labour in this round:
+  * O(batch_nnz * k): phi and both shape accumulations -> the same `sweep_kernel` as the full-batch
+    path, run over the batch's rows from both sides (two passes, no atomics, deterministic), plus the
+    row-list forms of `expect_kernel` / `segsum_kernel` (update_phi_csr PXI:666-692 always
+    max-subtracts; our E rows are max-normalised in every mode);
+  * O((nU+nI) * k) per batch: the reference recomputes whole tables with numpy statements every batch
+    (PXI:300,318,322 ...); here those statements are torch elementwise ops on the device tensors, in
+    the reference's order.  Fusing them into row kernels is left for a later round.
+No numerics run on the host; shuffles and seeds use numpy's generators so batches are the reference's.
 """
+import numpy as np
+import torch
+
+from . import _lib, layout
+
+_NAMES = ("Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "Theta", "Beta")
 
 
-def _todo(what):
-    raise NotImplementedError(
-        "hpfrec_amd: %s is not implemented on the HIP path yet (SURVEY.md section 8f); "
-        "full-batch fit (users_per_batch=None, items_per_batch=None) is." % what)
+class BatchSide:
+    """Segments over the rows touched by a batch (same fields the sweep launcher reads from SparseSide)."""
+
+    def __init__(self, rows, cols, y, seg_cap=layout.SEG_CAP):
+        """rows/cols: int64 device tensors of a COO batch; grouped by `rows` (stable)."""
+        order = torch.argsort(rows, stable=True)
+        r_s = rows[order]
+        self.rows, counts = torch.unique_consecutive(r_s, return_counts=True)   # rows present, ascending
+        self.idx = cols[order].to(torch.int32).contiguous()
+        self.y = y[order].to(torch.float32).contiguous()
+        indptr = torch.zeros(self.rows.shape[0] + 1, dtype=torch.int64, device=rows.device)
+        torch.cumsum(counts, 0, out=indptr[1:])
+        segs, self.row_seg_ptr = layout.build_segments(indptr, seg_cap)
+        if segs.shape[0] > 0:
+            local = segs[:, 1] >> 32
+            meta = (segs[:, 1] & 0xFFFFFFFF) & ~layout.SEG_WHOLE_ROW   # part[] is always wanted here
+            segs = torch.stack([segs[:, 0], meta | (self.rows[local] << 32)], dim=1).contiguous()
+        self.segs = segs
+        self.nseg = int(segs.shape[0])
+        self.nrows = int(self.rows.shape[0])
 
 
-def fit_hpf_svi(*args, **kwargs):
-    _todo("stochastic variational inference (users_per_batch / items_per_batch)")
+class DeviceModel:
+    """The variational state as padded device tables; `v(name)` is the [:, :k] view used by the dense algebra."""
+
+    def __init__(self, ops, k, nU, nI):
+        self.ops, self.k, self.ld = ops, int(k), _lib.ld_for_k(int(k))
+        self.nU, self.nI = int(nU), int(nI)
+        dev = ops.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        for n in ("Gamma_shp", "Gamma_rte", "Theta", "eT"):
+            setattr(self, n, torch.zeros((self.nU, self.ld), **f32))
+        for n in ("Lambda_shp", "Lambda_rte", "Beta", "eB"):
+            setattr(self, n, torch.zeros((self.nI, self.ld), **f32))
+        self.k_rte = torch.zeros(self.nU, **f32)
+        self.t_rte = torch.zeros(self.nI, **f32)
+        self._cs_part = torch.zeros((ops.finalize_grid(max(self.nU, self.nI)), self.ld), **f32)
+        self._cs = torch.zeros(self.ld, **f32)
+
+    def v(self, name):
+        return getattr(self, name)[:, : self.k]
+
+    def load(self, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta):
+        dev = self.ops.device
+        for n, a in zip(_NAMES, (Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, Theta, Beta)):
+            self.v(n).copy_(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev))
+        self.k_rte.copy_(torch.from_numpy(np.ascontiguousarray(k_rte, dtype=np.float32).reshape(-1)))
+        self.t_rte.copy_(torch.from_numpy(np.ascontiguousarray(t_rte, dtype=np.float32).reshape(-1)))
+
+    def store(self, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta):
+        for n, a in zip(_NAMES, (Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, Theta, Beta)):
+            a[:, :] = self.v(n).contiguous().cpu().numpy()
+        k_rte[:, :] = self.k_rte.cpu().numpy().reshape(-1, 1)
+        t_rte[:, :] = self.t_rte.cpu().numpy().reshape(-1, 1)
+
+    def colsum(self, name):
+        """tab.sum(axis=0) -> [k] (HIP colsum kernels; PXI:300,320,352,372)."""
+        tab = getattr(self, name)
+        self.ops.colsum(tab, tab.shape[0], self.ld, self._cs_part)
+        self.ops.colsum_reduce(self._cs_part, self._cs, self.ld)
+        return self._cs[: self.k].clone()
+
+    # ------------------------------------------------------------------------------------------
+    def batch_phi_sums(self, bu, bi, by):
+        """sum_n phi_n over the batch's nonzeros, grouped by user and by item (update_phi[_csr] +
+        update_G_n_L_sh[_csr] restricted to the batch), from the CURRENT shapes/rates.
+        Returns (users_present, sum_phi_users [nu,k], items_present, sum_phi_items [ni,k])."""
+        ops, k, ld = self.ops, self.k, self.ld
+        su = BatchSide(bu, bi, by)
+        si = BatchSide(bi, bu, by)
+        ops.expect(self.Gamma_shp, self.Gamma_rte, self.eT, su.nrows, k, ld, row_list=su.rows)
+        ops.expect(self.Lambda_shp, self.Lambda_rte, self.eB, si.nrows, k, ld, row_list=si.rows)
+        out = []
+        for side, e_self, e_other in ((su, self.eT, self.eB), (si, self.eB, self.eT)):
+            part = torch.empty((max(1, side.nseg), ld), dtype=torch.float32, device=ops.device)
+            ops.sweep(side, e_self, e_other, part, k, ld)
+            acc = torch.empty((max(1, side.nrows), ld), dtype=torch.float32, device=ops.device)
+            ops.segsum(part, side.row_seg_ptr, side.nrows, acc, ld)
+            out += [side.rows, (e_self[side.rows] * acc[: side.nrows])[:, :k]]
+        return tuple(out)
 
 
-def partial_fit_step(*args, **kwargs):
-    _todo("partial_fit")
+def _svi_step(m, hy, bu, bi, by, users_tb, items_tb, step, mult, user_batch, all_scalar_rows):
+    """One stochastic update in the reference's statement order (user batch: PXI:292-325 / 438-473;
+    item batch: PXI:344-377).  `hy` carries a, c, k_shp, t_shp, add_k_rte, add_t_rte as python floats."""
+    step_prev = float(np.float32(1) - np.float32(step))
+    step = float(np.float32(step))
+    mult = float(np.float32(mult))
+    up, phi_u, ip, phi_i = m.batch_phi_sums(bu, bi, by)           # phi from the OLD parameters
+    G_shp, G_rte, L_shp, L_rte = m.v("Gamma_shp"), m.v("Gamma_rte"), m.v("Lambda_shp"), m.v("Lambda_rte")
+    Theta, Beta = m.v("Theta"), m.v("Beta")
+    if user_batch:
+        G_rte.copy_(hy["k_shp"] / m.k_rte[:, None] + m.colsum("Beta")[None, :])
+        prev = L_shp[items_tb].clone()
+    else:
+        L_rte.copy_(hy["t_shp"] / m.t_rte[:, None] + m.colsum("Theta")[None, :])
+        prev = G_shp[users_tb].clone()
+    G_shp[users_tb] = hy["a"]
+    L_shp[items_tb] = hy["c"]
+    G_shp[up] += phi_u
+    L_shp[ip] += phi_i
+    if user_batch:
+        L_shp[items_tb] = step * mult * L_shp[items_tb] + step_prev * prev
+        Theta.copy_(G_shp / G_rte)
+        L_rte[items_tb] = step * (hy["t_shp"] / m.t_rte[items_tb][:, None] + m.colsum("Theta")[None, :]) \
+            + step_prev * L_rte[items_tb]
+        Beta.copy_(L_shp / L_rte)
+    else:
+        G_shp[users_tb] = step * mult * G_shp[users_tb] + step_prev * prev
+        Beta.copy_(L_shp / L_rte)
+        G_rte[users_tb] = step * (hy["k_shp"] / m.k_rte[users_tb][:, None] + m.colsum("Beta")[None, :]) \
+            + step_prev * G_rte[users_tb]
+        Theta.copy_(G_shp / G_rte)
+    if all_scalar_rows:   # partial_fit blends every row (PXI:472-473)
+        m.k_rte.copy_(step * (hy["add_k_rte"] + Theta.sum(dim=1)) + step_prev * m.k_rte)
+        m.t_rte.copy_(step * (hy["add_t_rte"] + Beta.sum(dim=1)) + step_prev * m.t_rte)
+    else:                 # SVI epochs only the batch rows (PXI:324-325, 376-377)
+        m.k_rte[users_tb] = step * (hy["add_k_rte"] + Theta[users_tb].sum(dim=1)) + step_prev * m.k_rte[users_tb]
+        m.t_rte[items_tb] = step * (hy["add_t_rte"] + Beta[items_tb].sum(dim=1)) + step_prev * m.t_rte[items_tb]
 
 
-def calc_user_factors(*args, **kwargs):
-    _todo("predict_factors / add_user fold-in")
+def _dev_ids(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a).astype(np.int64)).to(dev)
+
+
+# -- PXI:423-473 ------------------------------------------------------------------------------------
+def partial_fit_step(ops, Y_batch, ix_u_batch, ix_i_batch, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp,
+                     Lambda_rte, k_rte, t_rte, add_k_rte, add_t_rte, a, c, k_shp, t_shp, k, users_this_batch,
+                     items_this_batch, step_size_batch, multiplier_batch, user_batch):
+    nU, nI = Theta.shape[0], Beta.shape[0]
+    if ix_u_batch.size and (int(ix_u_batch.max()) >= nU or int(ix_i_batch.max()) >= nI):
+        raise ValueError("partial_fit: user/item id out of range")
+    m = DeviceModel(ops, k, nU, nI)
+    m.load(Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta)
+    dev = ops.device
+    hy = {"a": float(np.float32(a)), "c": float(np.float32(c)), "k_shp": float(np.float32(k_shp)),
+          "t_shp": float(np.float32(t_shp)), "add_k_rte": float(np.float32(add_k_rte)),
+          "add_t_rte": float(np.float32(add_t_rte))}
+    _svi_step(m, hy, _dev_ids(ix_u_batch, dev), _dev_ids(ix_i_batch, dev),
+              torch.from_numpy(np.ascontiguousarray(Y_batch, dtype=np.float32)).to(dev),
+              _dev_ids(users_this_batch, dev), _dev_ids(items_this_batch, dev), step_size_batch, multiplier_batch,
+              user_batch, all_scalar_rows=True)
+    m.store(Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta)
+
+
+# -- PXI:262-377 (+ the shared convergence tail PXI:380-418) ---------------------------------------------
+def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, maxiter,
+                stop_crit, check_every, stop_thr, users_per_batch, items_per_batch, step_size, save_folder,
+                random_seed, verbose, has_valset, Yval, ix_u_val, ix_i_val, full_llk, keep_all_objs, make_ops):
+    from . import cython_loops_float as be   # printing helpers and save_parameters
+    import time
+    ops = make_ops()
+    dev = ops.device
+    nU, k = Theta.shape
+    nI = Beta.shape[0]
+    m = DeviceModel(ops, k, nU, nI)
+    m.load(Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta)
+    hyd = {"a": float(hy.a), "c": float(hy.c), "k_shp": float(hy.k_shp), "t_shp": float(hy.t_shp),
+           "add_k_rte": float(hy.add_k_rte), "add_t_rte": float(hy.add_t_rte)}
+
+    tu = _dev_ids(ix_u, dev)
+    ti = _dev_ids(ix_i, dev)
+    ty = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(dev)
+    users, items, u_sorted = layout.build_sides(tu, ti, ty, nU, nI)
+
+    def gather_rows(side, rows):
+        """COO triplets (row, col, y) of the listed rows of a SparseSide."""
+        st = side.indptr[rows]
+        deg = side.indptr[rows + 1] - st
+        total = int(deg.sum().item())
+        offs = torch.cumsum(deg, 0) - deg
+        pos = torch.repeat_interleave(st - offs, deg, output_size=total) + torch.arange(total, device=dev)
+        return (torch.repeat_interleave(rows, deg, output_size=total), side.idx[pos].to(torch.int64), side.y[pos])
+
+    val = None
+    if has_valset and Yval is not None and Yval.shape[0] > 0:
+        val = (_dev_ids(ix_u_val, dev).to(torch.int32), _dev_ids(ix_i_val, dev).to(torch.int32),
+               torch.from_numpy(np.ascontiguousarray(Yval, dtype=np.float32)).to(dev))
+
+    users_numeration = np.arange(nU, dtype=np.uint64) if users_per_batch != 0 else None
+    items_numeration = np.arange(nI, dtype=np.uint64) if items_per_batch > 0 else None
+    nbatches_u = int(np.ceil(float(nU) / float(users_per_batch))) if users_per_batch != 0 else 0
+    nbatches_i = int(np.ceil(float(nI) / float(items_per_batch))) if items_per_batch > 0 else 0
+    rng = np.random.default_rng(seed=random_seed if random_seed > 0 else None)   # PXI:207
+
+    errs = np.zeros(2, dtype=np.longdouble)
+    last_crit = -np.inf
+    Theta_prev = m.Theta.clone() if stop_crit == "diff-norm" else None
+
+    def evaluate(final=False):
+        if val is not None:
+            t = ops.pair_llk(m.Theta, m.Beta, val[0], val[1], val[2], k, m.ld, full_llk).cpu().numpy()
+            if final:
+                sub = float(np.dot(m.v("Theta")[val[0].long()].sum(dim=0).cpu().numpy(),
+                                   m.v("Beta")[val[1].long()].sum(dim=0).cpu().numpy()))
+            else:
+                sub = t[2]
+            errs[0] = np.longdouble(t[0]) - np.longdouble(sub)
+            errs[1] = np.sqrt(np.longdouble(t[1]) / val[0].shape[0])
+        else:
+            t = ops.pair_llk(m.Theta, m.Beta, u_sorted, users.idx, users.y, k, m.ld, full_llk).cpu().numpy()
+            sub = np.dot(m.colsum("Theta").cpu().numpy(), m.colsum("Beta").cpu().numpy())
+            errs[0] = np.longdouble(t[0]) - np.longdouble(sub)
+            errs[1] = np.sqrt(np.longdouble(t[1]) / users.nnz)
+
+    if verbose > 0:
+        print("Initializing optimization procedure...")
+    st_time = time.time()
+    i = -1
+    for i in range(maxiter):
+        step = float(np.float32(step_size(i)))
+        if users_per_batch > 0 and items_per_batch > 0:
+            user_epoch = ((i + 1) % 2) == 0        # PXI:265-269: epoch 0 is an item epoch
+        else:
+            user_epoch = users_per_batch > 0
+        if user_epoch:
+            rng.shuffle(users_numeration)
+            for bt in range(nbatches_u):
+                ids = users_numeration[bt * users_per_batch: min(nU, (bt + 1) * users_per_batch)]
+                mult = float(nU) / float(ids.shape[0])
+                rows = _dev_ids(ids, dev)
+                bu, bi, by = gather_rows(users, rows)
+                items_tb = torch.unique(bi)
+                _svi_step(m, hyd, bu, bi, by, rows, items_tb, step, mult, True, all_scalar_rows=False)
+        else:
+            rng.shuffle(items_numeration)
+            for bt in range(nbatches_i):
+                ids = items_numeration[bt * items_per_batch: min(nI, (bt + 1) * items_per_batch)]
+                mult = float(nI) / float(ids.shape[0])
+                rows = _dev_ids(ids, dev)
+                bi, bu, by = gather_rows(items, rows)
+                users_tb = torch.unique(bu)
+                _svi_step(m, hyd, bu, bi, by, users_tb, rows, step, mult, False, all_scalar_rows=False)
+
+        if check_every > 0 and ((i + 1) % check_every) == 0:
+            if stop_crit == "diff-norm":
+                d = (m.Theta - Theta_prev).double()
+                last_crit = float(torch.sqrt((d * d).sum()).item())
+                if verbose:
+                    be._print_norm_diff(i + 1, check_every, last_crit)
+                if last_crit < stop_thr:
+                    break
+                Theta_prev.copy_(m.Theta)
+            else:
+                evaluate()
+                if verbose:
+                    be._print_llk_iter(i + 1, errs[0], float(errs[1]), has_valset)
+                if stop_crit != "maxiter":
+                    if (i + 1) == check_every:
+                        last_crit = errs[0]
+                    else:
+                        if (1.0 - errs[0] / last_crit) <= stop_thr:
+                            break
+                        last_crit = errs[0]
+
+    last_llk = None
+    if stop_crit in ("diff-norm", "maxiter") and verbose > 0:
+        evaluate(final=True)
+        last_llk = errs[0]
+    if verbose:
+        be._print_final_msg(i + 1, errs[0], float(errs[1]), (time.time() - st_time) / 60.0)
+
+    m.store(Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta)
+    temp = (Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte)
+    if save_folder != "":
+        be.save_parameters(verbose, save_folder,
+                           ["Theta", "Beta", "Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "kappa_rte", "tau_rte"],
+                           [Theta, Beta] + list(temp))
+    return i, (temp if keep_all_objs else None), last_llk
+
+
+# -- PXI:476-520 ------------------------------------------------------------------------------------
+def calc_user_factors(ops, a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_i, Theta, Beta, Lambda_shp, Lambda_rte,
+                      nY, k, maxiter, random_seed, stop_thr, return_all):
+    """Local CAVI for ONE user with the item parameters fixed.  Fills `Theta` (k,) in place; returns
+    (Gamma_shp, Gamma_rte, phi/Y) when return_all else None."""
+    f = np.float32
+    dev = ops.device
+    ld = _lib.ld_for_k(k)
+    a, a_prime, b_prime = f(a), f(a_prime), f(b_prime)
+    k_shp = f(a_prime + f(k) * a)
+    add_k_rte = f(a_prime / b_prime)
+    # initialisation: numpy default_rng stream, in the reference's draw order (PXI:490-497)
+    rng = np.random.default_rng(seed=random_seed if random_seed > 0 else None)
+    Theta[:] = rng.gamma(a, 1 / b_prime, size=k).astype(np.float32)
+    k_rte = f(b_prime + Theta.sum())
+    Beta_dev = torch.zeros((Beta.shape[0], ld), dtype=torch.float32, device=dev)
+    Beta_dev[:, :k] = torch.from_numpy(np.ascontiguousarray(Beta, dtype=np.float32)).to(dev)
+    csp = torch.zeros((ops.finalize_grid(Beta.shape[0]), ld), dtype=torch.float32, device=dev)
+    cs = torch.zeros(ld, dtype=torch.float32, device=dev)
+    ops.colsum(Beta_dev, Beta.shape[0], ld, csp)
+    ops.colsum_reduce(csp, cs, ld)
+    csB = cs[:k].cpu().numpy()                                   # Beta.sum(axis=0)
+    Gamma_rte = rng.gamma(a_prime, b_prime / a_prime, size=1).astype(np.float32) + csB
+    Gamma_shp = Gamma_rte * Theta * rng.uniform(low=.85, high=1.15, size=k).astype(np.float32)
+    np.nan_to_num(Gamma_shp, copy=False)
+    np.nan_to_num(Gamma_rte, copy=False)
+
+    # the user's items, renumbered 0..nY-1; only those rows of the item tables go to the device
+    ix = np.ascontiguousarray(ix_i).astype(np.int64)
+    n = int(nY)
+    Ls = torch.zeros((n, ld), dtype=torch.float32, device=dev)
+    Lr = torch.zeros((n, ld), dtype=torch.float32, device=dev)
+    Ls[:, :k] = torch.from_numpy(np.ascontiguousarray(Lambda_shp[ix], dtype=np.float32)).to(dev)
+    Lr[:, :k] = torch.from_numpy(np.ascontiguousarray(Lambda_rte[ix], dtype=np.float32)).to(dev)
+    eB = torch.zeros((n, ld), dtype=torch.float32, device=dev)
+    ops.expect(Ls, Lr, eB, n, k, ld)
+    side = BatchSide(torch.zeros(n, dtype=torch.int64, device=dev), torch.arange(n, dtype=torch.int64, device=dev),
+                     torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(dev))
+    Gs = torch.zeros((1, ld), dtype=torch.float32, device=dev)
+    Gr = torch.zeros((1, ld), dtype=torch.float32, device=dev)
+    eT = torch.zeros((1, ld), dtype=torch.float32, device=dev)
+    part = torch.zeros((max(1, side.nseg), ld), dtype=torch.float32, device=dev)
+    acc = torch.zeros((1, ld), dtype=torch.float32, device=dev)
+    Gs[0, :k] = torch.from_numpy(Gamma_shp).to(dev)
+    Gr[0, :k] = torch.from_numpy(Gamma_rte).to(dev)
+    th = torch.from_numpy(Theta.copy()).to(dev)
+    th_prev = th.clone()
+    csB_dev = cs[:k]
+    k_rte_d = torch.tensor(float(k_rte), dtype=torch.float32, device=dev)
+    for _ in range(maxiter):
+        ops.expect(Gs, Gr, eT, 1, k, ld)                          # phi from the current Gamma (PXI:505)
+        ops.sweep(side, eT, eB, part, k, ld)
+        ops.segsum(part, side.row_seg_ptr, 1, acc, ld)
+        Gr[0, :k] = float(k_shp) / k_rte_d + csB_dev              # PXI:507
+        Gs[0, :k] = float(a) + (eT[0] * acc[0])[:k]               # PXI:508: a + phi.sum(axis=0)
+        th = Gs[0, :k] / Gr[0, :k]
+        k_rte_d = float(add_k_rte) + th.sum()
+        if float(torch.linalg.norm(th - th_prev)) < stop_thr:
+            break
+        th_prev = th.clone()
+    Theta[:] = th.cpu().numpy()
+    if not return_all:
+        return None
+    # phi / Y: the multinomial probabilities of the LAST phi (computed from the Gamma before its final update)
+    prob = eT[0][None, :] * eB
+    prob = (prob / prob.sum(dim=1, keepdim=True))[:, :k]
+    return Gs[0, :k].cpu().numpy(), Gr[0, :k].cpu().numpy(), prob.contiguous().cpu().numpy()

@@ -117,12 +117,15 @@ int hpf_hip_colsum_reduce_f32(const float *cs_partial, int nblk, float *cs_out, 
 int hpf_hip_colsum_f32(const float *tab, int64_t nrows, int ld, float *cs_partial, int grid_blocks, void *stream);
 
 /* e[r] = exp(psi(shp[r]) - log(rte[r])) / rowmax, pads zeroed: the hoisted transcendental part of
- * update_phi (PXI:570,588) for rows whose shape/rate came from the host (initialisation, PXI:134-138). */
-int hpf_hip_expect_f32(const float *shp, const float *rte, float *e, int64_t nrows, int k, int ld, void *stream);
+ * update_phi (PXI:570,588,685) for rows whose shape/rate did not come out of hpf_hip_row_finalize_f32
+ * (initialisation PXI:134-138; the rows of an SVI batch).  r = row_list ? row_list[t] : t, t < nrows. */
+int hpf_hip_expect_f32(const float *shp, const float *rte, float *e, const int64_t *row_list, int64_t nrows, int k,
+                       int ld, void *stream);
 
-/* acc[r] = sum of the row's part[] segments (multi-GPU item side, before the all-reduce). */
-int hpf_hip_segsum_f32(const float *part, const int64_t *row_seg_ptr, int64_t nrows, float *acc, int ld,
-                       void *stream);
+/* acc[t] = sum of the part[] segments of row r = row_list ? row_list[t] : t, t < nrows (multi-GPU item
+ * side before the all-reduce; the batch rows of an SVI step). */
+int hpf_hip_segsum_f32(const float *part, const int64_t *row_seg_ptr, const int64_t *row_list, int64_t nrows,
+                       float *acc, int ld, void *stream);
 
 /*
  * Poisson log-likelihood terms over listed pairs.  Replaces llk_plus_rmse (PXI:627-658)

@@ -116,21 +116,26 @@ class CpuOps:
         cp[:] = 0
         cp[0] = _np(tab)[:nrows].astype(np.float64).sum(axis=0).astype(np.float32)
 
-    def expect(self, shp, rte, e, nrows, k, ld):
+    def expect(self, shp, rte, e, nrows, k, ld, row_list=None):
+        rows = np.arange(nrows) if row_list is None else _np(row_list)[:nrows].astype(np.int64)
+        if rows.shape[0] == 0:
+            return
         valid = np.arange(ld) < k
         with np.errstate(divide="ignore", invalid="ignore"):
-            E = sp.psi(_np(shp).astype(np.float64)) - np.log(_np(rte).astype(np.float64))
+            E = sp.psi(_np(shp).astype(np.float64)[rows]) - np.log(_np(rte).astype(np.float64)[rows])
         E = np.where(valid[None, :], E, -np.inf)
         E = E - E.max(axis=1, keepdims=True)
-        _np(e)[:] = np.exp(E).astype(np.float32)
+        _np(e)[rows] = np.exp(E).astype(np.float32)
 
-    def segsum(self, part, row_seg_ptr, nrows, acc, ld):
+    def segsum(self, part, row_seg_ptr, nrows, acc, ld, row_list=None):
+        rows = np.arange(nrows) if row_list is None else _np(row_list)[:nrows].astype(np.int64)
         rsp = _np(row_seg_ptr)
-        out = np.zeros((nrows, ld))
-        nz = rsp[1:] > rsp[:-1]
-        if nz.any():
-            out[nz] = np.add.reduceat(_np(part).astype(np.float64)[: rsp[-1]], rsp[:-1][nz], axis=0)
-        _np(acc)[:] = out.astype(np.float32)
+        P = _np(part).astype(np.float64)
+        out = np.zeros((rows.shape[0], ld))
+        for t, r in enumerate(rows):
+            if rsp[r + 1] > rsp[r]:
+                out[t] = P[rsp[r]: rsp[r + 1]].sum(axis=0)
+        _np(acc)[: rows.shape[0]] = out.astype(np.float32)
 
     def pair_llk(self, T, B, ix_u, ix_i, y, k, ld, full_llk):
         Tn = _np(T).astype(np.float64)[_np(ix_u).astype(np.int64)]

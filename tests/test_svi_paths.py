@@ -1,0 +1,105 @@
+"""Stochastic paths: partial_fit, SVI epochs, fold-in -- against the reference's
+golden vectors (tests/golden/c1_partial_fit.npz, c1_svi.npz, c1_predict.npz; ncores=1 captures).
+Each test body runs twice: on the numpy stand-in ops (host logic, no GPU) and on the HIP path (-m gpu)."""
+import os
+import warnings
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import datagen
+from conftest import GOLDEN
+from hpfrec_amd import HPF
+
+NAMES = ("Theta", "Beta", "Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "k_rte", "t_rte")
+
+
+def _maxrel(a, b):
+    return float(np.max(np.abs(a - b) / np.abs(b)))
+
+
+def _partial_fit_sequence():
+    batches, nU, nI = datagen.partial_fit_batches()
+    g = np.load(os.path.join(GOLDEN, "c1_partial_fit.npz"))
+    m = HPF(k=30, reindex=False, keep_data=False, random_seed=123, ncores=1)
+    for b, (kind, bdf) in enumerate(batches):
+        kw = dict(nusers=nU, nitems=nI) if b == 0 else {}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            assert m.partial_fit(bdf.copy(), batch_type=kind, **kw) is m
+        assert m.niter == int(g["call%d_niter" % (b + 1)]) and m.is_fitted
+        for n in NAMES:
+            assert getattr(m, n).shape == g["call%d_%s" % (b + 1, n)].shape
+            assert _maxrel(getattr(m, n), g["call%d_%s" % (b + 1, n)]) < 2e-5, (b, n)
+    # fresh model with the default keep_data=True: the reference crashes with NameError (INIT:799);
+    # here the evidently intended warning is issued and keep_data is switched off
+    m2 = HPF(k=5, reindex=False, random_seed=1)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m2.partial_fit(batches[0][1].copy(), nusers=nU, nitems=nI)
+    assert m2.keep_data is False and any("keep_data" in str(x.message) for x in w)
+    with pytest.raises(ValueError):
+        HPF(reindex=True).partial_fit(batches[0][1].copy(), nusers=nU, nitems=nI)
+
+
+def _svi_fits():
+    df, nU, nI = datagen.readme_counts()
+    g = np.load(os.path.join(GOLDEN, "c1_svi.npz"))
+    for tag, kw in (("both", dict(users_per_batch=20, items_per_batch=25)), ("users", dict(users_per_batch=30)),
+                    ("items", dict(items_per_batch=40))):
+        m = HPF(k=30, maxiter=4, random_seed=123, ncores=1, reindex=False, verbose=False, check_every=None, **kw)
+        m.fit(df.copy())
+        assert m.niter == 3
+        for n in NAMES:
+            # 4 epochs x several batches of chaotic amplification; expf vs exp in the reference's CSR phi
+            assert _maxrel(getattr(m, n), g["%s_%s" % (tag, n)]) < 1e-4, (tag, n)
+        # topN with exclude_seen still works after an SVI fit (the user index is kept, INIT:420-424)
+        assert len(m.topN(user=3, n=5)) == 5
+
+
+def _fold_in():
+    df, nU, nI = datagen.readme_counts()
+    gp = np.load(os.path.join(GOLDEN, "c1_predict.npz"))
+    m = HPF(k=30, maxiter=20, random_seed=123, reindex=False, verbose=False, check_every=None).fit(df.copy())
+    new = pd.DataFrame({"ItemId": gp["new_user_items"], "Count": gp["new_user_counts"]})
+    th = m.predict_factors(new.copy(), random_seed=1)
+    assert th.shape == (30,) and _maxrel(th, gp["predict_factors"]) < 2e-4
+    th2, gs, gr, phi = m.predict_factors(new.copy(), random_seed=1, return_all=True)
+    assert np.allclose(th2, th, rtol=1e-6) and phi.shape == (new.shape[0], 30)
+    assert np.allclose(phi.sum(axis=1), 1.0, atol=1e-5) and np.allclose(gs / gr, th, rtol=1e-5)
+    # add_user: new user appended, then refreshed in place
+    nu0 = m.Theta.shape[0]
+    assert m.add_user(user_id=nU + 1, counts_df=new.copy()) is True
+    assert m.Theta.shape[0] == nu0 + 1 and m.Gamma_shp.shape[0] == nu0 + 1 and m.k_rte.shape == (nu0 + 1, 1)
+    assert len(m.topN(user=nu0, n=5)) == 5
+    before = m.Theta[7].copy()
+    assert m.add_user(user_id=7, counts_df=new.copy(), update_existing=True)
+    assert not np.allclose(before, m.Theta[7])
+
+
+def test_partial_fit_on_standin(cpu_ops_backend):
+    _partial_fit_sequence()
+
+
+def test_svi_on_standin(cpu_ops_backend):
+    _svi_fits()
+
+
+def test_fold_in_on_standin(cpu_ops_backend):
+    _fold_in()
+
+
+@pytest.mark.gpu
+def test_partial_fit_on_gpu(hip_backend):
+    _partial_fit_sequence()
+
+
+@pytest.mark.gpu
+def test_svi_on_gpu(hip_backend):
+    _svi_fits()
+
+
+@pytest.mark.gpu
+def test_fold_in_on_gpu(hip_backend):
+    _fold_in()
