@@ -733,16 +733,11 @@ class HPF:
             return self.item_mapping_[ids] if self.reindex else ids
 
         if items_pool is None:
-            neg = -(self.Theta[user].dot(self.Beta.T))
-            nitems = self.Beta.shape[0]
-            if exclude_seen:
-                n_ext = int(min(n + self._n_seen_by_user[user], nitems))
-                cand = np.argpartition(neg, n_ext - 1)[:n_ext]
-                cand = np.setdiff1d(cand, self._seen_by(user))
-                return back(cand[np.argsort(neg[cand])[:n]])
-            n = int(min(n, nitems))
-            cand = np.argpartition(neg, n - 1)[:n]
-            return back(cand[np.argsort(neg[cand])])
+            # device path: GEMV over the (cached) item table + mask + top-k; same ids as the reference's
+            # argpartition/setdiff1d/argsort sequence (INIT:1337-1356), ties aside
+            be = self._backend()
+            rec = be.top_items(self.Theta[user], self.Beta, n, self._seen_by(user) if exclude_seen else None)
+            return back(rec)
 
         items_pool = np.require(items_pool, requirements=["ENSUREARRAY"]).reshape(-1)
         pool = items_pool

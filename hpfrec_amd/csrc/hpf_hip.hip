@@ -601,6 +601,34 @@ __global__ __launch_bounds__(BLOCK) void pair_dot_kernel(const float *__restrict
     }
 }
 
+// out[r] = <vec, tab[r]> for every row r: the scoring GEMV of HPF.topN (INIT:1337: Theta[user].dot(Beta.T))
+template <int LPR, int VPL>
+__global__ __launch_bounds__(BLOCK) void score_rows_kernel(const float *__restrict__ vec,
+                                                           const float *__restrict__ tab, int64_t nrows,
+                                                           float *__restrict__ out) {
+    constexpr int LD = 4 * LPR * VPL;
+    constexpr int NG = WAVE / LPR;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int g = lane / LPR, j = lane % LPR;
+    const int wid = threadIdx.x >> 6;
+    float4 v[VPL];
+#pragma unroll
+    for (int q = 0; q < VPL; q++) v[q] = reinterpret_cast<const float4 *>(vec)[q * LPR + j];
+    const int64_t ngroups = (int64_t)gridDim.x * WPB * NG;
+    const int64_t gid = ((int64_t)blockIdx.x * WPB + wid) * NG + g;
+    const int64_t iters = (nrows + ngroups - 1) / ngroups;
+    for (int64_t it = 0; it < iters; it++) {
+        const int64_t r = it * ngroups + gid;
+        const bool live = r < nrows;
+        const float4 *tp = reinterpret_cast<const float4 *>(tab + (size_t)(live ? r : 0) * LD);
+        float p = 0.f;
+#pragma unroll
+        for (int q = 0; q < VPL; q++) p += dot4(v[q], tp[q * LPR + j]);
+        p = group_sum<LPR>(p);
+        if (live && j == 0) out[r] = p;
+    }
+}
+
 inline int clamp_grid(int64_t want, int grid_blocks) {
     int64_t g = grid_blocks > 0 ? grid_blocks : 2048;
     if (want < g) g = want;
@@ -788,6 +816,21 @@ int hpf_hip_pair_dot_f32(const float *T, const float *B, const int32_t *ix_u, co
     {                                                                                                           \
         const int grid = clamp_grid((n + (WPB * (WAVE / LPR)) - 1) / (WPB * (WAVE / LPR)), 2048);              \
         hipLaunchKernelGGL((pair_dot_kernel<LPR, VPL>), dim3(grid), dim3(BLOCK), 0, st, T, B, ix_u, ix_i, n, out); \
+    }
+    HPF_DISPATCH_LD(ld, CALL)
+#undef CALL
+    return last_error();
+}
+
+int hpf_hip_score_rows_f32(const float *vec, const float *tab, int64_t nrows, float *out, int k, int ld,
+                           void *stream) {
+    if (nrows == 0) return 0;
+    if (!vec || !tab || !out || nrows < 0 || k <= 0 || ld != hpf_hip_ld_for_k(k)) return HPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(LPR, VPL)                                                                                         \
+    {                                                                                                          \
+        const int grid = clamp_grid((nrows + (WPB * (WAVE / LPR)) - 1) / (WPB * (WAVE / LPR)), 2048);         \
+        hipLaunchKernelGGL((score_rows_kernel<LPR, VPL>), dim3(grid), dim3(BLOCK), 0, st, vec, tab, nrows, out); \
     }
     HPF_DISPATCH_LD(ld, CALL)
 #undef CALL

@@ -211,8 +211,11 @@ def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta
     st_time = time.time()
     i = -1
     for i in range(maxiter):
-        model.iterate()
-        if check_every > 0 and ((i + 1) % check_every) == 0:
+        is_check = check_every > 0 and ((i + 1) % check_every) == 0
+        # Gamma/Lambda shape+rate tables are outputs only: written on check iterations (the loop may
+        # stop there) and on the last one; Theta/Beta/k_rte/t_rte are current after every iteration
+        model.iterate(store=(is_check or i == maxiter - 1))
+        if is_check:
             if stop_crit == "diff-norm":
                 last_crit = eng.theta_norm_diff(Theta_prev)
                 if verbose:
@@ -277,18 +280,31 @@ def partial_fit(Y_batch, ix_u_batch, ix_i_batch, Theta, Beta, Gamma_shp, Gamma_r
                          users_this_batch, items_this_batch, step_size_batch, multiplier_batch, bool(user_batch))
 
 
+def _pair_operands(M1, M2, ix_u, ix_i, dev):
+    """Device operands for the listed-pair kernels.  Few pairs relative to the tables: ship only the
+    rows the pairs touch (host-side row gather is indexing, not arithmetic); many pairs: ship the tables."""
+    k = int(M1.shape[1])
+    ld = cavi._lib.ld_for_k(k)
+    n = int(ix_u.shape[0])
+    iu = np.ascontiguousarray(ix_u).astype(np.int64)
+    ii = np.ascontiguousarray(ix_i).astype(np.int64)
+    if n and (int(iu.max()) >= M1.shape[0] or int(ii.max()) >= M2.shape[0]):
+        raise ValueError("user/item id out of range")
+    if 2 * n < M1.shape[0] + M2.shape[0]:
+        T = _padded(M1[iu], ld, dev)
+        B = _padded(M2[ii], ld, dev)
+        ar = torch.arange(n, dtype=torch.int32, device=dev)
+        return T, B, ar, ar, k, ld
+    return (_padded(M1, ld, dev), _padded(M2, ld, dev), torch.from_numpy(iu).to(dev).to(torch.int32),
+            torch.from_numpy(ii).to(dev).to(torch.int32), k, ld)
+
+
 # -- PXI:525-534 --------------------------------------------------------------------------
 def calc_llk(Y, ix_u, ix_i, Theta, Beta, k, nthreads, full_llk):
     """sum_n Y_n log(yhat_n) [- lgamma(Y_n+1)] - sum_n yhat_n over the listed pairs (HPF.eval_llk)."""
     ops = _make_ops()
-    dev = ops.device
-    k = int(k)
-    ld = cavi._lib.ld_for_k(k)
-    T = _padded(Theta, ld, dev)
-    B = _padded(Beta, ld, dev)
-    iu = _as_index_tensor(ix_u, Theta.shape[0], "UserId").to(dev).to(torch.int32)
-    ii = _as_index_tensor(ix_i, Beta.shape[0], "ItemId").to(dev).to(torch.int32)
-    y = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(dev)
+    T, B, iu, ii, k, ld = _pair_operands(Theta, Beta, ix_u, ix_i, ops.device)
+    y = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(ops.device)
     t = ops.pair_llk(T, B, iu, ii, y, k, ld, bool(full_llk)).cpu().numpy()
     return np.longdouble(t[0]) - np.longdouble(t[2])
 
@@ -296,14 +312,8 @@ def calc_llk(Y, ix_u, ix_i, Theta, Beta, k, nthreads, full_llk):
 # -- PXI:538-543 --------------------------------------------------------------------------
 def predict_arr(M1, M2, ix_u, ix_i, nthreads):
     ops = _make_ops()
-    dev = ops.device
-    k = int(M1.shape[1])
-    ld = cavi._lib.ld_for_k(k)
-    T = _padded(M1, ld, dev)
-    B = _padded(M2, ld, dev)
-    iu = _as_index_tensor(ix_u, M1.shape[0], "UserId").to(dev).to(torch.int32)
-    ii = _as_index_tensor(ix_i, M2.shape[0], "ItemId").to(dev).to(torch.int32)
-    out = torch.zeros(iu.shape[0], dtype=torch.float32, device=dev)
+    T, B, iu, ii, k, ld = _pair_operands(M1, M2, ix_u, ix_i, ops.device)
+    out = torch.zeros(iu.shape[0], dtype=torch.float32, device=ops.device)
     ops.pair_dot(T, B, iu, ii, out, k, ld)
     return out.cpu().numpy()
 
@@ -313,6 +323,45 @@ def _padded(host_arr, ld, dev):
     t = torch.zeros((n, ld), dtype=torch.float32, device=dev)
     t[:, :k] = torch.from_numpy(np.ascontiguousarray(host_arr, dtype=np.float32)).to(dev)
     return t
+
+
+# -- not in the reference's extension: the scoring product of HPF.topN (hpfrec/__init__.py:1337-1356) ----
+_ITEM_CACHE = {}
+
+
+def _fingerprint(arr):
+    flat = arr.reshape(-1)
+    step = max(1, flat.shape[0] // 2048)
+    return (id(arr), arr.shape, flat[::step].tobytes())
+
+
+def top_items(theta_row, Beta, n, exclude=None):
+    """Ids of the n rows of Beta with the largest theta_row . Beta[i], best first, optionally skipping
+    `exclude` (ids).  The item table is kept on the device between calls (keyed on a fingerprint of
+    the host array) so a query costs one GEMV over Beta, a mask and a top-k -- the reference does a host
+    GEMV + argpartition + setdiff1d + argsort per query."""
+    ops = _make_ops()
+    dev = ops.device
+    k = int(Beta.shape[1])
+    ld = cavi._lib.ld_for_k(k)
+    key = _fingerprint(Beta)
+    hit = _ITEM_CACHE.get("Beta")
+    if hit is None or hit[0] != key or hit[1].device != dev:
+        _ITEM_CACHE["Beta"] = hit = (key, _padded(Beta, ld, dev))
+    tab = hit[1]
+    vec = torch.zeros(ld, dtype=torch.float32, device=dev)
+    vec[:k] = torch.from_numpy(np.ascontiguousarray(theta_row, dtype=np.float32).reshape(-1)).to(dev)
+    scores = torch.empty(tab.shape[0], dtype=torch.float32, device=dev)
+    ops.score_rows(vec, tab, scores, k, ld)
+    n_avail = int(tab.shape[0])
+    if exclude is not None and len(exclude) > 0:
+        ex = torch.from_numpy(np.unique(np.asarray(exclude).astype(np.int64))).to(dev)
+        scores[ex] = -float("inf")
+        n_avail -= int(ex.shape[0])
+    n = int(max(0, min(n, n_avail)))
+    if n == 0:
+        return np.empty(0, dtype=np.int64)
+    return torch.topk(scores, n, largest=True, sorted=True).indices.cpu().numpy()
 
 
 # -- PXI:476-520 --------------------------------------------------------------------------

@@ -95,3 +95,7 @@ class HipOps:
     def pair_dot(self, T, B, ix_u, ix_i, out, k, ld):
         _lib.check(self.L.hpf_hip_pair_dot_f32(_ptr(T), _ptr(B), _ptr(ix_u), _ptr(ix_i), int(ix_u.shape[0]),
                                                _ptr(out), k, ld, self._stream()), "hpf_hip_pair_dot_f32")
+
+    def score_rows(self, vec, tab, out, k, ld):
+        _lib.check(self.L.hpf_hip_score_rows_f32(_ptr(vec), _ptr(tab), int(tab.shape[0]), _ptr(out), k, ld,
+                                                 self._stream()), "hpf_hip_score_rows_f32")

@@ -140,6 +140,11 @@ int hpf_hip_pair_llk_f32(const float *T, const float *B, const int32_t *ix_u, co
 int hpf_hip_pair_dot_f32(const float *T, const float *B, const int32_t *ix_u, const int32_t *ix_i, int64_t n,
                          float *out, int k, int ld, void *stream);
 
+/* out[r] = <vec, tab[r]>, r < nrows; vec is one padded row (ld floats).  Replaces the scoring product of
+ * HPF.topN, Theta[user].dot(Beta.T) (hpfrec/__init__.py:1337). */
+int hpf_hip_score_rows_f32(const float *vec, const float *tab, int64_t nrows, float *out, int k, int ld,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -151,3 +151,6 @@ class CpuOps:
         Tn = _np(T).astype(np.float64)[_np(ix_u).astype(np.int64)]
         Bn = _np(B).astype(np.float64)[_np(ix_i).astype(np.int64)]
         _np(out)[:] = (Tn * Bn).sum(axis=1).astype(np.float32)
+
+    def score_rows(self, vec, tab, out, k, ld):
+        _np(out)[:] = (_np(tab).astype(np.float64) @ _np(vec).astype(np.float64)).astype(np.float32)
