@@ -150,9 +150,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("HPF_FORCE_SHARDED") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29544")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
@@ -231,7 +232,10 @@ def main():
         # term).  Unfused: nnz*(4+4k) + rows*(8+4k) (segment descriptor + own row) per launch.
         dom = "sweep_finalize" if "sweep_finalize" in ksum else ("sweep" if "sweep" in ksum else None)
         if dom:
-            if dom == "sweep_finalize":
+            if dom == "sweep_finalize" and world > 1:
+                # sharded: only the user side is fused (the item finalizer follows the all-reduce)
+                b_launch = n_loc * (4 + 4 * k) + model.nU * (12 + 20 * k)
+            elif dom == "sweep_finalize":
                 b_launch = (n_loc * (8 + 8 * k) + model.nU * (12 + 20 * k) + model.nI * (4 + 24 * k)) / 2.0
             else:
                 b_launch = n_loc * (4 + 4 * k) + ((model.nU + model.nI) / 2.0) * (8 + 4 * k)

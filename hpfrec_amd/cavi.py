@@ -11,8 +11,9 @@ Statement order of the reference iteration, which this driver preserves:
   (7) k_rte = a'/b' + rowsum(Theta); t_rte = c'/d' + rowsum(Beta)   PXI:258-259
 
 Multi-GPU (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm): users are
-sharded in contiguous nnz-balanced ranges, item tables are replicated, and the only exchange is
-one sum all-reduce per iteration of [item accumulators (nI*ld) || colsum(Theta) (ld)].
+sharded in contiguous nnz-balanced ranges, item tables are replicated, and the exchange per iteration is
+one sum all-reduce of the item accumulators (nI*k floats, overlapped with the user side) plus a k-float
+all-reduce of colsum(Theta).
 
 The kernels are reached through an `ops` object (hpfrec_amd.ops_hip.HipOps).  There is no CPU
 implementation in this package.
@@ -39,8 +40,13 @@ class Hyper:
 
 
 def _dist():
+    """torch.distributed when this process is one rank of a multi-rank job, else None.
+    HPF_FORCE_SHARDED=1 takes the sharded code path even with a single rank (used to exercise the
+    RCCL/packed-exchange path on a one-GPU box)."""
+    import os
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size() > 1 or os.environ.get("HPF_FORCE_SHARDED") == "1"):
         return dist
     return None
 
@@ -92,10 +98,9 @@ class FullBatchCavi:
         self.csB_part = torch.zeros((self.gsi + self.gi, ld), **f32)
         self.cs_scratch = torch.zeros((max(self.gu, self.gi), ld), **f32)  # for whole-table column sums
         self.csB = torch.zeros(ld, **f32)
-        # [item accumulators || colsum(Theta)]: one flat buffer so that one all-reduce moves both
-        self.xbuf = torch.zeros(self.nI * ld + ld, **f32) if self.dist else None
-        self.csT = self.xbuf[self.nI * ld:] if self.dist else torch.zeros(ld, **f32)
-        self.acc_i = self.xbuf[: self.nI * ld].view(self.nI, ld) if self.dist else None
+        # multi-GPU exchange buffer: the item accumulators packed to k columns (pads are zero: not sent)
+        self.acc_i = torch.zeros((self.nI, self.k), **f32) if self.dist else None
+        self.csT = torch.zeros(ld, **f32)
         self.niter_done = 0
 
     # ------------------------------------------------------------------------------------
@@ -173,24 +178,40 @@ class FullBatchCavi:
     def iterate(self, store=True):
         """One CAVI iteration.  store=False skips writing Gamma/Lambda shape and rate tables (they are
         outputs only; Theta/Beta, the scalar rates and the E tables are always kept current)."""
-        ops, hy, k, ld = self.ops, self.hy, self.k, self.ld
+        if self.dist:
+            return self._iterate_sharded(store)
+        ops, hy, ld = self.ops, self.hy, self.ld
         # user side: phi-weighted gather over CSR rows, then the closed-form user updates
         self._side_update(self.users, self.nU, self.eT, self.eB, self.eT_next, self.part_u, self.Gamma_shp,
                           self.Gamma_rte, self.Theta, self.k_rte, self.csB, self.csT_part, self.gsu, self.gu,
                           hy.a, hy.k_shp, hy.add_k_rte, store)
         ops.colsum_reduce(self.csT_part, self.csT, ld)
         # item side: same kernel over CSC rows; still reads the OLD eT (double-buffered)
-        if self.dist:
-            ops.sweep(self.items, self.eB, self.eT, self.part_i, k, ld)
-            ops.segsum(self.part_i, self.items.row_seg_ptr, self.nI, self.acc_i, ld)
-            self.dist.all_reduce(self.xbuf)
-            ops.row_finalize(self.acc_i, None, self.nI, self.eB, self.eB, self.Lambda_shp if store else None,
-                             self.Lambda_rte if store else None, self.Beta, self.t_rte, self.csT,
-                             self.csB_part[self.gsi:], hy.c, hy.t_shp, hy.add_t_rte, k, ld)
-        else:
-            self._side_update(self.items, self.nI, self.eB, self.eT, self.eB, self.part_i, self.Lambda_shp,
-                              self.Lambda_rte, self.Beta, self.t_rte, self.csT, self.csB_part, self.gsi, self.gi,
-                              hy.c, hy.t_shp, hy.add_t_rte, store)
+        self._side_update(self.items, self.nI, self.eB, self.eT, self.eB, self.part_i, self.Lambda_shp,
+                          self.Lambda_rte, self.Beta, self.t_rte, self.csT, self.csB_part, self.gsi, self.gi,
+                          hy.c, hy.t_shp, hy.add_t_rte, store)
+        ops.colsum_reduce(self.csB_part, self.csB, ld)
+        self.eT, self.eT_next = self.eT_next, self.eT
+        self.niter_done += 1
+
+    def _iterate_sharded(self, store):
+        """Users sharded over ranks.  Both sweeps read only last iteration's eT/eB, so the ITEM sweep goes
+        first and its all-reduce (item accumulators, packed [nI,k]) runs on the communication stream while
+        this rank does its whole user side; a k-float all-reduce of colsum(Theta) follows, then the item
+        finalizer runs replicated on identical inputs (replicas stay bit-identical)."""
+        ops, hy, k, ld, dist = self.ops, self.hy, self.k, self.ld, self.dist
+        ops.sweep(self.items, self.eB, self.eT, self.part_i, k, ld)
+        ops.segsum(self.part_i, self.items.row_seg_ptr, self.nI, self.acc_i, ld, acc_ld=k)
+        pending = dist.all_reduce(self.acc_i, async_op=True)
+        self._side_update(self.users, self.nU, self.eT, self.eB, self.eT_next, self.part_u, self.Gamma_shp,
+                          self.Gamma_rte, self.Theta, self.k_rte, self.csB, self.csT_part, self.gsu, self.gu,
+                          hy.a, hy.k_shp, hy.add_k_rte, store)
+        ops.colsum_reduce(self.csT_part, self.csT, ld)
+        dist.all_reduce(self.csT)
+        pending.wait()
+        ops.row_finalize(self.acc_i, None, self.nI, self.eB, self.eB, self.Lambda_shp if store else None,
+                         self.Lambda_rte if store else None, self.Beta, self.t_rte, self.csT,
+                         self.csB_part[self.gsi:], hy.c, hy.t_shp, hy.add_t_rte, k, ld, part_ld=k)
         ops.colsum_reduce(self.csB_part, self.csB, ld)
         self.eT, self.eT_next = self.eT_next, self.eT
         self.niter_done += 1

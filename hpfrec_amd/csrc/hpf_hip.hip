@@ -324,7 +324,7 @@ __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
     const float *__restrict__ part, const int64_t *__restrict__ row_seg_ptr, const int64_t *__restrict__ row_list,
     int64_t nrows, const float *e_old, float *e_new, float *__restrict__ shp, float *__restrict__ rte,
     float *__restrict__ fac, float *rs, const float *__restrict__ cs_other, float *__restrict__ cs_partial,
-    float prior_shp, float top_shp, float add_rte, int k) {
+    float prior_shp, float top_shp, float add_rte, int k, int part_ld) {
     constexpr int CPL = (LD + WAVE - 1) / WAVE;  // factors per lane
     __shared__ float red[WPB][LD];
     const int lane = threadIdx.x & (WAVE - 1);
@@ -356,16 +356,16 @@ __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
             const int c = lane + WAVE * q;
             const bool valid = c < k;
             float a = 0.f;
-            if (c < LD) {
+            if (c < part_ld) {
                 // popular rows have up to ~1e3 segments: 8 independent loads in flight, fixed fold order
                 int64_t sg = s0;
                 for (; sg + 8 <= s1; sg += 8) {
                     float p[8];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) p[u] = part[(size_t)(sg + u) * LD + c];
+                    for (int u = 0; u < 8; u++) p[u] = part[(size_t)(sg + u) * part_ld + c];
                     a += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
                 }
-                for (; sg < s1; sg++) a += part[(size_t)sg * LD + c];
+                for (; sg < s1; sg++) a += part[(size_t)sg * part_ld + c];
             }
             const float eo = (c < LD) ? e_old[(size_t)r * LD + c] : 0.f;
             sh[q] = fmaf(eo, a, prior_shp);
@@ -501,14 +501,23 @@ __global__ __launch_bounds__(BLOCK) void expect_kernel(const float *__restrict__
 __global__ __launch_bounds__(BLOCK) void segsum_kernel(const float *__restrict__ part,
                                                        const int64_t *__restrict__ row_seg_ptr,
                                                        const int64_t *__restrict__ row_list, int64_t nrows,
-                                                       float *__restrict__ acc, int ld) {
-    const int64_t total = nrows * (int64_t)ld;
+                                                       float *__restrict__ acc, int ld, int acc_ld) {
+    // acc rows have stride acc_ld <= ld (acc_ld = k packs the all-reduce payload: pads are zero anyway)
+    const int64_t total = nrows * (int64_t)acc_ld;
     for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLOCK) {
-        const int64_t rr = t / ld;
-        const int c = (int)(t - rr * ld);
+        const int64_t rr = t / acc_ld;
+        const int c = (int)(t - rr * acc_ld);
         const int64_t r = row_list ? row_list[rr] : rr;
         float a = 0.f;
-        for (int64_t sg = row_seg_ptr[r]; sg < row_seg_ptr[r + 1]; sg++) a += part[(size_t)sg * ld + c];
+        int64_t sg = row_seg_ptr[r];
+        const int64_t s1 = row_seg_ptr[r + 1];
+        for (; sg + 8 <= s1; sg += 8) {  // same fold order as row_finalize_kernel
+            float p[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) p[u] = part[(size_t)(sg + u) * ld + c];
+            a += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        }
+        for (; sg < s1; sg++) a += part[(size_t)sg * ld + c];
         acc[t] = a;
     }
 }
@@ -735,15 +744,16 @@ int hpf_hip_sweep_finalize_f32(const hpf_segment *segs, int64_t nseg, const int3
 int hpf_hip_row_finalize_f32(const float *part, const int64_t *row_seg_ptr, const int64_t *row_list, int64_t nrows,
                              const float *e_old, float *e_new, float *shp, float *rte, float *fac, float *rs,
                              const float *cs_other, float *cs_partial, float prior_shp, float top_shp, float add_rte,
-                             int k, int ld, int grid_blocks, void *stream) {
+                             int k, int ld, int part_ld, int grid_blocks, void *stream) {
     if (!part || !e_old || !e_new || !rs || !cs_other || !cs_partial || nrows < 0 || k <= 0 ||
-        ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0)
+        ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0 || part_ld < k || part_ld > ld)
         return HPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     // the grid is NOT clamped: cs_partial has exactly grid_blocks rows and all are written
 #define CALL(LD)                                                                                                  \
     hipLaunchKernelGGL((row_finalize_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, part, row_seg_ptr, row_list, \
-                       nrows, e_old, e_new, shp, rte, fac, rs, cs_other, cs_partial, prior_shp, top_shp, add_rte, k);
+                       nrows, e_old, e_new, shp, rte, fac, rs, cs_other, cs_partial, prior_shp, top_shp, add_rte, k,   \
+                       part_ld);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
     return last_error();
@@ -780,12 +790,12 @@ int hpf_hip_expect_f32(const float *shp, const float *rte, float *e, const int64
 }
 
 int hpf_hip_segsum_f32(const float *part, const int64_t *row_seg_ptr, const int64_t *row_list, int64_t nrows,
-                       float *acc, int ld, void *stream) {
+                       float *acc, int ld, int acc_ld, void *stream) {
     if (nrows == 0) return 0;
-    if (!part || !row_seg_ptr || !acc || nrows < 0 || ld < 32) return HPF_EINVAL;
-    const int grid = clamp_grid((nrows * ld + BLOCK - 1) / BLOCK, 4096);
+    if (!part || !row_seg_ptr || !acc || nrows < 0 || ld < 32 || acc_ld <= 0 || acc_ld > ld) return HPF_EINVAL;
+    const int grid = clamp_grid((nrows * acc_ld + BLOCK - 1) / BLOCK, 4096);
     hipLaunchKernelGGL(segsum_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, part, row_seg_ptr, row_list,
-                       nrows, acc, ld);
+                       nrows, acc, ld, acc_ld);
     return last_error();
 }
 

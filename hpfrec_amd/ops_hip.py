@@ -57,13 +57,14 @@ class HipOps:
         return int(max(1, min(self.finalize_blocks, (nrows + 3) // 4)))
 
     def row_finalize(self, part, row_seg_ptr, nrows, e_old, e_new, shp, rte, fac, rs, cs_other, cs_partial,
-                     prior_shp, top_shp, add_rte, k, ld, row_list=None):
+                     prior_shp, top_shp, add_rte, k, ld, row_list=None, part_ld=None):
         grid = cs_partial.shape[0]
         _lib.check(self.L.hpf_hip_row_finalize_f32(_ptr(part), _ptr(row_seg_ptr), _ptr(row_list), nrows, _ptr(e_old),
                                                    _ptr(e_new),
                                                    _ptr(shp), _ptr(rte), _ptr(fac), _ptr(rs), _ptr(cs_other),
                                                    _ptr(cs_partial), float(prior_shp), float(top_shp),
-                                                   float(add_rte), k, ld, grid, self._stream()),
+                                                   float(add_rte), k, ld, ld if part_ld is None else part_ld, grid,
+                                                   self._stream()),
                    "hpf_hip_row_finalize_f32")
 
     def colsum_reduce(self, cs_partial, cs_out, ld):
@@ -78,9 +79,10 @@ class HipOps:
         _lib.check(self.L.hpf_hip_expect_f32(_ptr(shp), _ptr(rte), _ptr(e), _ptr(row_list), nrows, k, ld,
                                              self._stream()), "hpf_hip_expect_f32")
 
-    def segsum(self, part, row_seg_ptr, nrows, acc, ld, row_list=None):
+    def segsum(self, part, row_seg_ptr, nrows, acc, ld, row_list=None, acc_ld=None):
         _lib.check(self.L.hpf_hip_segsum_f32(_ptr(part), _ptr(row_seg_ptr), _ptr(row_list), nrows, _ptr(acc), ld,
-                                             self._stream()), "hpf_hip_segsum_f32")
+                                             ld if acc_ld is None else acc_ld, self._stream()),
+                   "hpf_hip_segsum_f32")
 
     def pair_llk(self, T, B, ix_u, ix_i, y, k, ld, full_llk):
         """-> float64 tensor [3]: sum y*log(yhat) [- lgamma(y+1)], sum (y-yhat)^2, sum yhat."""

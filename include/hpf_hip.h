@@ -104,11 +104,12 @@ int hpf_hip_sweep_finalize_f32(const hpf_segment *segs, int64_t nseg, const int3
  *   cs_partial[block] = per-block column sums of fac      -> hpf_hip_colsum_reduce_f32
  *
  * e_new may alias e_old.  rs is updated in place.  shp/rte/fac may be NULL (skip store).
+ * part_ld is the row stride of part[] (ld, or k for the packed all-reduce payload of the multi-GPU path).
  */
 int hpf_hip_row_finalize_f32(const float *part, const int64_t *row_seg_ptr, const int64_t *row_list, int64_t nrows,
                              const float *e_old, float *e_new, float *shp, float *rte, float *fac, float *rs,
                              const float *cs_other, float *cs_partial, float prior_shp, float top_shp,
-                             float add_rte, int k, int ld, int grid_blocks, void *stream);
+                             float add_rte, int k, int ld, int part_ld, int grid_blocks, void *stream);
 
 /* cs_out[c] = sum_b cs_partial[b][c], fixed order, double accumulation (Beta.sum(axis=0), PXI:236,255). */
 int hpf_hip_colsum_reduce_f32(const float *cs_partial, int nblk, float *cs_out, int ld, void *stream);
@@ -122,10 +123,10 @@ int hpf_hip_colsum_f32(const float *tab, int64_t nrows, int ld, float *cs_partia
 int hpf_hip_expect_f32(const float *shp, const float *rte, float *e, const int64_t *row_list, int64_t nrows, int k,
                        int ld, void *stream);
 
-/* acc[t] = sum of the part[] segments of row r = row_list ? row_list[t] : t, t < nrows (multi-GPU item
- * side before the all-reduce; the batch rows of an SVI step). */
+/* acc[t][0:acc_ld] = sum of the part[] segments of row r = row_list ? row_list[t] : t, t < nrows (multi-GPU
+ * item side before the all-reduce -- acc_ld = k packs the payload; the batch rows of an SVI step). */
 int hpf_hip_segsum_f32(const float *part, const int64_t *row_seg_ptr, const int64_t *row_list, int64_t nrows,
-                       float *acc, int ld, void *stream);
+                       float *acc, int ld, int acc_ld, void *stream);
 
 /*
  * Poisson log-likelihood terms over listed pairs.  Replaces llk_plus_rmse (PXI:627-658)

@@ -74,8 +74,12 @@ class CpuOps:
             _np(scatter_acc)[:] = acc.astype(np.float32)
 
     def row_finalize(self, part, row_seg_ptr, nrows, e_old, e_new, shp, rte, fac, rs, cs_other, cs_partial,
-                     prior_shp, top_shp, add_rte, k, ld, row_list=None):
+                     prior_shp, top_shp, add_rte, k, ld, row_list=None, part_ld=None):
         P = _np(part).astype(np.float64)
+        if part_ld is not None and part_ld != ld:   # packed accumulator rows (stride part_ld <= ld)
+            Pp = np.zeros((P.shape[0], ld))
+            Pp[:, :part_ld] = P
+            P = Pp
         rows = np.arange(nrows) if row_list is None else _np(row_list)[:nrows].astype(np.int64)
         cp = _np(cs_partial)
         cp[:] = 0
@@ -127,7 +131,8 @@ class CpuOps:
         E = E - E.max(axis=1, keepdims=True)
         _np(e)[rows] = np.exp(E).astype(np.float32)
 
-    def segsum(self, part, row_seg_ptr, nrows, acc, ld, row_list=None):
+    def segsum(self, part, row_seg_ptr, nrows, acc, ld, row_list=None, acc_ld=None):
+        acc_ld = ld if acc_ld is None else acc_ld
         rows = np.arange(nrows) if row_list is None else _np(row_list)[:nrows].astype(np.int64)
         rsp = _np(row_seg_ptr)
         P = _np(part).astype(np.float64)
@@ -135,7 +140,7 @@ class CpuOps:
         for t, r in enumerate(rows):
             if rsp[r + 1] > rsp[r]:
                 out[t] = P[rsp[r]: rsp[r + 1]].sum(axis=0)
-        _np(acc)[: rows.shape[0]] = out.astype(np.float32)
+        _np(acc)[: rows.shape[0]] = out[:, :acc_ld].astype(np.float32)
 
     def pair_llk(self, T, B, ix_u, ix_i, y, k, ld, full_llk):
         Tn = _np(T).astype(np.float64)[_np(ix_u).astype(np.int64)]

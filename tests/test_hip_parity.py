@@ -363,3 +363,16 @@ def test_fused_and_split_drivers_agree(hip_backend):
         cavi.FullBatchCavi.__init__ = orig
     for n in NAMES:
         assert _maxrel(a[n], b[n]) < 2e-6, n
+
+
+def test_sharded_path_single_rank_nccl():
+    """The multi-GPU code path (RCCL group, async packed all-reduce, packed-stride finalize) on one GPU."""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(here, "sharded_single_rank.py")], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert "SHARDED_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
