@@ -272,9 +272,19 @@ def main():
                 line["cpu_baseline"] = {"value": None, "error": repr(e)}
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line))
+    else:
+        line = None
     if dist:
         dist.destroy_process_group()
+    if line is not None:
+        # the JSON line must be the LAST line of stdout: flush whatever RCCL/HIP left in C stdio first
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 def _pmc_traffic(workload, world):
