@@ -219,8 +219,7 @@ class FullBatchCavi:
     # ------------------------------------------------------------------------------------
     def llk_terms(self, full_llk=False):
         """Global (all-reduced) float64 [sum y*log(yhat)(-lgamma), sum sq.err, sum yhat, nnz] over the training nonzeros."""
-        t = self.ops.pair_llk(self.Theta, self.Beta, self.u_sorted, self.users.idx, self.users.y, self.k, self.ld,
-                              full_llk)
+        t = self.ops.llk_sweep(self.users, self.Theta, self.Beta, self.k, self.ld, full_llk)
         out = torch.cat([t.to(torch.float64), torch.tensor([float(self.nnz)], dtype=torch.float64,
                                                            device=t.device)])
         if self.dist:

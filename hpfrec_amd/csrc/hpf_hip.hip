@@ -588,6 +588,93 @@ __global__ __launch_bounds__(BLOCK) void pair_llk_kernel(const float *__restrict
     if (threadIdx.x == 3) partial[(size_t)blockIdx.x * 4 + 3] = 0.0;
 }
 
+// train llk over the row-grouped layout: the user row is read once per segment, only the item rows
+// are gathered (the listed-pair kernel gathers both).  Same terms as pair_llk_kernel.
+template <int LPR, int VPL, bool FULL>
+__global__ __launch_bounds__(BLOCK) void llk_sweep_kernel(const hpf_segment *__restrict__ segs, int64_t nseg,
+                                                          const int32_t *__restrict__ idx,
+                                                          const float *__restrict__ y,
+                                                          const float *__restrict__ tab_self,
+                                                          const float *__restrict__ tab_other,
+                                                          double *__restrict__ partial) {
+    constexpr int LD = 4 * LPR * VPL;
+    constexpr int NG = WAVE / LPR;
+    constexpr int U = HPF_U;
+    __shared__ double red[WPB][3];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int g = lane / LPR;
+    const int j = lane % LPR;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WPB;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int64_t sg = (int64_t)blockIdx.x * WPB + wid; sg < nseg; sg += nwaves) {
+        const hpf_segment sgm = segs[sg];
+        const int len = sgm.len & HPF_SEG_LEN_MASK;
+        const float4 *selfp = reinterpret_cast<const float4 *>(tab_self + (size_t)sgm.row * LD);
+        float4 rv[VPL];
+#pragma unroll
+        for (int v = 0; v < VPL; v++) rv[v] = selfp[v * LPR + j];
+        const int32_t *ip = idx + sgm.begin;
+        const float *yp = y + sgm.begin;
+        for (int base = 0; base < len; base += WAVE) {
+            const int n = min(WAVE, len - base);
+            int myc = 0;
+            float myy = 0.f;
+            if (lane < n) {
+                myc = ip[base + lane];
+                myy = yp[base + lane];
+            }
+            int nsteps = (n + NG - 1) / NG;
+            nsteps = (nsteps + U - 1) & ~(U - 1);
+            for (int t0 = 0; t0 < nsteps; t0 += U) {
+                float4 o[U][VPL];
+                float yy[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int src = (t0 + u) * NG + g;
+                    const int c = __shfl(myc, src);
+                    yy[u] = __shfl(myy, src);
+                    const float4 *op = reinterpret_cast<const float4 *>(tab_other + (size_t)c * LD);
+#pragma unroll
+                    for (int v = 0; v < VPL; v++) o[u][v] = op[v * LPR + j];
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    float p = 0.f;
+#pragma unroll
+                    for (int v = 0; v < VPL; v++) p += dot4(rv[v], o[u][v]);
+                    const float yhat = group_sum<LPR>(p);
+                    if (j == 0 && yy[u] > 0.f) {  // padding slots carry y = 0
+                        if constexpr (FULL)
+                            a0 += (double)yy[u] * log((double)yhat) - lgamma((double)yy[u] + 1.0);
+                        else
+                            a0 += (double)(yy[u] * logf(yhat));
+                        const float d = yy[u] - yhat;
+                        a1 += (double)(d * d);
+                        a2 += (double)yhat;
+                    }
+                }
+            }
+        }
+    }
+    a0 = wave_sum_d(a0);
+    a1 = wave_sum_d(a1);
+    a2 = wave_sum_d(a2);
+    if (lane == 0) {
+        red[wid][0] = a0;
+        red[wid][1] = a1;
+        red[wid][2] = a2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double t = red[0][threadIdx.x];
+#pragma unroll
+        for (int w2 = 1; w2 < WPB; w2++) t += red[w2][threadIdx.x];
+        partial[(size_t)blockIdx.x * 4 + threadIdx.x] = t;
+    }
+    if (threadIdx.x == 3) partial[(size_t)blockIdx.x * 4 + 3] = 0.0;
+}
+
 template <int LPR, int VPL>
 __global__ __launch_bounds__(BLOCK) void pair_dot_kernel(const float *__restrict__ T, const float *__restrict__ B,
                                                          const int32_t *__restrict__ ix_u,
@@ -812,6 +899,25 @@ int hpf_hip_pair_llk_f32(const float *T, const float *B, const int32_t *ix_u, co
     else                                                                                                            \
         hipLaunchKernelGGL((pair_llk_kernel<LPR, VPL, false>), dim3(grid_blocks), dim3(BLOCK), 0, st, T, B, ix_u,  \
                            ix_i, y, n, partial);
+    HPF_DISPATCH_LD(ld, CALL)
+#undef CALL
+    return last_error();
+}
+
+int hpf_hip_llk_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y, const float *T,
+                          const float *B, double *partial, int k, int ld, int full_llk, int grid_blocks,
+                          void *stream) {
+    if (!T || !B || !partial || nseg < 0 || k <= 0 || ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0) return HPF_EINVAL;
+    if (nseg > 0 && (!segs || !idx || !y)) return HPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    // grid not clamped: partial has 4*grid_blocks entries and all are written
+#define CALL(LPR, VPL)                                                                                              \
+    if (full_llk)                                                                                                   \
+        hipLaunchKernelGGL((llk_sweep_kernel<LPR, VPL, true>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg,  \
+                           idx, y, T, B, partial);                                                                  \
+    else                                                                                                            \
+        hipLaunchKernelGGL((llk_sweep_kernel<LPR, VPL, false>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg, \
+                           idx, y, T, B, partial);
     HPF_DISPATCH_LD(ld, CALL)
 #undef CALL
     return last_error();

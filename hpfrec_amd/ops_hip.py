@@ -94,6 +94,15 @@ class HipOps:
                    "hpf_hip_pair_llk_f32")
         return partial.sum(dim=0)[:3]
 
+    def llk_sweep(self, side, T, B, k, ld, full_llk):
+        """pair_llk over the nonzeros of a row-grouped side (rows of T = side rows)."""
+        grid = self.sweep_grid(side.nseg)
+        partial = torch.empty((grid, 4), dtype=torch.float64, device=self.device)
+        _lib.check(self.L.hpf_hip_llk_sweep_f32(_ptr(side.segs), side.nseg, _ptr(side.idx), _ptr(side.y), _ptr(T),
+                                                _ptr(B), _ptr(partial), k, ld, int(bool(full_llk)), grid,
+                                                self._stream()), "hpf_hip_llk_sweep_f32")
+        return partial.sum(dim=0)[:3]
+
     def pair_dot(self, T, B, ix_u, ix_i, out, k, ld):
         _lib.check(self.L.hpf_hip_pair_dot_f32(_ptr(T), _ptr(B), _ptr(ix_u), _ptr(ix_i), int(ix_u.shape[0]),
                                                _ptr(out), k, ld, self._stream()), "hpf_hip_pair_dot_f32")

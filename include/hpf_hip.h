@@ -137,6 +137,12 @@ int hpf_hip_segsum_f32(const float *part, const int64_t *row_seg_ptr, const int6
 int hpf_hip_pair_llk_f32(const float *T, const float *B, const int32_t *ix_u, const int32_t *ix_i, const float *y,
                          int64_t n, double *partial, int k, int ld, int full_llk, int grid_blocks, void *stream);
 
+/* The same three sums over the training nonzeros in the row-grouped layout of hpf_hip_sweep_f32 (rows of T
+ * read once per segment, only B rows gathered): the train-llk evaluation of assess_convergence (PXI:75-79). */
+int hpf_hip_llk_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y, const float *T,
+                          const float *B, double *partial, int k, int ld, int full_llk, int grid_blocks,
+                          void *stream);
+
 /* out[n] = <T[ix_u[n]], B[ix_i[n]]>.  Replaces predict_multiple (PXI:803-810). */
 int hpf_hip_pair_dot_f32(const float *T, const float *B, const int32_t *ix_u, const int32_t *ix_i, int64_t n,
                          float *out, int k, int ld, void *stream);

@@ -152,6 +152,10 @@ class CpuOps:
             a0 -= sp.gammaln(yy + 1.0).sum()
         return torch.tensor([a0, ((yy - yhat) ** 2).sum(), yhat.sum()], dtype=torch.float64)
 
+    def llk_sweep(self, side, T, B, k, ld, full_llk):
+        rows = torch.repeat_interleave(torch.arange(side.nrows), side.indptr[1:] - side.indptr[:-1]).to(torch.int32)
+        return self.pair_llk(T, B, rows, side.idx, side.y, k, ld, full_llk)
+
     def pair_dot(self, T, B, ix_u, ix_i, out, k, ld):
         Tn = _np(T).astype(np.float64)[_np(ix_u).astype(np.int64)]
         Bn = _np(B).astype(np.float64)[_np(ix_i).astype(np.int64)]

@@ -376,3 +376,24 @@ def test_sharded_path_single_rank_nccl():
     out = subprocess.run([sys.executable, os.path.join(here, "sharded_single_rank.py")], env=env, capture_output=True,
                          text=True, timeout=600)
     assert "SHARDED_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("k", [30, 50, 200])
+def test_llk_sweep_op(ops, k):
+    rs = np.random.RandomState(k + 3)
+    ld = _lib.ld_for_k(k)
+    nU, nI, n = 300, 200, 20000
+    iu = torch.from_numpy((nU * rs.random_sample(n) ** 2).astype(np.int64))
+    ii = torch.from_numpy((nI * rs.random_sample(n) ** 3).astype(np.int64))
+    y = torch.from_numpy((rs.gamma(1, 1, size=n) + 1).astype(np.int32).astype(np.float32))
+    T, B = _rand_tables(rs, nU, k, ld), _rand_tables(rs, nI, k, ld)
+    users, items, u_sorted = layout.build_sides(iu, ii, y, nU, nI)
+    dside = layout.SparseSide.__new__(layout.SparseSide)
+    dside.__dict__.update({a: (v.cuda() if torch.is_tensor(v) else v) for a, v in users.__dict__.items()})
+    ref = cpu_ops.CpuOps()
+    for full in (0, 1):
+        want = ref.pair_llk(T, B, u_sorted, users.idx, users.y, k, ld, full).numpy()
+        got = ops.llk_sweep(dside, T.cuda(), B.cuda(), k, ld, full).cpu().numpy()
+        pair = ops.pair_llk(T.cuda(), B.cuda(), u_sorted.cuda(), users.idx.cuda(), users.y.cuda(), k, ld, full).cpu().numpy()
+        assert np.max(np.abs(got - want) / np.abs(want)) < 2e-6
+        assert np.max(np.abs(got - pair) / np.abs(pair)) < 1e-9
