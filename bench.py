@@ -163,7 +163,23 @@ def main():
     device = torch.device("cuda", local_rank if world > 1 else 0)
 
     nU, nI, nnz_target, k, label = WORKLOADS[args.workload]
-    iu, ii, y = synth_on_device(nU, nI, nnz_target, device)
+    if dist and world > 1:
+        # one generator run, broadcast over xGMI: every rank shards exactly the same matrix
+        if rank == 0:
+            iu, ii, y = synth_on_device(nU, nI, nnz_target, device)
+            n_t = torch.tensor([iu.shape[0]], dtype=torch.int64, device=device)
+        else:
+            n_t = torch.zeros(1, dtype=torch.int64, device=device)
+        dist.broadcast(n_t, 0)
+        if rank != 0:
+            n_all = int(n_t.item())
+            iu = torch.empty(n_all, dtype=torch.int64, device=device)
+            ii = torch.empty(n_all, dtype=torch.int64, device=device)
+            y = torch.empty(n_all, dtype=torch.float32, device=device)
+        for t in (iu, ii, y):
+            dist.broadcast(t, 0)
+    else:
+        iu, ii, y = synth_on_device(nU, nI, nnz_target, device)
     nnz = int(iu.shape[0])
 
     ops = TimedOps(device)

@@ -124,3 +124,33 @@ def test_fit_predict_topn_vs_golden_on_gpu(hip_backend):
     assert abs(float(m20.eval_llk(df.copy())["llk"]) / gl["eval_llk_it20"] - 1) < 1e-4
     mv = HPF(k=30, maxiter=10, random_seed=123, reindex=False, verbose=True, check_every=10).fit(df.copy())
     assert abs(float(mv.train_llk) / gl["train_llk_it10"] - 1) < 1e-4
+
+
+def test_save_folder_and_flags(cpu_ops_backend, tmp_path):
+    df, nU, nI = datagen.readme_counts()
+    df2 = df.copy()
+    df2["UserId"] = df2["UserId"] + 500
+    m = HPF(k=6, maxiter=3, random_seed=3, verbose=False, check_every=None, save_folder=str(tmp_path),
+            keep_all_objs=False, produce_dicts=False, full_llk=True).fit(df2)
+    files = set(os.listdir(str(tmp_path)))
+    # the reference writes the eight arrays under extension-less names (cython_loops.pxi:410)
+    assert {"Theta", "Beta", "Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "kappa_rte", "tau_rte",
+            "users.csv", "items.csv", "hyperparameters.txt"} <= files
+    saved = np.loadtxt(os.path.join(str(tmp_path), "Theta"), delimiter=",")
+    assert saved.shape == m.Theta.shape and np.allclose(saved, m.Theta, atol=1e-6)
+    assert "k: 6" in open(os.path.join(str(tmp_path), "hyperparameters.txt")).read()
+    assert not hasattr(m, "Gamma_shp") and m.user_dict_ is None          # keep_all_objs / produce_dicts off
+    assert np.isfinite(m.predict(user=int(m.user_mapping_[0]), item=int(m.item_mapping_[0])))
+    with pytest.raises(AssertionError):
+        m.predict_factors(df[["ItemId", "Count"]].head(5))                 # needs keep_all_objs
+    # diff-norm criterion stops, llk criteria reject counts < 1 rows with a warning
+    g = np.load(os.path.join(GOLDEN, "c1_full.npz"))
+    m3 = HPF(k=30, maxiter=200, stop_crit="diff-norm", check_every=5, stop_thr=1e-1, random_seed=123, verbose=False,
+             reindex=False).fit(df.copy())
+    assert m3.niter == int(g["diffnorm_stop_niter"])
+
+
+def test_use_float_false_is_refused():
+    df, nU, nI = datagen.readme_counts()
+    with pytest.raises(NotImplementedError):
+        HPF(use_float=False, verbose=False).fit(df.copy())

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the drop-in boundary at C3 scale: host COO arrays in, host Theta/Beta out
+(the PCIe-inclusive figure noted in DESIGN.md), through hpfrec_amd.cython_loops_float.fit_hpf."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from hpfrec_amd import cython_loops_float as be  # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+maxiter = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+nU, nI, nnz_t, k, label = bench.WORKLOADS[wl]
+dev = torch.device("cuda", 0)
+iu, ii, y = bench.synth_on_device(nU, nI, nnz_t, dev)
+Y = y.cpu().numpy()
+IU = iu.cpu().numpy().astype(np.uint64)
+II = ii.cpu().numpy().astype(np.uint64)
+del iu, ii, y
+torch.cuda.empty_cache()
+Theta = np.empty((nU, k), np.float32)
+Beta = np.empty((nI, k), np.float32)
+t0 = time.time()
+i, temp, llk = be.fit_hpf(0.3, 0.3, 1.0, 0.3, 0.3, 1.0, Y, IU, II, Theta, Beta, maxiter, "maxiter", 10, 1e-3, 0, 0, None, 0,
+                          np.zeros(1, np.uint64), "", 123, 1, 1, 0, 0, np.empty(0, np.float32), np.empty(0, np.uint64),
+                          np.empty(0, np.uint64), 0, 1, 0)
+dt = time.time() - t0
+print("E2E %s: nnz=%d k=%d maxiter=%d (llk every 10, verbose) wall=%.2fs -> %.1f it/s incl. init, H2D, CSR/CSC build, "
+      "llk checks, D2H of 8 arrays; last_llk=%.6g finite=%s" % (wl, Y.shape[0], k, maxiter, dt, maxiter / dt, float(llk),
+                                                                bool(np.isfinite(Theta).all() and np.isfinite(Beta).all())))
