@@ -18,6 +18,8 @@ all-reduce of colsum(Theta).
 The kernels are reached through an `ops` object (hpfrec_amd.ops_hip.HipOps).  There is no CPU
 implementation in this package.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -64,6 +66,16 @@ def shard_users(ix_u, ix_i, y, nU, rank, world):
     return ix_u[keep] - u0, ix_i[keep], y[keep], (u0, u1)
 
 
+class _SideView:
+    """The segments [seg_lo, seg_hi) of a SparseSide, as the sweep launcher sees a side."""
+
+    def __init__(self, side, seg_lo, seg_hi):
+        self.seg_lo = seg_lo
+        self.segs = side.segs[seg_lo:seg_hi]
+        self.nseg = seg_hi - seg_lo
+        self.idx, self.y = side.idx, side.y
+
+
 class FullBatchCavi:
     """Device-resident state + one-iteration step for (a shard of) the HPF model."""
 
@@ -98,8 +110,10 @@ class FullBatchCavi:
         self.csB_part = torch.zeros((self.gsi + self.gi, ld), **f32)
         self.cs_scratch = torch.zeros((max(self.gu, self.gi), ld), **f32)  # for whole-table column sums
         self.csB = torch.zeros(ld, **f32)
-        # multi-GPU exchange buffer: the item accumulators packed to k columns (pads are zero: not sent)
+        # multi-GPU exchange buffer: the item accumulators packed to k columns (pads are zero: not sent),
+        # cut into nnz-balanced item ranges so that the all-reduce of one range overlaps the sweep of the next
         self.acc_i = torch.zeros((self.nI, self.k), **f32) if self.dist else None
+        self.item_chunks = self._item_chunks(int(os.environ.get("HPF_AR_CHUNKS", "4"))) if self.dist else None
         self.csT = torch.zeros(ld, **f32)
         self.niter_done = 0
 
@@ -127,6 +141,22 @@ class FullBatchCavi:
         ops.expect(self.Lambda_shp, self.Lambda_rte, self.eB, self.nI, k, ld)
         ops.colsum(self.Beta, self.nI, ld, self.cs_scratch)
         ops.colsum_reduce(self.cs_scratch, self.csB, ld)
+
+    def _item_chunks(self, nchunks):
+        """Contiguous item ranges with ~equal nonzeros: [(row_lo, row_hi, SideView over their segments)]."""
+        it = self.items
+        # boundaries must be identical on every rank: balance the GLOBAL item degrees
+        deg = (it.indptr[1:] - it.indptr[:-1]).clone()
+        self.dist.all_reduce(deg)
+        gptr = torch.zeros(self.nI + 1, dtype=torch.int64, device=deg.device)
+        torch.cumsum(deg, 0, out=gptr[1:])
+        bounds = [lo for lo, _ in layout.nnz_balanced_ranges(gptr, max(1, nchunks))] + [self.nI]
+        rsp = it.row_seg_ptr.cpu()
+        out = []
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            if hi > lo:
+                out.append((lo, hi, _SideView(it, int(rsp[lo]), int(rsp[hi]))))
+        return out
 
     def set_fused(self, flag):
         """Choose between the fused sweep+finalize launches and separate launches.  Each mode writes
@@ -196,19 +226,24 @@ class FullBatchCavi:
 
     def _iterate_sharded(self, store):
         """Users sharded over ranks.  Both sweeps read only last iteration's eT/eB, so the ITEM sweep goes
-        first and its all-reduce (item accumulators, packed [nI,k]) runs on the communication stream while
-        this rank does its whole user side; a k-float all-reduce of colsum(Theta) follows, then the item
-        finalizer runs replicated on identical inputs (replicas stay bit-identical)."""
+        first, in nnz-balanced item ranges: the all-reduce of one range (item accumulators, packed [rows,k])
+        runs on the communication stream while the next range is swept and then while this rank does its
+        whole user side; a k-float all-reduce of colsum(Theta) follows, then the item finalizer runs
+        replicated on identical inputs (replicas stay bit-identical)."""
         ops, hy, k, ld, dist = self.ops, self.hy, self.k, self.ld, self.dist
-        ops.sweep(self.items, self.eB, self.eT, self.part_i, k, ld)
-        ops.segsum(self.part_i, self.items.row_seg_ptr, self.nI, self.acc_i, ld, acc_ld=k)
-        pending = dist.all_reduce(self.acc_i, async_op=True)
+        pending = []
+        for lo, hi, view in self.item_chunks:
+            if view.nseg > 0:
+                ops.sweep(view, self.eB, self.eT, self.part_i[view.seg_lo:], k, ld)
+            ops.segsum(self.part_i, self.items.row_seg_ptr[lo:], hi - lo, self.acc_i[lo:hi], ld, acc_ld=k)
+            pending.append(dist.all_reduce(self.acc_i[lo:hi], async_op=True))
         self._side_update(self.users, self.nU, self.eT, self.eB, self.eT_next, self.part_u, self.Gamma_shp,
                           self.Gamma_rte, self.Theta, self.k_rte, self.csB, self.csT_part, self.gsu, self.gu,
                           hy.a, hy.k_shp, hy.add_k_rte, store)
         ops.colsum_reduce(self.csT_part, self.csT, ld)
         dist.all_reduce(self.csT)
-        pending.wait()
+        for w in pending:
+            w.wait()
         ops.row_finalize(self.acc_i, None, self.nI, self.eB, self.eB, self.Lambda_shp if store else None,
                          self.Lambda_rte if store else None, self.Beta, self.t_rte, self.csT,
                          self.csB_part[self.gsi:], hy.c, hy.t_shp, hy.add_t_rte, k, ld, part_ld=k)
