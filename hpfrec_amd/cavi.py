@@ -143,7 +143,8 @@ class FullBatchCavi:
         ops.colsum_reduce(self.cs_scratch, self.csB, ld)
 
     def _item_chunks(self, nchunks):
-        """Contiguous item ranges with ~equal nonzeros: [(row_lo, row_hi, SideView over their segments)]."""
+        """Contiguous item ranges with ~equal nonzeros:
+        [(row_lo, row_hi, SideView over their segments, their split/empty rows)]."""
         it = self.items
         # boundaries must be identical on every rank: balance the GLOBAL item degrees
         deg = (it.indptr[1:] - it.indptr[:-1]).clone()
@@ -155,7 +156,8 @@ class FullBatchCavi:
         out = []
         for lo, hi in zip(bounds[:-1], bounds[1:]):
             if hi > lo:
-                out.append((lo, hi, _SideView(it, int(rsp[lo]), int(rsp[hi]))))
+                multi = it.multi_rows[(it.multi_rows >= lo) & (it.multi_rows < hi)].contiguous()
+                out.append((lo, hi, _SideView(it, int(rsp[lo]), int(rsp[hi])), multi))
         return out
 
     def set_fused(self, flag):
@@ -232,10 +234,13 @@ class FullBatchCavi:
         replicated on identical inputs (replicas stay bit-identical)."""
         ops, hy, k, ld, dist = self.ops, self.hy, self.k, self.ld, self.dist
         pending = []
-        for lo, hi, view in self.item_chunks:
+        for lo, hi, view, multi in self.item_chunks:
+            # whole-row segments write their accumulator straight into the packed buffer; only split
+            # rows (and rows without local nonzeros: zeros) go through part[] + segsum
             if view.nseg > 0:
-                ops.sweep(view, self.eB, self.eT, self.part_i[view.seg_lo:], k, ld)
-            ops.segsum(self.part_i, self.items.row_seg_ptr[lo:], hi - lo, self.acc_i[lo:hi], ld, acc_ld=k)
+                ops.sweep(view, self.eB, self.eT, self.part_i[view.seg_lo:], k, ld, acc_rows=self.acc_i, acc_ld=k)
+            ops.segsum(self.part_i, self.items.row_seg_ptr, int(multi.shape[0]), self.acc_i, ld, row_list=multi,
+                       acc_ld=k, acc_by_row=True)
             pending.append(dist.all_reduce(self.acc_i[lo:hi], async_op=True))
         self._side_update(self.users, self.nU, self.eT, self.eB, self.eT_next, self.part_u, self.Gamma_shp,
                           self.Gamma_rte, self.Theta, self.k_rte, self.csB, self.csT_part, self.gsu, self.gu,

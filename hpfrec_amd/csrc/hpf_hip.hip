@@ -133,6 +133,8 @@ struct FinalizeArgs {  // the row-finalize operands when it is fused into the sw
     float *cs_partial, *e_new, *shp, *rte, *fac, *rs;
     float prior_shp, top_shp, add_rte;
     int k;
+    float *acc_rows;  // !FUSE only: packed [rows][acc_ld] destination for whole-row segments (or null)
+    int acc_ld;
 };
 
 template <int LPR, int VPL, bool SCATTER, bool FUSE>
@@ -246,9 +248,21 @@ __global__ __launch_bounds__(BLOCK, HPF_SWEEP_WAVES_PER_EU) void sweep_kernel(co
                 acc[v].w += __shfl_xor(acc[v].w, m);
             }
         }
-        bool whole_row = false;
-        if constexpr (FUSE) whole_row = (sgm.len & HPF_SEG_WHOLE_ROW) != 0;
-        if (!whole_row) {
+        const bool whole_row = (sgm.len & HPF_SEG_WHOLE_ROW) != 0;
+        if (!FUSE && whole_row && fa.acc_rows) {
+            // the row's complete accumulator goes straight into the packed exchange buffer
+            if (g == 0) {
+                float *ar = fa.acc_rows + (size_t)sgm.row * fa.acc_ld;
+#pragma unroll
+                for (int v = 0; v < VPL; v++) {
+                    const int c = (v * LPR + j) * 4;
+                    if (c + 0 < fa.acc_ld) ar[c + 0] = acc[v].x;
+                    if (c + 1 < fa.acc_ld) ar[c + 1] = acc[v].y;
+                    if (c + 2 < fa.acc_ld) ar[c + 2] = acc[v].z;
+                    if (c + 3 < fa.acc_ld) ar[c + 3] = acc[v].w;
+                }
+            }
+        } else if (!FUSE || !whole_row) {
             if (g == 0) {
                 float4 *pp = reinterpret_cast<float4 *>(part + (size_t)sg * LD);
 #pragma unroll
@@ -501,7 +515,7 @@ __global__ __launch_bounds__(BLOCK) void expect_kernel(const float *__restrict__
 __global__ __launch_bounds__(BLOCK) void segsum_kernel(const float *__restrict__ part,
                                                        const int64_t *__restrict__ row_seg_ptr,
                                                        const int64_t *__restrict__ row_list, int64_t nrows,
-                                                       float *__restrict__ acc, int ld, int acc_ld) {
+                                                       float *__restrict__ acc, int ld, int acc_ld, int acc_by_row) {
     // acc rows have stride acc_ld <= ld (acc_ld = k packs the all-reduce payload: pads are zero anyway)
     const int64_t total = nrows * (int64_t)acc_ld;
     for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLOCK) {
@@ -518,7 +532,7 @@ __global__ __launch_bounds__(BLOCK) void segsum_kernel(const float *__restrict__
             a += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
         }
         for (; sg < s1; sg++) a += part[(size_t)sg * ld + c];
-        acc[t] = a;
+        acc[acc_by_row ? (size_t)r * acc_ld + c : (size_t)t] = a;
     }
 }
 
@@ -789,14 +803,17 @@ int hpf_hip_device_info(int *cu_count, char *arch, int arch_len) {
 }
 
 int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
-                      const float *tab_self, const float *tab_other, float *part, float *scatter_acc, int k, int ld,
-                      int grid_blocks, void *stream) {
+                      const float *tab_self, const float *tab_other, float *part, float *scatter_acc,
+                      float *acc_rows, int acc_ld, int k, int ld, int grid_blocks, void *stream) {
     if (nseg == 0) return 0;
     if (!segs || !idx || !y || !tab_self || !tab_other || !part || nseg < 0 || k <= 0 || ld != hpf_hip_ld_for_k(k))
         return HPF_EINVAL;
+    if (acc_rows && (acc_ld < k || acc_ld > ld)) return HPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int grid = clamp_grid((nseg + WPB - 1) / WPB, grid_blocks);
-    const FinalizeArgs fa = {};
+    FinalizeArgs fa = {};
+    fa.acc_rows = acc_rows;
+    fa.acc_ld = acc_ld;
 #define CALL(LPR, VPL)                                                                                              \
     if (scatter_acc)                                                                                                \
         hipLaunchKernelGGL((sweep_kernel<LPR, VPL, true, false>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg, idx, \
@@ -819,7 +836,7 @@ int hpf_hip_sweep_finalize_f32(const hpf_segment *segs, int64_t nseg, const int3
         return HPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     // grid NOT clamped: every block writes its cs_partial row
-    const FinalizeArgs fa = {cs_other, cs_partial, e_new, shp, rte, fac, rs, prior_shp, top_shp, add_rte, k};
+    const FinalizeArgs fa = {cs_other, cs_partial, e_new, shp, rte, fac, rs, prior_shp, top_shp, add_rte, k, nullptr, 0};
 #define CALL(LPR, VPL)                                                                                            \
     hipLaunchKernelGGL((sweep_kernel<LPR, VPL, false, true>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg, \
                        idx, y, tab_self, tab_other, part, (float *)nullptr, fa);
@@ -877,12 +894,12 @@ int hpf_hip_expect_f32(const float *shp, const float *rte, float *e, const int64
 }
 
 int hpf_hip_segsum_f32(const float *part, const int64_t *row_seg_ptr, const int64_t *row_list, int64_t nrows,
-                       float *acc, int ld, int acc_ld, void *stream) {
+                       float *acc, int ld, int acc_ld, int acc_by_row, void *stream) {
     if (nrows == 0) return 0;
     if (!part || !row_seg_ptr || !acc || nrows < 0 || ld < 32 || acc_ld <= 0 || acc_ld > ld) return HPF_EINVAL;
     const int grid = clamp_grid((nrows * acc_ld + BLOCK - 1) / BLOCK, 4096);
     hipLaunchKernelGGL(segsum_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, part, row_seg_ptr, row_list,
-                       nrows, acc, ld, acc_ld);
+                       nrows, acc, ld, acc_ld, acc_by_row);
     return last_error();
 }
 

@@ -35,10 +35,11 @@ class HipOps:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     # -- every method mirrors one C entry point ------------------------------------------
-    def sweep(self, side, tab_self, tab_other, part, k, ld, scatter_acc=None):
+    def sweep(self, side, tab_self, tab_other, part, k, ld, scatter_acc=None, acc_rows=None, acc_ld=0):
         _lib.check(self.L.hpf_hip_sweep_f32(_ptr(side.segs), side.nseg, _ptr(side.idx), _ptr(side.y),
                                             _ptr(tab_self), _ptr(tab_other), _ptr(part), _ptr(scatter_acc),
-                                            k, ld, self.sweep_blocks, self._stream()), "hpf_hip_sweep_f32")
+                                            _ptr(acc_rows), int(acc_ld), k, ld, self.sweep_blocks, self._stream()),
+                   "hpf_hip_sweep_f32")
 
     def sweep_grid(self, nseg):
         return int(max(1, min(self.sweep_blocks, (nseg + 3) // 4)))
@@ -79,10 +80,10 @@ class HipOps:
         _lib.check(self.L.hpf_hip_expect_f32(_ptr(shp), _ptr(rte), _ptr(e), _ptr(row_list), nrows, k, ld,
                                              self._stream()), "hpf_hip_expect_f32")
 
-    def segsum(self, part, row_seg_ptr, nrows, acc, ld, row_list=None, acc_ld=None):
+    def segsum(self, part, row_seg_ptr, nrows, acc, ld, row_list=None, acc_ld=None, acc_by_row=False):
         _lib.check(self.L.hpf_hip_segsum_f32(_ptr(part), _ptr(row_seg_ptr), _ptr(row_list), nrows, _ptr(acc), ld,
-                                             ld if acc_ld is None else acc_ld, self._stream()),
-                   "hpf_hip_segsum_f32")
+                                             ld if acc_ld is None else acc_ld, int(bool(acc_by_row)),
+                                             self._stream()), "hpf_hip_segsum_f32")
 
     def pair_llk(self, T, B, ix_u, ix_i, y, k, ld, full_llk):
         """-> float64 tensor [3]: sum y*log(yhat) [- lgamma(y+1)], sum (y-yhat)^2, sum yhat."""

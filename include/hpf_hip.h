@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 1
+#define HPF_HIP_ABI_VERSION 2
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -70,10 +70,12 @@ int hpf_hip_device_info(int *cu_count, char *arch, int arch_len);
  * see hpf_hip_row_finalize_f32), so that shape_row = prior + tab_self[row] (*) sum of
  * that row's part[] entries.  One wavefront per segment, 64/(ld/4) nonzeros per step.
  * scatter_acc may be NULL (the deterministic two-pass scheme: call once per side).
+ * acc_rows (optional): segments flagged HPF_SEG_WHOLE_ROW write their accumulator to
+ * acc_rows[row][0:acc_ld] (k <= acc_ld <= ld, packed) instead of part[g] -- the multi-GPU exchange buffer.
  */
 int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
                       const float *tab_self, const float *tab_other, float *part, float *scatter_acc,
-                      int k, int ld, int grid_blocks, void *stream);
+                      float *acc_rows, int acc_ld, int k, int ld, int grid_blocks, void *stream);
 
 /*
  * hpf_hip_sweep_f32 with the row finalizer (next entry) fused in: a segment flagged
@@ -123,10 +125,11 @@ int hpf_hip_colsum_f32(const float *tab, int64_t nrows, int ld, float *cs_partia
 int hpf_hip_expect_f32(const float *shp, const float *rte, float *e, const int64_t *row_list, int64_t nrows, int k,
                        int ld, void *stream);
 
-/* acc[t][0:acc_ld] = sum of the part[] segments of row r = row_list ? row_list[t] : t, t < nrows (multi-GPU
- * item side before the all-reduce -- acc_ld = k packs the payload; the batch rows of an SVI step). */
+/* acc[t][0:acc_ld] (or acc[r][0:acc_ld] when acc_by_row) = sum of the part[] segments of row
+ * r = row_list ? row_list[t] : t, t < nrows (multi-GPU item side before the all-reduce -- acc_ld = k packs the
+ * payload; the batch rows of an SVI step). */
 int hpf_hip_segsum_f32(const float *part, const int64_t *row_seg_ptr, const int64_t *row_list, int64_t nrows,
-                       float *acc, int ld, int acc_ld, void *stream);
+                       float *acc, int ld, int acc_ld, int acc_by_row, void *stream);
 
 /*
  * Poisson log-likelihood terms over listed pairs.  Replaces llk_plus_rmse (PXI:627-658)

@@ -51,7 +51,7 @@ class CpuOps:
         self.row_finalize(part, side.row_seg_ptr, int(single.shape[0]), e_old, e_new, shp, rte, fac, rs, cs_other,
                           cs_partial, prior_shp, top_shp, add_rte, k, ld, row_list=single)
 
-    def sweep(self, side, tab_self, tab_other, part, k, ld, scatter_acc=None):
+    def sweep(self, side, tab_self, tab_other, part, k, ld, scatter_acc=None, acc_rows=None, acc_ld=0):
         if side.nseg == 0:
             return
         begin, length, row = _decode_segs(side)
@@ -67,7 +67,12 @@ class CpuOps:
         w = np.where(y > 0, y / s, 0.0)
         contrib = w[:, None] * O
         out = np.add.reduceat(contrib, offs, axis=0)
-        _np(part)[: side.nseg] = out.astype(np.float32)
+        if acc_rows is not None:
+            whole = (_np(side.segs)[:, 1] & 0x40000000) != 0
+            _np(acc_rows)[row[whole], :acc_ld] = out[whole][:, :acc_ld].astype(np.float32)
+            _np(part)[: side.nseg][~whole] = out[~whole].astype(np.float32)
+        else:
+            _np(part)[: side.nseg] = out.astype(np.float32)
         if scatter_acc is not None:
             acc = _np(scatter_acc).astype(np.float64)
             np.add.at(acc, idx, w[:, None] * S)
@@ -131,7 +136,7 @@ class CpuOps:
         E = E - E.max(axis=1, keepdims=True)
         _np(e)[rows] = np.exp(E).astype(np.float32)
 
-    def segsum(self, part, row_seg_ptr, nrows, acc, ld, row_list=None, acc_ld=None):
+    def segsum(self, part, row_seg_ptr, nrows, acc, ld, row_list=None, acc_ld=None, acc_by_row=False):
         acc_ld = ld if acc_ld is None else acc_ld
         rows = np.arange(nrows) if row_list is None else _np(row_list)[:nrows].astype(np.int64)
         rsp = _np(row_seg_ptr)
@@ -140,7 +145,10 @@ class CpuOps:
         for t, r in enumerate(rows):
             if rsp[r + 1] > rsp[r]:
                 out[t] = P[rsp[r]: rsp[r + 1]].sum(axis=0)
-        _np(acc)[: rows.shape[0]] = out[:, :acc_ld].astype(np.float32)
+        if acc_by_row:
+            _np(acc)[rows] = out[:, :acc_ld].astype(np.float32)
+        else:
+            _np(acc)[: rows.shape[0]] = out[:, :acc_ld].astype(np.float32)
 
     def pair_llk(self, T, B, ix_u, ix_i, y, k, ld, full_llk):
         Tn = _np(T).astype(np.float64)[_np(ix_u).astype(np.int64)]
