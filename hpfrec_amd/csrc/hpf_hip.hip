@@ -97,22 +97,50 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b) {
 }
 
 // ----------------------------------------------------------------------------------------
-// exp(psi(x)) / r for x > 0, r > 0, in double.
-//   psi(x) = psi(x+6) - sum_{i<6} 1/(x+i)           (recurrence, only when x < 6)
+// exp(psi(x)) / r for x > 0, r > 0, in double, rounded once by the caller.
+//   psi(x) = psi(x+6) - sum_{i<6} 1/(x+i)            (recurrence, applied for every x: no divergence)
 //   psi(s) = log s - 1/(2s) - sum_n B_2n/(2n s^2n)   (asymptotic, s >= 6: truncation < 2e-13)
 // so exp(psi(x))/r = (s/r) * exp(-(1/(2s) + series + recurrence sum)) with no log at all.
 // Same series as the Cephes psi the reference calls through scipy (PXI:5,588).
+// Cost matters (it runs in the sweep's epilogue and, replicated, in the multi-GPU item finalizer):
+// one shared reciprocal for 1/s and the recurrence sum, Newton reciprocals instead of IEEE divides,
+// and a short exp (fdlibm-style ln2 split + degree-9 Taylor, rel. error < 1e-11) instead of ocml's.
 // ----------------------------------------------------------------------------------------
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);  // v_rcp_f64: ~24 good bits
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+__device__ __forceinline__ double exp_neg(double v) {  // exp(-v) for v >= 0
+    const double t = rint(v * 1.4426950408889634);
+    double f = fma(t, -6.93147180369123816490e-01, v);  // t*ln2_hi is exact for |t| < 2^11
+    f = fma(t, -1.90821492927058770002e-10, f);
+    const double g = -f;                                 // |g| <= 0.3466
+    double p = 1.0 / 362880.0;
+    p = fma(p, g, 1.0 / 40320.0);
+    p = fma(p, g, 1.0 / 5040.0);
+    p = fma(p, g, 1.0 / 720.0);
+    p = fma(p, g, 1.0 / 120.0);
+    p = fma(p, g, 1.0 / 24.0);
+    p = fma(p, g, 1.0 / 6.0);
+    p = fma(p, g, 0.5);
+    p = fma(p, g, 1.0);
+    p = fma(p, g, 1.0);
+    return ldexp(p, -(int)t);
+}
+
 __device__ __forceinline__ double expect_ratio(float shp, float rte) {
-    double x = (double)shp;
-    double s = x, w = 0.0;
-    if (x < 6.0) {
-        const double p01 = x * (x + 1.0), p23 = (x + 2.0) * (x + 3.0), p45 = (x + 4.0) * (x + 5.0);
-        const double n01 = 2.0 * x + 1.0, n23 = 2.0 * x + 5.0, n45 = 2.0 * x + 9.0;
-        w = (n01 * p23 * p45 + n23 * p01 * p45 + n45 * p01 * p23) / (p01 * p23 * p45);
-        s = x + 6.0;
-    }
-    const double r = 1.0 / s;
+    const double x = (double)shp;
+    const double p01 = x * (x + 1.0), p23 = (x + 2.0) * (x + 3.0), p45 = (x + 4.0) * (x + 5.0);
+    const double n01 = 2.0 * x + 1.0, n23 = 2.0 * x + 5.0, n45 = 2.0 * x + 9.0;
+    const double den = p01 * p23 * p45;                                   // prod_{i<6} (x+i)
+    const double num = fma(n01, p23 * p45, p01 * fma(n23, p45, n45 * p23));  // den * sum_{i<6} 1/(x+i)
+    const double s = x + 6.0;
+    const double R = fast_rcp(den * s);
+    const double r = R * den;          // 1/s
+    const double w = num * (R * s);    // sum_{i<6} 1/(x+i)
     const double z = r * r;
     double poly = 8.33333333333333333333E-2;
     poly = fma(poly, z, -2.10927960927960927961E-2);
@@ -122,7 +150,7 @@ __device__ __forceinline__ double expect_ratio(float shp, float rte) {
     poly = fma(poly, z, -8.33333333333333333333E-3);
     poly = fma(poly, z, 8.33333333333333333333E-2);
     const double v = fma(poly, z, 0.5 * r) + w;
-    return (s / (double)rte) * exp(-v);
+    return (s * exp_neg(v)) * fast_rcp((double)rte);
 }
 
 // ----------------------------------------------------------------------------------------

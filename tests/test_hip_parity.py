@@ -397,3 +397,16 @@ def test_llk_sweep_op(ops, k):
         pair = ops.pair_llk(T.cuda(), B.cuda(), u_sorted.cuda(), users.idx.cuda(), users.y.cuda(), k, ld, full).cpu().numpy()
         assert np.max(np.abs(got - want) / np.abs(want)) < 2e-6
         assert np.max(np.abs(got - pair) / np.abs(pair)) < 1e-9
+
+
+def test_2m_nnz_vs_oracle(hip_backend):
+    """100k x 30k, 2M nonzeros, k=50 (the BASELINE.md calibration size): every array against the CPU oracle
+    after 3 iterations, plus the train llk."""
+    nU, nI, k = 100_000, 30_000, 50
+    iu, ii, Y = datagen.synthetic_hpf_shaped(nU, nI, 2_000_000, seed=5)
+    st, caps = O.fit_full_batch(Y, iu, ii, nU, nI, k, 3, 77, capture_at=(3,), nthreads=O.max_threads())
+    i, arrs, llk = _fit(hip_backend, Y, iu, ii, nU, nI, k, 3, seed=77, verbose=1, check_every=3)
+    for n in NAMES:
+        assert _maxrel(arrs[n], caps[3][n]) < 3e-5, n
+    ref_llk, _ = O.train_llk(st, O._f32(Y), O._ind(iu), O._ind(ii), nthreads=O.max_threads())
+    assert abs(float(llk) / float(ref_llk) - 1) < 1e-5
