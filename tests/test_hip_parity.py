@@ -410,3 +410,46 @@ def test_2m_nnz_vs_oracle(hip_backend):
         assert _maxrel(arrs[n], caps[3][n]) < 3e-5, n
     ref_llk, _ = O.train_llk(st, O._f32(Y), O._ind(iu), O._ind(ii), nthreads=O.max_threads())
     assert abs(float(llk) / float(ref_llk) - 1) < 1e-5
+
+
+def test_invariants_at_c3_full_size(ops):
+    """BASELINE config C3 at full size (1M x 380k, ~48M nnz, k=50), on-device: the per-row phi-mass
+    identity for both sides, the closed forms, positivity -- and fused == unfused launches."""
+    import bench
+    from hpfrec_amd import cavi, cython_loops_float as be
+    nU, nI, nnz_t, k, _ = bench.WORKLOADS["c3"]
+    dev = torch.device("cuda", 0)
+    iu, ii, y = bench.synth_on_device(nU, nI, nnz_t, dev)
+    assert abs(iu.shape[0] / nnz_t - 1) < 0.02
+    ysum_u = torch.zeros(nU, dtype=torch.float64, device=dev).index_add_(0, iu, y.double())
+    ysum_i = torch.zeros(nI, dtype=torch.float64, device=dev).index_add_(0, ii, y.double())
+    hy = cavi.Hyper(k, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
+    Theta = np.empty((nU, k), np.float32)
+    Beta = np.empty((nI, k), np.float32)
+    init = be.initialize_parameters(Theta, Beta, 123, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
+    res = {}
+    for mode in ("fused", "split"):
+        m = cavi.FullBatchCavi(ops, dev, iu, ii, y, nU, nI, hy)
+        m.load_state(init[0], init[1], init[2], init[3], init[4], init[5], Theta, Beta)
+        if mode == "split":
+            m.set_fused(False)
+        m.iterate()
+        m.iterate()
+        torch.cuda.synchronize()
+        a = float(hy.a)
+        gu = m.Gamma_shp[:, :k].double().sum(dim=1) - k * a
+        gi = m.Lambda_shp[:, :k].double().sum(dim=1) - k * float(hy.c)
+        assert float(((gu - ysum_u).abs() / ysum_u.clamp_min(1)).max()) < 3e-5
+        assert float(((gi - ysum_i).abs() / ysum_i.clamp_min(1)).max()) < 3e-5
+        assert float((m.Theta[:, :k] / (m.Gamma_shp[:, :k] / m.Gamma_rte[:, :k]) - 1).abs().max()) < 1e-6
+        assert float((m.k_rte / (float(hy.add_k_rte) + m.Theta[:, :k].sum(dim=1)) - 1).abs().max()) < 1e-5
+        assert float((m.t_rte / (float(hy.add_t_rte) + m.Beta[:, :k].sum(dim=1)) - 1).abs().max()) < 1e-5
+        for t in (m.Theta, m.Beta, m.eT, m.eB):
+            assert bool(torch.isfinite(t).all()) and bool((t[:, :k] > 0).all()) and bool((t[:, k:] == 0).all())
+        assert float(m.eT.max()) == 1.0 and float(m.eB.max()) == 1.0      # rows are max-normalised
+        res[mode] = (m.Theta[:, :k].clone(), m.Beta[:, :k].clone(), m.llk_terms(False))
+        del m
+        torch.cuda.empty_cache()
+    assert float((res["fused"][0] / res["split"][0] - 1).abs().max()) < 5e-6
+    assert float((res["fused"][1] / res["split"][1] - 1).abs().max()) < 5e-6
+    assert abs(res["fused"][2][0] / res["split"][2][0] - 1) < 1e-7
