@@ -565,6 +565,141 @@ __global__ __launch_bounds__(BLOCK) void segsum_kernel(const float *__restrict__
 }
 
 // ----------------------------------------------------------------------------------------
+// stochastic-VI row kernels (one wavefront per row, lane <-> factor): the numpy statements the reference
+// executes around update_phi_csr in an SVI batch / partial_fit (PXI:300-325, 352-377, 443-473)
+// ----------------------------------------------------------------------------------------
+// shp[r] = w_new * (prior + e[r] (*) acc[t]) + w_old * shp[r]   for r = row_list[t]
+//   batch side:  w_new = 1, w_old = 0            (reset to the prior + this batch's phi, PXI:304,308-314)
+//   other side:  w_new = step*multiplier, w_old = 1-step          (PXI:316 / PXI:368)
+template <int LD>
+__global__ __launch_bounds__(BLOCK) void svi_shape_rows_kernel(const int64_t *__restrict__ row_list, int64_t nrows,
+                                                               const float *__restrict__ acc,
+                                                               const float *__restrict__ e, float *__restrict__ shp,
+                                                               float prior, float w_new, float w_old, int k) {
+    constexpr int CPL = (LD + WAVE - 1) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WPB;
+    for (int64_t t = (int64_t)blockIdx.x * WPB + wid; t < nrows; t += nwaves) {
+        const int64_t r = row_list[t];
+#pragma unroll
+        for (int q = 0; q < CPL; q++) {
+            const int c = lane + WAVE * q;
+            if (c < k) {
+                const size_t o = (size_t)r * LD + c;
+                const float a = acc ? acc[(size_t)t * LD + c] : 0.f;
+                const float fresh = fmaf(e[o], a, prior);
+                shp[o] = (w_old == 0.f) ? w_new * fresh : w_new * fresh + w_old * shp[o];
+            }
+        }
+    }
+}
+
+// whole-side refresh: [rte = top/rs + cs_other]  ->  fac = shp/rte  ->  [rs = step*(add + sum_k fac) + (1-step)*rs]
+// plus per-block column sums of fac (Theta[:,:] = Gamma_shp/Gamma_rte etc., PXI:300,318,322,352,370,374,472-473)
+template <int LD>
+__global__ __launch_bounds__(BLOCK) void svi_refresh_kernel(int64_t nrows, const float *__restrict__ shp,
+                                                            float *__restrict__ rte, float *__restrict__ fac,
+                                                            float *__restrict__ rs,
+                                                            const float *__restrict__ cs_other,
+                                                            float *__restrict__ cs_partial, float top, float add,
+                                                            float step, float step_prev, int refresh_rte,
+                                                            int blend_rs, int k) {
+    constexpr int CPL = (LD + WAVE - 1) / WAVE;
+    __shared__ float red[WPB][LD];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WPB;
+    float csl[CPL], csacc[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; q++) {
+        const int c = lane + WAVE * q;
+        csl[q] = (refresh_rte && c < k) ? cs_other[c] : 0.f;
+        csacc[q] = 0.f;
+    }
+    for (int64_t r = (int64_t)blockIdx.x * WPB + wid; r < nrows; r += nwaves) {
+        const float rs_old = rs[r];
+        const float base = top / rs_old;
+        float fsum = 0.f;
+#pragma unroll
+        for (int q = 0; q < CPL; q++) {
+            const int c = lane + WAVE * q;
+            if (c < LD) {
+                const size_t o = (size_t)r * LD + c;
+                float f = 0.f;
+                if (c < k) {
+                    float rt;
+                    if (refresh_rte) {
+                        rt = base + csl[q];
+                        rte[o] = rt;
+                    } else {
+                        rt = rte[o];
+                    }
+                    f = shp[o] / rt;
+                }
+                fac[o] = f;
+                fsum += f;
+                csacc[q] += f;
+            }
+        }
+        if (blend_rs) {
+            fsum = wave_sum(fsum);
+            if (lane == 0) rs[r] = step * (add + fsum) + step_prev * rs_old;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < CPL; q++) {
+        const int c = lane + WAVE * q;
+        if (c < LD) red[wid][c] = csacc[q];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < LD; c += BLOCK) {
+        float t = red[0][c];
+#pragma unroll
+        for (int w2 = 1; w2 < WPB; w2++) t += red[w2][c];
+        cs_partial[(size_t)blockIdx.x * LD + c] = t;
+    }
+}
+
+// listed rows: mode 0: rte[r] = step*(top/rs[r] + cs_other) + (1-step)*rte[r]       (PXI:320 / PXI:372)
+//              mode 1: rs[r]  = step*(add + sum_k fac[r]) + (1-step)*rs[r]          (PXI:324-325, 376-377)
+template <int LD>
+__global__ __launch_bounds__(BLOCK) void svi_rate_rows_kernel(const int64_t *__restrict__ row_list, int64_t nrows,
+                                                              float *__restrict__ rte, const float *__restrict__ fac,
+                                                              float *__restrict__ rs,
+                                                              const float *__restrict__ cs_other, float top,
+                                                              float add, float step, float step_prev, int mode,
+                                                              int k) {
+    constexpr int CPL = (LD + WAVE - 1) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WPB;
+    for (int64_t t = (int64_t)blockIdx.x * WPB + wid; t < nrows; t += nwaves) {
+        const int64_t r = row_list[t];
+        if (mode == 0) {
+            const float base = top / rs[r];
+#pragma unroll
+            for (int q = 0; q < CPL; q++) {
+                const int c = lane + WAVE * q;
+                if (c < k) {
+                    const size_t o = (size_t)r * LD + c;
+                    rte[o] = step * (base + cs_other[c]) + step_prev * rte[o];
+                }
+            }
+        } else {
+            float fsum = 0.f;
+#pragma unroll
+            for (int q = 0; q < CPL; q++) {
+                const int c = lane + WAVE * q;
+                if (c < k) fsum += fac[(size_t)r * LD + c];
+            }
+            fsum = wave_sum(fsum);
+            if (lane == 0) rs[r] = step * (add + fsum) + step_prev * rs[r];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
 // listed-pair kernels: LPR lanes per (user,item) pair
 // ----------------------------------------------------------------------------------------
 template <int LPR, int VPL>
@@ -979,6 +1114,53 @@ int hpf_hip_pair_dot_f32(const float *T, const float *B, const int32_t *ix_u, co
         hipLaunchKernelGGL((pair_dot_kernel<LPR, VPL>), dim3(grid), dim3(BLOCK), 0, st, T, B, ix_u, ix_i, n, out); \
     }
     HPF_DISPATCH_LD(ld, CALL)
+#undef CALL
+    return last_error();
+}
+
+int hpf_hip_svi_shape_rows_f32(const int64_t *row_list, int64_t nrows, const float *acc, const float *e, float *shp,
+                               float prior, float w_new, float w_old, int k, int ld, void *stream) {
+    if (nrows == 0) return 0;
+    if (!row_list || !e || !shp || nrows < 0 || k <= 0 || ld != hpf_hip_ld_for_k(k)) return HPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = clamp_grid((nrows + WPB - 1) / WPB, 2048);
+#define CALL(LD)                                                                                                   \
+    hipLaunchKernelGGL((svi_shape_rows_kernel<LD>), dim3(grid), dim3(BLOCK), 0, st, row_list, nrows, acc, e, shp,  \
+                       prior, w_new, w_old, k);
+    HPF_DISPATCH_LD1(ld, CALL)
+#undef CALL
+    return last_error();
+}
+
+int hpf_hip_svi_refresh_f32(int64_t nrows, const float *shp, float *rte, float *fac, float *rs, const float *cs_other,
+                            float *cs_partial, float top, float add, float step, float step_prev, int refresh_rte,
+                            int blend_rs, int k, int ld, int grid_blocks, void *stream) {
+    if (!shp || !rte || !fac || !rs || !cs_partial || (refresh_rte && !cs_other) || nrows <= 0 || k <= 0 ||
+        ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0)
+        return HPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    // grid not clamped: every block writes its cs_partial row
+#define CALL(LD)                                                                                                    \
+    hipLaunchKernelGGL((svi_refresh_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, nrows, shp, rte, fac, rs,  \
+                       cs_other, cs_partial, top, add, step, step_prev, refresh_rte, blend_rs, k);
+    HPF_DISPATCH_LD1(ld, CALL)
+#undef CALL
+    return last_error();
+}
+
+int hpf_hip_svi_rate_rows_f32(const int64_t *row_list, int64_t nrows, float *rte, const float *fac, float *rs,
+                              const float *cs_other, float top, float add, float step, float step_prev, int mode,
+                              int k, int ld, void *stream) {
+    if (nrows == 0) return 0;
+    if (!row_list || !rs || nrows < 0 || k <= 0 || ld != hpf_hip_ld_for_k(k) || (mode != 0 && mode != 1))
+        return HPF_EINVAL;
+    if ((mode == 0 && (!rte || !cs_other)) || (mode == 1 && !fac)) return HPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = clamp_grid((nrows + WPB - 1) / WPB, 2048);
+#define CALL(LD)                                                                                                   \
+    hipLaunchKernelGGL((svi_rate_rows_kernel<LD>), dim3(grid), dim3(BLOCK), 0, st, row_list, nrows, rte, fac, rs,  \
+                       cs_other, top, add, step, step_prev, mode, k);
+    HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
     return last_error();
 }

@@ -111,3 +111,22 @@ class HipOps:
     def score_rows(self, vec, tab, out, k, ld):
         _lib.check(self.L.hpf_hip_score_rows_f32(_ptr(vec), _ptr(tab), int(tab.shape[0]), _ptr(out), k, ld,
                                                  self._stream()), "hpf_hip_score_rows_f32")
+
+    # -- stochastic-VI row kernels ------------------------------------------------------------
+    def svi_shape_rows(self, row_list, acc, e, shp, prior, w_new, w_old, k, ld):
+        _lib.check(self.L.hpf_hip_svi_shape_rows_f32(_ptr(row_list), int(row_list.shape[0]), _ptr(acc), _ptr(e),
+                                                     _ptr(shp), float(prior), float(w_new), float(w_old), k, ld,
+                                                     self._stream()), "hpf_hip_svi_shape_rows_f32")
+
+    def svi_refresh(self, nrows, shp, rte, fac, rs, cs_other, cs_partial, top, add, step, step_prev, refresh_rte,
+                    blend_rs, k, ld):
+        _lib.check(self.L.hpf_hip_svi_refresh_f32(nrows, _ptr(shp), _ptr(rte), _ptr(fac), _ptr(rs), _ptr(cs_other),
+                                                  _ptr(cs_partial), float(top), float(add), float(step),
+                                                  float(step_prev), int(bool(refresh_rte)), int(bool(blend_rs)), k,
+                                                  ld, cs_partial.shape[0], self._stream()), "hpf_hip_svi_refresh_f32")
+
+    def svi_rate_rows(self, row_list, rte, fac, rs, cs_other, top, add, step, step_prev, mode, k, ld):
+        _lib.check(self.L.hpf_hip_svi_rate_rows_f32(_ptr(row_list), int(row_list.shape[0]), _ptr(rte), _ptr(fac),
+                                                    _ptr(rs), _ptr(cs_other), float(top), float(add), float(step),
+                                                    float(step_prev), int(mode), k, ld, self._stream()),
+                   "hpf_hip_svi_rate_rows_f32")

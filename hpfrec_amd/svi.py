@@ -8,8 +8,9 @@ Division of labour in this round:
     row-list forms of `expect_kernel` / `segsum_kernel` (update_phi_csr PXI:666-692 always
     max-subtracts; our E rows are max-normalised in every mode);
   * O((nU+nI) * k) per batch: the reference recomputes whole tables with numpy statements every batch
-    (PXI:300,318,322 ...); here those statements are torch elementwise ops on the device tensors, in
-    the reference's order.  Fusing them into row kernels is left for a later round.
+    (PXI:300,318,322 ...); here those statements are three HIP row kernels (svi_shape_rows,
+    svi_refresh, svi_rate_rows; include/hpf_hip.h) issued in the reference's order.
+torch is used for index plumbing only (grouping a batch by row, aligning accumulators with row lists).
 No numerics run on the host; shuffles and seeds use numpy's generators so batches are the reference's.
 """
 import numpy as np
@@ -57,7 +58,6 @@ class DeviceModel:
         self.k_rte = torch.zeros(self.nU, **f32)
         self.t_rte = torch.zeros(self.nI, **f32)
         self._cs_part = torch.zeros((ops.finalize_grid(max(self.nU, self.nI)), self.ld), **f32)
-        self._cs = torch.zeros(self.ld, **f32)
 
     def v(self, name):
         return getattr(self, name)[:, : self.k]
@@ -68,6 +68,8 @@ class DeviceModel:
             self.v(n).copy_(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev))
         self.k_rte.copy_(torch.from_numpy(np.ascontiguousarray(k_rte, dtype=np.float32).reshape(-1)))
         self.t_rte.copy_(torch.from_numpy(np.ascontiguousarray(t_rte, dtype=np.float32).reshape(-1)))
+        self.csT = self.colsum("Theta")     # Theta.sum(axis=0) / Beta.sum(axis=0), kept current by every step
+        self.csB = self.colsum("Beta")
 
     def store(self, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta):
         for n, a in zip(_NAMES, (Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, Theta, Beta)):
@@ -76,17 +78,18 @@ class DeviceModel:
         t_rte[:, :] = self.t_rte.cpu().numpy().reshape(-1, 1)
 
     def colsum(self, name):
-        """tab.sum(axis=0) -> [k] (HIP colsum kernels; PXI:300,320,352,372)."""
+        """tab.sum(axis=0) -> [ld] (HIP colsum kernels; PXI:300,320,352,372)."""
         tab = getattr(self, name)
         self.ops.colsum(tab, tab.shape[0], self.ld, self._cs_part)
-        self.ops.colsum_reduce(self._cs_part, self._cs, self.ld)
-        return self._cs[: self.k].clone()
+        out = torch.zeros(self.ld, dtype=torch.float32, device=self.ops.device)
+        self.ops.colsum_reduce(self._cs_part, out, self.ld)
+        return out
 
     # ------------------------------------------------------------------------------------------
     def batch_phi_sums(self, bu, bi, by):
-        """sum_n phi_n over the batch's nonzeros, grouped by user and by item (update_phi[_csr] +
-        update_G_n_L_sh[_csr] restricted to the batch), from the CURRENT shapes/rates.
-        Returns (users_present, sum_phi_users [nu,k], items_present, sum_phi_items [ni,k])."""
+        """Per touched row, sum_n w_n * (other side's E row) over the batch's nonzeros (update_phi[_csr] +
+        update_G_n_L_sh[_csr] restricted to the batch; sum phi = E_row (*) this), from the CURRENT
+        shapes/rates.  Returns (users_present, acc_users [nu,ld], items_present, acc_items [ni,ld])."""
         ops, k, ld = self.ops, self.k, self.ld
         su = BatchSide(bu, bi, by)
         si = BatchSide(bi, bu, by)
@@ -96,49 +99,62 @@ class DeviceModel:
         for side, e_self, e_other in ((su, self.eT, self.eB), (si, self.eB, self.eT)):
             part = torch.empty((max(1, side.nseg), ld), dtype=torch.float32, device=ops.device)
             ops.sweep(side, e_self, e_other, part, k, ld)
-            acc = torch.empty((max(1, side.nrows), ld), dtype=torch.float32, device=ops.device)
+            acc = torch.zeros((max(1, side.nrows), ld), dtype=torch.float32, device=ops.device)
             ops.segsum(part, side.row_seg_ptr, side.nrows, acc, ld)
-            out += [side.rows, (e_self[side.rows] * acc[: side.nrows])[:, :k]]
+            out += [side.rows, acc]
         return tuple(out)
+
+
+def _aligned(rows_tb, present, acc, ld):
+    """(sorted row list, accumulator rows aligned with it): rows of the batch list without any nonzero get a
+    zero accumulator.  `present` (ascending) must be a subset of rows_tb."""
+    tb = torch.sort(rows_tb).values.contiguous()
+    out = torch.zeros((max(1, tb.shape[0]), ld), dtype=torch.float32, device=acc.device)
+    if present.shape[0] > 0:
+        pos = torch.searchsorted(tb, present)
+        if bool((pos >= tb.shape[0]).any()) or not torch.equal(tb[pos.clamp(max=tb.shape[0] - 1)], present):
+            raise ValueError("the batch contains users/items that are not in users_in_batch/items_in_batch")
+        out[pos] = acc[: present.shape[0]]
+    return tb, out
 
 
 def _svi_step(m, hy, bu, bi, by, users_tb, items_tb, step, mult, user_batch, all_scalar_rows):
     """One stochastic update in the reference's statement order (user batch: PXI:292-325 / 438-473;
     item batch: PXI:344-377).  `hy` carries a, c, k_shp, t_shp, add_k_rte, add_t_rte as python floats."""
+    ops, k, ld = m.ops, m.k, m.ld
     step_prev = float(np.float32(1) - np.float32(step))
     step = float(np.float32(step))
-    mult = float(np.float32(mult))
-    up, phi_u, ip, phi_i = m.batch_phi_sums(bu, bi, by)           # phi from the OLD parameters
-    G_shp, G_rte, L_shp, L_rte = m.v("Gamma_shp"), m.v("Gamma_rte"), m.v("Lambda_shp"), m.v("Lambda_rte")
-    Theta, Beta = m.v("Theta"), m.v("Beta")
-    if user_batch:
-        G_rte.copy_(hy["k_shp"] / m.k_rte[:, None] + m.colsum("Beta")[None, :])
-        prev = L_shp[items_tb].clone()
-    else:
-        L_rte.copy_(hy["t_shp"] / m.t_rte[:, None] + m.colsum("Theta")[None, :])
-        prev = G_shp[users_tb].clone()
-    G_shp[users_tb] = hy["a"]
-    L_shp[items_tb] = hy["c"]
-    G_shp[up] += phi_u
-    L_shp[ip] += phi_i
-    if user_batch:
-        L_shp[items_tb] = step * mult * L_shp[items_tb] + step_prev * prev
-        Theta.copy_(G_shp / G_rte)
-        L_rte[items_tb] = step * (hy["t_shp"] / m.t_rte[items_tb][:, None] + m.colsum("Theta")[None, :]) \
-            + step_prev * L_rte[items_tb]
-        Beta.copy_(L_shp / L_rte)
-    else:
-        G_shp[users_tb] = step * mult * G_shp[users_tb] + step_prev * prev
-        Beta.copy_(L_shp / L_rte)
-        G_rte[users_tb] = step * (hy["k_shp"] / m.k_rte[users_tb][:, None] + m.colsum("Beta")[None, :]) \
-            + step_prev * G_rte[users_tb]
-        Theta.copy_(G_shp / G_rte)
-    if all_scalar_rows:   # partial_fit blends every row (PXI:472-473)
-        m.k_rte.copy_(step * (hy["add_k_rte"] + Theta.sum(dim=1)) + step_prev * m.k_rte)
-        m.t_rte.copy_(step * (hy["add_t_rte"] + Beta.sum(dim=1)) + step_prev * m.t_rte)
-    else:                 # SVI epochs only the batch rows (PXI:324-325, 376-377)
-        m.k_rte[users_tb] = step * (hy["add_k_rte"] + Theta[users_tb].sum(dim=1)) + step_prev * m.k_rte[users_tb]
-        m.t_rte[items_tb] = step * (hy["add_t_rte"] + Beta[items_tb].sum(dim=1)) + step_prev * m.t_rte[items_tb]
+    w_other = float(np.float32(step * float(np.float32(mult))))   # step*multiplier as one float32 scalar (PXI:316)
+    up, acc_u, ip, acc_i = m.batch_phi_sums(bu, bi, by)           # phi from the OLD parameters
+    utb, acc_utb = _aligned(users_tb, up, acc_u, ld)
+    itb, acc_itb = _aligned(items_tb, ip, acc_i, ld)
+
+    U = dict(n=m.nU, shp=m.Gamma_shp, rte=m.Gamma_rte, fac=m.Theta, rs=m.k_rte, e=m.eT, rows=utb, acc=acc_utb,
+             prior=hy["a"], top=hy["k_shp"], add=hy["add_k_rte"], cs="csT")
+    I = dict(n=m.nI, shp=m.Lambda_shp, rte=m.Lambda_rte, fac=m.Beta, rs=m.t_rte, e=m.eB, rows=itb, acc=acc_itb,
+             prior=hy["c"], top=hy["t_shp"], add=hy["add_t_rte"], cs="csB")
+    B, O = (U, I) if user_batch else (I, U)     # batch side, other side
+
+    # shapes: batch side = prior + phi ; other side blended with its previous value
+    ops.svi_shape_rows(B["rows"], B["acc"], B["e"], B["shp"], B["prior"], 1.0, 0.0, k, ld)
+    ops.svi_shape_rows(O["rows"], O["acc"], O["e"], O["shp"], O["prior"], w_other, step_prev, k, ld)
+    # batch side: rate for ALL its rows from the other side's current column sums, then its means
+    cs_other = getattr(m, O["cs"])
+    ops.svi_refresh(B["n"], B["shp"], B["rte"], B["fac"], B["rs"], cs_other, m._cs_part, B["top"], B["add"], step,
+                    step_prev, True, all_scalar_rows, k, ld)
+    cs_batch = torch.zeros(ld, dtype=torch.float32, device=ops.device)
+    ops.colsum_reduce(m._cs_part, cs_batch, ld)
+    setattr(m, B["cs"], cs_batch)
+    # other side: rate of the touched rows blended towards top/rs + colsum(batch-side means), then its means
+    ops.svi_rate_rows(O["rows"], O["rte"], None, O["rs"], cs_batch, O["top"], 0.0, step, step_prev, 0, k, ld)
+    ops.svi_refresh(O["n"], O["shp"], O["rte"], O["fac"], O["rs"], None, m._cs_part, O["top"], O["add"], step,
+                    step_prev, False, all_scalar_rows, k, ld)
+    cs_o = torch.zeros(ld, dtype=torch.float32, device=ops.device)
+    ops.colsum_reduce(m._cs_part, cs_o, ld)
+    setattr(m, O["cs"], cs_o)
+    if not all_scalar_rows:   # SVI epochs blend the scalar rates of the batch rows only (PXI:324-325, 376-377)
+        ops.svi_rate_rows(U["rows"], None, U["fac"], U["rs"], None, 0.0, U["add"], step, step_prev, 1, k, ld)
+        ops.svi_rate_rows(I["rows"], None, I["fac"], I["rs"], None, 0.0, I["add"], step, step_prev, 1, k, ld)
 
 
 def _dev_ids(a, dev):
@@ -221,7 +237,7 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
             errs[1] = np.sqrt(np.longdouble(t[1]) / val[0].shape[0])
         else:
             t = ops.pair_llk(m.Theta, m.Beta, u_sorted, users.idx, users.y, k, m.ld, full_llk).cpu().numpy()
-            sub = np.dot(m.colsum("Theta").cpu().numpy(), m.colsum("Beta").cpu().numpy())
+            sub = np.dot(m.csT[:k].cpu().numpy(), m.csB[:k].cpu().numpy())
             errs[0] = np.longdouble(t[0]) - np.longdouble(sub)
             errs[1] = np.sqrt(np.longdouble(t[1]) / users.nnz)
 

@@ -150,6 +150,28 @@ int hpf_hip_llk_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *
 int hpf_hip_pair_dot_f32(const float *T, const float *B, const int32_t *ix_u, const int32_t *ix_i, int64_t n,
                          float *out, int k, int ld, void *stream);
 
+/*
+ * Stochastic VI (fit_hpf SVI epochs PXI:262-377, partial_fit PXI:423-473): the dense statements around the
+ * batch's phi, as three row kernels.  `acc` holds sum_n (w_n * other-side E row) per listed row, i.e. the
+ * output of hpf_hip_sweep_f32 + hpf_hip_segsum_f32 over the batch's rows, aligned with row_list.
+ *
+ * shape rows:  shp[r] = w_new*(prior + e[r] (*) acc[t]) + w_old*shp[r],  r = row_list[t]
+ *              (batch side: w_new=1, w_old=0 -- PXI:304-314; other side: step*multiplier, 1-step -- PXI:316,368)
+ * refresh:     every row of a side: [rte = top/rs + cs_other] ; fac = shp/rte ;
+ *              [rs = step*(add + sum_k fac) + step_prev*rs] ; cs_partial = per-block column sums of fac
+ *              (PXI:300,318,322 / 352,370,374; the rs blend over all rows is partial_fit's PXI:472-473)
+ * rate rows:   mode 0: rte[r] = step*(top/rs[r] + cs_other) + step_prev*rte[r]        (PXI:320,372)
+ *              mode 1: rs[r]  = step*(add + sum_k fac[r])   + step_prev*rs[r]         (PXI:324-325,376-377)
+ */
+int hpf_hip_svi_shape_rows_f32(const int64_t *row_list, int64_t nrows, const float *acc, const float *e, float *shp,
+                               float prior, float w_new, float w_old, int k, int ld, void *stream);
+int hpf_hip_svi_refresh_f32(int64_t nrows, const float *shp, float *rte, float *fac, float *rs, const float *cs_other,
+                            float *cs_partial, float top, float add, float step, float step_prev, int refresh_rte,
+                            int blend_rs, int k, int ld, int grid_blocks, void *stream);
+int hpf_hip_svi_rate_rows_f32(const int64_t *row_list, int64_t nrows, float *rte, const float *fac, float *rs,
+                              const float *cs_other, float top, float add, float step, float step_prev, int mode,
+                              int k, int ld, void *stream);
+
 /* out[r] = <vec, tab[r]>, r < nrows; vec is one padded row (ld floats).  Replaces the scoring product of
  * HPF.topN, Theta[user].dot(Beta.T) (hpfrec/__init__.py:1337). */
 int hpf_hip_score_rows_f32(const float *vec, const float *tab, int64_t nrows, float *out, int k, int ld,

@@ -171,3 +171,43 @@ class CpuOps:
 
     def score_rows(self, vec, tab, out, k, ld):
         _np(out)[:] = (_np(tab).astype(np.float64) @ _np(vec).astype(np.float64)).astype(np.float32)
+
+    # -- stochastic-VI row kernels (float32 arithmetic, statement for statement) ------------------
+    def svi_shape_rows(self, row_list, acc, e, shp, prior, w_new, w_old, k, ld):
+        rows = _np(row_list).astype(np.int64)
+        if rows.shape[0] == 0:
+            return
+        f = np.float32
+        a = _np(acc)[: rows.shape[0], :k] if acc is not None else np.zeros((rows.shape[0], k), np.float32)
+        fresh = (f(prior) + _np(e)[rows, :k] * a).astype(np.float32)
+        S = _np(shp)
+        if w_old == 0:
+            S[rows, :k] = f(w_new) * fresh
+        else:
+            S[rows, :k] = f(w_new) * fresh + f(w_old) * S[rows, :k]
+
+    def svi_refresh(self, nrows, shp, rte, fac, rs, cs_other, cs_partial, top, add, step, step_prev, refresh_rte,
+                    blend_rs, k, ld):
+        f = np.float32
+        R = _np(rte)
+        if refresh_rte:
+            R[:, :k] = f(top) / _np(rs)[:, None] + _np(cs_other)[None, :k]
+        F = _np(fac)
+        F[:, :k] = _np(shp)[:, :k] / R[:, :k]
+        F[:, k:] = 0
+        if blend_rs:
+            _np(rs)[:] = f(step) * (f(add) + F[:, :k].sum(axis=1)) + f(step_prev) * _np(rs)
+        cp = _np(cs_partial)
+        cp[:] = 0
+        cp[0] = F.astype(np.float64).sum(axis=0).astype(np.float32)
+
+    def svi_rate_rows(self, row_list, rte, fac, rs, cs_other, top, add, step, step_prev, mode, k, ld):
+        rows = _np(row_list).astype(np.int64)
+        if rows.shape[0] == 0:
+            return
+        f = np.float32
+        if mode == 0:
+            R = _np(rte)
+            R[rows, :k] = f(step) * (f(top) / _np(rs)[rows][:, None] + _np(cs_other)[None, :k]) + f(step_prev) * R[rows, :k]
+        else:
+            _np(rs)[rows] = f(step) * (f(add) + _np(fac)[rows, :k].sum(axis=1)) + f(step_prev) * _np(rs)[rows]

@@ -453,3 +453,53 @@ def test_invariants_at_c3_full_size(ops):
     assert float((res["fused"][0] / res["split"][0] - 1).abs().max()) < 5e-6
     assert float((res["fused"][1] / res["split"][1] - 1).abs().max()) < 5e-6
     assert abs(res["fused"][2][0] / res["split"][2][0] - 1) < 1e-7
+
+
+@pytest.mark.parametrize("k", [30, 50, 130])
+def test_svi_row_ops(ops, k):
+    """svi_shape_rows / svi_refresh / svi_rate_rows against the numpy statements (float32, statement for statement)."""
+    rs = np.random.RandomState(k)
+    ld = _lib.ld_for_k(k)
+    n, nb = 700, 150
+    ref = cpu_ops.CpuOps()
+
+    def tabs():
+        return dict(shp=_rand_tables(rs, n, k, ld) + 0.3, rte=_rand_tables(rs, n, k, ld) + 0.5, fac=torch.zeros((n, ld)),
+                    e=_rand_tables(rs, n, k, ld), rsc=torch.from_numpy(rs.uniform(0.5, 20, size=n).astype(np.float32)))
+    base = tabs()
+    for t in ("shp", "rte"):
+        base[t][:, k:] = 0
+    rows = torch.from_numpy(np.sort(rs.choice(n, size=nb, replace=False)).astype(np.int64))
+    acc = torch.from_numpy(rs.gamma(1, 2, size=(nb, ld)).astype(np.float32))
+    cs = torch.zeros(ld)
+    cs[:k] = torch.from_numpy(rs.uniform(3, 30, size=k).astype(np.float32))
+
+    def run(o, dev):
+        T = {a: v.clone().to(dev) for a, v in base.items()}
+        r, a_, c_ = rows.to(dev), acc.to(dev), cs.to(dev)
+        o.svi_shape_rows(r, a_, T["e"], T["shp"], 0.3, 1.0, 0.0, k, ld)
+        o.svi_shape_rows(r[:40], None, T["e"], T["shp"], 0.3, 0.6, 0.4, k, ld)     # acc = None: rows without data
+        o.svi_shape_rows(r[40:], a_[40:].contiguous(), T["e"], T["shp"], 0.3, 0.35, 0.55, k, ld)
+        csp = torch.zeros((o.finalize_grid(n), ld), device=dev)
+        o.svi_refresh(n, T["shp"], T["rte"], T["fac"], T["rsc"], c_, csp, 15.3, 0.3, 0.7, 0.3, True, False, k, ld)
+        cs1 = torch.zeros(ld, device=dev)
+        o.colsum_reduce(csp, cs1, ld)
+        o.svi_rate_rows(r, T["rte"], None, T["rsc"], c_, 15.3, 0.0, 0.7, 0.3, 0, k, ld)
+        o.svi_refresh(n, T["shp"], T["rte"], T["fac"], T["rsc"], None, csp, 15.3, 0.3, 0.7, 0.3, False, True, k, ld)
+        cs2 = torch.zeros(ld, device=dev)
+        o.colsum_reduce(csp, cs2, ld)
+        o.svi_rate_rows(r, None, T["fac"], T["rsc"], None, 0.0, 0.3, 0.7, 0.3, 1, k, ld)
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        return {a: v.cpu() for a, v in T.items()}, cs1.cpu(), cs2.cpu()
+
+    want, w1, w2 = run(ref, "cpu")
+    got, g1, g2 = run(ops, "cuda")
+    for name in ("shp", "rte", "fac", "rsc"):
+        a, b = got[name], want[name]
+        if a.dim() == 2:
+            assert torch.all(a[:, k:] == b[:, k:]), name
+            a, b = a[:, :k], b[:, :k]
+        assert float(((a - b).abs() / b.abs().clamp_min(1e-30)).max()) < 2e-6, name
+    assert float(((g1 - w1).abs() / w1.abs().clamp_min(1e-30))[:k].max()) < 2e-6
+    assert float(((g2 - w2).abs() / w2.abs().clamp_min(1e-30))[:k].max()) < 2e-6
