@@ -230,8 +230,9 @@ class FullBatchCavi:
         """Users sharded over ranks.  Both sweeps read only last iteration's eT/eB, so the ITEM sweep goes
         first, in nnz-balanced item ranges: the all-reduce of one range (item accumulators, packed [rows,k])
         runs on the communication stream while the next range is swept and then while this rank does its
-        whole user side; a k-float all-reduce of colsum(Theta) follows, then the item finalizer runs
-        replicated on identical inputs (replicas stay bit-identical)."""
+        whole user side; a k-float all-reduce of colsum(Theta) follows, then the item finalizer runs range
+        by range (behind the reductions still in flight), replicated on identical inputs, so replicas stay
+        bit-identical."""
         ops, hy, k, ld, dist = self.ops, self.hy, self.k, self.ld, self.dist
         pending = []
         for lo, hi, view, multi in self.item_chunks:
@@ -247,11 +248,16 @@ class FullBatchCavi:
                           hy.a, hy.k_shp, hy.add_k_rte, store)
         ops.colsum_reduce(self.csT_part, self.csT, ld)
         dist.all_reduce(self.csT)
-        for w in pending:
+        # item finalizer range by range: range c is finished while the all-reduce of ranges c+1.. is in flight
+        nch = len(self.item_chunks)
+        gpc = max(1, self.gi // nch)
+        for c, ((lo, hi, view, multi), w) in enumerate(zip(self.item_chunks, pending)):
             w.wait()
-        ops.row_finalize(self.acc_i, None, self.nI, self.eB, self.eB, self.Lambda_shp if store else None,
-                         self.Lambda_rte if store else None, self.Beta, self.t_rte, self.csT,
-                         self.csB_part[self.gsi:], hy.c, hy.t_shp, hy.add_t_rte, k, ld, part_ld=k)
+            ops.row_finalize(self.acc_i[lo:hi], None, hi - lo, self.eB[lo:hi], self.eB[lo:hi],
+                             self.Lambda_shp[lo:hi] if store else None, self.Lambda_rte[lo:hi] if store else None,
+                             self.Beta[lo:hi], self.t_rte[lo:hi], self.csT,
+                             self.csB_part[self.gsi + c * gpc: self.gsi + (c + 1) * gpc], hy.c, hy.t_shp,
+                             hy.add_t_rte, k, ld, part_ld=k)
         ops.colsum_reduce(self.csB_part, self.csB, ld)
         self.eT, self.eT_next = self.eT_next, self.eT
         self.niter_done += 1
