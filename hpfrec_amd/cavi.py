@@ -107,13 +107,16 @@ class FullBatchCavi:
         self.gsu, self.gsi = ops.sweep_grid(self.users.nseg), ops.sweep_grid(self.items.nseg)
         self.gu, self.gi = ops.finalize_grid(self.nU), ops.finalize_grid(self.nI)
         self.csT_part = torch.zeros((self.gsu + self.gu, ld), **f32)
-        self.csB_part = torch.zeros((self.gsi + self.gi, ld), **f32)
+        self.csB_part = torch.zeros((self.gsi + self.gi, ld), **f32)   # re-sized below for the sharded path
         self.cs_scratch = torch.zeros((max(self.gu, self.gi), ld), **f32)  # for whole-table column sums
         self.csB = torch.zeros(ld, **f32)
         # multi-GPU exchange buffer: the item accumulators packed to k columns (pads are zero: not sent),
         # cut into nnz-balanced item ranges so that the all-reduce of one range overlaps the sweep of the next
         self.acc_i = torch.zeros((self.nI, self.k), **f32) if self.dist else None
         self.item_chunks = self._item_chunks(int(os.environ.get("HPF_AR_CHUNKS", "4"))) if self.dist else None
+        if self.dist:   # one block range of column-sum partials per item range
+            rows = self.gsi + sum(ops.finalize_grid(hi - lo) for lo, hi, _, _ in self.item_chunks)
+            self.csB_part = torch.zeros((max(rows, self.gsi + self.gi), ld), **f32)
         self.csT = torch.zeros(ld, **f32)
         self.niter_done = 0
 
@@ -249,15 +252,15 @@ class FullBatchCavi:
         ops.colsum_reduce(self.csT_part, self.csT, ld)
         dist.all_reduce(self.csT)
         # item finalizer range by range: range c is finished while the all-reduce of ranges c+1.. is in flight
-        nch = len(self.item_chunks)
-        gpc = max(1, self.gi // nch)
-        for c, ((lo, hi, view, multi), w) in enumerate(zip(self.item_chunks, pending)):
+        g0 = self.gsi
+        for (lo, hi, view, multi), w in zip(self.item_chunks, pending):
             w.wait()
+            g1 = g0 + ops.finalize_grid(hi - lo)
             ops.row_finalize(self.acc_i[lo:hi], None, hi - lo, self.eB[lo:hi], self.eB[lo:hi],
                              self.Lambda_shp[lo:hi] if store else None, self.Lambda_rte[lo:hi] if store else None,
-                             self.Beta[lo:hi], self.t_rte[lo:hi], self.csT,
-                             self.csB_part[self.gsi + c * gpc: self.gsi + (c + 1) * gpc], hy.c, hy.t_shp,
+                             self.Beta[lo:hi], self.t_rte[lo:hi], self.csT, self.csB_part[g0:g1], hy.c, hy.t_shp,
                              hy.add_t_rte, k, ld, part_ld=k)
+            g0 = g1
         ops.colsum_reduce(self.csB_part, self.csB, ld)
         self.eT, self.eT_next = self.eT_next, self.eT
         self.niter_done += 1
