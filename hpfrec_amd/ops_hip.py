@@ -29,7 +29,7 @@ class HipOps:
             self.cu_count, self.arch = _lib.device_info()
         # memory-bound grid: a few blocks per CU, grid-stride over the rest (CDNA guide, guideline 11)
         self.sweep_blocks = max(1, self.cu_count) * int(os.environ.get("HPF_SWEEP_BPC", "8"))
-        self.finalize_blocks = max(1, self.cu_count) * 4
+        self.finalize_blocks = max(1, self.cu_count) * int(os.environ.get("HPF_FIN_BPC", "4"))
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
