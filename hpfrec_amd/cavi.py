@@ -161,6 +161,9 @@ class FullBatchCavi:
             if hi > lo:
                 multi = it.multi_rows[(it.multi_rows >= lo) & (it.multi_rows < hi)].contiguous()
                 out.append((lo, hi, _SideView(it, int(rsp[lo]), int(rsp[hi])), multi))
+        # issue order: most rows (= largest all-reduce payload) first.  With nnz-balanced ranges every range
+        # costs the same sweep time, so the bulk of the exchange starts after 1/nchunks of the item sweep.
+        out.sort(key=lambda c: c[0] - c[1])
         return out
 
     def set_fused(self, flag):
