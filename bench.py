@@ -39,6 +39,7 @@ WORKLOADS = {
     "c2": (138_000, 27_000, 20_000_000, 50, "C2 MovieLens-20M-shaped synthetic 138k x 27k, 20M nnz, k=50, full batch"),
     "c4": (1_000_000, 380_000, 48_000_000, 100, "C4 MillionSong-shaped synthetic 1M x 380k, 48M nnz, k=100, full batch"),
     "small": (100_000, 30_000, 2_000_000, 50, "small synthetic 100k x 30k, 2M nnz, k=50 (debug)"),
+    "tiny": (2_000, 1_000, 50_000, 50, "tiny synthetic 2k x 1k, 50k nnz, k=50 (host-overhead probe)"),
     "k30": (1_000_000, 380_000, 48_000_000, 30, "C3 matrix with k=30 (ld=32: 8 nonzeros per wave step)"),
     "k200": (1_000_000, 380_000, 48_000_000, 200, "C3 matrix with k=200 (ld=256: 1 nonzero per wave step)"),
 }

@@ -113,12 +113,13 @@ class FullBatchCavi:
         # multi-GPU exchange buffer: the item accumulators packed to k columns (pads are zero: not sent),
         # cut into nnz-balanced item ranges so that the all-reduce of one range overlaps the sweep of the next
         self.acc_i = torch.zeros((self.nI, self.k), **f32) if self.dist else None
-        self.item_chunks = self._item_chunks(int(os.environ.get("HPF_AR_CHUNKS", "4"))) if self.dist else None
+        self.item_chunks = self._item_chunks(int(os.environ.get("HPF_AR_CHUNKS", "3"))) if self.dist else None
         if self.dist:   # one block range of column-sum partials per item range
             rows = self.gsi + sum(ops.finalize_grid(hi - lo) for lo, hi, _, _ in self.item_chunks)
             self.csB_part = torch.zeros((max(rows, self.gsi + self.gi), ld), **f32)
         self.csT = torch.zeros(ld, **f32)
         self.niter_done = 0
+        self._chunk_views = None
 
     # ------------------------------------------------------------------------------------
     def _pad(self, host_arr, out):
@@ -240,30 +241,37 @@ class FullBatchCavi:
         by range (behind the reductions still in flight), replicated on identical inputs, so replicas stay
         bit-identical."""
         ops, hy, k, ld, dist = self.ops, self.hy, self.k, self.ld, self.dist
+        if self._chunk_views is None:   # tensor views are built once: the loop below is host-overhead sensitive
+            self._chunk_views = []
+            g0 = self.gsi
+            for lo, hi, view, multi in self.item_chunks:
+                g1 = g0 + ops.finalize_grid(hi - lo)
+                self._chunk_views.append(dict(
+                    n=hi - lo, view=view, multi=multi, nmulti=int(multi.shape[0]), part=self.part_i[view.seg_lo:],
+                    acc=self.acc_i[lo:hi], eB=self.eB[lo:hi], shp=self.Lambda_shp[lo:hi], rte=self.Lambda_rte[lo:hi],
+                    fac=self.Beta[lo:hi], rs=self.t_rte[lo:hi], csp=self.csB_part[g0:g1]))
+                g0 = g1
         pending = []
-        for lo, hi, view, multi in self.item_chunks:
+        for c in self._chunk_views:
             # whole-row segments write their accumulator straight into the packed buffer; only split
             # rows (and rows without local nonzeros: zeros) go through part[] + segsum
-            if view.nseg > 0:
-                ops.sweep(view, self.eB, self.eT, self.part_i[view.seg_lo:], k, ld, acc_rows=self.acc_i, acc_ld=k)
-            ops.segsum(self.part_i, self.items.row_seg_ptr, int(multi.shape[0]), self.acc_i, ld, row_list=multi,
-                       acc_ld=k, acc_by_row=True)
-            pending.append(dist.all_reduce(self.acc_i[lo:hi], async_op=True))
+            if c["view"].nseg > 0:
+                ops.sweep(c["view"], self.eB, self.eT, c["part"], k, ld, acc_rows=self.acc_i, acc_ld=k)
+            if c["nmulti"] > 0:
+                ops.segsum(self.part_i, self.items.row_seg_ptr, c["nmulti"], self.acc_i, ld, row_list=c["multi"],
+                           acc_ld=k, acc_by_row=True)
+            pending.append(dist.all_reduce(c["acc"], async_op=True))
         self._side_update(self.users, self.nU, self.eT, self.eB, self.eT_next, self.part_u, self.Gamma_shp,
                           self.Gamma_rte, self.Theta, self.k_rte, self.csB, self.csT_part, self.gsu, self.gu,
                           hy.a, hy.k_shp, hy.add_k_rte, store)
         ops.colsum_reduce(self.csT_part, self.csT, ld)
         dist.all_reduce(self.csT)
         # item finalizer range by range: range c is finished while the all-reduce of ranges c+1.. is in flight
-        g0 = self.gsi
-        for (lo, hi, view, multi), w in zip(self.item_chunks, pending):
+        for c, w in zip(self._chunk_views, pending):
             w.wait()
-            g1 = g0 + ops.finalize_grid(hi - lo)
-            ops.row_finalize(self.acc_i[lo:hi], None, hi - lo, self.eB[lo:hi], self.eB[lo:hi],
-                             self.Lambda_shp[lo:hi] if store else None, self.Lambda_rte[lo:hi] if store else None,
-                             self.Beta[lo:hi], self.t_rte[lo:hi], self.csT, self.csB_part[g0:g1], hy.c, hy.t_shp,
+            ops.row_finalize(c["acc"], None, c["n"], c["eB"], c["eB"], c["shp"] if store else None,
+                             c["rte"] if store else None, c["fac"], c["rs"], self.csT, c["csp"], hy.c, hy.t_shp,
                              hy.add_t_rte, k, ld, part_ld=k)
-            g0 = g1
         ops.colsum_reduce(self.csB_part, self.csB, ld)
         self.eT, self.eT_next = self.eT_next, self.eT
         self.niter_done += 1
