@@ -821,7 +821,7 @@ __global__ __launch_bounds__(BLOCK) void llk_sweep_kernel(const hpf_segment *__r
 #pragma unroll
                     for (int v = 0; v < VPL; v++) p += dot4(rv[v], o[u][v]);
                     const float yhat = group_sum<LPR>(p);
-                    if (j == 0 && yy[u] > 0.f) {  // padding slots carry y = 0
+                    if (j == 0 && (t0 + u) * NG + g < n) {  // slots past the chunk's n entries are padding
                         if constexpr (FULL)
                             a0 += (double)yy[u] * log((double)yhat) - lgamma((double)yy[u] + 1.0);
                         else

@@ -386,6 +386,7 @@ def test_llk_sweep_op(ops, k):
     iu = torch.from_numpy((nU * rs.random_sample(n) ** 2).astype(np.int64))
     ii = torch.from_numpy((nI * rs.random_sample(n) ** 3).astype(np.int64))
     y = torch.from_numpy((rs.gamma(1, 1, size=n) + 1).astype(np.int32).astype(np.float32))
+    y[::7] = 0.0        # explicit zero counts: they contribute 0 to the llk term but do count in sq.err and sum yhat
     T, B = _rand_tables(rs, nU, k, ld), _rand_tables(rs, nI, k, ld)
     users, items, u_sorted = layout.build_sides(iu, ii, y, nU, nI)
     dside = layout.SparseSide.__new__(layout.SparseSide)
