@@ -504,3 +504,20 @@ def test_svi_row_ops(ops, k):
         assert float(((a - b).abs() / b.abs().clamp_min(1e-30)).max()) < 2e-6, name
     assert float(((g1 - w1).abs() / w1.abs().clamp_min(1e-30))[:k].max()) < 2e-6
     assert float(((g2 - w2).abs() / w2.abs().clamp_min(1e-30))[:k].max()) < 2e-6
+
+
+def test_c2_size_vs_oracle(hip_backend):
+    """BASELINE config C2 shape at full size (138k x 27k, ~19.4M unique nonzeros, k=50): every array against the
+    CPU oracle after 1 and 2 iterations.  At this size the reference's own arithmetic is the noisier side
+    (naive fp32 column sums over 138k rows, 1e5-term sequential fp32 scatter sums for popular items), so the
+    bar is the north_star's 1e-4; measured 1.5e-5 / 3.2e-5."""
+    import bench
+    nU, nI, nnz_t, k, _ = bench.WORKLOADS["c2"]
+    iu, ii, y = bench.synth_on_device(nU, nI, nnz_t, torch.device("cuda", 0))
+    Y, IU, II = y.cpu().numpy(), iu.cpu().numpy().astype(np.uint64), ii.cpu().numpy().astype(np.uint64)
+    del iu, ii, y
+    st, caps = O.fit_full_batch(Y, IU, II, nU, nI, k, 2, 123, capture_at=(1, 2), nthreads=O.max_threads())
+    for its in (1, 2):
+        i, arrs, _ = _fit(hip_backend, Y, IU, II, nU, nI, k, its)
+        for n in NAMES:
+            assert _maxrel(arrs[n], caps[its][n]) < 1e-4, (its, n)
