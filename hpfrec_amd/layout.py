@@ -9,9 +9,13 @@ reference treats them in full-batch mode (scipy's tocsr() would merge them; we n
 
 Everything here is index plumbing on torch tensors (any device, incl. CPU for the tests).
 """
+import os
+
 import torch
 
-SEG_CAP = 256  # nonzeros per segment: 64 steps of 4 nonzeros at ld=64
+# nonzeros per segment (256 steps of 4 nonzeros at ld=64).  Measured at C3, ms/iteration: 64: 4.09, 128: 3.87,
+# 256: 3.77, 512: 3.74, 1024: 3.70-3.72, 2048-4096: 3.73-3.74, 16384: 3.84 (tail imbalance).
+SEG_CAP = int(os.environ.get("HPF_SEG_CAP", "1024"))
 SEG_LEN_MASK = 0x00FFFFFF    # include/hpf_hip.h: HPF_SEG_LEN_MASK
 SEG_WHOLE_ROW = 0x40000000   # include/hpf_hip.h: HPF_SEG_WHOLE_ROW
 

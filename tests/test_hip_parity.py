@@ -105,12 +105,13 @@ def test_ragged_and_empty_rows_vs_oracle(hip_backend):
     """users/items with no data at all, a user with one nonzero, an item with >2 segments, duplicates."""
     rs = np.random.RandomState(4)
     nU, nI = 64, 40
-    iu = rs.randint(10, 60, size=3000).astype(np.uint64)   # users 0-9 and 60-63 empty
-    ii = rs.randint(0, 30, size=3000).astype(np.uint64)    # items 30-39 empty
-    ii[:900] = 7                                            # one hot item: 900+ nonzeros -> 4 segments
+    n = 9000
+    iu = rs.randint(10, 60, size=n).astype(np.uint64)      # users 0-9 and 60-63 empty
+    ii = rs.randint(0, 30, size=n).astype(np.uint64)       # items 30-39 empty
+    ii[:3500] = 7                                           # one hot item: 3500+ nonzeros -> 4 segments
     iu[-1], ii[-1] = 61, 35                                 # a singleton user/item pair
     iu[-3:-1], ii[-3:-1] = 12, 5                            # duplicated (u,i) observations stay separate
-    Y = (rs.gamma(1, 1, size=3000) + 1).astype(np.int32).astype(np.float32)
+    Y = (rs.gamma(1, 1, size=n) + 1).astype(np.int32).astype(np.float32)
     st, caps = O.fit_full_batch(Y, iu, ii, nU, nI, 20, 4, 3, capture_at=(4,))
     i, arrs, _ = _fit(hip_backend, Y, iu, ii, nU, nI, 20, 4, seed=3)
     for n in NAMES:
