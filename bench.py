@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extras (lean-iteration and llk-pass timings); used under rocprofv3 so that "
+                         "per-kernel averages cover exactly the warm-up + timed iterations")
     ap.add_argument("--no-fuse", action="store_true", help="separate sweep and row-finalize launches")
     ap.add_argument("--atomic", action="store_true", help="experimental one-pass variant with fp32 atomics")
     ap.add_argument("--lean", action="store_true",
@@ -228,7 +231,7 @@ def main():
     # what fit_hpf actually does between checks: Gamma/Lambda shape+rate tables (outputs only) are not
     # written.  Reported as an extra field; `value` above is the conservative all-tables-stored figure.
     lean_ms = None
-    if store:
+    if store and not args.no_extras:
         for _ in range(2):
             model.iterate(False)
         fence()
@@ -239,15 +242,17 @@ def main():
         lean_ms = (time.perf_counter() - t2) / args.steps * 1e3
 
     # the train-llk evaluation of the reference's default check_every=10, timed separately (never part of `value`)
-    model.llk_terms(False)          # warm
-    fence()
-    t1 = time.perf_counter()
-    for _ in range(3):
-        terms = model.llk_terms(False)
-        sub = model.colsum_dot()
-    fence()
-    llk_ms = (time.perf_counter() - t1) * 1e3 / 3
-    llk_val = float(terms[0] - sub)
+    llk_ms = llk_val = None
+    if not args.no_extras:
+        model.llk_terms(False)          # warm
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            terms = model.llk_terms(False)
+            sub = model.colsum_dot()
+        fence()
+        llk_ms = (time.perf_counter() - t1) * 1e3 / 3
+        llk_val = float(terms[0] - sub)
 
     # sanity: the state must be finite after the run (a NaN run would be a meaningless number)
     finite = bool(torch.isfinite(model.Beta).all().item() and torch.isfinite(model.Theta).all().item())
@@ -296,9 +301,10 @@ def main():
         }
         if lean_ms is not None:
             line["ms_per_step_without_output_table_stores"] = lean_ms
-        line["llk_pass_ms"] = llk_ms
-        line["iters_per_sec_incl_llk_every_10"] = 1e3 / (ms + llk_ms / 10.0)
-        line["train_llk_after_run"] = llk_val
+        if llk_ms is not None:
+            line["llk_pass_ms"] = llk_ms
+            line["iters_per_sec_incl_llk_every_10"] = 1e3 / (ms + llk_ms / 10.0)
+            line["train_llk_after_run"] = llk_val
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(nU, nI, k, nnz)

@@ -10,13 +10,13 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 S=$OUT/profile_summary.txt
 : > $S
-echo "# rocprofv3 summary, command: python bench.py $* " >> $S
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o kt -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > $OUT/kt.log 2>&1
+echo "# rocprofv3 summary. kernel trace: python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras $*; PMC passes: --steps 3 --warmup 1 --no-events --no-extras" >> $S
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o kt -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras "$@" > $OUT/kt.log 2>&1
 python tools/prof_summary.py /tmp/prof_kt hpf_ >> $S 2>&1
 grep -h '"metric"' $OUT/kt.log >> $S
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" ; do
   T=$(echo $C | tr ' ' '_')
-  rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$T -o pmc -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-events "$@" > $OUT/pmc_$T.log 2>&1
+  rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$T -o pmc -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-events --no-extras "$@" > $OUT/pmc_$T.log 2>&1
   python tools/prof_summary.py /tmp/prof_$T sweep_kernel row_finalize >> $S 2>&1
 done
 cat $S
