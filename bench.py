@@ -39,10 +39,14 @@ WORKLOADS = {
     "c2": (138_000, 27_000, 20_000_000, 50, "C2 MovieLens-20M-shaped synthetic 138k x 27k, 20M nnz, k=50, full batch"),
     "c4": (1_000_000, 380_000, 48_000_000, 100, "C4 MillionSong-shaped synthetic 1M x 380k, 48M nnz, k=100, full batch"),
     "small": (100_000, 30_000, 2_000_000, 50, "small synthetic 100k x 30k, 2M nnz, k=50 (debug)"),
+    "c3u": (1_000_000, 380_000, 48_000_000, 50, "C3 shape with UNIFORM item popularity (no hot items; SURVEY 8d variant)"),
     "tiny": (2_000, 1_000, 50_000, 50, "tiny synthetic 2k x 1k, 50k nnz, k=50 (host-overhead probe)"),
     "k30": (1_000_000, 380_000, 48_000_000, 30, "C3 matrix with k=30 (ld=32: 8 nonzeros per wave step)"),
     "k200": (1_000_000, 380_000, 48_000_000, 200, "C3 matrix with k=200 (ld=256: 1 nonzero per wave step)"),
 }
+
+
+POWER = {"c3u": 1.0}   # item-popularity exponent per workload (default 2.5)
 
 
 def synth_on_device(nU, nI, nnz_target, device, seed=1, item_power=2.5, sigma=1.0):
@@ -171,7 +175,7 @@ def main():
     if dist and world > 1:
         # one generator run, broadcast over xGMI: every rank shards exactly the same matrix
         if rank == 0:
-            iu, ii, y = synth_on_device(nU, nI, nnz_target, device)
+            iu, ii, y = synth_on_device(nU, nI, nnz_target, device, item_power=POWER.get(args.workload, 2.5))
             n_t = torch.tensor([iu.shape[0]], dtype=torch.int64, device=device)
         else:
             n_t = torch.zeros(1, dtype=torch.int64, device=device)
@@ -184,7 +188,7 @@ def main():
         for t in (iu, ii, y):
             dist.broadcast(t, 0)
     else:
-        iu, ii, y = synth_on_device(nU, nI, nnz_target, device)
+        iu, ii, y = synth_on_device(nU, nI, nnz_target, device, item_power=POWER.get(args.workload, 2.5))
     nnz = int(iu.shape[0])
 
     ops = TimedOps(device)
