@@ -96,6 +96,9 @@ class TimedOps(HipOps):
     def sweep_finalize(self, *a, **kw):
         return self._timed("sweep_finalize", super().sweep_finalize, *a, **kw)
 
+    def sweep_prefinalize(self, *a, **kw):
+        return self._timed("sweep_prefinalize", super().sweep_prefinalize, *a, **kw)
+
     def row_finalize(self, *a, **kw):
         return self._timed("row_finalize", super().row_finalize, *a, **kw)
 
@@ -273,20 +276,23 @@ def main():
         # term).  Unfused: nnz*(4+4k) + rows*(8+4k) (segment descriptor + own row) per launch.
         dom = "sweep_finalize" if "sweep_finalize" in ksum else ("sweep" if "sweep" in ksum else None)
         if dom:
-            if dom == "sweep_finalize" and world > 1:
-                # sharded: only the user side is fused (the item finalizer follows the all-reduce)
-                b_launch = n_loc * (4 + 4 * k) + model.nU * (12 + 20 * k)
-            elif dom == "sweep_finalize":
-                b_launch = (n_loc * (8 + 8 * k) + model.nU * (12 + 20 * k) + model.nI * (4 + 24 * k)) / 2.0
+            if dom == "sweep_finalize":
+                # both sides run sweep_kernel with the row finalizer fused in (sharded: the item side in ranges,
+                # as prologue): one user-side launch + the item-side launches own this rank's iteration bytes
+                b_rank = n_loc * (8 + 8 * k) + model.nU * (12 + 20 * k) + model.nI * (4 + 24 * k)
+                fused = [ksum[n] for n in ("sweep_finalize", "sweep_prefinalize", "sweep") if n in ksum]
+                t_both = sum(v["total_ms"] for v in fused) / args.steps * 1e-3     # per iteration, both sides
+                b_launch = b_rank / 2.0
+                t_k = t_both / 2.0
             else:
                 b_launch = n_loc * (4 + 4 * k) + ((model.nU + model.nI) / 2.0) * (8 + 4 * k)
-            t_k = ksum[dom]["avg_ms"] * 1e-3
+                t_k = ksum[dom]["avg_ms"] * 1e-3
             ach = b_launch / t_k
             roof = {"bound": "hbm", "kernel": "sweep_kernel (%s)" % ("fused with row finalize" if dom == "sweep_finalize"
                                                                      else "unfused"),
                     "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": _pmc_traffic(args.workload, world),
-                    "algorithmic_bytes_per_launch": b_launch, "avg_launch_ms": ksum[dom]["avg_ms"],
+                    "algorithmic_bytes_per_launch": b_launch, "avg_launch_ms": t_k * 1e3,
                     "launches": ksum[dom]["calls"],
                     "iteration": {"algorithmic_bytes": b_iter,
                                   "frac_of_hbm_peak": b_iter / (ms * 1e-3) / HBM_PEAK if world == 1 else None},

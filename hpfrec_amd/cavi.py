@@ -120,6 +120,7 @@ class FullBatchCavi:
         self.csT = torch.zeros(ld, **f32)
         self.niter_done = 0
         self._chunk_views = None
+        self.item_pending = False   # sharded path: acc_i holds reduced statistics not yet applied to the item tables
 
     # ------------------------------------------------------------------------------------
     def _pad(self, host_arr, out):
@@ -137,6 +138,7 @@ class FullBatchCavi:
         self._pad(Beta, self.Beta)
         self.k_rte.copy_(torch.from_numpy(np.ascontiguousarray(k_rte, dtype=np.float32).reshape(-1)))
         self.t_rte.copy_(torch.from_numpy(np.ascontiguousarray(t_rte, dtype=np.float32).reshape(-1)))
+        self.item_pending = False
         self.refresh_expectations()
 
     def refresh_expectations(self):
@@ -233,52 +235,92 @@ class FullBatchCavi:
         self.eT, self.eT_next = self.eT_next, self.eT
         self.niter_done += 1
 
+    def _sharded_views(self):
+        """Per item range: tensor views and column-sum partial slots, built once (the sharded loop is
+        host-overhead sensitive).  Two partial layouts: `csp` for the standalone finalizer (flush), and
+        `csp_lazy` for the prologue-fused sweep; each layout is written completely whenever it is used."""
+        if self._chunk_views is not None:
+            return self._chunk_views
+        ops, ld = self.ops, self.ld
+        f32 = dict(dtype=torch.float32, device=self.device)
+        gm = max(1, min(self.gi, (self.items.nmulti + 3) // 4))
+        lazy_rows = sum(ops.sweep_grid(v.nseg) for _, _, v, _ in self.item_chunks) + gm
+        self.csB_part_lazy = torch.zeros((lazy_rows, ld), **f32)
+        self._csp_multi = self.csB_part_lazy[lazy_rows - gm:]
+        views, g0, l0 = [], self.gsi, 0
+        for lo, hi, view, multi in self.item_chunks:
+            g1 = g0 + ops.finalize_grid(hi - lo)
+            l1 = l0 + ops.sweep_grid(view.nseg)
+            views.append(dict(
+                n=hi - lo, view=view, multi=multi, nmulti=int(multi.shape[0]), part=self.part_i[view.seg_lo:],
+                acc=self.acc_i[lo:hi], eB=self.eB[lo:hi], shp=self.Lambda_shp[lo:hi], rte=self.Lambda_rte[lo:hi],
+                fac=self.Beta[lo:hi], rs=self.t_rte[lo:hi], csp=self.csB_part[g0:g1],
+                csp_lazy=self.csB_part_lazy[l0:l1]))
+            g0, l0 = g1, l1
+        self._chunk_views = views
+        return views
+
     def _iterate_sharded(self, store):
         """Users sharded over ranks.  Both sweeps read only last iteration's eT/eB, so the ITEM sweep goes
         first, in nnz-balanced item ranges: the all-reduce of one range (item accumulators, packed [rows,k])
         runs on the communication stream while the next range is swept and then while this rank does its
-        whole user side; a k-float all-reduce of colsum(Theta) follows, then the item finalizer runs range
-        by range (behind the reductions still in flight), replicated on identical inputs, so replicas stay
-        bit-identical."""
+        whole user side; a k-float all-reduce of colsum(Theta) ends the iteration.
+
+        The replicated item finalizer is DEFERRED: the reduced accumulators stay in acc_i and the next
+        iteration's item sweep finishes each row in its prologue (hpf_hip_sweep_prefinalize_f32; split and
+        empty rows by a small launch before it), on identical inputs on every rank, so replicas stay
+        bit-identical.  flush_items() materialises the item tables when somebody needs them (llk, outputs)."""
         ops, hy, k, ld, dist = self.ops, self.hy, self.k, self.ld, self.dist
-        if self._chunk_views is None:   # tensor views are built once: the loop below is host-overhead sensitive
-            self._chunk_views = []
-            g0 = self.gsi
-            for lo, hi, view, multi in self.item_chunks:
-                g1 = g0 + ops.finalize_grid(hi - lo)
-                self._chunk_views.append(dict(
-                    n=hi - lo, view=view, multi=multi, nmulti=int(multi.shape[0]), part=self.part_i[view.seg_lo:],
-                    acc=self.acc_i[lo:hi], eB=self.eB[lo:hi], shp=self.Lambda_shp[lo:hi], rte=self.Lambda_rte[lo:hi],
-                    fac=self.Beta[lo:hi], rs=self.t_rte[lo:hi], csp=self.csB_part[g0:g1]))
-                g0 = g1
+        views = self._sharded_views()
+        lazy = self.item_pending
+        if lazy:
+            it = self.items
+            ops.row_finalize(self.acc_i, None, it.nmulti, self.eB, self.eB, self.Lambda_shp if store else None,
+                             self.Lambda_rte if store else None, self.Beta, self.t_rte, self.csT, self._csp_multi,
+                             hy.c, hy.t_shp, hy.add_t_rte, k, ld, row_list=it.multi_rows, part_ld=k)
         pending = []
-        for c in self._chunk_views:
-            # whole-row segments write their accumulator straight into the packed buffer; only split
-            # rows (and rows without local nonzeros: zeros) go through part[] + segsum
-            if c["view"].nseg > 0:
+        for c in views:
+            # whole-row segments leave their accumulator straight in the packed buffer; only split rows
+            # (and rows without local nonzeros: zeros) go through part[] + segsum
+            if lazy:
+                ops.sweep_prefinalize(c["view"], self.eB, self.eT, c["part"], self.acc_i, k,
+                                      self.Lambda_shp if store else None, self.Lambda_rte if store else None,
+                                      self.Beta, self.t_rte, self.csT, c["csp_lazy"], hy.c, hy.t_shp,
+                                      hy.add_t_rte, k, ld)
+            elif c["view"].nseg > 0:
                 ops.sweep(c["view"], self.eB, self.eT, c["part"], k, ld, acc_rows=self.acc_i, acc_ld=k)
             if c["nmulti"] > 0:
                 ops.segsum(self.part_i, self.items.row_seg_ptr, c["nmulti"], self.acc_i, ld, row_list=c["multi"],
                            acc_ld=k, acc_by_row=True)
             pending.append(dist.all_reduce(c["acc"], async_op=True))
+        if lazy:
+            ops.colsum_reduce(self.csB_part_lazy, self.csB, ld)   # colsum(Beta) of the rows just finished
         self._side_update(self.users, self.nU, self.eT, self.eB, self.eT_next, self.part_u, self.Gamma_shp,
                           self.Gamma_rte, self.Theta, self.k_rte, self.csB, self.csT_part, self.gsu, self.gu,
                           hy.a, hy.k_shp, hy.add_k_rte, store)
         ops.colsum_reduce(self.csT_part, self.csT, ld)
         dist.all_reduce(self.csT)
-        # item finalizer range by range: range c is finished while the all-reduce of ranges c+1.. is in flight
-        for c, w in zip(self._chunk_views, pending):
+        for w in pending:
             w.wait()
-            ops.row_finalize(c["acc"], None, c["n"], c["eB"], c["eB"], c["shp"] if store else None,
-                             c["rte"] if store else None, c["fac"], c["rs"], self.csT, c["csp"], hy.c, hy.t_shp,
-                             hy.add_t_rte, k, ld, part_ld=k)
-        ops.colsum_reduce(self.csB_part, self.csB, ld)
+        self.item_pending = True
         self.eT, self.eT_next = self.eT_next, self.eT
         self.niter_done += 1
+
+    def flush_items(self):
+        """Sharded path: apply the deferred item finalizer (Lambda_shp, Lambda_rte, Beta, t_rte, eB, colsum Beta)."""
+        if not (self.dist and self.item_pending):
+            return
+        ops, hy, k, ld = self.ops, self.hy, self.k, self.ld
+        for c in self._sharded_views():
+            ops.row_finalize(c["acc"], None, c["n"], c["eB"], c["eB"], c["shp"], c["rte"], c["fac"], c["rs"], self.csT,
+                             c["csp"], hy.c, hy.t_shp, hy.add_t_rte, k, ld, part_ld=k)
+        ops.colsum_reduce(self.csB_part, self.csB, ld)
+        self.item_pending = False
 
     # ------------------------------------------------------------------------------------
     def llk_terms(self, full_llk=False):
         """Global (all-reduced) float64 [sum y*log(yhat)(-lgamma), sum sq.err, sum yhat, nnz] over the training nonzeros."""
+        self.flush_items()
         t = self.ops.llk_sweep(self.users, self.Theta, self.Beta, self.k, self.ld, full_llk)
         out = torch.cat([t.to(torch.float64), torch.tensor([float(self.nnz)], dtype=torch.float64,
                                                            device=t.device)])
@@ -288,6 +330,7 @@ class FullBatchCavi:
 
     def pair_llk_terms(self, ix_u, ix_i, y, full_llk=False):
         """Same terms over caller-listed pairs (validation set); ix_u must be local to this shard."""
+        self.flush_items()
         t = self.ops.pair_llk(self.Theta, self.Beta, ix_u, ix_i, y, self.k, self.ld, full_llk)
         out = torch.cat([t.to(torch.float64), torch.tensor([float(ix_u.shape[0])], dtype=torch.float64,
                                                            device=t.device)])
@@ -297,6 +340,7 @@ class FullBatchCavi:
 
     def colsum_dot(self):
         """(sum_u Theta) . (sum_i Beta) in float32, the subtrahend of the train llk (PXI:78)."""
+        self.flush_items()
         if self.niter_done == 0:
             self.ops.colsum(self.Theta, self.nU, self.ld, self.cs_scratch)
             self.ops.colsum_reduce(self.cs_scratch, self.csT, self.ld)
@@ -309,6 +353,7 @@ class FullBatchCavi:
     # ------------------------------------------------------------------------------------
     def fetch(self, name):
         """Unpadded host copy of one state array (this rank's rows)."""
+        self.flush_items()
         t = getattr(self, name)
         if t.dim() == 1:
             return t.cpu().numpy().reshape(-1, 1).copy()

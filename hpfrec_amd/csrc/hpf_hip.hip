@@ -165,7 +165,11 @@ struct FinalizeArgs {  // the row-finalize operands when it is fused into the sw
     int acc_ld;
 };
 
-template <int LPR, int VPL, bool SCATTER, bool FUSE>
+// MODE: 0 = plain sweep; 1 = row finalize fused as EPILOGUE of whole-row segments (single GPU);
+//       2 = row finalize fused as PROLOGUE of whole-row segments from an already reduced accumulator row
+//           (sharded path: the previous iteration's all-reduced item statistics are turned into this
+//           iteration's E row by the very wave that then sweeps the row -- "deferred item finalize")
+template <int LPR, int VPL, bool SCATTER, int MODE>
 __global__ __launch_bounds__(BLOCK, HPF_SWEEP_WAVES_PER_EU) void sweep_kernel(const hpf_segment *__restrict__ segs, int64_t nseg,
                                                       const int32_t *__restrict__ idx,
                                                       const float *__restrict__ y,
@@ -177,6 +181,7 @@ __global__ __launch_bounds__(BLOCK, HPF_SWEEP_WAVES_PER_EU) void sweep_kernel(co
     constexpr int NG = WAVE / LPR;  // nonzeros per step
     constexpr int U = HPF_U;        // gathers in flight per wavefront (WAVE/NG = LPR >= 8 is a multiple)
     constexpr int NQ = 4 * VPL;     // factors held per lane during the sweep
+    constexpr bool FUSE = (MODE != 0);
     const int lane = threadIdx.x & (WAVE - 1);
     const int g = lane / LPR;
     const int j = lane % LPR;
@@ -199,6 +204,44 @@ __global__ __launch_bounds__(BLOCK, HPF_SWEEP_WAVES_PER_EU) void sweep_kernel(co
         }
     }
 
+    // the closed-form updates of one row with its factors dealt over all 64 lanes (lane (g,j) owns columns
+    // colq[t]): a = accumulator entries, eo = the row's old E entries; writes the row's tables, returns the new
+    // E entries (max-normalised) in en
+    auto finish_row = [&](const float (&a)[NC], const float (&eo)[NC], float (&en)[NC], int row) {
+        const float base_rte = fa.top_shp / fa.rs[row];
+        float sh[NC], rt[NC], fc[NC];
+        double ev[NC];
+        float fsum = 0.f;
+        double emax = 0.0;
+#pragma unroll
+        for (int t = 0; t < NC; t++) {
+            const bool valid = colq[t] < fa.k;
+            sh[t] = fmaf(eo[t], a[t], fa.prior_shp);
+            rt[t] = base_rte + csl[t];
+            fc[t] = valid ? sh[t] / rt[t] : 0.f;
+            ev[t] = valid ? expect_ratio(sh[t], rt[t]) : 0.0;
+            fsum += fc[t];
+            emax = fmax(emax, ev[t]);
+            csacc[t] += fc[t];
+        }
+        fsum = wave_sum(fsum);
+        emax = wave_max_d(emax);
+        const double inv = 1.0 / emax;
+#pragma unroll
+        for (int t = 0; t < NC; t++) {
+            const bool valid = colq[t] < fa.k;
+            en[t] = valid ? (float)(ev[t] * inv) : 0.f;
+            if (colq[t] < LD) {
+                const size_t o = (size_t)row * LD + colq[t];
+                fa.e_new[o] = en[t];
+                if (fa.shp) stream_store(fa.shp + o, valid ? sh[t] : 0.f);
+                if (fa.rte) stream_store(fa.rte + o, valid ? rt[t] : 0.f);
+                if (fa.fac) stream_store(fa.fac + o, fc[t]);
+            }
+        }
+        if (lane == 0) fa.rs[row] = fa.add_rte + fsum;
+    };
+
     for (int64_t sg = (int64_t)blockIdx.x * WPB + wid; sg < nseg; sg += nwaves) {
         const hpf_segment sgm = segs[sg];
         const int len = sgm.len & HPF_SEG_LEN_MASK;
@@ -211,6 +254,29 @@ __global__ __launch_bounds__(BLOCK, HPF_SWEEP_WAVES_PER_EU) void sweep_kernel(co
         }
         const int32_t *ip = idx + sgm.begin;
         const float *yp = y + sgm.begin;
+        const bool whole_row = (sgm.len & HPF_SEG_WHOLE_ROW) != 0;
+
+        if constexpr (MODE == 2) {
+            if (whole_row) {
+                // finish the row from last iteration's reduced accumulator, then sweep with the fresh E row
+                float a[NC], eo[NC], en[NC];
+#pragma unroll
+                for (int t = 0; t < NC; t++) {
+                    a[t] = (colq[t] < fa.acc_ld) ? fa.acc_rows[(size_t)sgm.row * fa.acc_ld + colq[t]] : 0.f;
+                    eo[t] = (colq[t] < LD) ? tab_self[(size_t)sgm.row * LD + colq[t]] : 0.f;
+                }
+                finish_row(a, eo, en, sgm.row);
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {  // back to the float4-per-lane layout, in every group
+                    const float val = __shfl(en[(NQ >= NG) ? q / NG : 0], (q % NG) * LPR + j);
+                    float4 &dst = rv[q >> 2];
+                    if ((q & 3) == 0) dst.x = val;
+                    if ((q & 3) == 1) dst.y = val;
+                    if ((q & 3) == 2) dst.z = val;
+                    if ((q & 3) == 3) dst.w = val;
+                }
+            }
+        }
 
         for (int base = 0; base < len; base += WAVE) {
             const int n = min(WAVE, len - base);
@@ -276,8 +342,7 @@ __global__ __launch_bounds__(BLOCK, HPF_SWEEP_WAVES_PER_EU) void sweep_kernel(co
                 acc[v].w += __shfl_xor(acc[v].w, m);
             }
         }
-        const bool whole_row = (sgm.len & HPF_SEG_WHOLE_ROW) != 0;
-        if (!FUSE && whole_row && fa.acc_rows) {
+        if (MODE != 1 && whole_row && fa.acc_rows) {
             // the row's complete accumulator goes straight into the packed exchange buffer
             if (g == 0) {
                 float *ar = fa.acc_rows + (size_t)sgm.row * fa.acc_ld;
@@ -290,57 +355,32 @@ __global__ __launch_bounds__(BLOCK, HPF_SWEEP_WAVES_PER_EU) void sweep_kernel(co
                     if (c + 3 < fa.acc_ld) ar[c + 3] = acc[v].w;
                 }
             }
-        } else if (!FUSE || !whole_row) {
+        } else if (MODE != 1 || !whole_row) {
             if (g == 0) {
                 float4 *pp = reinterpret_cast<float4 *>(part + (size_t)sg * LD);
 #pragma unroll
                 for (int v = 0; v < VPL; v++) pp[v * LPR + j] = acc[v];
             }
-        } else if constexpr (FUSE) {
+        } else if constexpr (MODE == 1) {
             // this segment is its row's only one: finish the row here (same math as
             // row_finalize_kernel), overlapping the fp64 work with other waves' gathers
-            const int row = sgm.row;
-            const float base_rte = fa.top_shp / fa.rs[row];
-            float sh[NC], rt[NC], fc[NC];
-            double ev[NC];
-            float fsum = 0.f;
-            double emax = 0.0;
+            float a[NC], eo[NC], en[NC];
 #pragma unroll
             for (int t = 0; t < NC; t++) {
                 const int q = g + t * NG;
-                float a = 0.f, eo = 0.f;
+                float av_ = 0.f, ov_ = 0.f;
 #pragma unroll
                 for (int qq = 0; qq < NQ; qq++) {  // pick float4 component q (q is lane-dependent)
                     const int v = qq >> 2, e = qq & 3;
                     const float av = (e == 0) ? acc[v].x : (e == 1) ? acc[v].y : (e == 2) ? acc[v].z : acc[v].w;
                     const float ov = (e == 0) ? rv[v].x : (e == 1) ? rv[v].y : (e == 2) ? rv[v].z : rv[v].w;
-                    a = (qq == q) ? av : a;
-                    eo = (qq == q) ? ov : eo;
+                    av_ = (qq == q) ? av : av_;
+                    ov_ = (qq == q) ? ov : ov_;
                 }
-                const bool valid = colq[t] < fa.k;
-                sh[t] = fmaf(eo, a, fa.prior_shp);
-                rt[t] = base_rte + csl[t];
-                fc[t] = valid ? sh[t] / rt[t] : 0.f;
-                ev[t] = valid ? expect_ratio(sh[t], rt[t]) : 0.0;
-                fsum += fc[t];
-                emax = fmax(emax, ev[t]);
-                csacc[t] += fc[t];
+                a[t] = av_;
+                eo[t] = ov_;
             }
-            fsum = wave_sum(fsum);
-            emax = wave_max_d(emax);
-            const double inv = 1.0 / emax;
-#pragma unroll
-            for (int t = 0; t < NC; t++) {
-                if (colq[t] < LD) {
-                    const size_t o = (size_t)row * LD + colq[t];
-                    const bool valid = colq[t] < fa.k;
-                    fa.e_new[o] = valid ? (float)(ev[t] * inv) : 0.f;
-                    if (fa.shp) stream_store(fa.shp + o, valid ? sh[t] : 0.f);
-                    if (fa.rte) stream_store(fa.rte + o, valid ? rt[t] : 0.f);
-                    if (fa.fac) stream_store(fa.fac + o, fc[t]);
-                }
-            }
-            if (lane == 0) fa.rs[row] = fa.add_rte + fsum;
+            finish_row(a, eo, en, sgm.row);
         }
     }
 
@@ -979,10 +1019,10 @@ int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx,
     fa.acc_ld = acc_ld;
 #define CALL(LPR, VPL)                                                                                              \
     if (scatter_acc)                                                                                                \
-        hipLaunchKernelGGL((sweep_kernel<LPR, VPL, true, false>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg, idx, \
+        hipLaunchKernelGGL((sweep_kernel<LPR, VPL, true, 0>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg, idx, \
                            y, tab_self, tab_other, part, scatter_acc, fa);                                          \
     else                                                                                                            \
-        hipLaunchKernelGGL((sweep_kernel<LPR, VPL, false, false>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg,     \
+        hipLaunchKernelGGL((sweep_kernel<LPR, VPL, false, 0>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg,     \
                            idx, y, tab_self, tab_other, part, scatter_acc, fa);
     HPF_DISPATCH_LD(ld, CALL)
 #undef CALL
@@ -1001,8 +1041,28 @@ int hpf_hip_sweep_finalize_f32(const hpf_segment *segs, int64_t nseg, const int3
     // grid NOT clamped: every block writes its cs_partial row
     const FinalizeArgs fa = {cs_other, cs_partial, e_new, shp, rte, fac, rs, prior_shp, top_shp, add_rte, k, nullptr, 0};
 #define CALL(LPR, VPL)                                                                                            \
-    hipLaunchKernelGGL((sweep_kernel<LPR, VPL, false, true>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg, \
+    hipLaunchKernelGGL((sweep_kernel<LPR, VPL, false, 1>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg, \
                        idx, y, tab_self, tab_other, part, (float *)nullptr, fa);
+    HPF_DISPATCH_LD(ld, CALL)
+#undef CALL
+    return last_error();
+}
+
+int hpf_hip_sweep_prefinalize_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
+                                  float *tab_self, const float *tab_other, float *part, float *acc_rows, int acc_ld,
+                                  float *shp, float *rte, float *fac, float *rs, const float *cs_other,
+                                  float *cs_partial, float prior_shp, float top_shp, float add_rte, int k, int ld,
+                                  int grid_blocks, void *stream) {
+    if (!segs || !idx || !y || !tab_self || !tab_other || !part || !acc_rows || !rs || !cs_other || !cs_partial ||
+        nseg <= 0 || k <= 0 || ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0 || acc_ld < k || acc_ld > ld)
+        return HPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    // grid NOT clamped: every block writes its cs_partial row
+    const FinalizeArgs fa = {cs_other, cs_partial, tab_self, shp, rte, fac, rs, prior_shp, top_shp, add_rte, k,
+                             acc_rows, acc_ld};
+#define CALL(LPR, VPL)                                                                                          \
+    hipLaunchKernelGGL((sweep_kernel<LPR, VPL, false, 2>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg, idx, \
+                       y, (const float *)tab_self, tab_other, part, (float *)nullptr, fa);
     HPF_DISPATCH_LD(ld, CALL)
 #undef CALL
     return last_error();

@@ -54,6 +54,16 @@ class HipOps:
                                                      float(add_rte), k, ld, cs_partial.shape[0], self._stream()),
                    "hpf_hip_sweep_finalize_f32")
 
+    def sweep_prefinalize(self, side, tab_self, tab_other, part, acc_rows, acc_ld, shp, rte, fac, rs, cs_other,
+                          cs_partial, prior_shp, top_shp, add_rte, k, ld):
+        """sharded item pass: whole-row segments first finish their row from acc_rows (last iteration's reduced
+        statistics), then sweep it and leave this iteration's local accumulator in acc_rows."""
+        _lib.check(self.L.hpf_hip_sweep_prefinalize_f32(
+            _ptr(side.segs), side.nseg, _ptr(side.idx), _ptr(side.y), _ptr(tab_self), _ptr(tab_other), _ptr(part),
+            _ptr(acc_rows), int(acc_ld), _ptr(shp), _ptr(rte), _ptr(fac), _ptr(rs), _ptr(cs_other), _ptr(cs_partial),
+            float(prior_shp), float(top_shp), float(add_rte), k, ld, cs_partial.shape[0], self._stream()),
+            "hpf_hip_sweep_prefinalize_f32")
+
     def finalize_grid(self, nrows):
         return int(max(1, min(self.finalize_blocks, (nrows + 3) // 4)))
 

@@ -92,6 +92,22 @@ int hpf_hip_sweep_finalize_f32(const hpf_segment *segs, int64_t nseg, const int3
                                void *stream);
 
 /*
+ * The sharded (multi-GPU) item pass with the row finalizer fused in as a PROLOGUE ("deferred item finalize"):
+ * acc_rows[row][0:acc_ld] holds LAST iteration's all-reduced accumulator of every row.  The wavefront that owns
+ * a whole-row segment first finishes that row from it (shp/rte/fac/rs/tab_self[row] updated exactly as
+ * hpf_hip_row_finalize_f32 would, cs_other = colsum of the other side's means), then sweeps the row with the
+ * fresh E row and overwrites acc_rows[row] with THIS iteration's local accumulator (the all-reduce payload).
+ * Split rows must have been finished beforehand (hpf_hip_row_finalize_f32 with their row_list, part = acc_rows,
+ * part_ld = acc_ld); their segments write part[] as usual.  cs_partial: grid_blocks rows, all written.
+ * This removes the replicated item finalizer launch from the multi-GPU critical path.
+ */
+int hpf_hip_sweep_prefinalize_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
+                                  float *tab_self, const float *tab_other, float *part, float *acc_rows, int acc_ld,
+                                  float *shp, float *rte, float *fac, float *rs, const float *cs_other,
+                                  float *cs_partial, float prior_shp, float top_shp, float add_rte, int k, int ld,
+                                  int grid_blocks, void *stream);
+
+/*
  * Closed-form updates for the rows of one side.  Replaces the numpy statements of
  * fit_hpf PXI:236-259 (and the psi/log/exp hoisted out of update_phi, PXI:588):
  *

@@ -51,6 +51,15 @@ class CpuOps:
         self.row_finalize(part, side.row_seg_ptr, int(single.shape[0]), e_old, e_new, shp, rte, fac, rs, cs_other,
                           cs_partial, prior_shp, top_shp, add_rte, k, ld, row_list=single)
 
+    def sweep_prefinalize(self, side, tab_self, tab_other, part, acc_rows, acc_ld, shp, rte, fac, rs, cs_other,
+                          cs_partial, prior_shp, top_shp, add_rte, k, ld):
+        begin, length, row = _decode_segs(side)
+        whole = (_np(side.segs)[:, 1] & 0x40000000) != 0
+        rows = torch.from_numpy(row[whole].astype(np.int64))
+        self.row_finalize(acc_rows, None, int(rows.shape[0]), tab_self, tab_self, shp, rte, fac, rs, cs_other,
+                          cs_partial, prior_shp, top_shp, add_rte, k, ld, row_list=rows, part_ld=acc_ld)
+        self.sweep(side, tab_self, tab_other, part, k, ld, acc_rows=acc_rows, acc_ld=acc_ld)
+
     def sweep(self, side, tab_self, tab_other, part, k, ld, scatter_acc=None, acc_rows=None, acc_ld=0):
         if side.nseg == 0:
             return
