@@ -28,7 +28,7 @@ SYMBOLS = (
     "hpf_hip_abi_version", "hpf_hip_ld_for_k", "hpf_hip_device_info", "hpf_hip_sweep_f32",
     "hpf_hip_sweep_finalize_f32", "hpf_hip_sweep_prefinalize_f32",
     "hpf_hip_row_finalize_f32", "hpf_hip_colsum_reduce_f32", "hpf_hip_colsum_f32", "hpf_hip_expect_f32",
-    "hpf_hip_segsum_f32", "hpf_hip_pair_llk_f32", "hpf_hip_llk_sweep_f32", "hpf_hip_pair_dot_f32", "hpf_hip_score_rows_f32",
+    "hpf_hip_segsum_f32", "hpf_hip_pair_llk_f32", "hpf_hip_llk_sweep_f32", "hpf_hip_pair_dot_f32", "hpf_hip_score_rows_f32", "hpf_hip_gather_probe_f32",
     "hpf_hip_svi_shape_rows_f32", "hpf_hip_svi_refresh_f32", "hpf_hip_svi_rate_rows_f32",
 )
 
@@ -83,6 +83,7 @@ def lib():
     L.hpf_hip_llk_sweep_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     L.hpf_hip_pair_dot_f32.argtypes = [vp, vp, vp, vp, i64, vp, ci, ci, vp]
     L.hpf_hip_score_rows_f32.argtypes = [vp, vp, i64, vp, ci, ci, vp]
+    L.hpf_hip_gather_probe_f32.argtypes = [vp, i64, vp, vp, ci, vp]
     L.hpf_hip_svi_shape_rows_f32.argtypes = [vp, i64, vp, vp, vp, cf, cf, cf, ci, ci, vp]
     L.hpf_hip_svi_refresh_f32.argtypes = [i64, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, ci, ci, ci, ci, ci, vp]
     L.hpf_hip_svi_rate_rows_f32.argtypes = [vp, i64, vp, vp, vp, vp, cf, cf, cf, cf, ci, ci, ci, vp]

@@ -942,6 +942,41 @@ __global__ __launch_bounds__(BLOCK) void score_rows_kernel(const float *__restri
     }
 }
 
+// Measurement aid (tools/gather_probe.py): the sweep's memory access pattern with the arithmetic stripped --
+// every 16-lane group gathers one 256-byte row per step, 8 steps in flight, rows taken from idx[].  Its GB/s is
+// the ceiling the sweep kernel can be held against for a given table size / index distribution.
+__global__ __launch_bounds__(BLOCK) void gather_probe_kernel(const int32_t *__restrict__ idx, int64_t n,
+                                                             const float *__restrict__ tab,
+                                                             float *__restrict__ sink) {
+    constexpr int LPR = 16, LD = 64, NG = WAVE / LPR, U = 8;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int g = lane / LPR, j = lane % LPR;
+    const int64_t nwaves = (int64_t)gridDim.x * WPB;
+    const int64_t w = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // each wave owns contiguous chunks of 64 indices, like a segment chunk in sweep_kernel
+    for (int64_t base = w * WAVE; base + WAVE <= n; base += nwaves * WAVE) {
+        const int myc = idx[base + lane];
+        for (int t0 = 0; t0 < LPR; t0 += U) {
+            float4 o[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int c = __shfl(myc, (t0 + u) * NG + g);
+                o[u] = reinterpret_cast<const float4 *>(tab + (size_t)c * LD)[j];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                acc.x += o[u].x;
+                acc.y += o[u].y;
+                acc.z += o[u].z;
+                acc.w += o[u].w;
+            }
+        }
+    }
+    const float r = acc.x + acc.y + acc.z + acc.w;
+    if (r == 123.456f) sink[0] = r;  // keeps the loads alive without a store stream
+}
+
 inline int clamp_grid(int64_t want, int grid_blocks) {
     int64_t g = grid_blocks > 0 ? grid_blocks : 2048;
     if (want < g) g = want;
@@ -1222,6 +1257,13 @@ int hpf_hip_svi_rate_rows_f32(const int64_t *row_list, int64_t nrows, float *rte
                        cs_other, top, add, step, step_prev, mode, k);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
+    return last_error();
+}
+
+int hpf_hip_gather_probe_f32(const int32_t *idx, int64_t n, const float *tab, float *sink, int grid_blocks,
+                             void *stream) {
+    if (!idx || !tab || !sink || n <= 0 || grid_blocks <= 0) return HPF_EINVAL;
+    hipLaunchKernelGGL(gather_probe_kernel, dim3(grid_blocks), dim3(BLOCK), 0, (hipStream_t)stream, idx, n, tab, sink);
     return last_error();
 }
 

@@ -188,6 +188,12 @@ int hpf_hip_svi_rate_rows_f32(const int64_t *row_list, int64_t nrows, float *rte
                               const float *cs_other, float top, float add, float step, float step_prev, int mode,
                               int k, int ld, void *stream);
 
+/* Measurement aid, not part of the replaced path: the sweep's gather pattern (256-byte rows of a [rows][64]
+ * table, row ids from idx[], 4 rows per wave step, 8 steps in flight) with the arithmetic stripped; used by
+ * tools/gather_probe.py to measure the gather-bandwidth ceiling the sweep kernel is held against. */
+int hpf_hip_gather_probe_f32(const int32_t *idx, int64_t n, const float *tab, float *sink, int grid_blocks,
+                             void *stream);
+
 /* out[r] = <vec, tab[r]>, r < nrows; vec is one padded row (ld floats).  Replaces the scoring product of
  * HPF.topN, Theta[user].dot(Beta.T) (hpfrec/__init__.py:1337). */
 int hpf_hip_score_rows_f32(const float *vec, const float *tab, int64_t nrows, float *out, int k, int ld,
