@@ -156,7 +156,7 @@ def main():
     ap.add_argument("--no-fuse", action="store_true", help="separate sweep and row-finalize launches")
     ap.add_argument("--atomic", action="store_true", help="experimental one-pass variant with fp32 atomics")
     ap.add_argument("--lean", action="store_true",
-                    help="skip the Gamma/Lambda shape+rate table stores (outputs only) in the timed iterations")
+                    help="skip the stores of the six [n,k] output tables in the timed iterations")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -235,8 +235,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # what fit_hpf actually does between checks: Gamma/Lambda shape+rate tables (outputs only) are not
-    # written.  Reported as an extra field; `value` above is the conservative all-tables-stored figure.
+    # what fit_hpf actually does between checks: the six [n,k] output tables (shapes, rates, Theta/Beta) are
+    # not written.  Reported as an extra field; `value` above is the conservative all-tables-stored figure.
     lean_ms = None
     if store and not args.no_extras:
         for _ in range(2):

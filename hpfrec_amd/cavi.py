@@ -183,7 +183,7 @@ class FullBatchCavi:
         single-segment row finishes it (fp64 work overlaps other waves' gathers); split and empty rows
         are finished by a small follow-up launch over side.multi_rows."""
         ops, k, ld = self.ops, self.k, self.ld
-        shp, rte, fac = (shp, rte, fac) if store else (None, None, fac)
+        shp, rte, fac = (shp, rte, fac) if store else (None, None, None)
         if self.fused and side.nseg > 0:
             ops.sweep_finalize(side, e_self, e_other, part, e_new, shp, rte, fac, rs, cs_other, cs_part[:gs],
                                prior, top, add, k, ld)
@@ -217,8 +217,10 @@ class FullBatchCavi:
         self.niter_done += 1
 
     def iterate(self, store=True):
-        """One CAVI iteration.  store=False skips writing Gamma/Lambda shape and rate tables (they are
-        outputs only; Theta/Beta, the scalar rates and the E tables are always kept current)."""
+        """One CAVI iteration.  store=False skips writing the Gamma/Lambda shape and rate tables AND the mean
+        tables Theta/Beta: all six are outputs (and llk inputs) only -- the iteration itself runs on the E
+        tables, the scalar rates and the column sums, which are always kept current.  Callers pass store=True
+        on the iterations whose state they read (checks, the last one)."""
         if self.dist:
             return self._iterate_sharded(store)
         ops, hy, ld = self.ops, self.hy, self.ld
@@ -276,7 +278,8 @@ class FullBatchCavi:
         if lazy:
             it = self.items
             ops.row_finalize(self.acc_i, None, it.nmulti, self.eB, self.eB, self.Lambda_shp if store else None,
-                             self.Lambda_rte if store else None, self.Beta, self.t_rte, self.csT, self._csp_multi,
+                             self.Lambda_rte if store else None, self.Beta if store else None, self.t_rte, self.csT,
+                             self._csp_multi,
                              hy.c, hy.t_shp, hy.add_t_rte, k, ld, row_list=it.multi_rows, part_ld=k)
         pending = []
         for c in views:
@@ -285,7 +288,7 @@ class FullBatchCavi:
             if lazy:
                 ops.sweep_prefinalize(c["view"], self.eB, self.eT, c["part"], self.acc_i, k,
                                       self.Lambda_shp if store else None, self.Lambda_rte if store else None,
-                                      self.Beta, self.t_rte, self.csT, c["csp_lazy"], hy.c, hy.t_shp,
+                                      self.Beta if store else None, self.t_rte, self.csT, c["csp_lazy"], hy.c, hy.t_shp,
                                       hy.add_t_rte, k, ld)
             elif c["view"].nseg > 0:
                 ops.sweep(c["view"], self.eB, self.eT, c["part"], k, ld, acc_rows=self.acc_i, acc_ld=k)

@@ -212,8 +212,9 @@ def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta
     i = -1
     for i in range(maxiter):
         is_check = check_every > 0 and ((i + 1) % check_every) == 0
-        # Gamma/Lambda shape+rate tables are outputs only: written on check iterations (the loop may
-        # stop there) and on the last one; Theta/Beta/k_rte/t_rte are current after every iteration
+        # the six [n,k] state tables (shapes, rates, Theta/Beta) are outputs / llk inputs only: written on
+        # check iterations (the loop may stop there) and on the last one; the E tables, k_rte/t_rte and the
+        # column sums that carry the iteration are current after every iteration
         model.iterate(store=(is_check or i == maxiter - 1))
         if is_check:
             if stop_crit == "diff-norm":
