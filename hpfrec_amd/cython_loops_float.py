@@ -336,6 +336,17 @@ def _fingerprint(arr):
     return (id(arr), arr.shape, flat[::step].tobytes())
 
 
+def device_item_table(Beta, ops):
+    """Padded device copy of the host item table, kept between calls (keyed on a fingerprint of the host array:
+    identity, shape and a strided sample of its values), shared by topN and the single-user fold-in."""
+    ld = cavi._lib.ld_for_k(int(Beta.shape[1]))
+    key = _fingerprint(Beta)
+    hit = _ITEM_CACHE.get("Beta")
+    if hit is None or hit[0] != key or hit[1].device != ops.device:
+        _ITEM_CACHE["Beta"] = hit = (key, _padded(Beta, ld, ops.device))
+    return hit[1]
+
+
 def top_items(theta_row, Beta, n, exclude=None):
     """Ids of the n rows of Beta with the largest theta_row . Beta[i], best first, optionally skipping
     `exclude` (ids).  The item table is kept on the device between calls (keyed on a fingerprint of
@@ -345,11 +356,7 @@ def top_items(theta_row, Beta, n, exclude=None):
     dev = ops.device
     k = int(Beta.shape[1])
     ld = cavi._lib.ld_for_k(k)
-    key = _fingerprint(Beta)
-    hit = _ITEM_CACHE.get("Beta")
-    if hit is None or hit[0] != key or hit[1].device != dev:
-        _ITEM_CACHE["Beta"] = hit = (key, _padded(Beta, ld, dev))
-    tab = hit[1]
+    tab = device_item_table(Beta, ops)
     vec = torch.zeros(ld, dtype=torch.float32, device=dev)
     vec[:k] = torch.from_numpy(np.ascontiguousarray(theta_row, dtype=np.float32).reshape(-1)).to(dev)
     scores = torch.empty(tab.shape[0], dtype=torch.float32, device=dev)
@@ -369,6 +376,7 @@ def top_items(theta_row, Beta, n, exclude=None):
 def calc_user_factors(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_i, Theta, Beta, Lambda_shp, Lambda_rte, nY, k,
                       maxiter, nthreads, random_seed, stop_thr, return_all):
     """Fold-in of one new user with item parameters fixed (HPF.predict_factors / add_user)."""
-    return svi.calc_user_factors(_make_ops(), a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_i, Theta, Beta,
+    ops = _make_ops()
+    return svi.calc_user_factors(ops, a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_i, Theta, Beta,
                                  Lambda_shp, Lambda_rte, int(nY), int(k), int(maxiter), int(random_seed),
-                                 float(stop_thr), bool(return_all))
+                                 float(stop_thr), bool(return_all), Beta_dev=device_item_table(Beta, ops))

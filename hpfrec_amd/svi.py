@@ -309,7 +309,7 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
 
 # -- PXI:476-520 ------------------------------------------------------------------------------------
 def calc_user_factors(ops, a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_i, Theta, Beta, Lambda_shp, Lambda_rte,
-                      nY, k, maxiter, random_seed, stop_thr, return_all):
+                      nY, k, maxiter, random_seed, stop_thr, return_all, Beta_dev=None):
     """Local CAVI for ONE user with the item parameters fixed.  Fills `Theta` (k,) in place; returns
     (Gamma_shp, Gamma_rte, phi/Y) when return_all else None."""
     f = np.float32
@@ -322,8 +322,9 @@ def calc_user_factors(ops, a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_i, Th
     rng = np.random.default_rng(seed=random_seed if random_seed > 0 else None)
     Theta[:] = rng.gamma(a, 1 / b_prime, size=k).astype(np.float32)
     k_rte = f(b_prime + Theta.sum())
-    Beta_dev = torch.zeros((Beta.shape[0], ld), dtype=torch.float32, device=dev)
-    Beta_dev[:, :k] = torch.from_numpy(np.ascontiguousarray(Beta, dtype=np.float32)).to(dev)
+    if Beta_dev is None:
+        Beta_dev = torch.zeros((Beta.shape[0], ld), dtype=torch.float32, device=dev)
+        Beta_dev[:, :k] = torch.from_numpy(np.ascontiguousarray(Beta, dtype=np.float32)).to(dev)
     csp = torch.zeros((ops.finalize_grid(Beta.shape[0]), ld), dtype=torch.float32, device=dev)
     cs = torch.zeros(ld, dtype=torch.float32, device=dev)
     ops.colsum(Beta_dev, Beta.shape[0], ld, csp)
