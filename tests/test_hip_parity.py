@@ -522,3 +522,21 @@ def test_c2_size_vs_oracle(hip_backend):
         i, arrs, _ = _fit(hip_backend, Y, IU, II, nU, nI, k, its)
         for n in NAMES:
             assert _maxrel(arrs[n], caps[its][n]) < 1e-4, (its, n)
+
+
+def test_tiny_shape_priors(hip_backend):
+    """a = c = 0.002: after the first iteration most shapes sit near 0.002, psi(shape) ~ -500, and
+    exp(psi_u + psi_i) underflows to 0 for those factors even in double (the case sum_exp_trick exists for).
+    The device path normalises every E row by its maximum in double before rounding, so it needs no switch:
+    compare with both reference branches (the trick branch carries its log-sum in float32, abs. error
+    ~6e-5 at magnitude 1e3, hence the looser bar there)."""
+    df, nU, nI = datagen.readme_counts()
+    Y, iu, ii = datagen.triplets(df)
+    hyper = dict(a=0.002, a_prime=0.3, b_prime=1.0, c=0.002, c_prime=0.3, d_prime=1.0)
+    _, plain = O.fit_full_batch(Y, iu, ii, nU, nI, 10, 3, 5, capture_at=(3,), **hyper)
+    _, trick = O.fit_full_batch(Y, iu, ii, nU, nI, 10, 3, 5, sum_exp_trick=1, capture_at=(3,), **hyper)
+    i, arrs, _ = _fit(hip_backend, Y, iu, ii, nU, nI, 10, 3, seed=5, **hyper)
+    for n in NAMES:
+        assert np.isfinite(arrs[n]).all() and (arrs[n] > 0).all(), n
+        assert _maxrel(arrs[n], plain[3][n]) < 2e-5, n
+        assert _maxrel(arrs[n], trick[3][n]) < 2e-3, n
