@@ -304,7 +304,9 @@ def main():
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": label, "users": nU, "items": nI, "nnz": nnz, "k": k, "ld": model.ld,
-                       "parallelism": "users sharded x%d, 1 all-reduce/iter" % world if world > 1 else "1 GPU",
+                       "parallelism": ("users sharded x%d; item statistics all-reduced per iteration in %d pipelined ranges "
+                                       "(RCCL), item finalize deferred into the next item sweep"
+                                       % (world, len(model.item_chunks))) if world > 1 else "1 GPU",
                        "seg_cap": cavi.layout.SEG_CAP, "fused_finalize": model.fused and world == 1,
                        "stores_all_state_tables": store, "state_finite": finite},
             "roofline": roof,
