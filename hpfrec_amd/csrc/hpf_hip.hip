@@ -1,11 +1,13 @@
 // hpf_hip.hip -- gfx950 (MI355X, CDNA4) kernels + C ABI for the HPF full-batch CAVI sweep.
 //
 // What is replaced (reference: /root/reference/hpfrec/cython_loops.pxi = "PXI"):
-//   sweep_kernel        <- update_phi PXI:551-591 fused with update_G_n_L_sh PXI:613-621
+//   sweep_kernel        <- update_phi PXI:551-591 fused with update_G_n_L_sh PXI:613-621; MODE 1/2 also
+//                          run the row finalizer for whole-row segments (epilogue / prologue)
 //   row_finalize_kernel <- numpy rate/shape statements of fit_hpf PXI:236-259 + the psi/log/exp
 //                          hoisted out of update_phi (PXI:588: they only depend on the row)
-//   pair_llk_kernel     <- llk_plus_rmse PXI:627-658, sum_prediction PXI:816-825
-//   pair_dot_kernel     <- predict_multiple PXI:803-810
+//   llk_sweep_kernel, pair_llk_kernel <- llk_plus_rmse PXI:627-658, sum_prediction PXI:816-825
+//   pair_dot_kernel     <- predict_multiple PXI:803-810;  score_rows_kernel <- HPF.topN's GEMV
+//   svi_*_kernel        <- the numpy statements of an SVI batch / partial_fit PXI:300-325,352-377,443-473
 //
 // Design: the reference evaluates, per nonzero and factor,
 //   exp(psi(Gs_uk) - log(Gr_uk) + psi(Ls_ik) - log(Lr_ik)) = eT_uk * eB_ik
@@ -156,12 +158,13 @@ __device__ __forceinline__ double expect_ratio(float shp, float rte) {
 // ----------------------------------------------------------------------------------------
 // sweep: one wavefront per segment
 // ----------------------------------------------------------------------------------------
-struct FinalizeArgs {  // the row-finalize operands when it is fused into the sweep (FUSE = true)
+struct FinalizeArgs {  // the row-finalize operands when it is fused into the sweep (MODE 1 or 2)
     const float *cs_other;
     float *cs_partial, *e_new, *shp, *rte, *fac, *rs;
     float prior_shp, top_shp, add_rte;
     int k;
-    float *acc_rows;  // !FUSE only: packed [rows][acc_ld] destination for whole-row segments (or null)
+    float *acc_rows;  // MODE 0/2: packed [rows][acc_ld] accumulator rows of whole-row segments (or null);
+                      // MODE 2 also reads last iteration's reduced statistics from it
     int acc_ld;
 };
 
