@@ -34,3 +34,20 @@ def hip_backend():
     from hpfrec_amd import cython_loops_float as backend
     assert backend._OPS_FACTORY is None
     return backend
+
+
+@pytest.fixture(params=["standin", pytest.param("hip", marks=pytest.mark.gpu)])
+def any_backend(request):
+    """Run a host-level test twice: on the numpy stand-in ops (no GPU) and, under -m gpu, on the HIP path."""
+    import cpu_ops
+    from hpfrec_amd import cython_loops_float as backend
+    old = backend._OPS_FACTORY
+    if request.param == "standin":
+        backend._OPS_FACTORY = cpu_ops.CpuOps
+    else:
+        import torch
+        if not torch.cuda.is_available():
+            pytest.skip("no GPU")
+        backend._OPS_FACTORY = None
+    yield backend
+    backend._OPS_FACTORY = old

@@ -49,7 +49,7 @@ def test_constructor_validation():
     assert HPF(reindex=False).produce_dicts is False
 
 
-def test_fit_flow_on_standin(cpu_ops_backend, capsys):
+def test_fit_flow(any_backend, capsys):
     m, df, nU, nI, g = _check_fit_against_golden(5e-5)
     assert m.Theta.shape == (nU, 30) and m.Beta.shape == (nI, 30) and m.Theta.dtype == np.float32
     assert not hasattr(m, "input_df") and not hasattr(m, "val_set")
@@ -79,7 +79,7 @@ def test_fit_flow_on_standin(cpu_ops_backend, capsys):
     assert ll["nobs"] == df2.shape[0] and np.isfinite(float(ll["llk"]))
 
 
-def test_fit_inputs_coo_array_and_zero_filter(cpu_ops_backend):
+def test_fit_inputs_coo_array_and_zero_filter(any_backend):
     df, nU, nI = datagen.readme_counts()
     m_df = HPF(k=8, maxiter=3, random_seed=1, reindex=False, verbose=False, check_every=None).fit(df.copy())
     X = coo_array((df.Count.to_numpy(), (df.UserId.to_numpy(), df.ItemId.to_numpy())), shape=(nU, nI))
@@ -99,7 +99,7 @@ def test_fit_inputs_coo_array_and_zero_filter(cpu_ops_backend):
         HPF(stop_crit="val-llk", verbose=False).fit(df.copy())
 
 
-def test_valset_stopping(cpu_ops_backend):
+def test_valset_stopping(any_backend):
     df, nU, nI = datagen.readme_counts()
     val = df.sample(200, random_state=1)
     m = HPF(k=10, maxiter=60, stop_crit="val-llk", check_every=5, stop_thr=1e-2, random_seed=2, verbose=False,
@@ -126,7 +126,7 @@ def test_fit_predict_topn_vs_golden_on_gpu(hip_backend):
     assert abs(float(mv.train_llk) / gl["train_llk_it10"] - 1) < 1e-4
 
 
-def test_save_folder_and_flags(cpu_ops_backend, tmp_path):
+def test_save_folder_and_flags(any_backend, tmp_path):
     df, nU, nI = datagen.readme_counts()
     df2 = df.copy()
     df2["UserId"] = df2["UserId"] + 500
