@@ -27,15 +27,13 @@ c_real_t = ctypes.c_float          # hpfrec/cython_float.pxi:9
 obj_ind_type = ctypes.c_size_t     # hpfrec/cython_float_nonwindows.pyx:10
 obj_long_double_type = ctypes.c_longdouble
 
-#: test seam: tests/ may install a CPU stand-in for HipOps here to exercise host logic without a
-#: GPU.  It is None in the product, in which case HipOps is required and fails loudly without a GPU.
-_OPS_FACTORY = None
-_DEVICE = None
+_DEVICE = None   # None = torch's current device; a multi-GPU launcher sets the device per rank beforehand
 
 
 def _make_ops():
-    if _OPS_FACTORY is not None:
-        return _OPS_FACTORY()
+    """The HIP op set.  There is no alternative implementation in this package: HipOps raises when the
+    extension or the GPU is missing.  (tests/ substitute this module's `HipOps` name with a numpy stand-in to
+    exercise the host logic on GPU-less machines.)"""
     return HipOps(_DEVICE)
 
 

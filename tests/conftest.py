@@ -20,10 +20,10 @@ def cpu_ops_backend():
     """Install the numpy stand-in ops (tests/cpu_ops.py) for host-logic tests; restore afterwards."""
     import cpu_ops
     from hpfrec_amd import cython_loops_float as backend
-    old = backend._OPS_FACTORY
-    backend._OPS_FACTORY = cpu_ops.CpuOps
+    old = backend.HipOps
+    backend.HipOps = lambda device=None: cpu_ops.CpuOps()
     yield backend
-    backend._OPS_FACTORY = old
+    backend.HipOps = old
 
 
 @pytest.fixture
@@ -32,7 +32,8 @@ def hip_backend():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from hpfrec_amd import cython_loops_float as backend
-    assert backend._OPS_FACTORY is None
+    from hpfrec_amd.ops_hip import HipOps
+    assert backend.HipOps is HipOps
     return backend
 
 
@@ -41,13 +42,14 @@ def any_backend(request):
     """Run a host-level test twice: on the numpy stand-in ops (no GPU) and, under -m gpu, on the HIP path."""
     import cpu_ops
     from hpfrec_amd import cython_loops_float as backend
-    old = backend._OPS_FACTORY
+    from hpfrec_amd.ops_hip import HipOps
+    old = backend.HipOps
     if request.param == "standin":
-        backend._OPS_FACTORY = cpu_ops.CpuOps
+        backend.HipOps = lambda device=None: cpu_ops.CpuOps()
     else:
         import torch
         if not torch.cuda.is_available():
             pytest.skip("no GPU")
-        backend._OPS_FACTORY = None
+        backend.HipOps = HipOps
     yield backend
-    backend._OPS_FACTORY = old
+    backend.HipOps = old

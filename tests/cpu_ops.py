@@ -3,8 +3,8 @@
 Same method names and argument meaning as HipOps, float64 arithmetic on CPU torch tensors.
 Two uses:
   * `-m "not gpu"` tests exercise the host logic (layout, driver loop, sharding over gloo,
-    the HPF class) on machines without a GPU by installing it in
-    hpfrec_amd.cython_loops_float._OPS_FACTORY;
+    the HPF class) on machines without a GPU by monkeypatching the name `HipOps` in
+    hpfrec_amd.cython_loops_float (tests/conftest.py fixtures);
   * `-m gpu` tests use it as the op-by-op reference of each HIP kernel (alongside the
     end-to-end comparison with the oracle / golden vectors).
 It lives under tests/ so that nothing in the package can route through it.

@@ -19,7 +19,7 @@ def run(rank, world, port, out_dir, k, its, case):
     import cpu_ops
     import datagen
     from hpfrec_amd import cython_loops_float as be
-    be._OPS_FACTORY = cpu_ops.CpuOps
+    be.HipOps = lambda device=None: cpu_ops.CpuOps()   # numpy stand-in for the kernels (host logic test)
     if case == "c1":
         df, nU, nI = datagen.readme_counts()
     else:

@@ -41,7 +41,8 @@ def test_missing_gpu_fails_loudly():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
     from hpfrec_amd import cython_loops_float as be
-    assert be._OPS_FACTORY is None
+    from hpfrec_amd.ops_hip import HipOps
+    assert be.HipOps is HipOps
     with pytest.raises(_lib.HpfHipError):
         be.predict_arr(np.ones((2, 3), np.float32), np.ones((2, 3), np.float32), np.zeros(1, np.uint64),
                        np.zeros(1, np.uint64), 1)
