@@ -99,6 +99,13 @@ class FullBatchCavi:
         self.Lambda_shp, self.Lambda_rte, self.Beta = z(self.nI), z(self.nI), z(self.nI)
         self.k_rte = torch.zeros(self.nU, **f32)
         self.t_rte = torch.zeros(self.nI, **f32)
+        # Gamma_rte = k_shp/k_rte_old + colsum(Beta_old) and Lambda_rte = t_shp/t_rte_old + colsum(Theta) are rank-1
+        # (row scalar + column vector): the iteration keeps only these factors (n + k floats per side) and the
+        # [n,k] rate tables are expanded on output (fetch), bit-identically to what the kernels would store
+        self.k_rte_prev = torch.zeros(self.nU, **f32)
+        self.t_rte_prev = torch.zeros(self.nI, **f32)
+        self.csB_used = torch.zeros(ld, **f32)
+        self.rte_factored = False
         self.eT, self.eT_next, self.eB = z(self.nU), z(self.nU), z(self.nI)
         self.part_u = torch.empty((max(1, self.users.nseg), ld), **f32)
         self.part_i = torch.empty((max(1, self.items.nseg), ld), **f32)
@@ -139,6 +146,7 @@ class FullBatchCavi:
         self.k_rte.copy_(torch.from_numpy(np.ascontiguousarray(k_rte, dtype=np.float32).reshape(-1)))
         self.t_rte.copy_(torch.from_numpy(np.ascontiguousarray(t_rte, dtype=np.float32).reshape(-1)))
         self.item_pending = False
+        self.rte_factored = False
         self.refresh_expectations()
 
     def refresh_expectations(self):
@@ -177,24 +185,24 @@ class FullBatchCavi:
         self.csB_part.zero_()
 
     # ------------------------------------------------------------------------------------
-    def _side_update(self, side, nrows, e_self, e_other, e_new, part, shp, rte, fac, rs, cs_other, cs_part, gs, gf,
+    def _side_update(self, side, nrows, e_self, e_other, e_new, part, shp, rs_prev, fac, rs, cs_other, cs_part, gs, gf,
                      prior, top, add, store):
         """sweep one side and apply its closed-form updates.  Fused mode: the wavefront that swept a
         single-segment row finishes it (fp64 work overlaps other waves' gathers); split and empty rows
         are finished by a small follow-up launch over side.multi_rows."""
         ops, k, ld = self.ops, self.k, self.ld
-        shp, rte, fac = (shp, rte, fac) if store else (None, None, None)
+        shp, fac = (shp, fac) if store else (None, None)
         if self.fused and side.nseg > 0:
-            ops.sweep_finalize(side, e_self, e_other, part, e_new, shp, rte, fac, rs, cs_other, cs_part[:gs],
-                               prior, top, add, k, ld)
+            ops.sweep_finalize(side, e_self, e_other, part, e_new, shp, None, fac, rs, cs_other, cs_part[:gs],
+                               prior, top, add, k, ld, rs_prev=rs_prev)
             nm = side.nmulti
             gm = max(1, min(gf, (nm + 3) // 4))
-            ops.row_finalize(part, side.row_seg_ptr, nm, e_self, e_new, shp, rte, fac, rs, cs_other,
-                             cs_part[gs: gs + gm], prior, top, add, k, ld, row_list=side.multi_rows)
+            ops.row_finalize(part, side.row_seg_ptr, nm, e_self, e_new, shp, None, fac, rs, cs_other,
+                             cs_part[gs: gs + gm], prior, top, add, k, ld, row_list=side.multi_rows, rs_prev=rs_prev)
         else:
             ops.sweep(side, e_self, e_other, part, k, ld)
-            ops.row_finalize(part, side.row_seg_ptr, nrows, e_self, e_new, shp, rte, fac, rs, cs_other,
-                             cs_part[gs:], prior, top, add, k, ld)
+            ops.row_finalize(part, side.row_seg_ptr, nrows, e_self, e_new, shp, None, fac, rs, cs_other,
+                             cs_part[gs:], prior, top, add, k, ld, rs_prev=rs_prev)
 
     def iterate_one_pass_atomic(self, store=True):
         """Experimental one-pass variant: the user sweep also scatters w*eT_u into the item accumulators
@@ -206,12 +214,14 @@ class FullBatchCavi:
         self.acc_atomic.zero_()
         ops.sweep(self.users, self.eT, self.eB, self.part_u, k, ld, scatter_acc=self.acc_atomic)
         ops.row_finalize(self.part_u, self.users.row_seg_ptr, self.nU, self.eT, self.eT_next,
-                         self.Gamma_shp if store else None, self.Gamma_rte if store else None, self.Theta,
-                         self.k_rte, self.csB, self.csT_part[self.gsu:], hy.a, hy.k_shp, hy.add_k_rte, k, ld)
+                         self.Gamma_shp if store else None, None, self.Theta,
+                         self.k_rte, self.csB, self.csT_part[self.gsu:], hy.a, hy.k_shp, hy.add_k_rte, k, ld,
+                         rs_prev=self.k_rte_prev)
         ops.colsum_reduce(self.csT_part, self.csT, ld)
+        self._keep_csB(store)
         ops.row_finalize(self.acc_atomic, None, self.nI, self.eB, self.eB, self.Lambda_shp if store else None,
-                         self.Lambda_rte if store else None, self.Beta, self.t_rte, self.csT,
-                         self.csB_part[self.gsi:], hy.c, hy.t_shp, hy.add_t_rte, k, ld)
+                         None, self.Beta, self.t_rte, self.csT,
+                         self.csB_part[self.gsi:], hy.c, hy.t_shp, hy.add_t_rte, k, ld, rs_prev=self.t_rte_prev)
         ops.colsum_reduce(self.csB_part, self.csB, ld)
         self.eT, self.eT_next = self.eT_next, self.eT
         self.niter_done += 1
@@ -226,12 +236,13 @@ class FullBatchCavi:
         ops, hy, ld = self.ops, self.hy, self.ld
         # user side: phi-weighted gather over CSR rows, then the closed-form user updates
         self._side_update(self.users, self.nU, self.eT, self.eB, self.eT_next, self.part_u, self.Gamma_shp,
-                          self.Gamma_rte, self.Theta, self.k_rte, self.csB, self.csT_part, self.gsu, self.gu,
+                          self.k_rte_prev, self.Theta, self.k_rte, self.csB, self.csT_part, self.gsu, self.gu,
                           hy.a, hy.k_shp, hy.add_k_rte, store)
         ops.colsum_reduce(self.csT_part, self.csT, ld)
         # item side: same kernel over CSC rows; still reads the OLD eT (double-buffered)
+        self._keep_csB(store)
         self._side_update(self.items, self.nI, self.eB, self.eT, self.eB, self.part_i, self.Lambda_shp,
-                          self.Lambda_rte, self.Beta, self.t_rte, self.csT, self.csB_part, self.gsi, self.gi,
+                          self.t_rte_prev, self.Beta, self.t_rte, self.csT, self.csB_part, self.gsi, self.gi,
                           hy.c, hy.t_shp, hy.add_t_rte, store)
         ops.colsum_reduce(self.csB_part, self.csB, ld)
         self.eT, self.eT_next = self.eT_next, self.eT
@@ -255,7 +266,7 @@ class FullBatchCavi:
             l1 = l0 + ops.sweep_grid(view.nseg)
             views.append(dict(
                 n=hi - lo, view=view, multi=multi, nmulti=int(multi.shape[0]), part=self.part_i[view.seg_lo:],
-                acc=self.acc_i[lo:hi], eB=self.eB[lo:hi], shp=self.Lambda_shp[lo:hi], rte=self.Lambda_rte[lo:hi],
+                acc=self.acc_i[lo:hi], eB=self.eB[lo:hi], shp=self.Lambda_shp[lo:hi], rsp=self.t_rte_prev[lo:hi],
                 fac=self.Beta[lo:hi], rs=self.t_rte[lo:hi], csp=self.csB_part[g0:g1],
                 csp_lazy=self.csB_part_lazy[l0:l1]))
             g0, l0 = g1, l1
@@ -278,18 +289,19 @@ class FullBatchCavi:
         if lazy:
             it = self.items
             ops.row_finalize(self.acc_i, None, it.nmulti, self.eB, self.eB, self.Lambda_shp if store else None,
-                             self.Lambda_rte if store else None, self.Beta if store else None, self.t_rte, self.csT,
+                             None, self.Beta if store else None, self.t_rte, self.csT,
                              self._csp_multi,
-                             hy.c, hy.t_shp, hy.add_t_rte, k, ld, row_list=it.multi_rows, part_ld=k)
+                             hy.c, hy.t_shp, hy.add_t_rte, k, ld, row_list=it.multi_rows, part_ld=k,
+                             rs_prev=self.t_rte_prev)
         pending = []
         for c in views:
             # whole-row segments leave their accumulator straight in the packed buffer; only split rows
             # (and rows without local nonzeros: zeros) go through part[] + segsum
             if lazy:
                 ops.sweep_prefinalize(c["view"], self.eB, self.eT, c["part"], self.acc_i, k,
-                                      self.Lambda_shp if store else None, self.Lambda_rte if store else None,
+                                      self.Lambda_shp if store else None, None,
                                       self.Beta if store else None, self.t_rte, self.csT, c["csp_lazy"], hy.c, hy.t_shp,
-                                      hy.add_t_rte, k, ld)
+                                      hy.add_t_rte, k, ld, rs_prev=self.t_rte_prev)
             elif c["view"].nseg > 0:
                 ops.sweep(c["view"], self.eB, self.eT, c["part"], k, ld, acc_rows=self.acc_i, acc_ld=k)
             if c["nmulti"] > 0:
@@ -298,8 +310,9 @@ class FullBatchCavi:
             pending.append(dist.all_reduce(c["acc"], async_op=True))
         if lazy:
             ops.colsum_reduce(self.csB_part_lazy, self.csB, ld)   # colsum(Beta) of the rows just finished
+        self._keep_csB(store)
         self._side_update(self.users, self.nU, self.eT, self.eB, self.eT_next, self.part_u, self.Gamma_shp,
-                          self.Gamma_rte, self.Theta, self.k_rte, self.csB, self.csT_part, self.gsu, self.gu,
+                          self.k_rte_prev, self.Theta, self.k_rte, self.csB, self.csT_part, self.gsu, self.gu,
                           hy.a, hy.k_shp, hy.add_k_rte, store)
         ops.colsum_reduce(self.csT_part, self.csT, ld)
         dist.all_reduce(self.csT)
@@ -315,8 +328,8 @@ class FullBatchCavi:
             return
         ops, hy, k, ld = self.ops, self.hy, self.k, self.ld
         for c in self._sharded_views():
-            ops.row_finalize(c["acc"], None, c["n"], c["eB"], c["eB"], c["shp"], c["rte"], c["fac"], c["rs"], self.csT,
-                             c["csp"], hy.c, hy.t_shp, hy.add_t_rte, k, ld, part_ld=k)
+            ops.row_finalize(c["acc"], None, c["n"], c["eB"], c["eB"], c["shp"], None, c["fac"], c["rs"], self.csT,
+                             c["csp"], hy.c, hy.t_shp, hy.add_t_rte, k, ld, part_ld=k, rs_prev=c["rsp"])
         ops.colsum_reduce(self.csB_part, self.csB, ld)
         self.item_pending = False
 
@@ -354,9 +367,29 @@ class FullBatchCavi:
         return np.dot(a, b)
 
     # ------------------------------------------------------------------------------------
+    def _keep_csB(self, store):
+        """Remember the colsum(Beta) the user side of this iteration used (Gamma_rte's rank-1 term) before
+        the item side replaces it."""
+        if store:
+            self.csB_used.copy_(self.csB)
+        self.rte_factored = True
+
+    def materialize_rates(self):
+        """Expand the rank-1 rate tables into Gamma_rte / Lambda_rte (PXI:236, PXI:255): the kernels keep
+        only the old scalar rate per row and the column sums; same fp32 operations as the table form."""
+        self.flush_items()
+        if not self.rte_factored:
+            return
+        k = self.k
+        self.Gamma_rte[:, :k] = (float(self.hy.k_shp) / self.k_rte_prev)[:, None] + self.csB_used[None, :k]
+        self.Lambda_rte[:, :k] = (float(self.hy.t_shp) / self.t_rte_prev)[:, None] + self.csT[None, :k]
+        self.rte_factored = False
+
     def fetch(self, name):
         """Unpadded host copy of one state array (this rank's rows)."""
         self.flush_items()
+        if name in ("Gamma_rte", "Lambda_rte"):
+            self.materialize_rates()
         t = getattr(self, name)
         if t.dim() == 1:
             return t.cpu().numpy().reshape(-1, 1).copy()

@@ -163,6 +163,8 @@ struct FinalizeArgs {  // the row-finalize operands when it is fused into the sw
     float *cs_partial, *e_new, *shp, *rte, *fac, *rs;
     float prior_shp, top_shp, add_rte;
     int k;
+    float *rs_prev;   // optional: receives the row's OLD scalar rate (rte = top/rs_prev + cs_other is rank-1,
+                      // so callers may keep this instead of the [rows][ld] rte table)
     float *acc_rows;  // MODE 0/2: packed [rows][acc_ld] accumulator rows of whole-row segments (or null);
                       // MODE 2 also reads last iteration's reduced statistics from it
     int acc_ld;
@@ -211,7 +213,8 @@ __global__ __launch_bounds__(BLOCK, HPF_SWEEP_WAVES_PER_EU) void sweep_kernel(co
     // colq[t]): a = accumulator entries, eo = the row's old E entries; writes the row's tables, returns the new
     // E entries (max-normalised) in en
     auto finish_row = [&](const float (&a)[NC], const float (&eo)[NC], float (&en)[NC], int row) {
-        const float base_rte = fa.top_shp / fa.rs[row];
+        const float rs_old = fa.rs[row];
+        const float base_rte = fa.top_shp / rs_old;
         float sh[NC], rt[NC], fc[NC];
         double ev[NC];
         float fsum = 0.f;
@@ -242,7 +245,10 @@ __global__ __launch_bounds__(BLOCK, HPF_SWEEP_WAVES_PER_EU) void sweep_kernel(co
                 if (fa.fac) stream_store(fa.fac + o, fc[t]);
             }
         }
-        if (lane == 0) fa.rs[row] = fa.add_rte + fsum;
+        if (lane == 0) {
+            fa.rs[row] = fa.add_rte + fsum;
+            if (fa.rs_prev) fa.rs_prev[row] = rs_old;
+        }
     };
 
     for (int64_t sg = (int64_t)blockIdx.x * WPB + wid; sg < nseg; sg += nwaves) {
@@ -408,8 +414,8 @@ template <int LD>
 __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
     const float *__restrict__ part, const int64_t *__restrict__ row_seg_ptr, const int64_t *__restrict__ row_list,
     int64_t nrows, const float *e_old, float *e_new, float *__restrict__ shp, float *__restrict__ rte,
-    float *__restrict__ fac, float *rs, const float *__restrict__ cs_other, float *__restrict__ cs_partial,
-    float prior_shp, float top_shp, float add_rte, int k, int part_ld) {
+    float *__restrict__ fac, float *rs, float *__restrict__ rs_prev, const float *__restrict__ cs_other,
+    float *__restrict__ cs_partial, float prior_shp, float top_shp, float add_rte, int k, int part_ld) {
     constexpr int CPL = (LD + WAVE - 1) / WAVE;  // factors per lane
     __shared__ float red[WPB][LD];
     const int lane = threadIdx.x & (WAVE - 1);
@@ -431,7 +437,8 @@ __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
             s0 = row_seg_ptr[r];
             s1 = row_seg_ptr[r + 1];
         }
-        const float base_rte = top_shp / rs[r];
+        const float rs_old = rs[r];
+        const float base_rte = top_shp / rs_old;
         float sh[CPL], rt[CPL], fc[CPL];
         double ev[CPL];
         float fsum = 0.f;
@@ -476,7 +483,10 @@ __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
                 if (fac) fac[o] = fc[q];
             }
         }
-        if (lane == 0) rs[r] = add_rte + fsum;
+        if (lane == 0) {
+            rs[r] = add_rte + fsum;
+            if (rs_prev) rs_prev[r] = rs_old;
+        }
     }
 
     // per-block column sums of fac (fixed order -> reproducible for a fixed grid)
@@ -1069,15 +1079,16 @@ int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx,
 
 int hpf_hip_sweep_finalize_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
                                const float *tab_self, const float *tab_other, float *part, float *e_new, float *shp,
-                               float *rte, float *fac, float *rs, const float *cs_other, float *cs_partial,
-                               float prior_shp, float top_shp, float add_rte, int k, int ld, int grid_blocks,
-                               void *stream) {
+                               float *rte, float *fac, float *rs, float *rs_prev, const float *cs_other,
+                               float *cs_partial, float prior_shp, float top_shp, float add_rte, int k, int ld,
+                               int grid_blocks, void *stream) {
     if (!segs || !idx || !y || !tab_self || !tab_other || !part || !e_new || !rs || !cs_other || !cs_partial ||
         nseg <= 0 || k <= 0 || ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0)
         return HPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     // grid NOT clamped: every block writes its cs_partial row
-    const FinalizeArgs fa = {cs_other, cs_partial, e_new, shp, rte, fac, rs, prior_shp, top_shp, add_rte, k, nullptr, 0};
+    const FinalizeArgs fa = {cs_other, cs_partial, e_new, shp, rte, fac, rs, prior_shp, top_shp, add_rte, k, rs_prev,
+                             nullptr, 0};
 #define CALL(LPR, VPL)                                                                                            \
     hipLaunchKernelGGL((sweep_kernel<LPR, VPL, false, 1>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg, \
                        idx, y, tab_self, tab_other, part, (float *)nullptr, fa);
@@ -1088,16 +1099,16 @@ int hpf_hip_sweep_finalize_f32(const hpf_segment *segs, int64_t nseg, const int3
 
 int hpf_hip_sweep_prefinalize_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
                                   float *tab_self, const float *tab_other, float *part, float *acc_rows, int acc_ld,
-                                  float *shp, float *rte, float *fac, float *rs, const float *cs_other,
-                                  float *cs_partial, float prior_shp, float top_shp, float add_rte, int k, int ld,
-                                  int grid_blocks, void *stream) {
+                                  float *shp, float *rte, float *fac, float *rs, float *rs_prev,
+                                  const float *cs_other, float *cs_partial, float prior_shp, float top_shp,
+                                  float add_rte, int k, int ld, int grid_blocks, void *stream) {
     if (!segs || !idx || !y || !tab_self || !tab_other || !part || !acc_rows || !rs || !cs_other || !cs_partial ||
         nseg <= 0 || k <= 0 || ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0 || acc_ld < k || acc_ld > ld)
         return HPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     // grid NOT clamped: every block writes its cs_partial row
     const FinalizeArgs fa = {cs_other, cs_partial, tab_self, shp, rte, fac, rs, prior_shp, top_shp, add_rte, k,
-                             acc_rows, acc_ld};
+                             rs_prev, acc_rows, acc_ld};
 #define CALL(LPR, VPL)                                                                                          \
     hipLaunchKernelGGL((sweep_kernel<LPR, VPL, false, 2>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg, idx, \
                        y, (const float *)tab_self, tab_other, part, (float *)nullptr, fa);
@@ -1108,8 +1119,8 @@ int hpf_hip_sweep_prefinalize_f32(const hpf_segment *segs, int64_t nseg, const i
 
 int hpf_hip_row_finalize_f32(const float *part, const int64_t *row_seg_ptr, const int64_t *row_list, int64_t nrows,
                              const float *e_old, float *e_new, float *shp, float *rte, float *fac, float *rs,
-                             const float *cs_other, float *cs_partial, float prior_shp, float top_shp, float add_rte,
-                             int k, int ld, int part_ld, int grid_blocks, void *stream) {
+                             float *rs_prev, const float *cs_other, float *cs_partial, float prior_shp, float top_shp,
+                             float add_rte, int k, int ld, int part_ld, int grid_blocks, void *stream) {
     if (!part || !e_old || !e_new || !rs || !cs_other || !cs_partial || nrows < 0 || k <= 0 ||
         ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0 || part_ld < k || part_ld > ld)
         return HPF_EINVAL;
@@ -1117,8 +1128,8 @@ int hpf_hip_row_finalize_f32(const float *part, const int64_t *row_seg_ptr, cons
     // the grid is NOT clamped: cs_partial has exactly grid_blocks rows and all are written
 #define CALL(LD)                                                                                                  \
     hipLaunchKernelGGL((row_finalize_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, part, row_seg_ptr, row_list, \
-                       nrows, e_old, e_new, shp, rte, fac, rs, cs_other, cs_partial, prior_shp, top_shp, add_rte, k,   \
-                       part_ld);
+                       nrows, e_old, e_new, shp, rte, fac, rs, rs_prev, cs_other, cs_partial, prior_shp, top_shp,      \
+                       add_rte, k, part_ld);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
     return last_error();

@@ -45,22 +45,23 @@ class HipOps:
         return int(max(1, min(self.sweep_blocks, (nseg + 3) // 4)))
 
     def sweep_finalize(self, side, tab_self, tab_other, part, e_new, shp, rte, fac, rs, cs_other, cs_partial,
-                       prior_shp, top_shp, add_rte, k, ld):
+                       prior_shp, top_shp, add_rte, k, ld, rs_prev=None):
         """sweep + fused row finalize of single-segment rows; cs_partial must have sweep_grid(nseg) rows."""
         _lib.check(self.L.hpf_hip_sweep_finalize_f32(_ptr(side.segs), side.nseg, _ptr(side.idx), _ptr(side.y),
                                                      _ptr(tab_self), _ptr(tab_other), _ptr(part), _ptr(e_new),
-                                                     _ptr(shp), _ptr(rte), _ptr(fac), _ptr(rs), _ptr(cs_other),
-                                                     _ptr(cs_partial), float(prior_shp), float(top_shp),
-                                                     float(add_rte), k, ld, cs_partial.shape[0], self._stream()),
-                   "hpf_hip_sweep_finalize_f32")
+                                                     _ptr(shp), _ptr(rte), _ptr(fac), _ptr(rs), _ptr(rs_prev),
+                                                     _ptr(cs_other), _ptr(cs_partial), float(prior_shp),
+                                                     float(top_shp), float(add_rte), k, ld, cs_partial.shape[0],
+                                                     self._stream()), "hpf_hip_sweep_finalize_f32")
 
     def sweep_prefinalize(self, side, tab_self, tab_other, part, acc_rows, acc_ld, shp, rte, fac, rs, cs_other,
-                          cs_partial, prior_shp, top_shp, add_rte, k, ld):
+                          cs_partial, prior_shp, top_shp, add_rte, k, ld, rs_prev=None):
         """sharded item pass: whole-row segments first finish their row from acc_rows (last iteration's reduced
         statistics), then sweep it and leave this iteration's local accumulator in acc_rows."""
         _lib.check(self.L.hpf_hip_sweep_prefinalize_f32(
             _ptr(side.segs), side.nseg, _ptr(side.idx), _ptr(side.y), _ptr(tab_self), _ptr(tab_other), _ptr(part),
-            _ptr(acc_rows), int(acc_ld), _ptr(shp), _ptr(rte), _ptr(fac), _ptr(rs), _ptr(cs_other), _ptr(cs_partial),
+            _ptr(acc_rows), int(acc_ld), _ptr(shp), _ptr(rte), _ptr(fac), _ptr(rs), _ptr(rs_prev), _ptr(cs_other),
+            _ptr(cs_partial),
             float(prior_shp), float(top_shp), float(add_rte), k, ld, cs_partial.shape[0], self._stream()),
             "hpf_hip_sweep_prefinalize_f32")
 
@@ -68,12 +69,12 @@ class HipOps:
         return int(max(1, min(self.finalize_blocks, (nrows + 3) // 4)))
 
     def row_finalize(self, part, row_seg_ptr, nrows, e_old, e_new, shp, rte, fac, rs, cs_other, cs_partial,
-                     prior_shp, top_shp, add_rte, k, ld, row_list=None, part_ld=None):
+                     prior_shp, top_shp, add_rte, k, ld, row_list=None, part_ld=None, rs_prev=None):
         grid = cs_partial.shape[0]
         _lib.check(self.L.hpf_hip_row_finalize_f32(_ptr(part), _ptr(row_seg_ptr), _ptr(row_list), nrows, _ptr(e_old),
                                                    _ptr(e_new),
-                                                   _ptr(shp), _ptr(rte), _ptr(fac), _ptr(rs), _ptr(cs_other),
-                                                   _ptr(cs_partial), float(prior_shp), float(top_shp),
+                                                   _ptr(shp), _ptr(rte), _ptr(fac), _ptr(rs), _ptr(rs_prev),
+                                                   _ptr(cs_other), _ptr(cs_partial), float(prior_shp), float(top_shp),
                                                    float(add_rte), k, ld, ld if part_ld is None else part_ld, grid,
                                                    self._stream()),
                    "hpf_hip_row_finalize_f32")

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 2
+#define HPF_HIP_ABI_VERSION 3
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -87,9 +87,9 @@ int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx,
  */
 int hpf_hip_sweep_finalize_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
                                const float *tab_self, const float *tab_other, float *part, float *e_new, float *shp,
-                               float *rte, float *fac, float *rs, const float *cs_other, float *cs_partial,
-                               float prior_shp, float top_shp, float add_rte, int k, int ld, int grid_blocks,
-                               void *stream);
+                               float *rte, float *fac, float *rs, float *rs_prev, const float *cs_other,
+                               float *cs_partial, float prior_shp, float top_shp, float add_rte, int k, int ld,
+                               int grid_blocks, void *stream);
 
 /*
  * The sharded (multi-GPU) item pass with the row finalizer fused in as a PROLOGUE ("deferred item finalize"):
@@ -103,9 +103,9 @@ int hpf_hip_sweep_finalize_f32(const hpf_segment *segs, int64_t nseg, const int3
  */
 int hpf_hip_sweep_prefinalize_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
                                   float *tab_self, const float *tab_other, float *part, float *acc_rows, int acc_ld,
-                                  float *shp, float *rte, float *fac, float *rs, const float *cs_other,
-                                  float *cs_partial, float prior_shp, float top_shp, float add_rte, int k, int ld,
-                                  int grid_blocks, void *stream);
+                                  float *shp, float *rte, float *fac, float *rs, float *rs_prev,
+                                  const float *cs_other, float *cs_partial, float prior_shp, float top_shp,
+                                  float add_rte, int k, int ld, int grid_blocks, void *stream);
 
 /*
  * Closed-form updates for the rows of one side.  Replaces the numpy statements of
@@ -122,11 +122,13 @@ int hpf_hip_sweep_prefinalize_f32(const hpf_segment *segs, int64_t nseg, const i
  *   cs_partial[block] = per-block column sums of fac      -> hpf_hip_colsum_reduce_f32
  *
  * e_new may alias e_old.  rs is updated in place.  shp/rte/fac may be NULL (skip store).
+ * rs_prev (optional) receives the row's OLD rs: rte = top_shp/rs_prev + cs_other is rank-1, so a caller can keep
+ * rs_prev (nrows floats) + cs_other (k floats) instead of the [nrows][ld] rte table and expand it on output.
  * part_ld is the row stride of part[] (ld, or k for the packed all-reduce payload of the multi-GPU path).
  */
 int hpf_hip_row_finalize_f32(const float *part, const int64_t *row_seg_ptr, const int64_t *row_list, int64_t nrows,
                              const float *e_old, float *e_new, float *shp, float *rte, float *fac, float *rs,
-                             const float *cs_other, float *cs_partial, float prior_shp, float top_shp,
+                             float *rs_prev, const float *cs_other, float *cs_partial, float prior_shp, float top_shp,
                              float add_rte, int k, int ld, int part_ld, int grid_blocks, void *stream);
 
 /* cs_out[c] = sum_b cs_partial[b][c], fixed order, double accumulation (Beta.sum(axis=0), PXI:236,255). */

@@ -42,22 +42,23 @@ class CpuOps:
         return int(max(1, min(self.sweep_blocks, (nseg + 3) // 4)))
 
     def sweep_finalize(self, side, tab_self, tab_other, part, e_new, shp, rte, fac, rs, cs_other, cs_partial,
-                       prior_shp, top_shp, add_rte, k, ld):
+                       prior_shp, top_shp, add_rte, k, ld, rs_prev=None):
         """sweep, then finish exactly the rows that consist of one segment (HPF_SEG_WHOLE_ROW)."""
         e_old = tab_self.clone()
         self.sweep(side, tab_self, tab_other, part, k, ld)
         rsp = _np(side.row_seg_ptr)
         single = torch.from_numpy(np.nonzero((rsp[1:] - rsp[:-1]) == 1)[0].astype(np.int64))
         self.row_finalize(part, side.row_seg_ptr, int(single.shape[0]), e_old, e_new, shp, rte, fac, rs, cs_other,
-                          cs_partial, prior_shp, top_shp, add_rte, k, ld, row_list=single)
+                          cs_partial, prior_shp, top_shp, add_rte, k, ld, row_list=single, rs_prev=rs_prev)
 
     def sweep_prefinalize(self, side, tab_self, tab_other, part, acc_rows, acc_ld, shp, rte, fac, rs, cs_other,
-                          cs_partial, prior_shp, top_shp, add_rte, k, ld):
+                          cs_partial, prior_shp, top_shp, add_rte, k, ld, rs_prev=None):
         begin, length, row = _decode_segs(side)
         whole = (_np(side.segs)[:, 1] & 0x40000000) != 0
         rows = torch.from_numpy(row[whole].astype(np.int64))
         self.row_finalize(acc_rows, None, int(rows.shape[0]), tab_self, tab_self, shp, rte, fac, rs, cs_other,
-                          cs_partial, prior_shp, top_shp, add_rte, k, ld, row_list=rows, part_ld=acc_ld)
+                          cs_partial, prior_shp, top_shp, add_rte, k, ld, row_list=rows, part_ld=acc_ld,
+                          rs_prev=rs_prev)
         self.sweep(side, tab_self, tab_other, part, k, ld, acc_rows=acc_rows, acc_ld=acc_ld)
 
     def sweep(self, side, tab_self, tab_other, part, k, ld, scatter_acc=None, acc_rows=None, acc_ld=0):
@@ -88,7 +89,7 @@ class CpuOps:
             _np(scatter_acc)[:] = acc.astype(np.float32)
 
     def row_finalize(self, part, row_seg_ptr, nrows, e_old, e_new, shp, rte, fac, rs, cs_other, cs_partial,
-                     prior_shp, top_shp, add_rte, k, ld, row_list=None, part_ld=None):
+                     prior_shp, top_shp, add_rte, k, ld, row_list=None, part_ld=None, rs_prev=None):
         P = _np(part).astype(np.float64)
         if part_ld is not None and part_ld != ld:   # packed accumulator rows (stride part_ld <= ld)
             Pp = np.zeros((P.shape[0], ld))
@@ -123,6 +124,8 @@ class CpuOps:
             _np(rte)[rows] = np.where(valid[None, :], rt, 0)
         if fac is not None:
             _np(fac)[rows] = fc
+        if rs_prev is not None:
+            _np(rs_prev)[rows] = _np(rs)[rows]
         _np(rs)[rows] = (f(add_rte) + fc.astype(np.float64).sum(axis=1)).astype(np.float32)
         cp[0] = fc.astype(np.float64).sum(axis=0).astype(np.float32)
 

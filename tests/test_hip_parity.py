@@ -437,6 +437,7 @@ def test_invariants_at_c3_full_size(ops):
             m.set_fused(False)
         m.iterate()
         m.iterate()
+        m.materialize_rates()
         torch.cuda.synchronize()
         a = float(hy.a)
         gu = m.Gamma_shp[:, :k].double().sum(dim=1) - k * a
