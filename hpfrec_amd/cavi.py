@@ -127,6 +127,7 @@ class FullBatchCavi:
         self.csT = torch.zeros(ld, **f32)
         self.niter_done = 0
         self._chunk_views = None
+        self.lazy_items = os.environ.get("HPF_LAZY_ITEMS", "1") == "1"
         self.item_pending = False   # sharded path: acc_i holds reduced statistics not yet applied to the item tables
 
     # ------------------------------------------------------------------------------------
@@ -321,14 +322,17 @@ class FullBatchCavi:
         self.item_pending = True
         self.eT, self.eT_next = self.eT_next, self.eT
         self.niter_done += 1
+        if not self.lazy_items:
+            self.flush_items(store)
 
-    def flush_items(self):
+    def flush_items(self, store=True):
         """Sharded path: apply the deferred item finalizer (Lambda_shp, Lambda_rte, Beta, t_rte, eB, colsum Beta)."""
         if not (self.dist and self.item_pending):
             return
         ops, hy, k, ld = self.ops, self.hy, self.k, self.ld
         for c in self._sharded_views():
-            ops.row_finalize(c["acc"], None, c["n"], c["eB"], c["eB"], c["shp"], None, c["fac"], c["rs"], self.csT,
+            ops.row_finalize(c["acc"], None, c["n"], c["eB"], c["eB"], c["shp"] if store else None, None,
+                             c["fac"] if store else None, c["rs"], self.csT,
                              c["csp"], hy.c, hy.t_shp, hy.add_t_rte, k, ld, part_ld=k, rs_prev=c["rsp"])
         ops.colsum_reduce(self.csB_part, self.csB, ld)
         self.item_pending = False

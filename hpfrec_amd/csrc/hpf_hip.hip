@@ -82,10 +82,24 @@ __device__ __forceinline__ float group_sum(float v) {
 
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 
-__device__ __forceinline__ double wave_max_d(double v) {
-#pragma unroll
-    for (int m = 1; m < WAVE; m <<= 1) v = fmax(v, __shfl_xor(v, m));
-    return v;
+// Row scale of the E tables.  Any positive per-row scale cancels in w*e; it only has to keep
+// fp32 in range.  Scale by the power of two that brings the row's largest entry into [1,2): exact (no rounding
+// besides the one fp64->fp32 conversion), and it costs an integer max over the high words (positive doubles order
+// like their bit patterns) instead of an fp64 max tree plus an fp64 divide.  `hi` = this lane's largest high word
+// (0 for lanes without a valid column); returns 2^-floor(log2(row max)) (2^1023 if the whole row underflowed).
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+
+__device__ __forceinline__ double row_pow2_scale(int hi) {
+    hi = max(hi, dpp_i<0xB1>(hi));
+    hi = max(hi, dpp_i<0x4E>(hi));
+    hi = max(hi, dpp_i<0x141>(hi));
+    hi = max(hi, dpp_i<0x140>(hi));
+    hi = max(hi, __shfl_xor(hi, 16));
+    hi = max(hi, __shfl_xor(hi, 32));
+    return __hiloint2double((2046 - (hi >> 20)) << 20, 0);
 }
 
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -105,7 +119,7 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b) {
 // so exp(psi(x))/r = (s/r) * exp(-(1/(2s) + series + recurrence sum)) with no log at all.
 // Same series as the Cephes psi the reference calls through scipy (PXI:5,588).
 // Cost matters (it runs in the sweep's epilogue and, replicated, in the multi-GPU item finalizer):
-// one shared reciprocal for 1/s and the recurrence sum, Newton reciprocals instead of IEEE divides,
+// one shared reciprocal for 1/s, the recurrence sum and 1/rte, Newton steps instead of an IEEE divide,
 // and a short exp (fdlibm-style ln2 split + degree-9 Taylor, rel. error < 1e-11) instead of ocml's.
 // ----------------------------------------------------------------------------------------
 __device__ __forceinline__ double fast_rcp(double x) {
@@ -140,9 +154,12 @@ __device__ __forceinline__ double expect_ratio(float shp, float rte) {
     const double den = p01 * p23 * p45;                                   // prod_{i<6} (x+i)
     const double num = fma(n01, p23 * p45, p01 * fma(n23, p45, n45 * p23));  // den * sum_{i<6} 1/(x+i)
     const double s = x + 6.0;
-    const double R = fast_rcp(den * s);
-    const double r = R * den;          // 1/s
-    const double w = num * (R * s);    // sum_{i<6} 1/(x+i)
+    const double rd = (double)rte;
+    const double ds = den * s;
+    const double R = fast_rcp(ds * rd);  // ONE reciprocal serves 1/s, the recurrence sum and 1/rte
+    const double Rr = R * rd;            // 1/(den*s)
+    const double r = Rr * den;           // 1/s
+    const double w = num * (Rr * s);     // sum_{i<6} 1/(x+i)
     const double z = r * r;
     double poly = 8.33333333333333333333E-2;
     poly = fma(poly, z, -2.10927960927960927961E-2);
@@ -152,7 +169,7 @@ __device__ __forceinline__ double expect_ratio(float shp, float rte) {
     poly = fma(poly, z, -8.33333333333333333333E-3);
     poly = fma(poly, z, 8.33333333333333333333E-2);
     const double v = fma(poly, z, 0.5 * r) + w;
-    return (s * exp_neg(v)) * fast_rcp((double)rte);
+    return (s * exp_neg(v)) * (R * ds);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -218,7 +235,7 @@ __global__ __launch_bounds__(BLOCK, HPF_SWEEP_WAVES_PER_EU) void sweep_kernel(co
         float sh[NC], rt[NC], fc[NC];
         double ev[NC];
         float fsum = 0.f;
-        double emax = 0.0;
+        int ehi = 0;
 #pragma unroll
         for (int t = 0; t < NC; t++) {
             const bool valid = colq[t] < fa.k;
@@ -227,12 +244,11 @@ __global__ __launch_bounds__(BLOCK, HPF_SWEEP_WAVES_PER_EU) void sweep_kernel(co
             fc[t] = valid ? sh[t] / rt[t] : 0.f;
             ev[t] = valid ? expect_ratio(sh[t], rt[t]) : 0.0;
             fsum += fc[t];
-            emax = fmax(emax, ev[t]);
+            ehi = max(ehi, __double2hiint(ev[t]));
             csacc[t] += fc[t];
         }
         fsum = wave_sum(fsum);
-        emax = wave_max_d(emax);
-        const double inv = 1.0 / emax;
+        const double inv = row_pow2_scale(ehi);
 #pragma unroll
         for (int t = 0; t < NC; t++) {
             const bool valid = colq[t] < fa.k;
@@ -410,7 +426,10 @@ __global__ __launch_bounds__(BLOCK, HPF_SWEEP_WAVES_PER_EU) void sweep_kernel(co
     }
 }
 
-template <int LD>
+// DENSE: every row has exactly one accumulator row (row_seg_ptr == row_list == nullptr; the replicated item
+// finalizer of the sharded path, over all-reduced statistics): the loads of the NEXT row are issued before the
+// fp64 work of the current one, and the generic segment loops are compiled out.
+template <int LD, bool DENSE>
 __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
     const float *__restrict__ part, const int64_t *__restrict__ row_seg_ptr, const int64_t *__restrict__ row_list,
     int64_t nrows, const float *e_old, float *e_new, float *__restrict__ shp, float *__restrict__ rte,
@@ -430,47 +449,26 @@ __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
         csacc[q] = 0.f;
     }
 
-    for (int64_t t = (int64_t)blockIdx.x * WPB + wid; t < nrows; t += nwaves) {
-        const int64_t r = row_list ? row_list[t] : t;
-        int64_t s0 = r, s1 = r + 1;
-        if (row_seg_ptr) {
-            s0 = row_seg_ptr[r];
-            s1 = row_seg_ptr[r + 1];
-        }
-        const float rs_old = rs[r];
+    // the closed-form updates of row r from its accumulator entries a[], old E entries eo[] and old scalar rate
+    auto finish = [&](int64_t r, const float (&a)[CPL], const float (&eo)[CPL], float rs_old) {
         const float base_rte = top_shp / rs_old;
         float sh[CPL], rt[CPL], fc[CPL];
         double ev[CPL];
         float fsum = 0.f;
-        double emax = 0.0;
+        int ehi = 0;
 #pragma unroll
         for (int q = 0; q < CPL; q++) {
-            const int c = lane + WAVE * q;
-            const bool valid = c < k;
-            float a = 0.f;
-            if (c < part_ld) {
-                // popular rows have up to ~1e3 segments: 8 independent loads in flight, fixed fold order
-                int64_t sg = s0;
-                for (; sg + 8 <= s1; sg += 8) {
-                    float p[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) p[u] = part[(size_t)(sg + u) * part_ld + c];
-                    a += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-                }
-                for (; sg < s1; sg++) a += part[(size_t)sg * part_ld + c];
-            }
-            const float eo = (c < LD) ? e_old[(size_t)r * LD + c] : 0.f;
-            sh[q] = fmaf(eo, a, prior_shp);
+            const bool valid = lane + WAVE * q < k;
+            sh[q] = fmaf(eo[q], a[q], prior_shp);
             rt[q] = base_rte + csl[q];
             fc[q] = valid ? sh[q] / rt[q] : 0.f;
             ev[q] = valid ? expect_ratio(sh[q], rt[q]) : 0.0;
             fsum += fc[q];
-            emax = fmax(emax, ev[q]);
+            ehi = max(ehi, __double2hiint(ev[q]));
             csacc[q] += fc[q];
         }
         fsum = wave_sum(fsum);
-        emax = wave_max_d(emax);
-        const double inv = 1.0 / emax;
+        const double inv = row_pow2_scale(ehi);
 #pragma unroll
         for (int q = 0; q < CPL; q++) {
             const int c = lane + WAVE * q;
@@ -486,6 +484,60 @@ __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
         if (lane == 0) {
             rs[r] = add_rte + fsum;
             if (rs_prev) rs_prev[r] = rs_old;
+        }
+    };
+
+    if constexpr (DENSE) {
+        auto fetch = [&](int64_t r, float (&a)[CPL], float (&eo)[CPL], float &rs_old) {
+#pragma unroll
+            for (int q = 0; q < CPL; q++) {
+                const int c = lane + WAVE * q;
+                a[q] = (c < part_ld) ? part[(size_t)r * part_ld + c] : 0.f;
+                eo[q] = (c < LD) ? e_old[(size_t)r * LD + c] : 0.f;
+            }
+            rs_old = rs[r];
+        };
+        int64_t t = (int64_t)blockIdx.x * WPB + wid;
+        float a_n[CPL], eo_n[CPL], rs_n = 1.f;
+        if (t < nrows) fetch(t, a_n, eo_n, rs_n);
+        for (; t < nrows; t += nwaves) {
+            float a[CPL], eo[CPL];
+            const float rs_old = rs_n;
+#pragma unroll
+            for (int q = 0; q < CPL; q++) {
+                a[q] = a_n[q];
+                eo[q] = eo_n[q];
+            }
+            if (t + nwaves < nrows) fetch(t + nwaves, a_n, eo_n, rs_n);
+            finish(t, a, eo, rs_old);
+        }
+    } else {
+        for (int64_t t = (int64_t)blockIdx.x * WPB + wid; t < nrows; t += nwaves) {
+            const int64_t r = row_list ? row_list[t] : t;
+            int64_t s0 = r, s1 = r + 1;
+            if (row_seg_ptr) {
+                s0 = row_seg_ptr[r];
+                s1 = row_seg_ptr[r + 1];
+            }
+            float a[CPL], eo[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL; q++) {
+                const int c = lane + WAVE * q;
+                a[q] = 0.f;
+                if (c < part_ld) {
+                    // popular rows have up to ~1e3 segments: 8 independent loads in flight, fixed fold order
+                    int64_t sg = s0;
+                    for (; sg + 8 <= s1; sg += 8) {
+                        float p[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) p[u] = part[(size_t)(sg + u) * part_ld + c];
+                        a[q] += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+                    }
+                    for (; sg < s1; sg++) a[q] += part[(size_t)sg * part_ld + c];
+                }
+                eo[q] = (c < LD) ? e_old[(size_t)r * LD + c] : 0.f;
+            }
+            finish(r, a, eo, rs[r]);
         }
     }
 
@@ -576,15 +628,14 @@ __global__ __launch_bounds__(BLOCK) void expect_kernel(const float *__restrict__
     for (int64_t t = (int64_t)blockIdx.x * WPB + wid; t < nrows; t += nwaves) {
         const int64_t r = row_list ? row_list[t] : t;
         double ev[CPL];
-        double emax = 0.0;
+        int ehi = 0;
 #pragma unroll
         for (int q = 0; q < CPL; q++) {
             const int c = lane + WAVE * q;
             ev[q] = (c < k) ? expect_ratio(shp[(size_t)r * LD + c], rte[(size_t)r * LD + c]) : 0.0;
-            emax = fmax(emax, ev[q]);
+            ehi = max(ehi, __double2hiint(ev[q]));
         }
-        emax = wave_max_d(emax);
-        const double inv = 1.0 / emax;
+        const double inv = row_pow2_scale(ehi);
 #pragma unroll
         for (int q = 0; q < CPL; q++) {
             const int c = lane + WAVE * q;
@@ -1127,9 +1178,14 @@ int hpf_hip_row_finalize_f32(const float *part, const int64_t *row_seg_ptr, cons
     hipStream_t st = (hipStream_t)stream;
     // the grid is NOT clamped: cs_partial has exactly grid_blocks rows and all are written
 #define CALL(LD)                                                                                                  \
-    hipLaunchKernelGGL((row_finalize_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, part, row_seg_ptr, row_list, \
-                       nrows, e_old, e_new, shp, rte, fac, rs, rs_prev, cs_other, cs_partial, prior_shp, top_shp,      \
-                       add_rte, k, part_ld);
+    if (!row_seg_ptr && !row_list)                                                                                     \
+        hipLaunchKernelGGL((row_finalize_kernel<LD, true>), dim3(grid_blocks), dim3(BLOCK), 0, st, part, row_seg_ptr,      \
+                           row_list, nrows, e_old, e_new, shp, rte, fac, rs, rs_prev, cs_other, cs_partial, prior_shp,     \
+                           top_shp, add_rte, k, part_ld);                                                                  \
+    else                                                                                                               \
+        hipLaunchKernelGGL((row_finalize_kernel<LD, false>), dim3(grid_blocks), dim3(BLOCK), 0, st, part, row_seg_ptr,     \
+                           row_list, nrows, e_old, e_new, shp, rte, fac, rs, rs_prev, cs_other, cs_partial, prior_shp,     \
+                           top_shp, add_rte, k, part_ld);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
     return last_error();

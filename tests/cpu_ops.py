@@ -14,6 +14,9 @@ import scipy.special as sp
 import torch
 
 
+_LN2 = float(np.log(2.0))
+
+
 def _np(t):
     return t.numpy()
 
@@ -116,7 +119,7 @@ class CpuOps:
         with np.errstate(divide="ignore", invalid="ignore"):
             E = sp.psi(sh.astype(np.float64)) - np.log(rt.astype(np.float64))
         E = np.where(valid[None, :], E, -np.inf)
-        E = E - E.max(axis=1, keepdims=True)
+        E = E - _LN2 * np.floor(E.max(axis=1, keepdims=True) / _LN2)   # power-of-two row scale: max in [1,2)
         _np(e_new)[rows] = np.exp(E).astype(np.float32)
         if shp is not None:
             _np(shp)[rows] = np.where(valid[None, :], sh, 0)
@@ -145,7 +148,7 @@ class CpuOps:
         with np.errstate(divide="ignore", invalid="ignore"):
             E = sp.psi(_np(shp).astype(np.float64)[rows]) - np.log(_np(rte).astype(np.float64)[rows])
         E = np.where(valid[None, :], E, -np.inf)
-        E = E - E.max(axis=1, keepdims=True)
+        E = E - _LN2 * np.floor(E.max(axis=1, keepdims=True) / _LN2)   # power-of-two row scale: max in [1,2)
         _np(e)[rows] = np.exp(E).astype(np.float32)
 
     def segsum(self, part, row_seg_ptr, nrows, acc, ld, row_list=None, acc_ld=None, acc_by_row=False):

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Compute-side cost of ONE rank of an N-way user-sharded C3 run, measured on a single GPU: shard r of N
+(cavi.shard_users) is run through the sharded code path inside a one-rank process group, so the all-reduces
+are local no-ops and what is timed is this rank's kernels + host launch work.  3.63 ms / that time bounds the
+speed-up an N-GPU run can reach before any communication cost.
+
+    HPF_FORCE_SHARDED=1 python tools/shard_probe.py [N ...]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+os.environ["HPF_FORCE_SHARDED"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from hpfrec_amd import cavi  # noqa: E402
+from hpfrec_amd import cython_loops_float as backend  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29561")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+nU, nI, nnz_t, k, _ = bench.WORKLOADS["c3"]
+iu, ii, y = bench.synth_on_device(nU, nI, nnz_t, dev)
+Theta = np.empty((nU, k), np.float32)
+Beta = np.empty((nI, k), np.float32)
+init = backend.initialize_parameters(Theta, Beta, 123, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
+hy = cavi.Hyper(k, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
+for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
+    for r in sorted({0, world - 1}):
+        lu, li, ly, (u0, u1) = cavi.shard_users(iu, ii, y, nU, r, world)
+        ops = bench.TimedOps(dev)
+        m = cavi.FullBatchCavi(ops, dev, lu, li, ly, u1 - u0, nI, hy)
+        s = slice(u0, u1)
+        m.load_state(init[0][s], init[1][s], init[2], init[3], init[4][s], init[5], Theta[s], Beta)
+        for store in (True, False):
+            for _ in range(3):
+                m.iterate(store)
+            torch.cuda.synchronize()
+            ops.events, ops.recording = {}, store and os.environ.get('PROBE_EVENTS', '1') == '1'
+            t0 = time.perf_counter()
+            steps = 30
+            for _ in range(steps):
+                m.iterate(store)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps * 1e3
+            ops.recording = False
+            if store:
+                ks = {n: round(v["total_ms"] / steps, 3) for n, v in ops.summary().items()}
+                print("world %d rank %d: %d users, %d nnz: %.3f ms/iteration (all tables stored); kernels ms/iter %s"
+                      % (world, r, u1 - u0, m.nnz, dt, ks), flush=True)
+            else:
+                print("world %d rank %d: %.3f ms/iteration without the output-table stores" % (world, r, dt), flush=True)
+        del m, ops, lu, li, ly
+        torch.cuda.empty_cache()
+dist.destroy_process_group()
