@@ -41,6 +41,11 @@ constexpr int WPB = BLOCK / WAVE;
 #ifndef HPF_SWEEP_WAVES_PER_EU
 #define HPF_SWEEP_WAVES_PER_EU 1
 #endif
+#ifndef HPF_FUSED_MAX_WAVES
+// occupancy cap (waves per SIMD) of the sweep with a fused row finalizer: 4 x 8 gathers in flight per SIMD is the
+// measured optimum at C3; a 5th wave (which the register count would allow) costs 1.4 % through L2 thrash
+#define HPF_FUSED_MAX_WAVES 4
+#endif
 
 template <typename T>
 __device__ __forceinline__ void stream_store(T *p, T v) {
@@ -192,7 +197,8 @@ struct FinalizeArgs {  // the row-finalize operands when it is fused into the sw
 //           (sharded path: the previous iteration's all-reduced item statistics are turned into this
 //           iteration's E row by the very wave that then sweeps the row -- "deferred item finalize")
 template <int LPR, int VPL, bool SCATTER, int MODE>
-__global__ __launch_bounds__(BLOCK, HPF_SWEEP_WAVES_PER_EU) void sweep_kernel(const hpf_segment *__restrict__ segs, int64_t nseg,
+__global__ __launch_bounds__(BLOCK)
+__attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUSED_MAX_WAVES : 8))) void sweep_kernel(const hpf_segment *__restrict__ segs, int64_t nseg,
                                                       const int32_t *__restrict__ idx,
                                                       const float *__restrict__ y,
                                                       const float *tab_self,  // may alias fa.e_new
@@ -598,6 +604,14 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float *__rest
     double s = 0.0;
     if (c < ld) {
         int b = chunk;
+        // up to ~2k partial rows, 128 per chain: 32 loads in flight (the launch sits on the iteration's critical path)
+        for (; b + 16 * 31 < nblk; b += 16 * 32) {
+            float p[32];
+#pragma unroll
+            for (int u = 0; u < 32; u++) p[u] = cs_partial[(size_t)(b + 16 * u) * ld + c];
+#pragma unroll
+            for (int u = 0; u < 32; u++) s += (double)p[u];
+        }
         for (; b + 16 * 7 < nblk; b += 16 * 8) {
             float p[8];
 #pragma unroll

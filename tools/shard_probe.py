@@ -47,15 +47,17 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
             steps = 30
             for _ in range(steps):
                 m.iterate(store)
+            t_issue = (time.perf_counter() - t0) / steps * 1e3
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps * 1e3
             ops.recording = False
             if store:
                 ks = {n: round(v["total_ms"] / steps, 3) for n, v in ops.summary().items()}
-                print("world %d rank %d: %d users, %d nnz: %.3f ms/iteration (all tables stored); kernels ms/iter %s"
-                      % (world, r, u1 - u0, m.nnz, dt, ks), flush=True)
+                print("world %d rank %d: %d users, %d nnz: %.3f ms/iteration (all tables stored; host issue time %.3f ms); "
+                      "kernels ms/iter %s" % (world, r, u1 - u0, m.nnz, dt, t_issue, ks), flush=True)
             else:
-                print("world %d rank %d: %.3f ms/iteration without the output-table stores" % (world, r, dt), flush=True)
+                print("world %d rank %d: %.3f ms/iteration without the output-table stores (host issue time %.3f ms)"
+                      % (world, r, dt, t_issue), flush=True)
         del m, ops, lu, li, ly
         torch.cuda.empty_cache()
 dist.destroy_process_group()
