@@ -234,7 +234,7 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
 
     // the closed-form updates of one row with its factors dealt over all 64 lanes (lane (g,j) owns columns
     // colq[t]): a = accumulator entries, eo = the row's old E entries; writes the row's tables, returns the new
-    // E entries (max-normalised) in en
+    // E entries (row scaled by a power of two: max in [1,2)) in en
     auto finish_row = [&](const float (&a)[NC], const float (&eo)[NC], float (&en)[NC], int row) {
         const float rs_old = fa.rs[row];
         const float base_rte = fa.top_shp / rs_old;

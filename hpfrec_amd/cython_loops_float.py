@@ -163,7 +163,7 @@ def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta
 
     `nthreads`, `par_sh` (allow_inconsistent_math) and `alloc_full_phi` are accepted and ignored:
     the device path is always parallel, always reproducible and never materialises phi.
-    `sum_exp_trick` is honoured implicitly: E rows are max-normalised in every mode.
+    `sum_exp_trick` is honoured implicitly: E rows are rescaled per row (power of two) in every mode.
     """
     nU, k = Theta.shape
     nI = Beta.shape[0]

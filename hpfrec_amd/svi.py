@@ -6,7 +6,7 @@ Division of labour in this round:
   * O(batch_nnz * k): phi and both shape accumulations -> the same `sweep_kernel` as the full-batch
     path, run over the batch's rows from both sides (two passes, no atomics, deterministic), plus the
     row-list forms of `expect_kernel` / `segsum_kernel` (update_phi_csr PXI:666-692 always
-    max-subtracts; our E rows are max-normalised in every mode);
+    max-subtracts; our E rows are rescaled per row in every mode);
   * O((nU+nI) * k) per batch: the reference recomputes whole tables with numpy statements every batch
     (PXI:300,318,322 ...); here those statements are three HIP row kernels (svi_shape_rows,
     svi_refresh, svi_rate_rows; include/hpf_hip.h) issued in the reference's order.
