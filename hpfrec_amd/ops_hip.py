@@ -27,8 +27,9 @@ class HipOps:
         self.L = _lib.lib()
         with torch.cuda.device(self.device):
             self.cu_count, self.arch = _lib.device_info()
-        # memory-bound grid: a few blocks per CU, grid-stride over the rest (CDNA guide, guideline 11)
-        self.sweep_blocks = max(1, self.cu_count) * int(os.environ.get("HPF_SWEEP_BPC", "8"))
+        # memory-bound grid: blocks per CU (a multiple of the 4 resident ones), grid-stride over the rest (CDNA guide,
+        # guideline 11); 16 rather than 8 evens out the tail: +0.8 % at C3 (6 -- not a multiple -- costs 6 %)
+        self.sweep_blocks = max(1, self.cu_count) * int(os.environ.get("HPF_SWEEP_BPC", "16"))
         self.finalize_blocks = max(1, self.cu_count) * int(os.environ.get("HPF_FIN_BPC", "4"))
 
     def _stream(self):
