@@ -1,5 +1,6 @@
 """Worker for tests/test_dist_gloo.py: one rank of a world_size-N gloo job running the sharded
-driver on the numpy stand-in ops."""
+driver on the numpy stand-in ops -- or, with device="cuda", on the real HIP kernels (all ranks share cuda:0;
+gloo moves the CUDA tensors through the host: a correctness run of the N>1 path on a one-GPU box)."""
 import os
 import sys
 
@@ -11,7 +12,7 @@ for p in (os.path.dirname(HERE), HERE):
         sys.path.insert(0, p)
 
 
-def run(rank, world, port, out_dir, k, its, case):
+def run(rank, world, port, out_dir, k, its, case, device="cpu"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -19,7 +20,11 @@ def run(rank, world, port, out_dir, k, its, case):
     import cpu_ops
     import datagen
     from hpfrec_amd import cython_loops_float as be
-    be.HipOps = lambda device=None: cpu_ops.CpuOps()   # numpy stand-in for the kernels (host logic test)
+    if device == "cpu":
+        be.HipOps = lambda device=None: cpu_ops.CpuOps()   # numpy stand-in for the kernels (host logic test)
+    else:
+        import torch
+        torch.cuda.set_device(0)
     if case == "c1":
         df, nU, nI = datagen.readme_counts()
     else:

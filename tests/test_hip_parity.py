@@ -545,3 +545,36 @@ def test_tiny_shape_priors(hip_backend):
         assert np.isfinite(arrs[n]).all() and (arrs[n] > 0).all(), n
         assert _maxrel(arrs[n], plain[3][n]) < 2e-5, n
         assert _maxrel(arrs[n], trick[3][n]) < 2e-3, n
+
+
+@pytest.mark.parametrize("world,lazy", [(2, "1"), (3, "1"), (2, "0")])
+def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypatch, world, lazy):
+    """The N>1 path on the REAL kernels: `world` processes, all on cuda:0, gloo backend (it stages the CUDA tensors
+    through the host), user-sharded fit with the pipelined item exchange and the deferred item finalize; every
+    rank must end with the same full model as the single-process HIP fit."""
+    import socket
+    import torch.multiprocessing as mp
+    import dist_worker
+    monkeypatch.setenv("HPF_LAZY_ITEMS", lazy)   # "0": standalone item finalizer right after the exchange
+    k, its = 20, 5
+    df, nU, nI = datagen.mid_counts(nusers=600, nitems=400, nobs=20000)
+    Y, iu, ii = datagen.triplets(df)
+    Theta = np.empty((nU, k), np.float32)
+    Beta = np.empty((nI, k), np.float32)
+    i, temp, llk = hip_backend.fit_hpf(0.3, 0.3, 1.0, 0.3, 0.3, 1.0, Y, iu, ii, Theta, Beta, its, "maxiter", its, 1e-3,
+                                       0, 0, None, 0, np.zeros(1, np.uint64), "", 123, 1, 1, 0, 0,
+                                       np.empty(0, np.float32), np.empty(0, np.uint64), np.empty(0, np.uint64), 0, 1, 0)
+    names = ("Theta", "Beta", "Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "k_rte", "t_rte")
+    single = dict(zip(names, (Theta, Beta) + tuple(temp)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(dist_worker.run, args=(world, port, str(tmp_path), k, its, "mid", "cuda"), nprocs=world, join=True)
+    outs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    for r in range(world):
+        assert int(outs[r]["niter"]) == i
+        assert abs(float(outs[r]["llk"]) / float(llk) - 1) < 1e-6
+        for n in names:
+            assert np.max(np.abs(outs[r][n] - single[n]) / np.abs(single[n])) < 1e-5, (r, n)
+            assert np.array_equal(outs[r][n], outs[0][n]), (r, n)   # replicas agree bit for bit
