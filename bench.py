@@ -263,6 +263,7 @@ def main():
     # the train-llk evaluation of the reference's default check_every=10, timed separately (never part of `value`)
     llk_ms = llk_val = None
     if not args.no_extras:
+        model.iterate(True)             # the lean iterations above left Theta/Beta stale: one storing iteration first
         model.llk_terms(False)          # warm
         fence()
         t1 = time.perf_counter()
@@ -274,6 +275,7 @@ def main():
         llk_val = float(terms[0] - sub)
 
     # sanity: the state must be finite after the run (a NaN run would be a meaningless number)
+    model.flush_items()   # sharded runs: gather the item tables (each rank finalizes a slice of the items)
     finite = bool(torch.isfinite(model.Beta).all().item() and torch.isfinite(model.Theta).all().item())
 
     if rank == 0:
@@ -317,9 +319,13 @@ def main():
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": label, "users": nU, "items": nI, "nnz": nnz, "k": k, "ld": model.ld,
-                       "parallelism": ("users sharded x%d; item statistics all-reduced per iteration in %d pipelined ranges "
-                                       "(RCCL), item finalize deferred into the next item sweep"
-                                       % (world, len(model.item_chunks))) if world > 1 else "1 GPU",
+                       "parallelism": (("users sharded x%d; item statistics reduce-scattered in %d pipelined ranges (RCCL), "
+                                        "each rank finalizes 1/%d of the items, new E rows all-gathered under the next "
+                                        "item sweep" % (world, len(model.item_chunks), world))
+                                       if model.shard_mode == "scatter" else
+                                       ("users sharded x%d; item statistics all-reduced per iteration in %d pipelined "
+                                        "ranges (RCCL), item finalize deferred into the next item sweep"
+                                        % (world, len(model.item_chunks)))) if world > 1 else "1 GPU",
                        "seg_cap": cavi.layout.SEG_CAP, "fused_finalize": model.fused and world == 1,
                        "stores_all_state_tables": store, "state_finite": finite},
             "roofline": roof,

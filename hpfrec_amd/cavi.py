@@ -98,18 +98,31 @@ class FullBatchCavi:
         ld = self.ld
         f32 = dict(dtype=torch.float32, device=dev)
         z = lambda n: torch.zeros((n, ld), **f32)
+        # sharded exchange: "scatter" = reduce-scatter of the item statistics, each rank finalizes 1/N of the items,
+        # all-gather of the new E rows; "allreduce" = all-reduce + replicated (deferred) finalizer
+        self.world = self.dist.get_world_size() if self.dist else 1
+        self.rank = self.dist.get_rank() if self.dist else 0
+        # default by world size: the sharded finalizer pays for its two extra collectives from 4 ranks on
+        # (per-rank cost at C3, tools/shard_probe.py: N=2 2.04 vs 1.94 ms, N=4 1.14 vs 1.19, N=8 0.73 vs 0.84)
+        self.shard_mode = os.environ.get("HPF_SHARD_MODE", "scatter" if self.world >= 4 else "allreduce") \
+            if self.dist else None
+        assert self.shard_mode in (None, "scatter", "allreduce"), self.shard_mode
+        nchunks = int(os.environ.get("HPF_AR_CHUNKS", "2" if self.shard_mode == "scatter" else "3"))
+        self.item_bounds = self._item_bounds(nchunks) if self.dist else None
+        # scatter mode: item tables carry a few pad rows so that every range splits into N equal slices
+        nIa = self.nI_alloc = self.item_bounds[-1][1] if self.shard_mode == "scatter" else self.nI
         self.Gamma_shp, self.Gamma_rte, self.Theta = z(self.nU), z(self.nU), z(self.nU)
-        self.Lambda_shp, self.Lambda_rte, self.Beta = z(self.nI), z(self.nI), z(self.nI)
+        self.Lambda_shp, self.Lambda_rte, self.Beta = z(nIa), z(nIa), z(nIa)
         self.k_rte = torch.zeros(self.nU, **f32)
-        self.t_rte = torch.zeros(self.nI, **f32)
+        self.t_rte = torch.ones(nIa, **f32)
         # Gamma_rte = k_shp/k_rte_old + colsum(Beta_old) and Lambda_rte = t_shp/t_rte_old + colsum(Theta) are rank-1
         # (row scalar + column vector): the iteration keeps only these factors (n + k floats per side) and the
         # [n,k] rate tables are expanded on output (fetch), bit-identically to what the kernels would store
         self.k_rte_prev = torch.zeros(self.nU, **f32)
-        self.t_rte_prev = torch.zeros(self.nI, **f32)
+        self.t_rte_prev = torch.ones(nIa, **f32)
         self.csB_used = torch.zeros(ld, **f32)
         self.rte_factored = False
-        self.eT, self.eT_next, self.eB = z(self.nU), z(self.nU), z(self.nI)
+        self.eT, self.eT_next, self.eB = z(self.nU), z(self.nU), z(nIa)
         self.part_u = torch.empty((max(1, self.users.nseg), ld), **f32)
         self.part_i = torch.empty((max(1, self.items.nseg), ld), **f32)
         # column-sum partials: [fused-sweep blocks | finalize blocks of the rows the sweep cannot finish]
@@ -122,8 +135,9 @@ class FullBatchCavi:
         self.csB = torch.zeros(ld, **f32)
         # multi-GPU exchange buffer: the item accumulators packed to k columns (pads are zero: not sent),
         # cut into nnz-balanced item ranges so that the all-reduce of one range overlaps the sweep of the next
-        self.acc_i = torch.zeros((self.nI, self.k), **f32) if self.dist else None
-        self.item_chunks = self._item_chunks(int(os.environ.get("HPF_AR_CHUNKS", "3"))) if self.dist else None
+        self.acc_i = torch.zeros((nIa, self.k), **f32) if self.dist else None
+        self.item_chunks = self._item_chunks() if self.dist else None
+        self._ag_work, self._csB_work, self._tables_split = [], None, False
         if self.dist:   # one block range of column-sum partials per item range
             rows = self.gsi + sum(ops.finalize_grid(hi - lo) for lo, hi, _, _ in self.item_chunks)
             self.csB_part = torch.zeros((max(rows, self.gsi + self.gi), ld), **f32)
@@ -137,7 +151,7 @@ class FullBatchCavi:
     def _pad(self, host_arr, out):
         t = torch.from_numpy(np.ascontiguousarray(host_arr, dtype=np.float32)).to(self.device)
         out.zero_()
-        out[:, : self.k] = t.view(out.shape[0], self.k)
+        out[: t.shape[0], : self.k] = t.view(-1, self.k)   # item tables may carry pad rows (scatter mode)
 
     def load_state(self, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta):
         """Upload host arrays ([n,k] / [n,1], this rank's user rows) and derive eT, eB and colsum(Beta)."""
@@ -148,8 +162,9 @@ class FullBatchCavi:
         self._pad(Theta, self.Theta)
         self._pad(Beta, self.Beta)
         self.k_rte.copy_(torch.from_numpy(np.ascontiguousarray(k_rte, dtype=np.float32).reshape(-1)))
-        self.t_rte.copy_(torch.from_numpy(np.ascontiguousarray(t_rte, dtype=np.float32).reshape(-1)))
+        self.t_rte[: self.nI].copy_(torch.from_numpy(np.ascontiguousarray(t_rte, dtype=np.float32).reshape(-1)))
         self.item_pending = False
+        self._ag_work, self._csB_work, self._tables_split = [], None, False
         self.rte_factored = False
         self.refresh_expectations()
 
@@ -160,25 +175,42 @@ class FullBatchCavi:
         ops.colsum(self.Beta, self.nI, ld, self.cs_scratch)
         ops.colsum_reduce(self.cs_scratch, self.csB, ld)
 
-    def _item_chunks(self, nchunks):
-        """Contiguous item ranges with ~equal nonzeros:
-        [(row_lo, row_hi, SideView over their segments, their split/empty rows)]."""
+    def _item_bounds(self, nchunks):
+        """Contiguous item ranges [(lo, hi)] with ~equal GLOBAL nonzeros (identical on every rank).  Scatter mode:
+        every range is a multiple of the world size long; the last one runs past nI into pad rows."""
         it = self.items
-        # boundaries must be identical on every rank: balance the GLOBAL item degrees
         deg = (it.indptr[1:] - it.indptr[:-1]).clone()
         self.dist.all_reduce(deg)
         gptr = torch.zeros(self.nI + 1, dtype=torch.int64, device=deg.device)
         torch.cumsum(deg, 0, out=gptr[1:])
-        bounds = [lo for lo, _ in layout.nnz_balanced_ranges(gptr, max(1, nchunks))] + [self.nI]
+        cuts = [lo for lo, _ in layout.nnz_balanced_ranges(gptr, max(1, nchunks))] + [self.nI]
+        if self.shard_mode == "scatter":
+            W, fixed = self.world, [0]
+            for c in cuts[1:-1]:
+                c = fixed[-1] + ((c - fixed[-1] + W - 1) // W) * W
+                if fixed[-1] < c < self.nI:
+                    fixed.append(c)
+            fixed.append(fixed[-1] + ((self.nI - fixed[-1] + W - 1) // W) * W)
+            cuts = fixed
+        return [(lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:]) if hi > lo]
+
+    def _item_chunks(self):
+        """[(row_lo, row_hi, SideView over the range's segments, its split/empty rows)] in issue order."""
+        it = self.items
         rsp = it.row_seg_ptr.cpu()
         out = []
-        for lo, hi in zip(bounds[:-1], bounds[1:]):
-            if hi > lo:
-                multi = it.multi_rows[(it.multi_rows >= lo) & (it.multi_rows < hi)].contiguous()
-                out.append((lo, hi, _SideView(it, int(rsp[lo]), int(rsp[hi])), multi))
-        # issue order: most rows (= largest all-reduce payload) first.  With nnz-balanced ranges every range
-        # costs the same sweep time, so the bulk of the exchange starts after 1/nchunks of the item sweep.
-        out.sort(key=lambda c: c[0] - c[1])
+        for lo, hi in self.item_bounds:
+            top = min(hi, self.nI)
+            multi = it.multi_rows[(it.multi_rows >= lo) & (it.multi_rows < top)].contiguous()
+            out.append((lo, hi, _SideView(it, int(rsp[lo]), int(rsp[top])), multi))
+        if self.shard_mode == "scatter":
+            # fewest rows first: the all-gather of the big range (the tail items) then overlaps the sweep of the
+            # small one in the next iteration, and its reduce-scatter overlaps the user side in this one
+            out.sort(key=lambda c: c[1] - c[0])
+        else:
+            # issue order: most rows (= largest all-reduce payload) first.  With nnz-balanced ranges every range
+            # costs the same sweep time, so the bulk of the exchange starts after 1/nchunks of the item sweep.
+            out.sort(key=lambda c: c[0] - c[1])
         return out
 
     def set_fused(self, flag):
@@ -236,7 +268,7 @@ class FullBatchCavi:
         tables, the scalar rates and the column sums, which are always kept current.  Callers pass store=True
         on the iterations whose state they read (checks, the last one)."""
         if self.dist:
-            return self._iterate_sharded(store)
+            return self._iterate_scatter(store) if self.shard_mode == "scatter" else self._iterate_sharded(store)
         ops, hy, ld = self.ops, self.hy, self.ld
         # user side: phi-weighted gather over CSR rows, then the closed-form user updates
         self._side_update(self.users, self.nU, self.eT, self.eB, self.eT_next, self.part_u, self.Gamma_shp,
@@ -328,8 +360,98 @@ class FullBatchCavi:
         if not self.lazy_items:
             self.flush_items(store)
 
+    # ------------------------------------------------------------------------------------
+    def _scatter_views(self):
+        """Scatter mode, per item range: the range, this rank's slice of it and the exchange buffers."""
+        if self._chunk_views is not None:
+            return self._chunk_views
+        ops, ld, k, W, r = self.ops, self.ld, self.k, self.world, self.rank
+        f32 = dict(dtype=torch.float32, device=self.device)
+        grids = [ops.finalize_grid((hi - lo) // W) for lo, hi, _, _ in self.item_chunks]
+        self.csB_part_sc = torch.zeros((sum(grids), ld), **f32)
+        self.csB_local = torch.zeros(ld, **f32)
+        views, g0 = [], 0
+        for (lo, hi, view, multi), g in zip(self.item_chunks, grids):
+            m = (hi - lo) // W
+            o0 = lo + r * m
+            n_real = max(0, min(m, self.nI - o0))
+            gr = ops.finalize_grid(n_real) if n_real > 0 else 0
+            views.append(dict(
+                lo=lo, hi=hi, m=m, o0=o0, o1=o0 + m, n_real=n_real, view=view, multi=multi, nmulti=int(multi.shape[0]),
+                part=self.part_i[view.seg_lo:], acc=self.acc_i[lo:hi], acc_own=torch.zeros((m, k), **f32),
+                e_own=torch.zeros((m, ld), **f32), csp=self.csB_part_sc[g0: g0 + gr]))
+            g0 += g
+        self._chunk_views = views
+        return views
+
+    def _iterate_scatter(self, store):
+        """Users sharded over ranks, item FINALIZER sharded too.  Per item range (fewest rows first):
+        sweep the local CSC slice into the packed exchange buffer, then an asynchronous REDUCE-SCATTER leaves each
+        rank with the global statistics of its 1/N slice of the range; the user side runs under the exchange; after
+        the k-float all-reduce of colsum(Theta) each rank finalizes only its slices (dense row_finalize: 1/N of the
+        fp64 work and of the table stores), and an asynchronous ALL-GATHER of the new E rows -- straight into the
+        replicated E table -- is waited for only by the next iteration's sweep of that range.  colsum(Beta) is a
+        k-float all-reduce of the per-rank partial sums, off the critical path.  Same bytes on the wire as the
+        all-reduce form.  Lambda_shp / Beta / t_rte are current on the owning rank only; flush_items() gathers them."""
+        ops, hy, k, ld, dist = self.ops, self.hy, self.k, self.ld, self.dist
+        views = self._scatter_views()
+        ag = self._ag_work or [None] * len(views)
+        rs_work = []
+        for c, w in zip(views, ag):
+            if w is not None:
+                w.wait()            # this range's E rows from the previous iteration's finalizers
+            if c["view"].nseg > 0:
+                ops.sweep(c["view"], self.eB, self.eT, c["part"], k, ld, acc_rows=self.acc_i, acc_ld=k)
+            if c["nmulti"] > 0:
+                ops.segsum(self.part_i, self.items.row_seg_ptr, c["nmulti"], self.acc_i, ld, row_list=c["multi"],
+                           acc_ld=k, acc_by_row=True)
+            rs_work.append(dist.reduce_scatter_tensor(c["acc_own"], c["acc"], async_op=True))
+        self._ag_work = []
+        if self._csB_work is not None:
+            self._csB_work.wait()
+            self._csB_work = None
+        self._keep_csB(store)
+        self._side_update(self.users, self.nU, self.eT, self.eB, self.eT_next, self.part_u, self.Gamma_shp,
+                          self.k_rte_prev, self.Theta, self.k_rte, self.csB, self.csT_part, self.gsu, self.gu,
+                          hy.a, hy.k_shp, hy.add_k_rte, store)
+        ops.colsum_reduce(self.csT_part, self.csT, ld)
+        dist.all_reduce(self.csT)
+        for c, w in zip(views, rs_work):
+            w.wait()
+            o0, o1 = c["o0"], c["o1"]
+            if c["n_real"] > 0:
+                ops.row_finalize(c["acc_own"], None, c["n_real"], self.eB[o0:o1], c["e_own"],
+                                 self.Lambda_shp[o0:o1] if store else None, None, self.Beta[o0:o1] if store else None,
+                                 self.t_rte[o0:o1], self.csT, c["csp"], hy.c, hy.t_shp, hy.add_t_rte, k, ld, part_ld=k,
+                                 rs_prev=self.t_rte_prev[o0:o1])
+        ops.colsum_reduce(self.csB_part_sc, self.csB_local, ld)
+        self.csB.copy_(self.csB_local)
+        self._csB_work = dist.all_reduce(self.csB, async_op=True)
+        for c in views:
+            self._ag_work.append(dist.all_gather_into_tensor(self.eB[c["lo"]: c["hi"]], c["e_own"], async_op=True))
+        self._tables_split = True
+        self.eT, self.eT_next = self.eT_next, self.eT
+        self.niter_done += 1
+
+    def _sync_scatter(self):
+        """Scatter mode: wait for the outstanding exchanges and gather the per-owner item tables."""
+        for w in self._ag_work:
+            w.wait()
+        self._ag_work = []
+        if self._csB_work is not None:
+            self._csB_work.wait()
+            self._csB_work = None
+        if self._tables_split:
+            for c in self._scatter_views():
+                for tab in (self.Lambda_shp, self.Beta, self.t_rte, self.t_rte_prev):
+                    self.dist.all_gather_into_tensor(tab[c["lo"]: c["hi"]], tab[c["o0"]: c["o1"]].clone())
+            self._tables_split = False
+
     def flush_items(self, store=True):
-        """Sharded path: apply the deferred item finalizer (Lambda_shp, Lambda_rte, Beta, t_rte, eB, colsum Beta)."""
+        """Sharded path: make the item tables current on this rank.  All-reduce mode: apply the deferred item
+        finalizer (Lambda_shp, Lambda_rte, Beta, t_rte, eB, colsum Beta); scatter mode: wait + gather."""
+        if self.dist and self.shard_mode == "scatter":
+            return self._sync_scatter()
         if not (self.dist and self.item_pending):
             return
         ops, hy, k, ld = self.ops, self.hy, self.k, self.ld
@@ -389,7 +511,8 @@ class FullBatchCavi:
             return
         k = self.k
         self.Gamma_rte[:, :k] = (float(self.hy.k_shp) / self.k_rte_prev)[:, None] + self.csB_used[None, :k]
-        self.Lambda_rte[:, :k] = (float(self.hy.t_shp) / self.t_rte_prev)[:, None] + self.csT[None, :k]
+        nI = self.nI
+        self.Lambda_rte[:nI, :k] = (float(self.hy.t_shp) / self.t_rte_prev[:nI])[:, None] + self.csT[None, :k]
         self.rte_factored = False
 
     def fetch(self, name):
@@ -398,6 +521,8 @@ class FullBatchCavi:
         if name in ("Gamma_rte", "Lambda_rte"):
             self.materialize_rates()
         t = getattr(self, name)
+        if name in ("Lambda_shp", "Lambda_rte", "Beta", "t_rte", "eB"):
+            t = t[: self.nI]          # scatter mode keeps pad rows at the end of the item tables
         if t.dim() == 1:
             return t.cpu().numpy().reshape(-1, 1).copy()
         return t[:, : self.k].contiguous().cpu().numpy()

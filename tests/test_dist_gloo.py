@@ -1,5 +1,4 @@
-"""The N>1 path on CPU: world_size 2 and 3 over gloo (user-sharded driver, one all-reduce of
-[item accumulators || colsum(Theta)] per iteration), numpy stand-in ops.  Every rank must end with
+"""The N>1 path on CPU: world_size 2 and 3 over gloo (user-sharded driver, both exchange modes), numpy stand-in ops.  Every rank must end with
 the full, identical model, equal (to rounding: the sum order changes) to the single-process run."""
 import os
 import socket
@@ -23,8 +22,12 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,case", [(2, "c1"), (3, "mid")])
-def test_sharded_equals_single(tmp_path, cpu_ops_backend, world, case, capsys):
+@pytest.mark.parametrize("world,case,mode", [(2, "c1", "scatter"), (3, "mid", "scatter"), (3, "c1", "scatter"),
+                                             (2, "c1", "allreduce"), (3, "mid", "allreduce")])
+def test_sharded_equals_single(tmp_path, cpu_ops_backend, monkeypatch, world, case, mode):
+    """mode: "scatter" = reduce-scatter / sharded item finalizer / all-gather (default); "allreduce" = all-reduce +
+    replicated deferred finalizer.  (3, c1): 100 items over 3 ranks -> pad rows in the item tables."""
+    monkeypatch.setenv("HPF_SHARD_MODE", mode)
     k, its = 20, 5
     if case == "c1":
         df, nU, nI = datagen.readme_counts()

@@ -369,14 +369,17 @@ def test_fused_and_split_drivers_agree(hip_backend):
         assert _maxrel(a[n], b[n]) < 2e-6, n
 
 
-def test_sharded_path_single_rank_nccl():
-    """The multi-GPU code path (RCCL group, async packed all-reduce, packed-stride finalize) on one GPU."""
+@pytest.mark.parametrize("mode", ["scatter", "allreduce"])
+def test_sharded_path_single_rank_nccl(mode):
+    """The multi-GPU code path on one GPU with a real RCCL group: "scatter" = asynchronous reduce-scatter / dense
+    finalize of the own slice / all-gather into the E table; "allreduce" = async packed all-reduce + deferred finalize."""
     import subprocess
     import sys
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HPF_SHARD_MODE=mode)
     out = subprocess.run([sys.executable, os.path.join(here, "sharded_single_rank.py")], env=env, capture_output=True,
                          text=True, timeout=600)
     assert "SHARDED_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
@@ -547,15 +550,17 @@ def test_tiny_shape_priors(hip_backend):
         assert _maxrel(arrs[n], trick[3][n]) < 2e-3, n
 
 
-@pytest.mark.parametrize("world,lazy", [(2, "1"), (3, "1"), (2, "0")])
-def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypatch, world, lazy):
+@pytest.mark.parametrize("world,mode,lazy", [(2, "scatter", "1"), (3, "scatter", "1"), (2, "allreduce", "1"),
+                                             (3, "allreduce", "1"), (2, "allreduce", "0")])
+def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypatch, world, mode, lazy):
     """The N>1 path on the REAL kernels: `world` processes, all on cuda:0, gloo backend (it stages the CUDA tensors
     through the host), user-sharded fit with the pipelined item exchange and the deferred item finalize; every
     rank must end with the same full model as the single-process HIP fit."""
     import socket
     import torch.multiprocessing as mp
     import dist_worker
-    monkeypatch.setenv("HPF_LAZY_ITEMS", lazy)   # "0": standalone item finalizer right after the exchange
+    monkeypatch.setenv("HPF_SHARD_MODE", mode)   # reduce-scatter + sharded finalizer, or all-reduce + replicated one
+    monkeypatch.setenv("HPF_LAZY_ITEMS", lazy)   # all-reduce mode, "0": standalone item finalizer after the exchange
     k, its = 20, 5
     df, nU, nI = datagen.mid_counts(nusers=600, nitems=400, nobs=20000)
     Y, iu, ii = datagen.triplets(df)
