@@ -369,7 +369,6 @@ class FullBatchCavi:
         f32 = dict(dtype=torch.float32, device=self.device)
         grids = [ops.finalize_grid((hi - lo) // W) for lo, hi, _, _ in self.item_chunks]
         self.csB_part_sc = torch.zeros((sum(grids), ld), **f32)
-        self.csB_local = torch.zeros(ld, **f32)
         views, g0 = [], 0
         for (lo, hi, view, multi), g in zip(self.item_chunks, grids):
             m = (hi - lo) // W
@@ -424,9 +423,8 @@ class FullBatchCavi:
                                  self.Lambda_shp[o0:o1] if store else None, None, self.Beta[o0:o1] if store else None,
                                  self.t_rte[o0:o1], self.csT, c["csp"], hy.c, hy.t_shp, hy.add_t_rte, k, ld, part_ld=k,
                                  rs_prev=self.t_rte_prev[o0:o1])
-        ops.colsum_reduce(self.csB_part_sc, self.csB_local, ld)
-        self.csB.copy_(self.csB_local)
-        self._csB_work = dist.all_reduce(self.csB, async_op=True)
+        ops.colsum_reduce(self.csB_part_sc, self.csB, ld)      # this rank's partial colsum(Beta) ...
+        self._csB_work = dist.all_reduce(self.csB, async_op=True)   # ... summed over ranks, off the critical path
         for c in views:
             self._ag_work.append(dist.all_gather_into_tensor(self.eB[c["lo"]: c["hi"]], c["e_own"], async_op=True))
         self._tables_split = True
