@@ -11,9 +11,10 @@ Statement order of the reference iteration, which this driver preserves:
   (7) k_rte = a'/b' + rowsum(Theta); t_rte = c'/d' + rowsum(Beta)   PXI:258-259
 
 Multi-GPU (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm): users are
-sharded in contiguous nnz-balanced ranges, item tables are replicated, and the exchange per iteration is
-one sum all-reduce of the item accumulators (nI*k floats, overlapped with the user side) plus a k-float
-all-reduce of colsum(Theta).
+sharded in contiguous nnz-balanced ranges, the item E table is replicated, and the exchange per iteration is
+the sum of the item accumulators (nI*k floats, overlapped with the user side) plus k-float all-reduces of the
+column sums -- either as a reduce-scatter / sharded item finalizer / all-gather of the new E rows ("scatter",
+_iterate_scatter) or as an all-reduce with a replicated finalizer ("allreduce", _iterate_sharded).
 
 The kernels are reached through an `ops` object (hpfrec_amd.ops_hip.HipOps).  There is no CPU
 implementation in this package.
