@@ -27,6 +27,19 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
 
+class _Done:
+    def wait(self):
+        pass
+
+
+class _EvWork:
+    def __init__(self, e):
+        self.e = e
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.e)
+
+
 class EmulatedRank:
     """Stands in for torch.distributed inside cavi: reports (rank, world) of the emulated job; every collective is a
     real call on the one-rank RCCL group (so the stream hand-overs are paid) plus the local data movement that
@@ -35,6 +48,7 @@ class EmulatedRank:
     def __init__(self, rank, world):
         self.rank, self.world = rank, world
         self.tiny = torch.zeros(64, device=dev)
+        self.side = torch.cuda.Stream()
 
     def get_world_size(self):
         return self.world
@@ -42,18 +56,33 @@ class EmulatedRank:
     def get_rank(self):
         return self.rank
 
+    def _call(self, t, async_op):
+        mode = os.environ.get("PROBE_NO_COLLECTIVES", "0")
+        if mode == "1":     # pure kernel pipeline: no stream hand-overs at all
+            return _Done()
+        if mode == "sync":  # every collective synchronous (async_op=False)
+            dist.all_reduce(t)
+            return _Done()
+        if mode == "events":   # only what a hand-over needs: record -> side stream waits, records -> we wait
+            e0, e1 = torch.cuda.Event(), torch.cuda.Event()
+            e0.record()
+            self.side.wait_event(e0)
+            e1.record(self.side)
+            return _EvWork(e1) if async_op else torch.cuda.current_stream().wait_event(e1) or _Done()
+        return dist.all_reduce(t, async_op=async_op) or _Done()
+
     def all_reduce(self, t, op=None, async_op=False):
-        return dist.all_reduce(t, async_op=async_op)
+        return self._call(t, async_op)
 
     def reduce_scatter_tensor(self, out, inp, async_op=False):
         m = out.shape[0]
         out.copy_(inp[self.rank * m: (self.rank + 1) * m])
-        return dist.all_reduce(self.tiny, async_op=async_op)
+        return self._call(self.tiny, async_op)
 
     def all_gather_into_tensor(self, out, inp, async_op=False):
         m = inp.shape[0]
         out[self.rank * m: (self.rank + 1) * m].copy_(inp)
-        return dist.all_reduce(self.tiny, async_op=async_op)
+        return self._call(self.tiny, async_op)
 
 
 nU, nI, nnz_t, k, _ = bench.WORKLOADS["c3"]
