@@ -109,7 +109,11 @@ class FullBatchCavi:
         self.shard_mode = os.environ.get("HPF_SHARD_MODE", "scatter" if self.world >= 4 else "allreduce") \
             if self.dist else None
         assert self.shard_mode in (None, "scatter", "allreduce"), self.shard_mode
-        nchunks = int(os.environ.get("HPF_AR_CHUNKS", "2" if self.shard_mode == "scatter" else "3"))
+        # item ranges per iteration.  scatter mode: the all-gather of range j+1 hides under the sweep of range j and
+        # the first range's is exposed, so more ranges expose less -- but each extra range costs 0.06 ms of launches
+        # and stream dependencies per iteration at 8 ranks (tools/shard_probe.py): two ranges (18 % / 82 % of the rows)
+        default_chunks = "2" if self.shard_mode == "scatter" else "3"
+        nchunks = int(os.environ.get("HPF_AR_CHUNKS", default_chunks))
         self.item_bounds = self._item_bounds(nchunks) if self.dist else None
         # scatter mode: item tables carry a few pad rows so that every range splits into N equal slices
         nIa = self.nI_alloc = self.item_bounds[-1][1] if self.shard_mode == "scatter" else self.nI
