@@ -85,7 +85,7 @@ class EmulatedRank:
         return self._call(self.tiny, async_op)
 
 
-nU, nI, nnz_t, k, _ = bench.WORKLOADS["c3"]
+nU, nI, nnz_t, k, _ = bench.WORKLOADS[os.environ.get("PROBE_WORKLOAD", "c3")]
 iu, ii, y = bench.synth_on_device(nU, nI, nnz_t, dev)
 Theta = np.empty((nU, k), np.float32)
 Beta = np.empty((nI, k), np.float32)
