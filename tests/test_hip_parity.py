@@ -583,3 +583,28 @@ def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypat
         for n in names:
             assert np.max(np.abs(outs[r][n] - single[n]) / np.abs(single[n])) < 1e-5, (r, n)
             assert np.array_equal(outs[r][n], outs[0][n]), (r, n)   # replicas agree bit for bit
+
+
+def test_rank1_rate_tables_expand_bit_identically(ops):
+    """The iteration keeps the rate tables factored (old scalar rate per row + column sums); what fetch() expands
+    with torch must be bit-identical to what the kernel stores when it is given an rte pointer (PXI:236, PXI:255)."""
+    k, ld, nrows = 50, 64, 5000
+    rs = np.random.RandomState(5)
+    part = torch.from_numpy(rs.gamma(1, 3, size=(nrows, ld)).astype(np.float32))
+    part[:, k:] = 0
+    e_old = _rand_tables(rs, nrows, k, ld).cuda()
+    rs_old = torch.from_numpy(rs.uniform(0.05, 300, size=nrows).astype(np.float32)).cuda()
+    cs = torch.zeros(ld)
+    cs[:k] = torch.from_numpy(rs.uniform(0.5, 5e4, size=k).astype(np.float32))
+    cs = cs.cuda()
+    top = float(np.float32(0.3 + 50 * 0.3))
+    e_new, shp, rte, fac = (torch.zeros((nrows, ld), device="cuda") for _ in range(4))
+    rs_cur, rs_prev = rs_old.clone(), torch.zeros(nrows, device="cuda")
+    csp = torch.zeros((ops.finalize_grid(nrows), ld), device="cuda")
+    ops.row_finalize(part.cuda(), None, nrows, e_old, e_new, shp, rte, fac, rs_cur, cs, csp, 0.3, top, 0.3, k, ld,
+                     rs_prev=rs_prev)
+    torch.cuda.synchronize()
+    assert torch.equal(rs_prev, rs_old)
+    expanded = (top / rs_prev)[:, None] + cs[None, :k]
+    assert torch.equal(expanded, rte[:, :k])
+    assert torch.all(rte[:, k:] == 0)
