@@ -337,7 +337,7 @@ class FullBatchCavi:
                              self._csp_multi,
                              hy.c, hy.t_shp, hy.add_t_rte, k, ld, row_list=it.multi_rows, part_ld=k,
                              rs_prev=self.t_rte_prev)
-        pending = []
+        xs = self._xstream()
         for c in views:
             # whole-row segments leave their accumulator straight in the packed buffer; only split rows
             # (and rows without local nonzeros: zeros) go through part[] + segsum
@@ -351,7 +351,8 @@ class FullBatchCavi:
             if c["nmulti"] > 0:
                 ops.segsum(self.part_i, self.items.row_seg_ptr, c["nmulti"], self.acc_i, ld, row_list=c["multi"],
                            acc_ld=k, acc_by_row=True)
-            pending.append(dist.all_reduce(c["acc"], async_op=True))
+            with self._exchange(xs):       # stream-ordered on the exchange stream (see _iterate_scatter)
+                dist.all_reduce(c["acc"])
         if lazy:
             ops.colsum_reduce(self.csB_part_lazy, self.csB, ld)   # colsum(Beta) of the rows just finished
         self._keep_csB(store)
@@ -360,8 +361,7 @@ class FullBatchCavi:
                           hy.a, hy.k_shp, hy.add_k_rte, store)
         ops.colsum_reduce(self.csT_part, self.csT, ld)
         dist.all_reduce(self.csT)
-        for w in pending:
-            w.wait()
+        self._wait(self._mark(xs))
         self.item_pending = True
         self.eT, self.eT_next = self.eT_next, self.eT
         self.niter_done += 1
