@@ -693,19 +693,21 @@ template <int LD>
 __global__ __launch_bounds__(BLOCK) void svi_shape_rows_kernel(const int64_t *__restrict__ row_list, int64_t nrows,
                                                                const float *__restrict__ acc,
                                                                const float *__restrict__ e, float *__restrict__ shp,
-                                                               float prior, float w_new, float w_old, int k) {
+                                                               float prior, float w_new, float w_old, int k,
+                                                               int acc_by_row) {
     constexpr int CPL = (LD + WAVE - 1) / WAVE;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * WPB;
     for (int64_t t = (int64_t)blockIdx.x * WPB + wid; t < nrows; t += nwaves) {
         const int64_t r = row_list[t];
+        const int64_t ar = acc_by_row ? r : t;   // accumulator table indexed by row id, or aligned with the list
 #pragma unroll
         for (int q = 0; q < CPL; q++) {
             const int c = lane + WAVE * q;
             if (c < k) {
                 const size_t o = (size_t)r * LD + c;
-                const float a = acc ? acc[(size_t)t * LD + c] : 0.f;
+                const float a = acc ? acc[(size_t)ar * LD + c] : 0.f;
                 const float fresh = fmaf(e[o], a, prior);
                 shp[o] = (w_old == 0.f) ? w_new * fresh : w_new * fresh + w_old * shp[o];
             }
@@ -735,34 +737,53 @@ __global__ __launch_bounds__(BLOCK) void svi_refresh_kernel(int64_t nrows, const
         csl[q] = (refresh_rte && c < k) ? cs_other[c] : 0.f;
         csacc[q] = 0.f;
     }
-    for (int64_t r = (int64_t)blockIdx.x * WPB + wid; r < nrows; r += nwaves) {
-        const float rs_old = rs[r];
-        const float base = top / rs_old;
-        float fsum = 0.f;
+    // a streaming kernel with one short row per wavefront: R rows are loaded before any is processed, so a wave
+    // keeps R*LD*4 bytes of reads in flight (the row loop is otherwise latency-bound at 16 waves per CU)
+    constexpr int R = (CPL <= 4) ? 4 : (CPL <= 8 ? 2 : 1);
+    for (int64_t r0 = (int64_t)blockIdx.x * WPB + wid; r0 < nrows; r0 += R * nwaves) {
+        float sv[R][CPL], rv[R][CPL], rs_old[R];
 #pragma unroll
-        for (int q = 0; q < CPL; q++) {
-            const int c = lane + WAVE * q;
-            if (c < LD) {
+        for (int i = 0; i < R; i++) {
+            const int64_t r = r0 + i * nwaves;
+            const bool live = r < nrows;
+            rs_old[i] = live ? rs[r] : 1.f;
+#pragma unroll
+            for (int q = 0; q < CPL; q++) {
+                const int c = lane + WAVE * q;
                 const size_t o = (size_t)r * LD + c;
-                float f = 0.f;
-                if (c < k) {
-                    float rt;
-                    if (refresh_rte) {
-                        rt = base + csl[q];
-                        rte[o] = rt;
-                    } else {
-                        rt = rte[o];
-                    }
-                    f = shp[o] / rt;
-                }
-                fac[o] = f;
-                fsum += f;
-                csacc[q] += f;
+                sv[i][q] = (live && c < k) ? shp[o] : 0.f;
+                rv[i][q] = (live && c < k && !refresh_rte) ? rte[o] : 1.f;
             }
         }
-        if (blend_rs) {
-            fsum = wave_sum(fsum);
-            if (lane == 0) rs[r] = step * (add + fsum) + step_prev * rs_old;
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int64_t r = r0 + i * nwaves;
+            if (r >= nrows) break;
+            const float base = top / rs_old[i];
+            float fsum = 0.f;
+#pragma unroll
+            for (int q = 0; q < CPL; q++) {
+                const int c = lane + WAVE * q;
+                if (c < LD) {
+                    const size_t o = (size_t)r * LD + c;
+                    float f = 0.f;
+                    if (c < k) {
+                        float rt = rv[i][q];
+                        if (refresh_rte) {
+                            rt = base + csl[q];
+                            rte[o] = rt;
+                        }
+                        f = sv[i][q] / rt;
+                    }
+                    fac[o] = f;
+                    fsum += f;
+                    csacc[q] += f;
+                }
+            }
+            if (blend_rs) {
+                fsum = wave_sum(fsum);
+                if (lane == 0) rs[r] = step * (add + fsum) + step_prev * rs_old[i];
+            }
         }
     }
 #pragma unroll
@@ -1298,14 +1319,14 @@ int hpf_hip_pair_dot_f32(const float *T, const float *B, const int32_t *ix_u, co
 }
 
 int hpf_hip_svi_shape_rows_f32(const int64_t *row_list, int64_t nrows, const float *acc, const float *e, float *shp,
-                               float prior, float w_new, float w_old, int k, int ld, void *stream) {
+                               float prior, float w_new, float w_old, int k, int ld, int acc_by_row, void *stream) {
     if (nrows == 0) return 0;
     if (!row_list || !e || !shp || nrows < 0 || k <= 0 || ld != hpf_hip_ld_for_k(k)) return HPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int grid = clamp_grid((nrows + WPB - 1) / WPB, 2048);
 #define CALL(LD)                                                                                                   \
     hipLaunchKernelGGL((svi_shape_rows_kernel<LD>), dim3(grid), dim3(BLOCK), 0, st, row_list, nrows, acc, e, shp,  \
-                       prior, w_new, w_old, k);
+                       prior, w_new, w_old, k, acc_by_row);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
     return last_error();

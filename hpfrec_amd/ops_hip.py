@@ -31,6 +31,7 @@ class HipOps:
         # guideline 11); 16 rather than 8 evens out the tail: +0.8 % at C3 (6 -- not a multiple -- costs 6 %)
         self.sweep_blocks = max(1, self.cu_count) * int(os.environ.get("HPF_SWEEP_BPC", "16"))
         self.finalize_blocks = max(1, self.cu_count) * int(os.environ.get("HPF_FIN_BPC", "4"))
+        self.refresh_blocks = max(1, self.cu_count) * int(os.environ.get("HPF_REFRESH_BPC", "8"))
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -125,10 +126,14 @@ class HipOps:
                                                  self._stream()), "hpf_hip_score_rows_f32")
 
     # -- stochastic-VI row kernels ------------------------------------------------------------
-    def svi_shape_rows(self, row_list, acc, e, shp, prior, w_new, w_old, k, ld):
+    def svi_shape_rows(self, row_list, acc, e, shp, prior, w_new, w_old, k, ld, acc_by_row=False):
         _lib.check(self.L.hpf_hip_svi_shape_rows_f32(_ptr(row_list), int(row_list.shape[0]), _ptr(acc), _ptr(e),
                                                      _ptr(shp), float(prior), float(w_new), float(w_old), k, ld,
-                                                     self._stream()), "hpf_hip_svi_shape_rows_f32")
+                                                     int(bool(acc_by_row)), self._stream()), "hpf_hip_svi_shape_rows_f32")
+
+    def refresh_grid(self, nrows):
+        """Grid (= column-sum partial rows) of the whole-table SVI refresh: a pure streaming kernel."""
+        return int(max(1, min(self.refresh_blocks, (nrows + 15) // 16)))
 
     def svi_refresh(self, nrows, shp, rte, fac, rs, cs_other, cs_partial, top, add, step, step_prev, refresh_rte,
                     blend_rs, k, ld):

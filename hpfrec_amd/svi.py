@@ -24,23 +24,31 @@ _NAMES = ("Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "Theta", "Beta")
 class BatchSide:
     """Segments over the rows touched by a batch (same fields the sweep launcher reads from SparseSide)."""
 
-    def __init__(self, rows, cols, y, seg_cap=layout.SEG_CAP):
-        """rows/cols: int64 device tensors of a COO batch; grouped by `rows` (stable)."""
-        order = torch.argsort(rows, stable=True)
-        r_s = rows[order]
+    def __init__(self, rows, cols, y, seg_cap=layout.SEG_CAP, grouped=False):
+        """rows/cols: int64 device tensors of a COO batch.  grouped=True: the triplets already come grouped by
+        ascending `rows` (what gather_rows returns for a sorted row list) -- no sort needed; otherwise they are
+        grouped here with a stable sort."""
+        if grouped:
+            r_s, c_s, y_s = rows, cols, y
+        else:
+            order = torch.argsort(rows, stable=True)
+            r_s, c_s, y_s = rows[order], cols[order], y[order]
         self.rows, counts = torch.unique_consecutive(r_s, return_counts=True)   # rows present, ascending
-        self.idx = cols[order].to(torch.int32).contiguous()
-        self.y = y[order].to(torch.float32).contiguous()
+        self.idx = c_s.to(torch.int32).contiguous()
+        self.y = y_s.to(torch.float32).contiguous()
         indptr = torch.zeros(self.rows.shape[0] + 1, dtype=torch.int64, device=rows.device)
         torch.cumsum(counts, 0, out=indptr[1:])
         segs, self.row_seg_ptr = layout.build_segments(indptr, seg_cap)
         if segs.shape[0] > 0:
             local = segs[:, 1] >> 32
-            meta = (segs[:, 1] & 0xFFFFFFFF) & ~layout.SEG_WHOLE_ROW   # part[] is always wanted here
+            meta = segs[:, 1] & 0xFFFFFFFF      # length | whole-row flag
             segs = torch.stack([segs[:, 0], meta | (self.rows[local] << 32)], dim=1).contiguous()
         self.segs = segs
         self.nseg = int(segs.shape[0])
         self.nrows = int(self.rows.shape[0])
+        nseg_row = self.row_seg_ptr[1:] - self.row_seg_ptr[:-1]
+        self.multi_local = torch.nonzero(nseg_row > 1).reshape(-1)              # rows cut into several segments
+        self.nmulti = int(self.multi_local.shape[0])
 
 
 class DeviceModel:
@@ -57,7 +65,10 @@ class DeviceModel:
             setattr(self, n, torch.zeros((self.nI, self.ld), **f32))
         self.k_rte = torch.zeros(self.nU, **f32)
         self.t_rte = torch.zeros(self.nI, **f32)
-        self._cs_part = torch.zeros((ops.finalize_grid(max(self.nU, self.nI)), self.ld), **f32)
+        self._cs_part = torch.zeros((ops.refresh_grid(max(self.nU, self.nI)), self.ld), **f32)
+        # full-height accumulator tables: the batch sweeps write a row's phi-sums straight to acc[row]
+        self.acc_u = torch.zeros((self.nU, self.ld), **f32)
+        self.acc_i = torch.zeros((self.nI, self.ld), **f32)
 
     def v(self, name):
         return getattr(self, name)[:, : self.k]
@@ -80,54 +91,46 @@ class DeviceModel:
     def colsum(self, name):
         """tab.sum(axis=0) -> [ld] (HIP colsum kernels; PXI:300,320,352,372)."""
         tab = getattr(self, name)
-        self.ops.colsum(tab, tab.shape[0], self.ld, self._cs_part)
+        part = torch.zeros((self.ops.finalize_grid(tab.shape[0]), self.ld), dtype=torch.float32, device=self.ops.device)
+        self.ops.colsum(tab, tab.shape[0], self.ld, part)
         out = torch.zeros(self.ld, dtype=torch.float32, device=self.ops.device)
-        self.ops.colsum_reduce(self._cs_part, out, self.ld)
+        self.ops.colsum_reduce(part, out, self.ld)
         return out
 
     # ------------------------------------------------------------------------------------------
-    def batch_phi_sums(self, bu, bi, by):
+    def batch_phi_sums(self, su, si):
         """Per touched row, sum_n w_n * (other side's E row) over the batch's nonzeros (update_phi[_csr] +
-        update_G_n_L_sh[_csr] restricted to the batch; sum phi = E_row (*) this), from the CURRENT
-        shapes/rates.  Returns (users_present, acc_users [nu,ld], items_present, acc_items [ni,ld])."""
+        update_G_n_L_sh[_csr] restricted to the batch; sum phi = E_row (*) this), from the CURRENT shapes/rates,
+        left in acc_u[user] / acc_i[item] for the rows present in the batch (su / si: its two BatchSides)."""
         ops, k, ld = self.ops, self.k, self.ld
-        su = BatchSide(bu, bi, by)
-        si = BatchSide(bi, bu, by)
         ops.expect(self.Gamma_shp, self.Gamma_rte, self.eT, su.nrows, k, ld, row_list=su.rows)
         ops.expect(self.Lambda_shp, self.Lambda_rte, self.eB, si.nrows, k, ld, row_list=si.rows)
-        out = []
-        for side, e_self, e_other in ((su, self.eT, self.eB), (si, self.eB, self.eT)):
-            part = torch.empty((max(1, side.nseg), ld), dtype=torch.float32, device=ops.device)
-            ops.sweep(side, e_self, e_other, part, k, ld)
-            acc = torch.zeros((max(1, side.nrows), ld), dtype=torch.float32, device=ops.device)
-            ops.segsum(part, side.row_seg_ptr, side.nrows, acc, ld)
-            out += [side.rows, acc]
-        return tuple(out)
+        for side, e_self, e_other, acc in ((su, self.eT, self.eB, self.acc_u), (si, self.eB, self.eT, self.acc_i)):
+            if side.nseg == 0:
+                continue
+            part = torch.empty((side.nseg, ld), dtype=torch.float32, device=ops.device)
+            # a row that is one segment long writes its sums straight to acc[row]; split rows go through part[]
+            ops.sweep(side, e_self, e_other, part, k, ld, acc_rows=acc, acc_ld=ld)
+            if side.nmulti > 0:
+                tmp = torch.zeros((side.nmulti, ld), dtype=torch.float32, device=ops.device)
+                ops.segsum(part, side.row_seg_ptr, side.nmulti, tmp, ld, row_list=side.multi_local)
+                acc.index_copy_(0, side.rows[side.multi_local], tmp)
 
 
-def _aligned(rows_tb, present, acc, ld):
-    """(sorted row list, accumulator rows aligned with it): rows of the batch list without any nonzero get a
-    zero accumulator.  `present` (ascending) must be a subset of rows_tb."""
-    tb = torch.sort(rows_tb).values.contiguous()
-    out = torch.zeros((max(1, tb.shape[0]), ld), dtype=torch.float32, device=acc.device)
-    if present.shape[0] > 0:
-        pos = torch.searchsorted(tb, present)
-        if bool((pos >= tb.shape[0]).any()) or not torch.equal(tb[pos.clamp(max=tb.shape[0] - 1)], present):
-            raise ValueError("the batch contains users/items that are not in users_in_batch/items_in_batch")
-        out[pos] = acc[: present.shape[0]]
-    return tb, out
-
-
-def _svi_step(m, hy, bu, bi, by, users_tb, items_tb, step, mult, user_batch, all_scalar_rows):
+def _svi_step(m, hy, su, si, users_tb, items_tb, step, mult, user_batch, all_scalar_rows):
     """One stochastic update in the reference's statement order (user batch: PXI:292-325 / 438-473;
-    item batch: PXI:344-377).  `hy` carries a, c, k_shp, t_shp, add_k_rte, add_t_rte as python floats."""
+    item batch: PXI:344-377).  su / si: the batch grouped by user / by item; users_tb / items_tb: the row lists
+    the updates run over (supersets of the rows present in the batch: listed rows without a nonzero get a zero
+    phi-sum).  `hy` carries a, c, k_shp, t_shp, add_k_rte, add_t_rte as python floats."""
     ops, k, ld = m.ops, m.k, m.ld
     step_prev = float(np.float32(1) - np.float32(step))
     step = float(np.float32(step))
     w_other = float(np.float32(step * float(np.float32(mult))))   # step*multiplier as one float32 scalar (PXI:316)
-    up, acc_u, ip, acc_i = m.batch_phi_sums(bu, bi, by)           # phi from the OLD parameters
-    utb, acc_utb = _aligned(users_tb, up, acc_u, ld)
-    itb, acc_itb = _aligned(items_tb, ip, acc_i, ld)
+    for tb, side, acc in ((users_tb, su, m.acc_u), (items_tb, si, m.acc_i)):
+        if tb.shape[0] != side.nrows:        # listed rows without any nonzero in the batch
+            acc.index_fill_(0, tb, 0.0)
+    m.batch_phi_sums(su, si)                                      # phi from the OLD parameters
+    utb, acc_utb, itb, acc_itb = users_tb, m.acc_u, items_tb, m.acc_i
 
     U = dict(n=m.nU, shp=m.Gamma_shp, rte=m.Gamma_rte, fac=m.Theta, rs=m.k_rte, e=m.eT, rows=utb, acc=acc_utb,
              prior=hy["a"], top=hy["k_shp"], add=hy["add_k_rte"], cs="csT")
@@ -136,8 +139,8 @@ def _svi_step(m, hy, bu, bi, by, users_tb, items_tb, step, mult, user_batch, all
     B, O = (U, I) if user_batch else (I, U)     # batch side, other side
 
     # shapes: batch side = prior + phi ; other side blended with its previous value
-    ops.svi_shape_rows(B["rows"], B["acc"], B["e"], B["shp"], B["prior"], 1.0, 0.0, k, ld)
-    ops.svi_shape_rows(O["rows"], O["acc"], O["e"], O["shp"], O["prior"], w_other, step_prev, k, ld)
+    ops.svi_shape_rows(B["rows"], B["acc"], B["e"], B["shp"], B["prior"], 1.0, 0.0, k, ld, acc_by_row=True)
+    ops.svi_shape_rows(O["rows"], O["acc"], O["e"], O["shp"], O["prior"], w_other, step_prev, k, ld, acc_by_row=True)
     # batch side: rate for ALL its rows from the other side's current column sums, then its means
     cs_other = getattr(m, O["cs"])
     ops.svi_refresh(B["n"], B["shp"], B["rte"], B["fac"], B["rs"], cs_other, m._cs_part, B["top"], B["add"], step,
@@ -174,10 +177,13 @@ def partial_fit_step(ops, Y_batch, ix_u_batch, ix_i_batch, Theta, Beta, Gamma_sh
     hy = {"a": float(np.float32(a)), "c": float(np.float32(c)), "k_shp": float(np.float32(k_shp)),
           "t_shp": float(np.float32(t_shp)), "add_k_rte": float(np.float32(add_k_rte)),
           "add_t_rte": float(np.float32(add_t_rte))}
-    _svi_step(m, hy, _dev_ids(ix_u_batch, dev), _dev_ids(ix_i_batch, dev),
-              torch.from_numpy(np.ascontiguousarray(Y_batch, dtype=np.float32)).to(dev),
-              _dev_ids(users_this_batch, dev), _dev_ids(items_this_batch, dev), step_size_batch, multiplier_batch,
-              user_batch, all_scalar_rows=True)
+    bu, bi = _dev_ids(ix_u_batch, dev), _dev_ids(ix_i_batch, dev)
+    by = torch.from_numpy(np.ascontiguousarray(Y_batch, dtype=np.float32)).to(dev)
+    su, si = BatchSide(bu, bi, by), BatchSide(bi, bu, by)
+    users_tb, items_tb = _dev_ids(users_this_batch, dev), _dev_ids(items_this_batch, dev)
+    if not (bool(torch.isin(su.rows, users_tb).all()) and bool(torch.isin(si.rows, items_tb).all())):
+        raise ValueError("the batch contains users/items that are not in users_in_batch/items_in_batch")
+    _svi_step(m, hy, su, si, users_tb, items_tb, step_size_batch, multiplier_batch, user_batch, all_scalar_rows=True)
     m.store(Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta)
 
 
@@ -256,19 +262,19 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
             for bt in range(nbatches_u):
                 ids = users_numeration[bt * users_per_batch: min(nU, (bt + 1) * users_per_batch)]
                 mult = float(nU) / float(ids.shape[0])
-                rows = _dev_ids(ids, dev)
+                rows = torch.sort(_dev_ids(ids, dev)).values       # ascending: the gathered triplets come grouped
                 bu, bi, by = gather_rows(users, rows)
-                items_tb = torch.unique(bi)
-                _svi_step(m, hyd, bu, bi, by, rows, items_tb, step, mult, True, all_scalar_rows=False)
+                su, si = BatchSide(bu, bi, by, grouped=True), BatchSide(bi, bu, by)
+                _svi_step(m, hyd, su, si, rows, si.rows, step, mult, True, all_scalar_rows=False)
         else:
             rng.shuffle(items_numeration)
             for bt in range(nbatches_i):
                 ids = items_numeration[bt * items_per_batch: min(nI, (bt + 1) * items_per_batch)]
                 mult = float(nI) / float(ids.shape[0])
-                rows = _dev_ids(ids, dev)
+                rows = torch.sort(_dev_ids(ids, dev)).values
                 bi, bu, by = gather_rows(items, rows)
-                users_tb = torch.unique(bu)
-                _svi_step(m, hyd, bu, bi, by, users_tb, rows, step, mult, False, all_scalar_rows=False)
+                su, si = BatchSide(bu, bi, by), BatchSide(bi, bu, by, grouped=True)
+                _svi_step(m, hyd, su, si, su.rows, rows, step, mult, False, all_scalar_rows=False)
 
         if check_every > 0 and ((i + 1) % check_every) == 0:
             if stop_crit == "diff-norm":

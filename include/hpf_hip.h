@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 3
+#define HPF_HIP_ABI_VERSION 4
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -178,11 +178,13 @@ int hpf_hip_pair_dot_f32(const float *T, const float *B, const int32_t *ix_u, co
  * refresh:     every row of a side: [rte = top/rs + cs_other] ; fac = shp/rte ;
  *              [rs = step*(add + sum_k fac) + step_prev*rs] ; cs_partial = per-block column sums of fac
  *              (PXI:300,318,322 / 352,370,374; the rs blend over all rows is partial_fit's PXI:472-473)
+ *              acc row of list entry t: acc[t] (acc_by_row = 0) or acc[row_list[t]] (acc_by_row = 1: a full-height
+ *              accumulator table the batch sweeps wrote straight into)
  * rate rows:   mode 0: rte[r] = step*(top/rs[r] + cs_other) + step_prev*rte[r]        (PXI:320,372)
  *              mode 1: rs[r]  = step*(add + sum_k fac[r])   + step_prev*rs[r]         (PXI:324-325,376-377)
  */
 int hpf_hip_svi_shape_rows_f32(const int64_t *row_list, int64_t nrows, const float *acc, const float *e, float *shp,
-                               float prior, float w_new, float w_old, int k, int ld, void *stream);
+                               float prior, float w_new, float w_old, int k, int ld, int acc_by_row, void *stream);
 int hpf_hip_svi_refresh_f32(int64_t nrows, const float *shp, float *rte, float *fac, float *rs, const float *cs_other,
                             float *cs_partial, float top, float add, float step, float step_prev, int refresh_rte,
                             int blend_rs, int k, int ld, int grid_blocks, void *stream);

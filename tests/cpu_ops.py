@@ -188,12 +188,18 @@ class CpuOps:
         _np(out)[:] = (_np(tab).astype(np.float64) @ _np(vec).astype(np.float64)).astype(np.float32)
 
     # -- stochastic-VI row kernels (float32 arithmetic, statement for statement) ------------------
-    def svi_shape_rows(self, row_list, acc, e, shp, prior, w_new, w_old, k, ld):
+    def refresh_grid(self, nrows):
+        return self.finalize_grid(nrows)
+
+    def svi_shape_rows(self, row_list, acc, e, shp, prior, w_new, w_old, k, ld, acc_by_row=False):
         rows = _np(row_list).astype(np.int64)
         if rows.shape[0] == 0:
             return
         f = np.float32
-        a = _np(acc)[: rows.shape[0], :k] if acc is not None else np.zeros((rows.shape[0], k), np.float32)
+        if acc is None:
+            a = np.zeros((rows.shape[0], k), np.float32)
+        else:
+            a = _np(acc)[rows, :k] if acc_by_row else _np(acc)[: rows.shape[0], :k]
         fresh = (f(prior) + _np(e)[rows, :k] * a).astype(np.float32)
         S = _np(shp)
         if w_old == 0:
