@@ -293,7 +293,9 @@ def main():
             if dom == "sweep_finalize":
                 # both sides run sweep_kernel with the row finalizer fused in (sharded: the item side in ranges,
                 # as prologue): one user-side launch + the item-side launches own this rank's iteration bytes
-                b_rank = n_loc * (8 + 8 * k) + model.nU * (12 + 20 * k) + model.nI * (4 + 24 * k)
+                # (scatter mode: this rank finalizes only its 1/N slice of the item rows)
+                ni_rank = model.nI / world if getattr(model, "shard_mode", None) == "scatter" else model.nI
+                b_rank = n_loc * (8 + 8 * k) + model.nU * (12 + 20 * k) + ni_rank * (4 + 24 * k)
                 fused = [ksum[n] for n in ("sweep_finalize", "sweep_prefinalize", "sweep") if n in ksum]
                 t_both = sum(v["total_ms"] for v in fused) / ev_steps * 1e-3     # per iteration, both sides
                 b_launch = b_rank / 2.0
