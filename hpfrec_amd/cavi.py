@@ -150,6 +150,7 @@ class FullBatchCavi:
         self.csT = torch.zeros(ld, **f32)
         self.niter_done = 0
         self._chunk_views = None
+        self.item_stream = os.environ.get("HPF_ITEM_STREAM", "1") == "1"   # scatter mode: item pass on its own stream
         self.lazy_items = os.environ.get("HPF_LAZY_ITEMS", "1") == "1"
         self.item_pending = False   # sharded path: acc_i holds reduced statistics not yet applied to the item tables
 
@@ -408,15 +409,37 @@ class FullBatchCavi:
         ops, hy, k, ld, dist = self.ops, self.hy, self.k, self.ld, self.dist
         views = self._scatter_views()
         xs = self._xstream()
-        for c in views:
-            self._wait(c.get("ag_done"))     # this range's E rows from the previous iteration's finalizers
-            if c["view"].nseg > 0:
-                ops.sweep(c["view"], self.eB, self.eT, c["part"], k, ld, acc_rows=self.acc_i, acc_ld=k)
-            if c["nmulti"] > 0:
-                ops.segsum(self.part_i, self.items.row_seg_ptr, c["nmulti"], self.acc_i, ld, row_list=c["multi"],
-                           acc_ld=k, acc_by_row=True)
-            with self._exchange(xs):
-                dist.reduce_scatter_tensor(c["acc_own"], c["acc"])
+        its = self._istream() if self.item_stream else None
+        if its is not None:
+            # the item pass runs on its OWN stream, concurrently with the user side: both only read last iteration's
+            # E tables.  A range's sweep waits for that range's all-gather only; the user side (below, compute
+            # stream) needs all of them.  The short launches of a many-rank run then fill each other's tails, and
+            # the dependencies of the item pass stall a stream the GPU is not waiting for.
+            if views[0].get("ag_done") is None:
+                its.wait_event(self._mark(torch.cuda.current_stream(self.device)))   # first iteration: after load_state
+            for c in views:
+                if c.get("ag_done") is not None:
+                    its.wait_event(c["ag_done"])
+                with torch.cuda.stream(its):
+                    if c["view"].nseg > 0:
+                        ops.sweep(c["view"], self.eB, self.eT, c["part"], k, ld, acc_rows=self.acc_i, acc_ld=k)
+                    if c["nmulti"] > 0:
+                        ops.segsum(self.part_i, self.items.row_seg_ptr, c["nmulti"], self.acc_i, ld,
+                                   row_list=c["multi"], acc_ld=k, acc_by_row=True)
+                    with self._exchange(xs):       # exchange stream continues after the item stream's sweep
+                        dist.reduce_scatter_tensor(c["acc_own"], c["acc"])
+            for c in views:
+                self._wait(c.get("ag_done"))
+        else:
+            for c in views:
+                self._wait(c.get("ag_done"))     # this range's E rows from the previous iteration's finalizers
+                if c["view"].nseg > 0:
+                    ops.sweep(c["view"], self.eB, self.eT, c["part"], k, ld, acc_rows=self.acc_i, acc_ld=k)
+                if c["nmulti"] > 0:
+                    ops.segsum(self.part_i, self.items.row_seg_ptr, c["nmulti"], self.acc_i, ld, row_list=c["multi"],
+                               acc_ld=k, acc_by_row=True)
+                with self._exchange(xs):
+                    dist.reduce_scatter_tensor(c["acc_own"], c["acc"])
         rs_done = self._mark(xs)
         # colsum(Beta) of the previous iteration was all-reduced ahead of the all-gathers just waited for
         self._keep_csB(store)
@@ -451,13 +474,20 @@ class FullBatchCavi:
             self._xs = torch.cuda.Stream(device=self.device)
         return self._xs
 
+    def _istream(self):
+        if self.device.type != "cuda":
+            return None
+        if getattr(self, "_is", None) is None:
+            self._is = torch.cuda.Stream(device=self.device)
+        return self._is
+
     def _event(self):
         """Events are re-used round-robin (a re-recorded event is only ever waited for after its latest record)."""
         pool = getattr(self, "_ev_pool", None)
         if pool is None:
-            pool = self._ev_pool = [torch.cuda.Event() for _ in range(16)]
+            pool = self._ev_pool = [torch.cuda.Event() for _ in range(32)]
             self._ev_next = -1
-        self._ev_next = (self._ev_next + 1) % 16
+        self._ev_next = (self._ev_next + 1) % 32
         return pool[self._ev_next]
 
     def _exchange(self, xs):
