@@ -409,37 +409,31 @@ class FullBatchCavi:
         ops, hy, k, ld, dist = self.ops, self.hy, self.k, self.ld, self.dist
         views = self._scatter_views()
         xs = self._xstream()
+        # The item pass runs on its OWN stream, concurrently with the user side: both only read last iteration's E
+        # tables.  A range's sweep waits for that range's all-gather only; the user side (below, compute stream)
+        # needs all of them.  The short launches of a many-rank run then fill each other's tails, and the
+        # dependencies of the item pass stall a stream the GPU is not waiting for.  (No GPU / HPF_ITEM_STREAM=0:
+        # `its` is None and everything below is issued in order on the one stream.)
         its = self._istream() if self.item_stream else None
-        if its is not None:
-            # the item pass runs on its OWN stream, concurrently with the user side: both only read last iteration's
-            # E tables.  A range's sweep waits for that range's all-gather only; the user side (below, compute
-            # stream) needs all of them.  The short launches of a many-rank run then fill each other's tails, and
-            # the dependencies of the item pass stall a stream the GPU is not waiting for.
-            if views[0].get("ag_done") is None:
-                its.wait_event(self._mark(torch.cuda.current_stream(self.device)))   # first iteration: after load_state
-            for c in views:
+        if its is not None and views[0].get("ag_done") is None:
+            its.wait_event(self._mark(torch.cuda.current_stream(self.device)))   # first iteration: after load_state
+        for c in views:
+            if its is not None:
                 if c.get("ag_done") is not None:
                     its.wait_event(c["ag_done"])
-                with torch.cuda.stream(its):
-                    if c["view"].nseg > 0:
-                        ops.sweep(c["view"], self.eB, self.eT, c["part"], k, ld, acc_rows=self.acc_i, acc_ld=k)
-                    if c["nmulti"] > 0:
-                        ops.segsum(self.part_i, self.items.row_seg_ptr, c["nmulti"], self.acc_i, ld,
-                                   row_list=c["multi"], acc_ld=k, acc_by_row=True)
-                    with self._exchange(xs):       # exchange stream continues after the item stream's sweep
-                        dist.reduce_scatter_tensor(c["acc_own"], c["acc"])
-            for c in views:
-                self._wait(c.get("ag_done"))
-        else:
-            for c in views:
+            else:
                 self._wait(c.get("ag_done"))     # this range's E rows from the previous iteration's finalizers
+            with (torch.cuda.stream(its) if its is not None else contextlib.nullcontext()):
                 if c["view"].nseg > 0:
                     ops.sweep(c["view"], self.eB, self.eT, c["part"], k, ld, acc_rows=self.acc_i, acc_ld=k)
                 if c["nmulti"] > 0:
                     ops.segsum(self.part_i, self.items.row_seg_ptr, c["nmulti"], self.acc_i, ld, row_list=c["multi"],
                                acc_ld=k, acc_by_row=True)
-                with self._exchange(xs):
+                with self._exchange(xs):           # the exchange stream continues after this range's sweep
                     dist.reduce_scatter_tensor(c["acc_own"], c["acc"])
+        if its is not None:
+            for c in views:
+                self._wait(c.get("ag_done"))
         rs_done = self._mark(xs)
         # colsum(Beta) of the previous iteration was all-reduced ahead of the all-gathers just waited for
         self._keep_csB(store)
