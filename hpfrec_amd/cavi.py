@@ -387,7 +387,10 @@ class FullBatchCavi:
             views.append(dict(
                 lo=lo, hi=hi, m=m, o0=o0, o1=o0 + m, n_real=n_real, view=view, multi=multi, nmulti=int(multi.shape[0]),
                 part=self.part_i[view.seg_lo:], acc=self.acc_i[lo:hi], acc_own=torch.zeros((m, k), **f32),
-                e_own=torch.zeros((m, ld), **f32), csp=self.csB_part_sc[g0: g0 + gr]))
+                e_own=torch.zeros((m, ld), **f32), csp=self.csB_part_sc[g0: g0 + gr],
+                # views used every iteration (slicing costs host time in a loop that is ~40 % host-bound at 8 ranks)
+                eB_range=self.eB[lo:hi], eB_own=self.eB[o0:o0 + m], shp_own=self.Lambda_shp[o0:o0 + m],
+                fac_own=self.Beta[o0:o0 + m], rs_own=self.t_rte[o0:o0 + m], rsp_own=self.t_rte_prev[o0:o0 + m]))
             g0 += g
         self._chunk_views = views
         return views
@@ -444,17 +447,16 @@ class FullBatchCavi:
         dist.all_reduce(self.csT)
         self._wait(rs_done)
         for c in views:
-            o0, o1 = c["o0"], c["o1"]
             if c["n_real"] > 0:
-                ops.row_finalize(c["acc_own"], None, c["n_real"], self.eB[o0:o1], c["e_own"],
-                                 self.Lambda_shp[o0:o1] if store else None, None, self.Beta[o0:o1] if store else None,
-                                 self.t_rte[o0:o1], self.csT, c["csp"], hy.c, hy.t_shp, hy.add_t_rte, k, ld, part_ld=k,
-                                 rs_prev=self.t_rte_prev[o0:o1])
+                ops.row_finalize(c["acc_own"], None, c["n_real"], c["eB_own"], c["e_own"],
+                                 c["shp_own"] if store else None, None, c["fac_own"] if store else None,
+                                 c["rs_own"], self.csT, c["csp"], hy.c, hy.t_shp, hy.add_t_rte, k, ld, part_ld=k,
+                                 rs_prev=c["rsp_own"])
         ops.colsum_reduce(self.csB_part_sc, self.csB, ld)      # this rank's partial colsum(Beta) ...
         with self._exchange(xs):
             dist.all_reduce(self.csB)                          # ... summed over ranks
             for c in views:
-                dist.all_gather_into_tensor(self.eB[c["lo"]: c["hi"]], c["e_own"])
+                dist.all_gather_into_tensor(c["eB_range"], c["e_own"])
                 c["ag_done"] = self._mark(xs)
         self._tables_split = True
         self.eT, self.eT_next = self.eT_next, self.eT
