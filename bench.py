@@ -116,7 +116,7 @@ class TimedOps(HipOps):
         return out
 
 
-def cpu_baseline(nU, nI, k, nnz_full, sample_users=40_000, iters=2):
+def cpu_baseline(nU, nI, k, nnz_full, sample_users=200_000, iters=4):
     """The CPU oracle (port of the reference's loops: materialised phi, per-nonzero double
     psi/log/exp, serial scatter, numpy rate updates) on this node's host cores, on a bounded sample:
     the first `sample_users` users of a same-shaped matrix (all items kept).  Extrapolated linearly
@@ -124,6 +124,7 @@ def cpu_baseline(nU, nI, k, nnz_full, sample_users=40_000, iters=2):
     from oracle import hpf_oracle as O
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import datagen
+    sample_users = min(sample_users, nU)
     nnz_s = int(nnz_full * (sample_users / nU))
     iu, ii, Y = datagen.synthetic_hpf_shaped(sample_users, nI, nnz_s, seed=1)
     cores = O.max_threads()
