@@ -105,7 +105,8 @@ class FullBatchCavi:
         self.world = self.dist.get_world_size() if self.dist else 1
         self.rank = self.dist.get_rank() if self.dist else 0
         # default by world size: the sharded finalizer pays for its two extra collectives from 4 ranks on
-        # (per-rank cost at C3, tools/shard_probe.py: N=2 2.04 vs 1.94 ms, N=4 1.14 vs 1.19, N=8 0.73 vs 0.84)
+        # (per-rank cost at C3, tools/shard_probe.py: N=2 1.97 vs 1.94 ms, N=4 1.09 vs 1.14, N=8 0.68 vs 0.84; with real
+        # links the all-gather of scatter mode is also harder to hide at 2 ranks: one xGMI link per pair)
         self.shard_mode = os.environ.get("HPF_SHARD_MODE", "scatter" if self.world >= 4 else "allreduce") \
             if self.dist else None
         assert self.shard_mode in (None, "scatter", "allreduce"), self.shard_mode
