@@ -156,6 +156,8 @@ def main():
                          "per-kernel averages cover exactly the warm-up + timed iterations")
     ap.add_argument("--no-fuse", action="store_true", help="separate sweep and row-finalize launches")
     ap.add_argument("--atomic", action="store_true", help="experimental one-pass variant with fp32 atomics")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="N>1: do not try the exchange configurations first, use the defaults of hpfrec_amd.cavi")
     ap.add_argument("--lean", action="store_true",
                     help="skip the stores of the six [n,k] output tables in the timed iterations")
     args = ap.parse_args()
@@ -163,12 +165,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("HPF_BENCH_SELFTEST_GLOO") == "1":
+        local_rank = 0      # code-path self-test on a ONE-GPU box: all ranks on cuda:0, gloo instead of RCCL (not a benchmark)
     if world > 1 or os.environ.get("HPF_FORCE_SHARDED") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29544")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if os.environ.get("HPF_BENCH_SELFTEST_GLOO") == "1":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -199,14 +206,46 @@ def main():
     hy = cavi.Hyper(k, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
     lu, li, ly, (u0, u1) = cavi.shard_users(iu, ii, y, nU, rank, world)
     del iu, ii, y
-    model = cavi.FullBatchCavi(ops, device, lu, li, ly, u1 - u0, nI, hy)
-    del lu, li, ly
     Theta = np.empty((nU, k), np.float32)
     Beta = np.empty((nI, k), np.float32)
     init = backend.initialize_parameters(Theta, Beta, 123, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
     s = slice(u0, u1)
-    model.load_state(init[0][s], init[1][s], init[2], init[3], init[4][s], init[5], Theta[s], Beta)
-    del init, Theta, Beta
+
+    def build_model():
+        m = cavi.FullBatchCavi(ops, device, lu, li, ly, u1 - u0, nI, hy)
+        m.load_state(init[0][s], init[1][s], init[2], init[3], init[4][s], init[5], Theta[s], Beta)
+        return m
+
+    # N>1: the exchange mode / number of pipelined item ranges that is fastest depends on what the links and RCCL
+    # deliver on this node, so (unless the environment pins them) each candidate runs a few untimed iterations
+    # first and the fastest one -- by the slowest rank's clock -- is the configuration that is then benchmarked.
+    autotune = None
+    if dist and world > 1 and not args.no_autotune and "HPF_SHARD_MODE" not in os.environ \
+            and "HPF_AR_CHUNKS" not in os.environ:
+        autotune = {}
+        for mode, chunks in (("scatter", "2"), ("scatter", "3"), ("allreduce", "3")):
+            os.environ["HPF_SHARD_MODE"], os.environ["HPF_AR_CHUNKS"] = mode, chunks
+            m = build_model()
+            for _ in range(3):
+                m.iterate(not args.lean)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                m.iterate(not args.lean)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t = torch.tensor([(time.perf_counter() - t0) / 10 * 1e3], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            autotune["%s/%s" % (mode, chunks)] = float(t.item())
+            m.flush_items()
+            del m
+            torch.cuda.empty_cache()
+        best = min(autotune, key=autotune.get)
+        os.environ["HPF_SHARD_MODE"], os.environ["HPF_AR_CHUNKS"] = best.split("/")
+        autotune = {"ms_per_iteration": autotune, "chosen": best}
+    model = build_model()
+    del lu, li, ly, init, Theta, Beta
     torch.cuda.empty_cache()
 
     if args.no_fuse:
@@ -329,6 +368,7 @@ def main():
                                        ("users sharded x%d; item statistics all-reduced per iteration in %d pipelined "
                                         "ranges (RCCL), item finalize deferred into the next item sweep"
                                         % (world, len(model.item_chunks)))) if world > 1 else "1 GPU",
+                       "exchange_autotune": autotune,
                        "seg_cap": cavi.layout.SEG_CAP, "fused_finalize": model.fused and world == 1,
                        "stores_all_state_tables": store, "state_finite": finite},
             "roofline": roof,
