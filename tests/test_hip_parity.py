@@ -611,3 +611,27 @@ def test_rank1_rate_tables_expand_bit_identically(ops):
     expanded = (top / rs_prev)[:, None] + cs[None, :k]
     assert torch.equal(expanded, rte[:, :k])
     assert torch.all(rte[:, k:] == 0)
+
+
+def test_bench_multi_rank_path_selftest():
+    """bench.py's N>1 path (rank-0 generation + broadcast, sharding, exchange autotune, separate event pass, one JSON
+    line from rank 0) with two gloo ranks sharing the GPU -- a code-path test, not a measurement."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HPF_BENCH_SELFTEST_GLOO="1")
+    for v in ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_FORCE_SHARDED"):
+        env.pop(v, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29588", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "small"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["state_finite"] is True
+    assert set(d["config"]["exchange_autotune"]["ms_per_iteration"]) == {"scatter/2", "scatter/3", "allreduce/3"}
+    assert d["roofline"]["events"].startswith("separate pass") and d["cpu_baseline"] is None
