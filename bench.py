@@ -231,11 +231,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(10):
+            for _ in range(20):
                 m.iterate(not args.lean)
             dist.barrier()
             torch.cuda.synchronize()
-            t = torch.tensor([(time.perf_counter() - t0) / 10 * 1e3], dtype=torch.float64, device=device)
+            t = torch.tensor([(time.perf_counter() - t0) / 20 * 1e3], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             autotune["%s/%s" % (mode, chunks)] = float(t.item())
             m.flush_items()
