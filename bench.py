@@ -220,11 +220,12 @@ def main():
     # deliver on this node, so (unless the environment pins them) each candidate runs a few untimed iterations
     # first and the fastest one -- by the slowest rank's clock -- is the configuration that is then benchmarked.
     autotune = None
-    if dist and world > 1 and not args.no_autotune and "HPF_SHARD_MODE" not in os.environ \
-            and "HPF_AR_CHUNKS" not in os.environ:
+    if dist and world > 1 and not args.no_autotune and not any(
+            v in os.environ for v in ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM")):
         autotune = {}
-        for mode, chunks in (("scatter", "2"), ("scatter", "3"), ("allreduce", "3")):
-            os.environ["HPF_SHARD_MODE"], os.environ["HPF_AR_CHUNKS"] = mode, chunks
+        for mode, chunks, istream in (("scatter", "2", "1"), ("scatter", "3", "1"), ("scatter", "2", "0"),
+                                      ("allreduce", "3", "1"), ("allreduce", "2", "1")):
+            os.environ["HPF_SHARD_MODE"], os.environ["HPF_AR_CHUNKS"], os.environ["HPF_ITEM_STREAM"] = mode, chunks, istream
             m = build_model()
             for _ in range(3):
                 m.iterate(not args.lean)
@@ -237,12 +238,13 @@ def main():
             torch.cuda.synchronize()
             t = torch.tensor([(time.perf_counter() - t0) / 20 * 1e3], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            autotune["%s/%s" % (mode, chunks)] = float(t.item())
+            autotune["%s/%s%s" % (mode, chunks, "" if istream == "1" else "/items-on-compute-stream")] = float(t.item())
             m.flush_items()
             del m
             torch.cuda.empty_cache()
         best = min(autotune, key=autotune.get)
-        os.environ["HPF_SHARD_MODE"], os.environ["HPF_AR_CHUNKS"] = best.split("/")
+        os.environ["HPF_SHARD_MODE"], os.environ["HPF_AR_CHUNKS"] = best.split("/")[:2]
+        os.environ["HPF_ITEM_STREAM"] = "0" if best.endswith("items-on-compute-stream") else "1"
         autotune = {"ms_per_iteration": autotune, "chosen": best}
     model = build_model()
     del lu, li, ly, init, Theta, Beta
