@@ -116,7 +116,7 @@ class TimedOps(HipOps):
         return out
 
 
-def cpu_baseline(nU, nI, k, nnz_full, sample_users=200_000, iters=4):
+def cpu_baseline(nU, nI, k, nnz_full, sample_users=200_000, iters=4, device=None):
     """The CPU oracle (port of the reference's loops: materialised phi, per-nonzero double
     psi/log/exp, serial scatter, numpy rate updates) on this node's host cores, on a bounded sample:
     the first `sample_users` users of a same-shaped matrix (all items kept).  Extrapolated linearly
@@ -130,6 +130,7 @@ def cpu_baseline(nU, nI, k, nnz_full, sample_users=200_000, iters=4):
     cores = O.max_threads()
     hy = O.Hyper(k, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
     st = O.State(sample_users, nI, hy, 123)
+    init = {n: getattr(st, n).copy() for n in O.State.names}      # for the parity check below
     phi = np.empty((Y.shape[0], k), dtype=np.float32)
     Yc, iuc, iic = O._f32(Y), O._ind(iu), O._ind(ii)
     O.cavi_iteration(st, hy, Yc, iuc, iic, phi, 0, cores)  # warm (page-in phi)
@@ -138,9 +139,35 @@ def cpu_baseline(nU, nI, k, nnz_full, sample_users=200_000, iters=4):
         O.cavi_iteration(st, hy, Yc, iuc, iic, phi, 0, cores)
     dt = (time.time() - t0) / iters
     per_full = dt * (nnz_full / Y.shape[0])
-    return {"value": 1.0 / per_full, "unit": "iters/s", "cores": cores, "kind": "port",
-            "sample": "%d users x %d items, %d nnz, k=%d, %d timed iterations at %.2f s/iter; scaled by nnz to %d nnz"
-                      % (sample_users, nI, Y.shape[0], k, iters, dt, nnz_full)}
+    out = {"value": 1.0 / per_full, "unit": "iters/s", "cores": cores, "kind": "port",
+           "sample": "%d users x %d items, %d nnz, k=%d, %d timed iterations at %.2f s/iter; scaled by nnz to %d nnz"
+                     % (sample_users, nI, Y.shape[0], k, iters, dt, nnz_full)}
+    # the oracle is the checker: the HIP path on the same sample, same start, same number of iterations
+    if device is not None:
+        hyd = cavi.Hyper(k, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
+        m = cavi.FullBatchCavi(HipOps(device), device, torch.from_numpy(iu.astype(np.int64)),
+                               torch.from_numpy(ii.astype(np.int64)), torch.from_numpy(Y), sample_users, nI, hyd)
+        m.load_state(init["Gamma_shp"], init["Gamma_rte"], init["Lambda_shp"], init["Lambda_rte"], init["k_rte"],
+                     init["t_rte"], init["Theta"], init["Beta"])
+        for _ in range(iters + 1):
+            m.iterate(True)
+        got = {n: m.fetch(n) for n in ("Theta", "Beta")}
+        del m
+        torch.cuda.empty_cache()
+
+        def worst(ref):
+            return max(float(np.max(np.abs(got[n] - getattr(ref, n)) / np.abs(getattr(ref, n)))) for n in got)
+        # numpy's float32 row-by-row column sums (PXI:236,255), which the port reproduces bit for bit, are themselves
+        # ~1e-4 off at 10^5..10^6 rows; the same port with float64 column sums shows what is left without that
+        st64 = O.State(sample_users, nI, hy, 123)
+        for _ in range(iters + 1):
+            O.cavi_iteration(st64, hy, Yc, iuc, iic, phi, 0, cores, exact_colsums=True)
+        out["parity_vs_gpu_on_sample"] = {
+            "iterations": iters + 1, "max_rel_dev_Theta_Beta_vs_port": worst(st),
+            "max_rel_dev_vs_port_with_float64_column_sums": worst(st64),
+            "note": "the port reproduces numpy's float32 row-by-row column sums of the reference (PXI:236,255), whose own "
+                    "error is ~1e-4 at 1e5..1e6 rows (SURVEY.md section 7); the GPU sums them in fp64 trees"}
+    return out
 
 
 def main():
@@ -383,7 +410,7 @@ def main():
             line["train_llk_after_run"] = llk_val
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(nU, nI, k, nnz)
+                line["cpu_baseline"] = cpu_baseline(nU, nI, k, nnz, device=device)
             except Exception as e:  # the bench line must survive a broken host toolchain
                 line["cpu_baseline"] = {"value": None, "error": repr(e)}
         else:

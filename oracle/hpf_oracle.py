@@ -131,19 +131,29 @@ class State:
         return {n: getattr(self, n).copy() for n in self.names}
 
 
-def cavi_iteration(st, hy, Y, ix_u, ix_i, phi, sum_exp_trick=0, nthreads=1):
-    """One full-batch sweep, PXI:232-259, in the reference's statement order."""
+def cavi_iteration(st, hy, Y, ix_u, ix_i, phi, sum_exp_trick=0, nthreads=1, exact_colsums=False):
+    """One full-batch sweep, PXI:232-259, in the reference's statement order.
+
+    exact_colsums=True is NOT the reference: the two column sums (PXI:236, PXI:255) are then accumulated in float64
+    instead of numpy's row-by-row float32 adds, whose own error reaches 1e-4 relative at 10^5..10^6 rows (SURVEY.md
+    section 7).  Used only to show where a deviation at that scale comes from."""
     L = lib()
     k = hy.k
     nY = Y.shape[0]
+
+    def colsum(a):
+        if exact_colsums:
+            return a.sum(axis=0, keepdims=True, dtype=np.float64).astype(np.float32)
+        return a.sum(axis=0, keepdims=True)
+
     L.hpf_oracle_update_phi_f32(_p(st.Gamma_shp), _p(st.Gamma_rte), _p(st.Lambda_shp), _p(st.Lambda_rte),
                                 _p(phi), _p(Y), k, int(sum_exp_trick), _p(ix_u), _p(ix_i), nY, int(nthreads))
-    st.Gamma_rte = float(hy.k_shp) / st.k_rte + st.Beta.sum(axis=0, keepdims=True)
+    st.Gamma_rte = float(hy.k_shp) / st.k_rte + colsum(st.Beta)
     st.Gamma_shp[:, :] = float(hy.a)
     st.Lambda_shp[:, :] = float(hy.c)
     L.hpf_oracle_scatter_f32(_p(st.Gamma_shp), _p(st.Lambda_shp), _p(phi), k, _p(ix_u), _p(ix_i), nY)
     st.Theta[:, :] = st.Gamma_shp / st.Gamma_rte
-    st.Lambda_rte = float(hy.t_shp) / st.t_rte + st.Theta.sum(axis=0, keepdims=True)
+    st.Lambda_rte = float(hy.t_shp) / st.t_rte + colsum(st.Theta)
     st.Beta[:, :] = st.Lambda_shp / st.Lambda_rte
     st.k_rte = float(hy.add_k_rte) + st.Theta.sum(axis=1, keepdims=True)
     st.t_rte = float(hy.add_t_rte) + st.Beta.sum(axis=1, keepdims=True)
