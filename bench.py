@@ -249,30 +249,34 @@ def main():
     autotune = None
     if dist and world > 1 and not args.no_autotune and not any(
             v in os.environ for v in ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM")):
-        autotune = {}
+        autotune, failed = {}, {}
         for mode, chunks, istream in (("scatter", "2", "1"), ("scatter", "3", "1"), ("scatter", "2", "0"),
                                       ("allreduce", "3", "1"), ("allreduce", "2", "1")):
             os.environ["HPF_SHARD_MODE"], os.environ["HPF_AR_CHUNKS"], os.environ["HPF_ITEM_STREAM"] = mode, chunks, istream
-            m = build_model()
-            for _ in range(3):
-                m.iterate(not args.lean)
-            dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(20):
-                m.iterate(not args.lean)
-            dist.barrier()
-            torch.cuda.synchronize()
-            t = torch.tensor([(time.perf_counter() - t0) / 20 * 1e3], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            autotune["%s/%s%s" % (mode, chunks, "" if istream == "1" else "/items-on-compute-stream")] = float(t.item())
-            m.flush_items()
-            del m
+            key = "%s/%s%s" % (mode, chunks, "" if istream == "1" else "/items-on-compute-stream")
+            try:        # a configuration that fails on this node (same error on every rank) is skipped, not fatal
+                m = build_model()
+                for _ in range(3):
+                    m.iterate(not args.lean)
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    m.iterate(not args.lean)
+                dist.barrier()
+                torch.cuda.synchronize()
+                t = torch.tensor([(time.perf_counter() - t0) / 20 * 1e3], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                autotune[key] = float(t.item())
+                m.flush_items()
+                del m
+            except Exception as exc:   # noqa: BLE001
+                failed[key] = "%s: %s" % (type(exc).__name__, str(exc)[:200])
             torch.cuda.empty_cache()
         best = min(autotune, key=autotune.get)
         os.environ["HPF_SHARD_MODE"], os.environ["HPF_AR_CHUNKS"] = best.split("/")[:2]
         os.environ["HPF_ITEM_STREAM"] = "0" if best.endswith("items-on-compute-stream") else "1"
-        autotune = {"ms_per_iteration": autotune, "chosen": best}
+        autotune = {"ms_per_iteration": autotune, "chosen": best, "failed": failed}
     model = build_model()
     del lu, li, ly, init, Theta, Beta
     torch.cuda.empty_cache()
