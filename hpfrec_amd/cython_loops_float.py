@@ -170,18 +170,26 @@ def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta
     hy = cavi.Hyper(k, a, a_prime, b_prime, c, c_prime, d_prime)
     if verbose > 0:
         print("Initializing parameters...")
-    Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte = initialize_parameters(
-        Theta, Beta, random_seed, float(hy.a), float(hy.a_prime), float(hy.b_prime), float(hy.c),
-        float(hy.c_prime), float(hy.d_prime))
-
+    init_args = (Theta, Beta, random_seed, float(hy.a), float(hy.a_prime), float(hy.b_prime), float(hy.c),
+                 float(hy.c_prime), float(hy.d_prime))
     full_updates = (users_per_batch == 0) and (items_per_batch == 0)
+    eng = None
+    if full_updates:
+        # the reference's initialisation is 4 numpy RNG passes over (nU+nI)*k floats (0.3 s at C3; the generator's
+        # fill loops release the GIL): it runs beside the upload + CSR/CSC build of the engine
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            fut = pool.submit(initialize_parameters, *init_args)
+            eng = _Engine(hy, Y, ix_u, ix_i, nU, nI, Yval if has_valset else None, ix_u_val, ix_i_val)
+            Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte = fut.result()
+    else:
+        Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte = initialize_parameters(*init_args)
     if not full_updates:
         return svi.fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte,
                                t_rte, maxiter, stop_crit, check_every, stop_thr, users_per_batch, items_per_batch,
                                step_size, save_folder, random_seed, verbose, has_valset, Yval, ix_u_val, ix_i_val,
                                full_llk, keep_all_objs, _make_ops)
 
-    eng = _Engine(hy, Y, ix_u, ix_i, nU, nI, Yval if has_valset else None, ix_u_val, ix_i_val)
     eng.upload(Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta)
     model = eng.model
     errs = np.zeros(2, dtype=np.longdouble)
