@@ -71,11 +71,13 @@ def shard_users(ix_u, ix_i, y, nU, rank, world):
 class _SideView:
     """The segments [seg_lo, seg_hi) of a SparseSide, as the sweep launcher sees a side."""
 
-    def __init__(self, side, seg_lo, seg_hi):
+    def __init__(self, side, seg_lo, seg_hi, nnz=None):
         self.seg_lo = seg_lo
         self.segs = side.segs[seg_lo:seg_hi]
         self.nseg = seg_hi - seg_lo
         self.idx, self.y = side.idx, side.y
+        # launch hint (hpf_hip_sweep_f32): a shard of a many-rank run leaves ~16 nonzeros per item row
+        self.short_rows = nnz is not None and self.nseg > 0 and nnz / self.nseg < layout.SHORT_ROW_NNZ
 
 
 class FullBatchCavi:
@@ -208,11 +210,12 @@ class FullBatchCavi:
         """[(row_lo, row_hi, SideView over the range's segments, its split/empty rows)] in issue order."""
         it = self.items
         rsp = it.row_seg_ptr.cpu()
+        ptr = it.indptr.cpu()
         out = []
         for lo, hi in self.item_bounds:
             top = min(hi, self.nI)
             multi = it.multi_rows[(it.multi_rows >= lo) & (it.multi_rows < top)].contiguous()
-            out.append((lo, hi, _SideView(it, int(rsp[lo]), int(rsp[top])), multi))
+            out.append((lo, hi, _SideView(it, int(rsp[lo]), int(rsp[top]), nnz=int(ptr[top] - ptr[lo])), multi))
         if self.shard_mode == "scatter":
             # fewest rows first: the all-gather of the big range (the tail items) then overlaps the sweep of the
             # small one in the next iteration, and its reduce-scatter overlaps the user side in this one

@@ -196,7 +196,7 @@ struct FinalizeArgs {  // the row-finalize operands when it is fused into the sw
 //       2 = row finalize fused as PROLOGUE of whole-row segments from an already reduced accumulator row
 //           (sharded path: the previous iteration's all-reduced item statistics are turned into this
 //           iteration's E row by the very wave that then sweeps the row -- "deferred item finalize")
-template <int LPR, int VPL, bool SCATTER, int MODE>
+template <int LPR, int VPL, bool SCATTER, int MODE, int UU = HPF_U>
 __global__ __launch_bounds__(BLOCK)
 __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUSED_MAX_WAVES : 8))) void sweep_kernel(const hpf_segment *__restrict__ segs, int64_t nseg,
                                                       const int32_t *__restrict__ idx,
@@ -207,7 +207,7 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
                                                       const FinalizeArgs fa) {
     constexpr int LD = 4 * LPR * VPL;
     constexpr int NG = WAVE / LPR;  // nonzeros per step
-    constexpr int U = HPF_U;        // gathers in flight per wavefront (WAVE/NG = LPR >= 8 is a multiple)
+    constexpr int U = UU;           // gathers in flight per wavefront (WAVE/NG = LPR >= 8 is a multiple)
     constexpr int NQ = 4 * VPL;     // factors held per lane during the sweep
     constexpr bool FUSE = (MODE != 0);
     const int lane = threadIdx.x & (WAVE - 1);
@@ -1141,7 +1141,7 @@ int hpf_hip_device_info(int *cu_count, char *arch, int arch_len) {
 
 int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
                       const float *tab_self, const float *tab_other, float *part, float *scatter_acc,
-                      float *acc_rows, int acc_ld, int k, int ld, int grid_blocks, void *stream) {
+                      float *acc_rows, int acc_ld, int k, int ld, int short_rows, int grid_blocks, void *stream) {
     if (nseg == 0) return 0;
     if (!segs || !idx || !y || !tab_self || !tab_other || !part || nseg < 0 || k <= 0 || ld != hpf_hip_ld_for_k(k))
         return HPF_EINVAL;
@@ -1151,10 +1151,16 @@ int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx,
     FinalizeArgs fa = {};
     fa.acc_rows = acc_rows;
     fa.acc_ld = acc_ld;
+    // short rows (a batch or a shard of a many-rank run: ~16 nonzeros per row): half the gathers in flight per wave
+    // fill just as well and the smaller register file buys occupancy (-15 % at N=8)
+    constexpr int US = (HPF_U >= 8) ? HPF_U / 2 : HPF_U;
 #define CALL(LPR, VPL)                                                                                              \
     if (scatter_acc)                                                                                                \
         hipLaunchKernelGGL((sweep_kernel<LPR, VPL, true, 0>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg, idx, \
                            y, tab_self, tab_other, part, scatter_acc, fa);                                          \
+    else if (short_rows)                                                                                            \
+        hipLaunchKernelGGL((sweep_kernel<LPR, VPL, false, 0, US>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg,     \
+                           idx, y, tab_self, tab_other, part, scatter_acc, fa);                                     \
     else                                                                                                            \
         hipLaunchKernelGGL((sweep_kernel<LPR, VPL, false, 0>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg,     \
                            idx, y, tab_self, tab_other, part, scatter_acc, fa);

@@ -40,7 +40,8 @@ class HipOps:
     def sweep(self, side, tab_self, tab_other, part, k, ld, scatter_acc=None, acc_rows=None, acc_ld=0):
         _lib.check(self.L.hpf_hip_sweep_f32(_ptr(side.segs), side.nseg, _ptr(side.idx), _ptr(side.y),
                                             _ptr(tab_self), _ptr(tab_other), _ptr(part), _ptr(scatter_acc),
-                                            _ptr(acc_rows), int(acc_ld), k, ld, self.sweep_blocks, self._stream()),
+                                            _ptr(acc_rows), int(acc_ld), k, ld, int(getattr(side, "short_rows", False)),
+                                            self.sweep_blocks, self._stream()),
                    "hpf_hip_sweep_f32")
 
     def sweep_grid(self, nseg):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 4
+#define HPF_HIP_ABI_VERSION 5
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -72,10 +72,12 @@ int hpf_hip_device_info(int *cu_count, char *arch, int arch_len);
  * scatter_acc may be NULL (the deterministic two-pass scheme: call once per side).
  * acc_rows (optional): segments flagged HPF_SEG_WHOLE_ROW write their accumulator to
  * acc_rows[row][0:acc_ld] (k <= acc_ld <= ld, packed) instead of part[g] -- the multi-GPU exchange buffer.
+ * short_rows != 0: tuning hint, the rows average a few dozen nonzeros at most (half the gathers in flight per
+ * wavefront, more wavefronts resident); results do not depend on it.
  */
 int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
                       const float *tab_self, const float *tab_other, float *part, float *scatter_acc,
-                      float *acc_rows, int acc_ld, int k, int ld, int grid_blocks, void *stream);
+                      float *acc_rows, int acc_ld, int k, int ld, int short_rows, int grid_blocks, void *stream);
 
 /*
  * hpf_hip_sweep_f32 with the row finalizer (next entry) fused in: a segment flagged
