@@ -133,40 +133,55 @@ def cpu_baseline(nU, nI, k, nnz_full, sample_users=200_000, iters=4, device=None
     init = {n: getattr(st, n).copy() for n in O.State.names}      # for the parity check below
     phi = np.empty((Y.shape[0], k), dtype=np.float32)
     Yc, iuc, iic = O._f32(Y), O._ind(iu), O._ind(ii)
+    snaps = {}
     O.cavi_iteration(st, hy, Yc, iuc, iic, phi, 0, cores)  # warm (page-in phi)
     t0 = time.time()
-    for _ in range(iters):
+    t_snap = 0.0
+    for i in range(iters):
         O.cavi_iteration(st, hy, Yc, iuc, iic, phi, 0, cores)
-    dt = (time.time() - t0) / iters
+        if i + 2 == 3:                                       # state after 3 iterations, for the parity check below
+            ts = time.time()
+            snaps[3] = {n: getattr(st, n).copy() for n in ("Theta", "Beta")}
+            t_snap = time.time() - ts
+    dt = (time.time() - t0 - t_snap) / iters
+    total_its = iters + 1
+    snaps[total_its] = {n: getattr(st, n) for n in ("Theta", "Beta")}
     per_full = dt * (nnz_full / Y.shape[0])
     out = {"value": 1.0 / per_full, "unit": "iters/s", "cores": cores, "kind": "port",
            "sample": "%d users x %d items, %d nnz, k=%d, %d timed iterations at %.2f s/iter; scaled by nnz to %d nnz"
                      % (sample_users, nI, Y.shape[0], k, iters, dt, nnz_full)}
-    # the oracle is the checker: the HIP path on the same sample, same start, same number of iterations
+    # the oracle is the checker: the HIP path on the same sample, same start, same numbers of iterations
     if device is not None:
         hyd = cavi.Hyper(k, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
         m = cavi.FullBatchCavi(HipOps(device), device, torch.from_numpy(iu.astype(np.int64)),
                                torch.from_numpy(ii.astype(np.int64)), torch.from_numpy(Y), sample_users, nI, hyd)
         m.load_state(init["Gamma_shp"], init["Gamma_rte"], init["Lambda_shp"], init["Lambda_rte"], init["k_rte"],
                      init["t_rte"], init["Theta"], init["Beta"])
-        for _ in range(iters + 1):
+        got = {}
+        for i in range(total_its):
             m.iterate(True)
-        got = {n: m.fetch(n) for n in ("Theta", "Beta")}
+            if i + 1 in snaps:
+                got[i + 1] = {n: m.fetch(n) for n in ("Theta", "Beta")}
         del m
         torch.cuda.empty_cache()
 
-        def worst(ref):
-            return max(float(np.max(np.abs(got[n] - getattr(ref, n)) / np.abs(getattr(ref, n)))) for n in got)
+        def worst(a, b):
+            return max(float(np.max(np.abs(a[n] - b[n]) / np.abs(b[n]))) for n in ("Theta", "Beta"))
         # numpy's float32 row-by-row column sums (PXI:236,255), which the port reproduces bit for bit, are themselves
         # ~1e-4 off at 10^5..10^6 rows; the same port with float64 column sums shows what is left without that
         st64 = O.State(sample_users, nI, hy, 123)
-        for _ in range(iters + 1):
+        snaps64 = {}
+        for i in range(total_its):
             O.cavi_iteration(st64, hy, Yc, iuc, iic, phi, 0, cores, exact_colsums=True)
+            if i + 1 in snaps:
+                snaps64[i + 1] = {n: getattr(st64, n).copy() for n in ("Theta", "Beta")}
         out["parity_vs_gpu_on_sample"] = {
-            "iterations": iters + 1, "max_rel_dev_Theta_Beta_vs_port": worst(st),
-            "max_rel_dev_vs_port_with_float64_column_sums": worst(st64),
-            "note": "the port reproduces numpy's float32 row-by-row column sums of the reference (PXI:236,255), whose own "
-                    "error is ~1e-4 at 1e5..1e6 rows (SURVEY.md section 7); the GPU sums them in fp64 trees"}
+            "max_rel_dev_Theta_Beta": {"after_%d_iterations" % n: {
+                "vs_port": worst(got[n], snaps[n]), "vs_port_with_float64_column_sums": worst(got[n], snaps64[n])}
+                for n in sorted(snaps)},
+            "note": "element-wise parity is a short-horizon property (rounding noise grows ~x1.2 per iteration); the port "
+                    "reproduces numpy's float32 row-by-row column sums of the reference (PXI:236,255), whose own error is "
+                    "~1e-4 at 1e5..1e6 rows (SURVEY.md section 7); the GPU sums them in fp64 trees"}
     return out
 
 
