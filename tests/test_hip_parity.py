@@ -550,9 +550,11 @@ def test_tiny_shape_priors(hip_backend):
         assert _maxrel(arrs[n], trick[3][n]) < 2e-3, n
 
 
-@pytest.mark.parametrize("world,mode,lazy", [(2, "scatter", "1"), (3, "scatter", "1"), (2, "scatter", "no-item-stream"),
-                                             (2, "allreduce", "1"), (3, "allreduce", "1"), (2, "allreduce", "0")])
-def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypatch, world, mode, lazy):
+@pytest.mark.parametrize("world,mode,lazy,k", [(2, "scatter", "1", 20), (3, "scatter", "1", 20),
+                                               (2, "scatter", "no-item-stream", 20), (2, "scatter", "1", 100),
+                                               (2, "allreduce", "1", 20), (3, "allreduce", "1", 20),
+                                               (2, "allreduce", "0", 20), (2, "allreduce", "1", 100)])
+def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypatch, world, mode, lazy, k):
     """The N>1 path on the REAL kernels: `world` processes, all on cuda:0, gloo backend (it stages the CUDA tensors
     through the host), user-sharded fit with the pipelined item exchange and the deferred item finalize; every
     rank must end with the same full model as the single-process HIP fit."""
@@ -564,7 +566,7 @@ def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypat
         monkeypatch.setenv("HPF_ITEM_STREAM", "0")
         lazy = "1"
     monkeypatch.setenv("HPF_LAZY_ITEMS", lazy)   # all-reduce mode, "0": standalone item finalizer after the exchange
-    k, its = 20, 5
+    its = 5
     df, nU, nI = datagen.mid_counts(nusers=600, nitems=400, nobs=20000)
     Y, iu, ii = datagen.triplets(df)
     Theta = np.empty((nU, k), np.float32)
