@@ -240,6 +240,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank != 0:
+        # only rank 0 reports: whatever another rank's libraries leave in stdio at exit (RCCL banners ...) must not
+        # trail rank 0's JSON line on the shared stdout
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     if os.environ.get("HPF_BENCH_SELFTEST_GLOO") == "1":
         local_rank = 0      # code-path self-test on a ONE-GPU box: all ranks on cuda:0, gloo instead of RCCL (not a benchmark)
     if world > 1 or os.environ.get("HPF_FORCE_SHARDED") == "1":
