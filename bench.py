@@ -300,7 +300,7 @@ def main():
     # first and the fastest one -- by the slowest rank's clock -- is the configuration that is then benchmarked.
     autotune = None
     if dist and world > 1 and not args.no_autotune and not any(
-            v in os.environ for v in ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM")):
+            v in os.environ for v in ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_RS_ALLTOALL")):
         autotune, failed = {}, {}
         # Safety net: this multi-rank path could only be exercised with gloo ranks on one GPU before the driver's
         # run.  If anything after a completed candidate stops making progress, rank 0 still reports that candidate's
@@ -309,10 +309,13 @@ def main():
             workload=label, users=nU, items=nI, nnz=nnz, k=k, world=world, rank=rank, workload_key=args.workload)
         _arm_watchdog(float(os.environ.get("HPF_BENCH_WATCHDOG_S", "240")))
         # the plain all-reduce configurations go first: they are the most conservative use of RCCL
-        for mode, chunks, istream in (("allreduce", "3", "1"), ("allreduce", "2", "1"), ("scatter", "2", "1"),
-                                      ("scatter", "3", "1"), ("scatter", "2", "0")):
+        for mode, chunks, istream, a2a in (("allreduce", "3", "1", "0"), ("allreduce", "2", "1", "0"),
+                                           ("scatter", "2", "1", "0"), ("scatter", "3", "1", "0"),
+                                           ("scatter", "2", "0", "0"), ("scatter", "2", "1", "1")):
             os.environ["HPF_SHARD_MODE"], os.environ["HPF_AR_CHUNKS"], os.environ["HPF_ITEM_STREAM"] = mode, chunks, istream
-            key = "%s/%s%s" % (mode, chunks, "" if istream == "1" else "/items-on-compute-stream")
+            os.environ["HPF_RS_ALLTOALL"] = a2a
+            key = "%s/%s%s%s" % (mode, chunks, "" if istream == "1" else "/items-on-compute-stream",
+                                 "/all-to-all" if a2a == "1" else "")
             try:        # a configuration that fails on this node (same error on every rank) is skipped, not fatal
                 m = build_model()
                 for _ in range(3):
@@ -334,7 +337,8 @@ def main():
             torch.cuda.empty_cache()
         best = min(autotune, key=autotune.get)
         os.environ["HPF_SHARD_MODE"], os.environ["HPF_AR_CHUNKS"] = best.split("/")[:2]
-        os.environ["HPF_ITEM_STREAM"] = "0" if best.endswith("items-on-compute-stream") else "1"
+        os.environ["HPF_ITEM_STREAM"] = "0" if "items-on-compute-stream" in best else "1"
+        os.environ["HPF_RS_ALLTOALL"] = "1" if best.endswith("all-to-all") else "0"
         autotune = {"ms_per_iteration": autotune, "chosen": best, "failed": failed}
     model = build_model()
     del lu, li, ly, init, Theta, Beta

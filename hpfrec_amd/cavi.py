@@ -153,6 +153,7 @@ class FullBatchCavi:
         self.csT = torch.zeros(ld, **f32)
         self.niter_done = 0
         self._chunk_views = None
+        self.rs_alltoall = os.environ.get("HPF_RS_ALLTOALL", "0") == "1"   # scatter mode: all-to-all + local sum
         self.item_stream = os.environ.get("HPF_ITEM_STREAM", "1") == "1"   # scatter mode: item pass on its own stream
         self.lazy_items = os.environ.get("HPF_LAZY_ITEMS", "1") == "1"
         self.item_pending = False   # sharded path: acc_i holds reduced statistics not yet applied to the item tables
@@ -393,6 +394,7 @@ class FullBatchCavi:
                 part=self.part_i[view.seg_lo:], acc=self.acc_i[lo:hi], acc_own=torch.zeros((m, k), **f32),
                 e_own=torch.zeros((m, ld), **f32), csp=self.csB_part_sc[g0: g0 + gr],
                 # views used every iteration (slicing costs host time in a loop that is ~40 % host-bound at 8 ranks)
+                a2a_recv=torch.zeros((W * m, k), **f32) if self.rs_alltoall else None,
                 eB_range=self.eB[lo:hi], eB_own=self.eB[o0:o0 + m], shp_own=self.Lambda_shp[o0:o0 + m],
                 fac_own=self.Beta[o0:o0 + m], rs_own=self.t_rte[o0:o0 + m], rsp_own=self.t_rte_prev[o0:o0 + m]))
             g0 += g
@@ -437,7 +439,13 @@ class FullBatchCavi:
                     ops.segsum(self.part_i, self.items.row_seg_ptr, c["nmulti"], self.acc_i, ld, row_list=c["multi"],
                                acc_ld=k, acc_by_row=True)
                 with self._exchange(xs):           # the exchange stream continues after this range's sweep
-                    dist.reduce_scatter_tensor(c["acc_own"], c["acc"])
+                    if self.rs_alltoall:
+                        # direct form: slice j of the range goes straight to rank j (one hop over every xGMI link at
+                        # once), which then adds up the N slices it received, in rank order
+                        dist.all_to_all_single(c["a2a_recv"], c["acc"])
+                        torch.sum(c["a2a_recv"].view(self.world, c["m"], k), dim=0, out=c["acc_own"])
+                    else:
+                        dist.reduce_scatter_tensor(c["acc_own"], c["acc"])
         if its is not None:
             for c in views:
                 self._wait(c.get("ag_done"))

@@ -552,6 +552,7 @@ def test_tiny_shape_priors(hip_backend):
 
 @pytest.mark.parametrize("world,mode,lazy,k", [(2, "scatter", "1", 20), (3, "scatter", "1", 20),
                                                (2, "scatter", "no-item-stream", 20), (2, "scatter", "1", 100),
+                                               (3, "scatter", "a2a", 20),
                                                (2, "allreduce", "1", 20), (3, "allreduce", "1", 20),
                                                (2, "allreduce", "0", 20), (2, "allreduce", "1", 100)])
 def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypatch, world, mode, lazy, k):
@@ -564,6 +565,9 @@ def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypat
     monkeypatch.setenv("HPF_SHARD_MODE", mode)   # reduce-scatter + sharded finalizer, or all-reduce + replicated one
     if lazy == "no-item-stream":                  # scatter mode with the item pass on the compute stream
         monkeypatch.setenv("HPF_ITEM_STREAM", "0")
+        lazy = "1"
+    if lazy == "a2a":                             # scatter mode, reduce-scatter as all-to-all + local sum
+        monkeypatch.setenv("HPF_RS_ALLTOALL", "1")
         lazy = "1"
     monkeypatch.setenv("HPF_LAZY_ITEMS", lazy)   # all-reduce mode, "0": standalone item finalizer after the exchange
     its = 5
