@@ -311,7 +311,8 @@ def main():
         # the plain all-reduce configurations go first: they are the most conservative use of RCCL
         for mode, chunks, istream, a2a in (("allreduce", "3", "1", "0"), ("allreduce", "2", "1", "0"),
                                            ("scatter", "2", "1", "0"), ("scatter", "3", "1", "0"),
-                                           ("scatter", "2", "0", "0"), ("scatter", "2", "1", "1")):
+                                           ("scatter", "2", "0", "0"), ("scatter", "1", "1", "0"),
+                                           ("scatter", "2", "1", "1")):
             os.environ["HPF_SHARD_MODE"], os.environ["HPF_AR_CHUNKS"], os.environ["HPF_ITEM_STREAM"] = mode, chunks, istream
             os.environ["HPF_RS_ALLTOALL"] = a2a
             key = "%s/%s%s%s" % (mode, chunks, "" if istream == "1" else "/items-on-compute-stream",
