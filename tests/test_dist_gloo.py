@@ -23,13 +23,17 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,case,mode", [(2, "c1", "scatter"), (3, "mid", "scatter"), (3, "c1", "scatter"),
-                                             (3, "c1", "scatter-a2a"), (2, "c1", "allreduce"), (3, "mid", "allreduce")])
+                                             (3, "c1", "scatter-a2a"), (3, "c1", "scatter-one-range"),
+                                             (2, "c1", "allreduce"), (3, "mid", "allreduce")])
 def test_sharded_equals_single(tmp_path, cpu_ops_backend, monkeypatch, world, case, mode):
     """mode: "scatter" = reduce-scatter / sharded item finalizer / all-gather (default); "allreduce" = all-reduce +
     replicated deferred finalizer.  (3, c1): 100 items over 3 ranks -> pad rows in the item tables."""
     if mode == "scatter-a2a":                     # reduce-scatter as all-to-all + local sum
         mode = "scatter"
         monkeypatch.setenv("HPF_RS_ALLTOALL", "1")
+    if mode == "scatter-one-range":               # no exchange pipelining
+        mode = "scatter"
+        monkeypatch.setenv("HPF_AR_CHUNKS", "1")
     monkeypatch.setenv("HPF_SHARD_MODE", mode)
     k, its = 20, 5
     if case == "c1":
