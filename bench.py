@@ -451,6 +451,9 @@ def main():
                                   "frac_of_hbm_peak": b_iter / (ms * 1e-3) / HBM_PEAK if world == 1 else None},
                     "kernels_ms_per_step": {n: v["total_ms"] / ev_steps for n, v in ksum.items()},
                     "events": "timed region" if events_in_timed else "separate pass of %d iterations after the timed region" % ev_steps}
+            if roof["frac"] > 1.0:
+                roof["note"] = ("algorithmic bytes exceed what HBM delivers: at this size the gathered tables stay in "
+                                "L2 / Infinity Cache (each gather is still counted at face value, SURVEY.md section 8d)")
         watchdog_state["done"] = True
         line = {
             "metric": "full-batch CAVI iters/sec (48M nnz, k=50)" if args.workload == "c3" else
