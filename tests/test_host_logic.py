@@ -60,6 +60,18 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     assert L.hpf_hip_ld_for_k(2000) == EUNSUPPORTED
 
 
+def test_integration_doc_stub_matches_the_abi():
+    """The ctypes stub shown in INTEGRATION.md must stay in step with include/hpf_hip.h."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"lib\.hpf_hip_sweep_f32\.argtypes = \[(.*?)\]", doc)
+    hdr = open(os.path.join(ROOT, "include", "hpf_hip.h")).read()
+    decl = re.search(r"int hpf_hip_sweep_f32\((.*?)\);", hdr, re.S).group(1)
+    assert len(m.group(1).split(",")) == len(decl.split(","))
+    L = _lib.lib() if torch.cuda.is_available() else None
+    if L is not None:
+        assert len(L.hpf_hip_sweep_f32.argtypes) == len(decl.split(","))
+
+
 def test_missing_gpu_fails_loudly():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
