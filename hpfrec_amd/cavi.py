@@ -77,7 +77,8 @@ class _SideView:
         self.nseg = seg_hi - seg_lo
         self.idx, self.y = side.idx, side.y
         # launch hint (hpf_hip_sweep_f32): a shard of a many-rank run leaves ~16 nonzeros per item row
-        self.short_rows = nnz is not None and self.nseg > 0 and nnz / self.nseg < layout.SHORT_ROW_NNZ
+        self.short_rows = layout.SHORT_VARIANT if (nnz is not None and self.nseg > 0 and
+                                                   nnz / self.nseg < layout.SHORT_ROW_NNZ) else 0
 
 
 class FullBatchCavi:
@@ -96,9 +97,15 @@ class FullBatchCavi:
                                                                    self.nU, self.nI, seg_cap)
         self.nnz = self.users.nnz
         self.dist = _dist()
+        # sweep grid of THIS model (the op set is shared): sharded launches cover short item ranges and want fewer,
+        # fatter blocks (16 per CU costs 3 % at N=8, gains 1 % at N=1)
+        self.sweep_blocks = ops.sweep_blocks
         if self.dist and "HPF_SWEEP_BPC" not in os.environ and hasattr(ops, "cu_count"):
-            # sharded launches cover short item ranges: fewer, fatter blocks (16 per CU costs 3 % at N=8, gains 1 % at N=1)
-            ops.sweep_blocks = max(1, ops.cu_count) * 8
+            self.sweep_blocks = max(1, ops.cu_count) * 8
+        # the sharded item pass is many short rows: more, smaller blocks even out its tail (tools/sweep_micro.py:
+        # 203 us at 32 blocks per CU vs 220 at 8 for rank 0 of 8 at C3)
+        self.item_sweep_blocks = max(1, getattr(ops, "cu_count", 1)) * int(os.environ.get("HPF_ITEM_SWEEP_BPC", "32")) \
+            if hasattr(ops, "cu_count") else self.sweep_blocks
         ld = self.ld
         f32 = dict(dtype=torch.float32, device=dev)
         z = lambda n: torch.zeros((n, ld), **f32)
@@ -136,7 +143,8 @@ class FullBatchCavi:
         self.part_i = torch.empty((max(1, self.items.nseg), ld), **f32)
         # column-sum partials: [fused-sweep blocks | finalize blocks of the rows the sweep cannot finish]
         self.fused = True
-        self.gsu, self.gsi = ops.sweep_grid(self.users.nseg), ops.sweep_grid(self.items.nseg)
+        self.gsu = ops.sweep_grid(self.users.nseg, self.sweep_blocks)
+        self.gsi = ops.sweep_grid(self.items.nseg, self.sweep_blocks)
         self.gu, self.gi = ops.finalize_grid(self.nU), ops.finalize_grid(self.nI)
         self.csT_part = torch.zeros((self.gsu + self.gu, ld), **f32)
         self.csB_part = torch.zeros((self.gsi + self.gi, ld), **f32)   # re-sized below for the sharded path
@@ -154,7 +162,7 @@ class FullBatchCavi:
         self.niter_done = 0
         self._chunk_views = None
         self.rs_alltoall = os.environ.get("HPF_RS_ALLTOALL", "0") == "1"   # scatter mode: all-to-all + local sum
-        self.item_stream = os.environ.get("HPF_ITEM_STREAM", "1") == "1"   # scatter mode: item pass on its own stream
+        self.item_stream = os.environ.get("HPF_ITEM_STREAM", "0") == "1"   # scatter mode: item pass on its own stream
         self.lazy_items = os.environ.get("HPF_LAZY_ITEMS", "1") == "1"
         self.item_pending = False   # sharded path: acc_i holds reduced statistics not yet applied to the item tables
 
@@ -250,7 +258,7 @@ class FullBatchCavi:
             ops.row_finalize(part, side.row_seg_ptr, nm, e_self, e_new, shp, None, fac, rs, cs_other,
                              cs_part[gs: gs + gm], prior, top, add, k, ld, row_list=side.multi_rows, rs_prev=rs_prev)
         else:
-            ops.sweep(side, e_self, e_other, part, k, ld)
+            ops.sweep(side, e_self, e_other, part, k, ld, grid_blocks=self.sweep_blocks)
             ops.row_finalize(part, side.row_seg_ptr, nrows, e_self, e_new, shp, None, fac, rs, cs_other,
                              cs_part[gs:], prior, top, add, k, ld, rs_prev=rs_prev)
 
@@ -298,6 +306,60 @@ class FullBatchCavi:
         self.eT, self.eT_next = self.eT_next, self.eT
         self.niter_done += 1
 
+    def iterate_many(self, n, store=True):
+        """n iterations with the same `store` flag.  Scatter mode on RCCL with HPF_GRAPH=1: pairs of iterations (the E
+        tables are double-buffered, so a pair restores every pointer) are replayed from a captured hipGraph -- one
+        host call per pair instead of ~25 launches / collective calls / stream operations per iteration; anything
+        that cannot be captured falls back to plain calls for good."""
+        n = int(n)
+        if n >= 4 and self._graph_capable():
+            while self.niter_done < 2:      # warm up eagerly first (lazy allocations, RCCL channel setup)
+                self.iterate(store)
+                n -= 1
+            g = self._pair_graph(bool(store))
+            if g is not None:
+                for _ in range(n // 2):
+                    g.replay()
+                self.niter_done += 2 * (n // 2)
+                n -= 2 * (n // 2)
+        for _ in range(n):
+            self.iterate(store)
+
+    def _graph_capable(self):
+        if not (self.dist and self.shard_mode == "scatter" and self.device.type == "cuda"):
+            return False
+        if os.environ.get("HPF_GRAPH", "0") != "1" or getattr(self, "_graph_failed", False):
+            return False
+        try:
+            return self.dist.get_backend() == "nccl"     # gloo collectives run on the host: nothing to capture
+        except Exception:   # noqa: BLE001  (stand-ins for torch.distributed in probes: assume capturable)
+            return True
+
+    def _pair_graph(self, store):
+        graphs = self.__dict__.setdefault("_graphs", {})
+        if store in graphs:
+            return graphs[store]
+        g = None
+        done0 = self.niter_done
+        try:
+            self._sync_scatter_streams()
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self.iterate(store)
+                self.iterate(store)
+                self._sync_scatter_streams()    # side streams join the capturing stream
+            torch.cuda.synchronize(self.device)
+        except Exception as exc:   # noqa: BLE001
+            g = None
+            self._graph_failed = True
+            self._graph_error = "%s: %s" % (type(exc).__name__, str(exc)[:200])
+            torch.cuda.synchronize(self.device)
+            self._sc_fresh = True
+        self.niter_done = done0         # capture records the launches, it does not run them
+        graphs[store] = g
+        return g
+
     def _sharded_views(self):
         """Per item range: tensor views and column-sum partial slots, built once (the sharded loop is
         host-overhead sensitive).  Two partial layouts: `csp` for the standalone finalizer (flush), and
@@ -307,13 +369,13 @@ class FullBatchCavi:
         ops, ld = self.ops, self.ld
         f32 = dict(dtype=torch.float32, device=self.device)
         gm = max(1, min(self.gi, (self.items.nmulti + 3) // 4))
-        lazy_rows = sum(ops.sweep_grid(v.nseg) for _, _, v, _ in self.item_chunks) + gm
+        lazy_rows = sum(ops.sweep_grid(v.nseg, self.sweep_blocks) for _, _, v, _ in self.item_chunks) + gm
         self.csB_part_lazy = torch.zeros((lazy_rows, ld), **f32)
         self._csp_multi = self.csB_part_lazy[lazy_rows - gm:]
         views, g0, l0 = [], self.gsi, 0
         for lo, hi, view, multi in self.item_chunks:
             g1 = g0 + ops.finalize_grid(hi - lo)
-            l1 = l0 + ops.sweep_grid(view.nseg)
+            l1 = l0 + ops.sweep_grid(view.nseg, self.sweep_blocks)
             views.append(dict(
                 n=hi - lo, view=view, multi=multi, nmulti=int(multi.shape[0]), part=self.part_i[view.seg_lo:],
                 acc=self.acc_i[lo:hi], eB=self.eB[lo:hi], shp=self.Lambda_shp[lo:hi], rsp=self.t_rte_prev[lo:hi],
@@ -347,13 +409,14 @@ class FullBatchCavi:
         for c in views:
             # whole-row segments leave their accumulator straight in the packed buffer; only split rows
             # (and rows without local nonzeros: zeros) go through part[] + segsum
-            if lazy:
+            if lazy and c["view"].nseg > 0:   # (a range without local nonzeros: its rows are all in multi_rows)
                 ops.sweep_prefinalize(c["view"], self.eB, self.eT, c["part"], self.acc_i, k,
                                       self.Lambda_shp if store else None, None,
                                       self.Beta if store else None, self.t_rte, self.csT, c["csp_lazy"], hy.c, hy.t_shp,
                                       hy.add_t_rte, k, ld, rs_prev=self.t_rte_prev)
-            elif c["view"].nseg > 0:
-                ops.sweep(c["view"], self.eB, self.eT, c["part"], k, ld, acc_rows=self.acc_i, acc_ld=k)
+            elif not lazy and c["view"].nseg > 0:
+                ops.sweep(c["view"], self.eB, self.eT, c["part"], k, ld, acc_rows=self.acc_i, acc_ld=k,
+                          grid_blocks=self.sweep_blocks)
             if c["nmulti"] > 0:
                 ops.segsum(self.part_i, self.items.row_seg_ptr, c["nmulti"], self.acc_i, ld, row_list=c["multi"],
                            acc_ld=k, acc_by_row=True)
@@ -376,28 +439,38 @@ class FullBatchCavi:
 
     # ------------------------------------------------------------------------------------
     def _scatter_views(self):
-        """Scatter mode, per item range: the range, this rank's slice of it and the exchange buffers."""
+        """Scatter mode, per item range: the range, this rank's slice of it and the exchange buffers.  The slices
+        this rank owns of all ranges are concatenated (reduce-scatter outputs `acc_own_all`, new E rows `e_own_all`)
+        so that ONE finalize launch covers them (hpf_hip_row_finalize_ranges_f32)."""
         if self._chunk_views is not None:
             return self._chunk_views
         ops, ld, k, W, r = self.ops, self.ld, self.k, self.world, self.rank
         f32 = dict(dtype=torch.float32, device=self.device)
-        grids = [ops.finalize_grid((hi - lo) // W) for lo, hi, _, _ in self.item_chunks]
-        self.csB_part_sc = torch.zeros((sum(grids), ld), **f32)
-        views, g0 = [], 0
-        for (lo, hi, view, multi), g in zip(self.item_chunks, grids):
+        cuda = self.device.type == "cuda"
+        total = sum((hi - lo) // W for lo, hi, _, _ in self.item_chunks)
+        self.acc_own_all = torch.zeros((total, k), **f32)
+        self.e_own_all = torch.zeros((total, ld), **f32)
+        views, t0, ranges = [], 0, []
+        for lo, hi, view, multi in self.item_chunks:
             m = (hi - lo) // W
             o0 = lo + r * m
             n_real = max(0, min(m, self.nI - o0))
-            gr = ops.finalize_grid(n_real) if n_real > 0 else 0
+            if n_real > 0:
+                ranges.append((n_real, t0, o0))
             views.append(dict(
                 lo=lo, hi=hi, m=m, o0=o0, o1=o0 + m, n_real=n_real, view=view, multi=multi, nmulti=int(multi.shape[0]),
-                part=self.part_i[view.seg_lo:], acc=self.acc_i[lo:hi], acc_own=torch.zeros((m, k), **f32),
-                e_own=torch.zeros((m, ld), **f32), csp=self.csB_part_sc[g0: g0 + gr],
+                part=self.part_i[view.seg_lo:], acc=self.acc_i[lo:hi], acc_own=self.acc_own_all[t0:t0 + m],
+                e_own=self.e_own_all[t0:t0 + m],
                 # views used every iteration (slicing costs host time in a loop that is ~40 % host-bound at 8 ranks)
                 a2a_recv=torch.zeros((W * m, k), **f32) if self.rs_alltoall else None,
-                eB_range=self.eB[lo:hi], eB_own=self.eB[o0:o0 + m], shp_own=self.Lambda_shp[o0:o0 + m],
-                fac_own=self.Beta[o0:o0 + m], rs_own=self.t_rte[o0:o0 + m], rsp_own=self.t_rte_prev[o0:o0 + m]))
-            g0 += g
+                eB_range=self.eB[lo:hi],
+                # dedicated events (re-recorded every iteration, waited for before the next record)
+                sw_done=torch.cuda.Event() if cuda else None, ag_done=torch.cuda.Event() if cuda else None))
+            t0 += m
+        self._fin_ranges = ranges
+        self.csB_part_sc = torch.zeros((ops.finalize_grid(max(1, sum(n for n, _, _ in ranges))), ld), **f32)
+        self._csT_ready = torch.cuda.Event() if cuda else None
+        self._sc_fresh = True
         self._chunk_views = views
         return views
 
@@ -405,71 +478,81 @@ class FullBatchCavi:
         """Users sharded over ranks, item FINALIZER sharded too.  Per item range (fewest rows first):
         sweep the local CSC slice into the packed exchange buffer, then a REDUCE-SCATTER on the exchange stream
         leaves each rank with the global statistics of its 1/N slice of the range; the user side runs under the
-        exchange; after the k-float all-reduce of colsum(Theta) each rank finalizes only its slices (dense
-        row_finalize: 1/N of the fp64 work and of the table stores), and an ALL-GATHER of the new E rows -- straight
-        into the replicated E table -- is waited for only by the next iteration's sweep of that range.  colsum(Beta)
-        is a k-float all-reduce of the per-rank partial sums on the exchange stream, ahead of the all-gathers.  Same
-        bytes on the wire as the all-reduce form.  Lambda_shp / Beta / t_rte are current on the owning rank only;
-        flush_items() gathers them.
+        exchange.  Everything after it is ONE in-order chain on the exchange stream: the k-float all-reduce of
+        colsum(Theta), the finalizer of this rank's slices (ONE dense launch over the slices of all ranges: 1/N of
+        the fp64 work and of the table stores), the ALL-GATHERS of the new E rows -- straight into the replicated E
+        table, each waited for only by the next iteration's sweep of that range -- and, behind them (the next user
+        side is its only reader), the k-float all-reduce of this rank's partial colsum(Beta).  Same bytes on the
+        wire as the all-reduce form.  Lambda_shp / Beta / t_rte are current on the owning rank only; flush_items()
+        gathers them.
 
-        The collectives are issued with async_op=False inside the exchange stream's context: they are then ordered
-        on THAT stream, and the dependencies on the compute stream are this function's own events -- three each way
-        per iteration instead of two per collective (2.4 % of an N=8 iteration at C3)."""
+        Streams: compute (sweeps, user finalizer), exchange (collectives + item finalizer; collectives are issued
+        with async_op=False inside the exchange stream's context, i.e. ordered on THAT stream) and, with
+        HPF_ITEM_STREAM=1, a third one for the item sweeps.  A cross-stream dependency costs ~15-20 us on the
+        waiting stream (tools/handover_probe.py), so the critical cycle user side -> finalizer -> all-gather ->
+        next sweep crosses streams exactly twice; all other waits are for work that finished long before."""
         ops, hy, k, ld, dist = self.ops, self.hy, self.k, self.ld, self.dist
         views = self._scatter_views()
         xs = self._xstream()
-        # The item pass runs on its OWN stream, concurrently with the user side: both only read last iteration's E
-        # tables.  A range's sweep waits for that range's all-gather only; the user side (below, compute stream)
-        # needs all of them.  The short launches of a many-rank run then fill each other's tails, and the
-        # dependencies of the item pass stall a stream the GPU is not waiting for.  (No GPU / HPF_ITEM_STREAM=0:
-        # `its` is None and everything below is issued in order on the one stream.)
-        its = self._istream() if self.item_stream else None
-        if its is not None and views[0].get("ag_done") is None:
-            its.wait_event(self._mark(torch.cuda.current_stream(self.device)))   # first iteration: after load_state
+        cuda = xs is not None
+        cs = torch.cuda.current_stream(self.device) if cuda else None
+        ist = (self._istream() if self.item_stream else cs) if cuda else None
+        fresh = self._sc_fresh
+        if cuda and fresh:
+            for st in (ist, xs):            # first iteration after load_state: order after whatever the caller queued
+                if st is not cs:
+                    st.wait_event(self._mark(cs))
+        on = (lambda st: torch.cuda.stream(st)) if cuda else (lambda st: contextlib.nullcontext())
         for c in views:
-            if its is not None:
-                if c.get("ag_done") is not None:
-                    its.wait_event(c["ag_done"])
-            else:
-                self._wait(c.get("ag_done"))     # this range's E rows from the previous iteration's finalizers
-            with (torch.cuda.stream(its) if its is not None else contextlib.nullcontext()):
+            if cuda and not fresh:
+                ist.wait_event(c["ag_done"])   # this range's E rows from the previous iteration's finalizers
+            with on(ist):
                 if c["view"].nseg > 0:
-                    ops.sweep(c["view"], self.eB, self.eT, c["part"], k, ld, acc_rows=self.acc_i, acc_ld=k)
+                    ops.sweep(c["view"], self.eB, self.eT, c["part"], k, ld, acc_rows=self.acc_i, acc_ld=k,
+                              grid_blocks=self.item_sweep_blocks)
                 if c["nmulti"] > 0:
                     ops.segsum(self.part_i, self.items.row_seg_ptr, c["nmulti"], self.acc_i, ld, row_list=c["multi"],
                                acc_ld=k, acc_by_row=True)
-                with self._exchange(xs):           # the exchange stream continues after this range's sweep
-                    if self.rs_alltoall:
-                        # direct form: slice j of the range goes straight to rank j (one hop over every xGMI link at
-                        # once), which then adds up the N slices it received, in rank order
-                        dist.all_to_all_single(c["a2a_recv"], c["acc"])
-                        torch.sum(c["a2a_recv"].view(self.world, c["m"], k), dim=0, out=c["acc_own"])
-                    else:
-                        dist.reduce_scatter_tensor(c["acc_own"], c["acc"])
-        if its is not None:
-            for c in views:
-                self._wait(c.get("ag_done"))
-        rs_done = self._mark(xs)
-        # colsum(Beta) of the previous iteration was all-reduced ahead of the all-gathers just waited for
+            if cuda:
+                c["sw_done"].record(ist)
+                xs.wait_event(c["sw_done"])
+            with on(xs):
+                if self.rs_alltoall:
+                    # direct form: slice j of the range goes straight to rank j (one hop over every xGMI link at
+                    # once), which then adds up the N slices it received, in rank order
+                    dist.all_to_all_single(c["a2a_recv"], c["acc"])
+                    torch.sum(c["a2a_recv"].view(self.world, c["m"], k), dim=0, out=c["acc_own"])
+                else:
+                    dist.reduce_scatter_tensor(c["acc_own"], c["acc"])
+        if cuda and not fresh:
+            if ist is not cs:                  # (same stream: the sweeps above waited already; the last range's
+                for c in views:                # all-gather also orders the colsum(Beta) all-reduce issued ahead of it)
+                    cs.wait_event(c["ag_done"])
         self._keep_csB(store)
         self._side_update(self.users, self.nU, self.eT, self.eB, self.eT_next, self.part_u, self.Gamma_shp,
                           self.k_rte_prev, self.Theta, self.k_rte, self.csB, self.csT_part, self.gsu, self.gu,
                           hy.a, hy.k_shp, hy.add_k_rte, store)
         ops.colsum_reduce(self.csT_part, self.csT, ld)
-        dist.all_reduce(self.csT)
-        self._wait(rs_done)
-        for c in views:
-            if c["n_real"] > 0:
-                ops.row_finalize(c["acc_own"], None, c["n_real"], c["eB_own"], c["e_own"],
-                                 c["shp_own"] if store else None, None, c["fac_own"] if store else None,
-                                 c["rs_own"], self.csT, c["csp"], hy.c, hy.t_shp, hy.add_t_rte, k, ld, part_ld=k,
-                                 rs_prev=c["rsp_own"])
-        ops.colsum_reduce(self.csB_part_sc, self.csB, ld)      # this rank's partial colsum(Beta) ...
-        with self._exchange(xs):
-            dist.all_reduce(self.csB)                          # ... summed over ranks
-            for c in views:
+        if cuda:
+            self._csT_ready.record(cs)
+            xs.wait_event(self._csT_ready)
+        with on(xs):
+            dist.all_reduce(self.csT)
+            if self._fin_ranges:
+                ops.row_finalize_ranges(self.acc_own_all, self._fin_ranges, self.eB, self.e_own_all,
+                                        self.Lambda_shp if store else None, None, self.Beta if store else None,
+                                        self.t_rte, self.csT, self.csB_part_sc, hy.c, hy.t_shp, hy.add_t_rte, k, ld, k,
+                                        rs_prev=self.t_rte_prev)
+            for j, c in enumerate(views):
+                if j == len(views) - 1:
+                    # colsum(Beta) -- read by the next USER side only -- goes ahead of the last all-gather (which the
+                    # user side waits for anyway) and behind the first one (which the next item sweep is waiting for)
+                    ops.colsum_reduce(self.csB_part_sc, self.csB, ld)      # this rank's partial colsum(Beta) ...
+                    dist.all_reduce(self.csB)                              # ... summed over ranks
                 dist.all_gather_into_tensor(c["eB_range"], c["e_own"])
-                c["ag_done"] = self._mark(xs)
+                if cuda:
+                    c["ag_done"].record(xs)
+        self._sc_fresh = False
         self._tables_split = True
         self.eT, self.eT_next = self.eT_next, self.eT
         self.niter_done += 1
@@ -520,11 +603,17 @@ class FullBatchCavi:
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
 
+    def _sync_scatter_streams(self):
+        """Scatter mode: the current stream waits for the exchanges still in flight on the side streams."""
+        views = self._chunk_views or []
+        if views and not getattr(self, "_sc_fresh", True):
+            for c in views:
+                self._wait(c["ag_done"])
+            self._sc_fresh = True        # the next iteration re-synchronises its side streams with this one
+
     def _sync_scatter(self):
         """Scatter mode: wait for the outstanding exchanges and gather the per-owner item tables."""
-        for c in (self._chunk_views or []):
-            self._wait(c.get("ag_done"))
-            c["ag_done"] = None
+        self._sync_scatter_streams()
         if self._tables_split:
             for c in self._scatter_views():
                 for tab in (self.Lambda_shp, self.Beta, self.t_rte, self.t_rte_prev):

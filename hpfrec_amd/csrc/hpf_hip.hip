@@ -35,6 +35,9 @@ constexpr int WPB = BLOCK / WAVE;
 #ifndef HPF_U
 #define HPF_U 8  // gathers in flight per wavefront (U=4: -3%, U=2: -11%, U=16: -12% at C3)
 #endif
+#ifndef HPF_UG
+#define HPF_UG 4  // gathers in flight per lane group of sweep_groups_kernel (short rows)
+#endif
 #ifndef HPF_NT
 #define HPF_NT 0  // 1: non-temporal hints on the streamed operands (idx, y, part)
 #endif
@@ -432,15 +435,118 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
     }
 }
 
+// Short rows (a shard of a many-rank run leaves ~16 nonzeros per item row; SVI batches): ONE SEGMENT PER LANE GROUP
+// instead of one per wavefront -- the NG = 64/LPR groups of a wave each own a segment (its E row, its accumulator),
+// so a wave's pass over the segment list carries NG rows through the descriptor -> idx/y -> gather latency chain
+// at once and no lane idles while a 16-nonzero row is 4 steps long.  Same arithmetic per nonzero as sweep_kernel
+// (MODE 0); the accumulation order inside a row is sequential here (one group), so sums differ from the
+// wave-per-segment kernel in rounding only.  Fixed order -> bit-reproducible.
+template <int LPR, int UU>
+__global__ __launch_bounds__(BLOCK) void sweep_groups_kernel(const hpf_segment *__restrict__ segs, int64_t nseg,
+                                                             const int32_t *__restrict__ idx,
+                                                             const float *__restrict__ y,
+                                                             const float *__restrict__ tab_self,
+                                                             const float *__restrict__ tab_other,
+                                                             float *__restrict__ part, float *__restrict__ acc_rows,
+                                                             int acc_ld) {
+    constexpr int LD = 4 * LPR;
+    constexpr int NG = WAVE / LPR;
+    constexpr int U = UU;
+    static_assert(LPR % UU == 0, "a chunk of LPR nonzeros is a whole number of batches");
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int gbase = lane & ~(LPR - 1);
+    const int g = lane / LPR;
+    const int j = lane % LPR;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WPB;
+    for (int64_t s0 = ((int64_t)blockIdx.x * WPB + wid) * NG; s0 < nseg; s0 += nwaves * NG) {
+        const int64_t sg = s0 + g;
+        const bool live = sg < nseg;
+        hpf_segment sgm;
+        sgm.begin = 0;
+        sgm.len = 0;
+        sgm.row = 0;
+        if (live) sgm = segs[sg];
+        const int len = sgm.len & HPF_SEG_LEN_MASK;
+        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f), acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) rv = reinterpret_cast<const float4 *>(tab_self + (size_t)sgm.row * LD)[j];
+        const int32_t *ip = idx + sgm.begin;
+        const float *yp = y + sgm.begin;
+        int maxlen = len;
+#pragma unroll
+        for (int m = LPR; m < WAVE; m <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m));
+        maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+        for (int base = 0; base < maxlen; base += LPR) {
+            const int n = len - base;   // this group's remaining nonzeros (may be <= 0)
+            int myc = 0;
+            float myy = 0.f;
+            if (j < n) {
+                myc = ip[base + j];
+                myy = yp[base + j];
+            }
+            int nsteps = min(LPR, maxlen - base);
+            nsteps = (nsteps + U - 1) & ~(U - 1);
+            for (int t0 = 0; t0 < nsteps; t0 += U) {
+                float4 o[U];
+                float yy[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int src = gbase + t0 + u;
+                    const int cc = __shfl(myc, src);
+                    yy[u] = __shfl(myy, src);
+                    o[u] = reinterpret_cast<const float4 *>(tab_other + (size_t)cc * LD)[j];
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const float s = group_sum<LPR>(dot4(rv, o[u]));
+                    const float w = (yy[u] > 0.f) ? yy[u] * __builtin_amdgcn_rcpf(s) : 0.f;
+                    acc.x = fmaf(w, o[u].x, acc.x);
+                    acc.y = fmaf(w, o[u].y, acc.y);
+                    acc.z = fmaf(w, o[u].z, acc.z);
+                    acc.w = fmaf(w, o[u].w, acc.w);
+                }
+            }
+        }
+        if (live) {
+            if ((sgm.len & HPF_SEG_WHOLE_ROW) && acc_rows) {
+                float *ar = acc_rows + (size_t)sgm.row * acc_ld;
+                const int c = j * 4;
+                if (acc_ld == LD) {
+                    reinterpret_cast<float4 *>(ar)[j] = acc;
+                } else {
+                    if (c + 0 < acc_ld) ar[c + 0] = acc.x;
+                    if (c + 1 < acc_ld) ar[c + 1] = acc.y;
+                    if (c + 2 < acc_ld) ar[c + 2] = acc.z;
+                    if (c + 3 < acc_ld) ar[c + 3] = acc.w;
+                }
+            } else {
+                reinterpret_cast<float4 *>(part + (size_t)sg * LD)[j] = acc;
+            }
+        }
+    }
+}
+
 // DENSE: every row has exactly one accumulator row (row_seg_ptr == row_list == nullptr; the replicated item
 // finalizer of the sharded path, over all-reduced statistics): the loads of the NEXT row are issued before the
 // fp64 work of the current one, and the generic segment loops are compiled out.
+// DENSE only: the launch covers virtual rows v = 0..nrows-1; v in range i (v_begin[i] <= v < v_begin[i+1]) stands for
+// accumulator row t = t_begin[i] + (v - v_begin[i]) of `part` -- e_new is indexed by t as well: it is the all-gather
+// send buffer -- and table row r = row_begin[i] + (v - v_begin[i]) of e_old/shp/rte/fac/rs.  The slices one rank owns
+// of several item ranges are finished by ONE launch.
+struct RowRanges {
+    int n;                                   // 0: identity (accumulator row t <-> table row t, e_new row t)
+    int64_t v_begin[HPF_MAX_ROW_RANGES];     // first virtual index of range i (prefix sums of the range lengths)
+    int64_t t_begin[HPF_MAX_ROW_RANGES];     // its first accumulator row (and e_new row)
+    int64_t row_begin[HPF_MAX_ROW_RANGES];   // its first table row
+};
+
 template <int LD, bool DENSE>
 __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
     const float *__restrict__ part, const int64_t *__restrict__ row_seg_ptr, const int64_t *__restrict__ row_list,
     int64_t nrows, const float *e_old, float *e_new, float *__restrict__ shp, float *__restrict__ rte,
     float *__restrict__ fac, float *rs, float *__restrict__ rs_prev, const float *__restrict__ cs_other,
-    float *__restrict__ cs_partial, float prior_shp, float top_shp, float add_rte, int k, int part_ld) {
+    float *__restrict__ cs_partial, float prior_shp, float top_shp, float add_rte, int k, int part_ld,
+    const RowRanges rr) {
     constexpr int CPL = (LD + WAVE - 1) / WAVE;  // factors per lane
     __shared__ float red[WPB][LD];
     const int lane = threadIdx.x & (WAVE - 1);
@@ -456,7 +562,7 @@ __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
     }
 
     // the closed-form updates of row r from its accumulator entries a[], old E entries eo[] and old scalar rate
-    auto finish = [&](int64_t r, const float (&a)[CPL], const float (&eo)[CPL], float rs_old) {
+    auto finish = [&](int64_t r, int64_t re, const float (&a)[CPL], const float (&eo)[CPL], float rs_old) {
         const float base_rte = top_shp / rs_old;
         float sh[CPL], rt[CPL], fc[CPL];
         double ev[CPL];
@@ -481,7 +587,7 @@ __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
             if (c < LD) {
                 const size_t o = (size_t)r * LD + c;
                 const bool valid = c < k;
-                e_new[o] = valid ? (float)(ev[q] * inv) : 0.f;
+                e_new[(size_t)re * LD + c] = valid ? (float)(ev[q] * inv) : 0.f;
                 if (shp) shp[o] = valid ? sh[q] : 0.f;
                 if (rte) rte[o] = valid ? rt[q] : 0.f;
                 if (fac) fac[o] = fc[q];
@@ -494,28 +600,50 @@ __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
     };
 
     if constexpr (DENSE) {
-        auto fetch = [&](int64_t r, float (&a)[CPL], float (&eo)[CPL], float &rs_old) {
+        auto locate = [&](int64_t v, int64_t &t, int64_t &r) {
+            t = v;
+            r = v;
+            if (rr.n > 0) {
+                t = rr.t_begin[0] + v;
+                r = rr.row_begin[0] + v;
+#pragma unroll
+                for (int i = 1; i < HPF_MAX_ROW_RANGES; i++)
+                    if (i < rr.n && v >= rr.v_begin[i]) {
+                        t = rr.t_begin[i] + (v - rr.v_begin[i]);
+                        r = rr.row_begin[i] + (v - rr.v_begin[i]);
+                    }
+            }
+        };
+        auto fetch = [&](int64_t t, int64_t r, float (&a)[CPL], float (&eo)[CPL], float &rs_old) {
 #pragma unroll
             for (int q = 0; q < CPL; q++) {
                 const int c = lane + WAVE * q;
-                a[q] = (c < part_ld) ? part[(size_t)r * part_ld + c] : 0.f;
+                a[q] = (c < part_ld) ? part[(size_t)t * part_ld + c] : 0.f;
                 eo[q] = (c < LD) ? e_old[(size_t)r * LD + c] : 0.f;
             }
             rs_old = rs[r];
         };
-        int64_t t = (int64_t)blockIdx.x * WPB + wid;
+        int64_t v = (int64_t)blockIdx.x * WPB + wid;
         float a_n[CPL], eo_n[CPL], rs_n = 1.f;
-        if (t < nrows) fetch(t, a_n, eo_n, rs_n);
-        for (; t < nrows; t += nwaves) {
+        int64_t t_n = 0, r_n = 0;
+        if (v < nrows) {
+            locate(v, t_n, r_n);
+            fetch(t_n, r_n, a_n, eo_n, rs_n);
+        }
+        for (; v < nrows; v += nwaves) {
             float a[CPL], eo[CPL];
             const float rs_old = rs_n;
+            const int64_t r = r_n, t = t_n;
 #pragma unroll
             for (int q = 0; q < CPL; q++) {
                 a[q] = a_n[q];
                 eo[q] = eo_n[q];
             }
-            if (t + nwaves < nrows) fetch(t + nwaves, a_n, eo_n, rs_n);
-            finish(t, a, eo, rs_old);
+            if (v + nwaves < nrows) {
+                locate(v + nwaves, t_n, r_n);
+                fetch(t_n, r_n, a_n, eo_n, rs_n);
+            }
+            finish(r, (rr.n > 0) ? t : r, a, eo, rs_old);
         }
     } else {
         for (int64_t t = (int64_t)blockIdx.x * WPB + wid; t < nrows; t += nwaves) {
@@ -543,7 +671,7 @@ __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
                 }
                 eo[q] = (c < LD) ? e_old[(size_t)r * LD + c] : 0.f;
             }
-            finish(r, a, eo, rs[r]);
+            finish(r, r, a, eo, rs[r]);
         }
     }
 
@@ -1154,6 +1282,21 @@ int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx,
     // short rows (a batch or a shard of a many-rank run: ~16 nonzeros per row): half the gathers in flight per wave
     // fill just as well and the smaller register file buys occupancy (-15 % at N=8)
     constexpr int US = (HPF_U >= 8) ? HPF_U / 2 : HPF_U;
+    if (short_rows == 2 && !scatter_acc && ld <= 128) {
+        // one segment per lane group (sweep_groups_kernel): 8 / 4 / 2 segments per wavefront at ld = 32 / 64 / 128
+        const int per_block = WPB * (WAVE / (ld / 4));
+        const int ggrid = clamp_grid((nseg + per_block - 1) / per_block, grid_blocks);
+        if (ld == 32)
+            hipLaunchKernelGGL((sweep_groups_kernel<8, HPF_UG>), dim3(ggrid), dim3(BLOCK), 0, st, segs, nseg, idx, y,
+                               tab_self, tab_other, part, acc_rows, acc_ld);
+        else if (ld == 64)
+            hipLaunchKernelGGL((sweep_groups_kernel<16, HPF_UG>), dim3(ggrid), dim3(BLOCK), 0, st, segs, nseg, idx, y,
+                               tab_self, tab_other, part, acc_rows, acc_ld);
+        else
+            hipLaunchKernelGGL((sweep_groups_kernel<32, HPF_UG>), dim3(ggrid), dim3(BLOCK), 0, st, segs, nseg, idx, y,
+                               tab_self, tab_other, part, acc_rows, acc_ld);
+        return last_error();
+    }
 #define CALL(LPR, VPL)                                                                                              \
     if (scatter_acc)                                                                                                \
         hipLaunchKernelGGL((sweep_kernel<LPR, VPL, true, 0>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg, idx, \
@@ -1217,16 +1360,47 @@ int hpf_hip_row_finalize_f32(const float *part, const int64_t *row_seg_ptr, cons
         ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0 || part_ld < k || part_ld > ld)
         return HPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    RowRanges rr = {};   // n = 0: identity
     // the grid is NOT clamped: cs_partial has exactly grid_blocks rows and all are written
 #define CALL(LD)                                                                                                  \
     if (!row_seg_ptr && !row_list)                                                                                     \
         hipLaunchKernelGGL((row_finalize_kernel<LD, true>), dim3(grid_blocks), dim3(BLOCK), 0, st, part, row_seg_ptr,      \
                            row_list, nrows, e_old, e_new, shp, rte, fac, rs, rs_prev, cs_other, cs_partial, prior_shp,     \
-                           top_shp, add_rte, k, part_ld);                                                                  \
+                           top_shp, add_rte, k, part_ld, rr);                                                              \
     else                                                                                                               \
         hipLaunchKernelGGL((row_finalize_kernel<LD, false>), dim3(grid_blocks), dim3(BLOCK), 0, st, part, row_seg_ptr,     \
                            row_list, nrows, e_old, e_new, shp, rte, fac, rs, rs_prev, cs_other, cs_partial, prior_shp,     \
-                           top_shp, add_rte, k, part_ld);
+                           top_shp, add_rte, k, part_ld, rr);
+    HPF_DISPATCH_LD1(ld, CALL)
+#undef CALL
+    return last_error();
+}
+
+int hpf_hip_row_finalize_ranges_f32(const float *acc, int nranges, const int64_t *range_rows,
+                                    const int64_t *range_acc_begin, const int64_t *range_row_begin,
+                                    const float *e_old, float *e_new, float *shp, float *rte, float *fac, float *rs,
+                                    float *rs_prev, const float *cs_other, float *cs_partial, float prior_shp,
+                                    float top_shp, float add_rte, int k, int ld, int acc_ld, int grid_blocks,
+                                    void *stream) {
+    if (!acc || !range_rows || !range_acc_begin || !range_row_begin || !e_old || !e_new || !rs || !cs_other ||
+        !cs_partial || nranges <= 0 || nranges > HPF_MAX_ROW_RANGES || k <= 0 || ld != hpf_hip_ld_for_k(k) ||
+        grid_blocks <= 0 || acc_ld < k || acc_ld > ld)
+        return HPF_EINVAL;
+    RowRanges rr = {};
+    rr.n = nranges;
+    int64_t nrows = 0;
+    for (int i = 0; i < nranges; i++) {
+        if (range_rows[i] < 0 || range_acc_begin[i] < 0 || range_row_begin[i] < 0) return HPF_EINVAL;
+        rr.v_begin[i] = nrows;
+        rr.t_begin[i] = range_acc_begin[i];
+        rr.row_begin[i] = range_row_begin[i];
+        nrows += range_rows[i];
+    }
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(LD)                                                                                                       \
+    hipLaunchKernelGGL((row_finalize_kernel<LD, true>), dim3(grid_blocks), dim3(BLOCK), 0, st, acc,                    \
+                       (const int64_t *)nullptr, (const int64_t *)nullptr, nrows, e_old, e_new, shp, rte, fac, rs,     \
+                       rs_prev, cs_other, cs_partial, prior_shp, top_shp, add_rte, k, acc_ld, rr);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
     return last_error();

@@ -216,12 +216,18 @@ def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta
         print("Initializing optimization procedure...")
     st_time = time.time()
     i = -1
-    for i in range(maxiter):
-        is_check = check_every > 0 and ((i + 1) % check_every) == 0
+    while i + 1 < maxiter:
         # the six [n,k] state tables (shapes, rates, Theta/Beta) are outputs / llk inputs only: written on
         # check iterations (the loop may stop there) and on the last one; the E tables, k_rte/t_rte and the
-        # column sums that carry the iteration are current after every iteration
-        model.iterate(store=(is_check or i == maxiter - 1))
+        # column sums that carry the iteration are current after every iteration.  The iterations in between go
+        # to the engine in one call (it may replay them from a captured hipGraph, cavi.iterate_many).
+        nxt = maxiter - 1
+        if check_every > 0:
+            nxt = min(nxt, (i + 1) + (check_every - 1 - ((i + 1) % check_every)))
+        model.iterate_many(nxt - (i + 1), store=False)
+        i = nxt
+        is_check = check_every > 0 and ((i + 1) % check_every) == 0
+        model.iterate(store=True)
         if is_check:
             if stop_crit == "diff-norm":
                 last_crit = eng.theta_norm_diff(Theta_prev)

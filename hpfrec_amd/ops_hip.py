@@ -37,15 +37,15 @@ class HipOps:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     # -- every method mirrors one C entry point ------------------------------------------
-    def sweep(self, side, tab_self, tab_other, part, k, ld, scatter_acc=None, acc_rows=None, acc_ld=0):
+    def sweep(self, side, tab_self, tab_other, part, k, ld, scatter_acc=None, acc_rows=None, acc_ld=0, grid_blocks=None):
         _lib.check(self.L.hpf_hip_sweep_f32(_ptr(side.segs), side.nseg, _ptr(side.idx), _ptr(side.y),
                                             _ptr(tab_self), _ptr(tab_other), _ptr(part), _ptr(scatter_acc),
-                                            _ptr(acc_rows), int(acc_ld), k, ld, int(getattr(side, "short_rows", False)),
-                                            self.sweep_blocks, self._stream()),
+                                            _ptr(acc_rows), int(acc_ld), k, ld, int(getattr(side, "short_rows", 0)),
+                                            grid_blocks or self.sweep_blocks, self._stream()),
                    "hpf_hip_sweep_f32")
 
-    def sweep_grid(self, nseg):
-        return int(max(1, min(self.sweep_blocks, (nseg + 3) // 4)))
+    def sweep_grid(self, nseg, blocks=None):
+        return int(max(1, min(blocks or self.sweep_blocks, (nseg + 3) // 4)))
 
     def sweep_finalize(self, side, tab_self, tab_other, part, e_new, shp, rte, fac, rs, cs_other, cs_partial,
                        prior_shp, top_shp, add_rte, k, ld, rs_prev=None):
@@ -81,6 +81,19 @@ class HipOps:
                                                    float(add_rte), k, ld, ld if part_ld is None else part_ld, grid,
                                                    self._stream()),
                    "hpf_hip_row_finalize_f32")
+
+    def row_finalize_ranges(self, acc, ranges, e_old, e_new, shp, rte, fac, rs, cs_other, cs_partial, prior_shp,
+                            top_shp, add_rte, k, ld, acc_ld, rs_prev=None):
+        """Dense finalize of several row ranges in one launch; ranges = [(rows, first acc row, first table row)]."""
+        import ctypes
+        n = len(ranges)
+        arr = (ctypes.c_int64 * n)
+        rows, t0, r0 = (arr(*[int(r[i]) for r in ranges]) for i in range(3))
+        _lib.check(self.L.hpf_hip_row_finalize_ranges_f32(
+            _ptr(acc), n, ctypes.addressof(rows), ctypes.addressof(t0), ctypes.addressof(r0), _ptr(e_old), _ptr(e_new),
+            _ptr(shp), _ptr(rte), _ptr(fac), _ptr(rs), _ptr(rs_prev), _ptr(cs_other), _ptr(cs_partial),
+            float(prior_shp), float(top_shp), float(add_rte), k, ld, int(acc_ld), cs_partial.shape[0], self._stream()),
+            "hpf_hip_row_finalize_ranges_f32")
 
     def colsum_reduce(self, cs_partial, cs_out, ld):
         _lib.check(self.L.hpf_hip_colsum_reduce_f32(_ptr(cs_partial), cs_partial.shape[0], _ptr(cs_out), ld,

@@ -46,7 +46,8 @@ class BatchSide:
         self.segs = segs
         self.nseg = int(segs.shape[0])
         self.nrows = int(self.rows.shape[0])
-        self.short_rows = self.nseg > 0 and int(self.y.shape[0]) / self.nseg < layout.SHORT_ROW_NNZ
+        self.short_rows = layout.SHORT_VARIANT if (self.nseg > 0 and
+                                                   int(self.y.shape[0]) / self.nseg < layout.SHORT_ROW_NNZ) else 0
         nseg_row = self.row_seg_ptr[1:] - self.row_seg_ptr[:-1]
         self.multi_local = torch.nonzero(nseg_row > 1).reshape(-1)              # rows cut into several segments
         self.nmulti = int(self.multi_local.shape[0])

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 5
+#define HPF_HIP_ABI_VERSION 6
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -72,8 +72,10 @@ int hpf_hip_device_info(int *cu_count, char *arch, int arch_len);
  * scatter_acc may be NULL (the deterministic two-pass scheme: call once per side).
  * acc_rows (optional): segments flagged HPF_SEG_WHOLE_ROW write their accumulator to
  * acc_rows[row][0:acc_ld] (k <= acc_ld <= ld, packed) instead of part[g] -- the multi-GPU exchange buffer.
- * short_rows != 0: tuning hint, the rows average a few dozen nonzeros at most (half the gathers in flight per
- * wavefront, more wavefronts resident); results do not depend on it.
+ * short_rows: tuning hint for rows that average a few dozen nonzeros at most.  1: the wave-per-segment kernel with
+ * half the gathers in flight per wavefront (more wavefronts resident); 2: one segment per LANE GROUP (64/(ld/4)
+ * segments per wavefront, ld <= 128; wider tables fall back to 1).  Results agree to rounding (2 accumulates a
+ * row sequentially instead of in 64/(ld/4) interleaved partial sums).
  */
 int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
                       const float *tab_self, const float *tab_other, float *part, float *scatter_acc,
@@ -132,6 +134,24 @@ int hpf_hip_row_finalize_f32(const float *part, const int64_t *row_seg_ptr, cons
                              const float *e_old, float *e_new, float *shp, float *rte, float *fac, float *rs,
                              float *rs_prev, const float *cs_other, float *cs_partial, float prior_shp, float top_shp,
                              float add_rte, int k, int ld, int part_ld, int grid_blocks, void *stream);
+
+/*
+ * hpf_hip_row_finalize_f32 for accumulator rows that are dense and already reduced (row_seg_ptr == row_list == NULL),
+ * over SEVERAL row ranges in one launch: range i covers range_rows[i] rows, accumulator rows
+ * acc[range_acc_begin[i] + j][0:acc_ld] <-> table rows range_row_begin[i] + j of e_old/shp/rte/fac/rs/rs_prev; the
+ * new E row is written to e_new[range_acc_begin[i] + j] (e_new is indexed like acc: it is the all-gather send
+ * buffer).  The multi-GPU "scatter" exchange leaves each rank with one slice of every item range (the
+ * reduce-scatter outputs, concatenated in acc); this finishes all of them at once.  The three range arrays are
+ * HOST arrays of nranges <= HPF_MAX_ROW_RANGES entries, read during the call.  cs_partial: grid_blocks rows, all
+ * written.
+ */
+#define HPF_MAX_ROW_RANGES 8
+int hpf_hip_row_finalize_ranges_f32(const float *acc, int nranges, const int64_t *range_rows,
+                                    const int64_t *range_acc_begin, const int64_t *range_row_begin,
+                                    const float *e_old, float *e_new, float *shp, float *rte, float *fac, float *rs,
+                                    float *rs_prev, const float *cs_other, float *cs_partial, float prior_shp,
+                                    float top_shp, float add_rte, int k, int ld, int acc_ld, int grid_blocks,
+                                    void *stream);
 
 /* cs_out[c] = sum_b cs_partial[b][c], fixed order, double accumulation (Beta.sum(axis=0), PXI:236,255). */
 int hpf_hip_colsum_reduce_f32(const float *cs_partial, int nblk, float *cs_out, int ld, void *stream);

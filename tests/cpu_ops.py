@@ -41,8 +41,8 @@ class CpuOps:
     def finalize_grid(self, nrows):
         return int(max(1, min(self.finalize_blocks, (nrows + 3) // 4)))
 
-    def sweep_grid(self, nseg):
-        return int(max(1, min(self.sweep_blocks, (nseg + 3) // 4)))
+    def sweep_grid(self, nseg, blocks=None):
+        return int(max(1, min(blocks or self.sweep_blocks, (nseg + 3) // 4)))
 
     def sweep_finalize(self, side, tab_self, tab_other, part, e_new, shp, rte, fac, rs, cs_other, cs_partial,
                        prior_shp, top_shp, add_rte, k, ld, rs_prev=None):
@@ -64,7 +64,7 @@ class CpuOps:
                           rs_prev=rs_prev)
         self.sweep(side, tab_self, tab_other, part, k, ld, acc_rows=acc_rows, acc_ld=acc_ld)
 
-    def sweep(self, side, tab_self, tab_other, part, k, ld, scatter_acc=None, acc_rows=None, acc_ld=0):
+    def sweep(self, side, tab_self, tab_other, part, k, ld, scatter_acc=None, acc_rows=None, acc_ld=0, grid_blocks=None):
         if side.nseg == 0:
             return
         begin, length, row = _decode_segs(side)
@@ -131,6 +131,27 @@ class CpuOps:
             _np(rs_prev)[rows] = _np(rs)[rows]
         _np(rs)[rows] = (f(add_rte) + fc.astype(np.float64).sum(axis=1)).astype(np.float32)
         cp[0] = fc.astype(np.float64).sum(axis=0).astype(np.float32)
+
+    def row_finalize_ranges(self, acc, ranges, e_old, e_new, shp, rte, fac, rs, cs_other, cs_partial, prior_shp,
+                            top_shp, add_rte, k, ld, acc_ld, rs_prev=None):
+        """ranges = [(rows, first acc row, first table row)]: acc / e_new are indexed by accumulator row, the tables
+        by table row (hpf_hip_row_finalize_ranges_f32)."""
+        total = np.zeros(ld, np.float64)
+        for n, t0, r0 in ranges:
+            if n <= 0:
+                continue
+            rows = torch.arange(r0, r0 + n, dtype=torch.int64)
+            tmp_e = torch.zeros((int(e_old.shape[0]), ld), dtype=torch.float32)
+            big = torch.zeros((int(e_old.shape[0]), acc_ld), dtype=torch.float32)
+            big[r0:r0 + n] = acc[t0:t0 + n, :acc_ld]
+            cp = torch.zeros_like(cs_partial)
+            self.row_finalize(big, None, n, e_old, tmp_e, shp, rte, fac, rs, cs_other, cp, prior_shp, top_shp, add_rte,
+                              k, ld, row_list=rows, part_ld=acc_ld, rs_prev=rs_prev)
+            _np(e_new)[t0:t0 + n] = _np(tmp_e)[r0:r0 + n]
+            total += _np(cp).astype(np.float64).sum(axis=0)
+        cpo = _np(cs_partial)
+        cpo[:] = 0
+        cpo[0] = total.astype(np.float32)
 
     def colsum_reduce(self, cs_partial, cs_out, ld):
         _np(cs_out)[:] = _np(cs_partial).astype(np.float64).sum(axis=0).astype(np.float32)

@@ -169,6 +169,87 @@ def test_sweep_op(ops, k):
         assert float(((acc.cpu() - want_acc).abs() / want_acc.abs().clamp_min(1e-3)).max()) < 5e-5
 
 
+@pytest.mark.parametrize("k", [20, 30, 50, 100, 200])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_short_row_sweep_variants(ops, k, variant):
+    """hpf_hip_sweep_f32 with the short-row hints (1: wave per segment, half the gathers in flight; 2: one segment
+    per lane group) against the numpy reference: ragged short rows, a few long (split) ones, rows without data,
+    whole-row accumulators written packed (acc_ld = k) into the exchange buffer, the rest into part[]."""
+    rs = np.random.RandomState(100 * k + variant)
+    ld = _lib.ld_for_k(k)
+    nU, nI, n = 5000, 700, 40000
+    iu = torch.from_numpy(rs.randint(0, nU, size=n).astype(np.int64))
+    ii = torch.from_numpy(np.minimum((nI * rs.random_sample(n) ** 3).astype(np.int64) + 5, nI - 1))   # items 0-4 empty
+    y = torch.from_numpy((rs.gamma(1, 1, size=n) + 1).astype(np.float32))
+    eT, eB = _rand_tables(rs, nU, k, ld), _rand_tables(rs, nI, k, ld)
+    users, items, _ = layout.build_sides(iu, ii, y, nU, nI)
+    assert items.nmulti > 5
+    ref = cpu_ops.CpuOps()
+    for side, ts, to in ((users, eT, eB), (items, eB, eT)):
+        nrows = ts.shape[0]
+        want_part, want_acc = torch.zeros((side.nseg, ld)), torch.zeros((nrows, k))
+        ref.sweep(side, ts, to, want_part, k, ld, acc_rows=want_acc, acc_ld=k)
+        dside = layout.SparseSide.__new__(layout.SparseSide)
+        dside.__dict__.update({a: (v.cuda() if torch.is_tensor(v) else v) for a, v in side.__dict__.items()})
+        dside.short_rows = variant
+        got_part = torch.zeros((side.nseg, ld), device="cuda")
+        got_acc = torch.zeros((nrows, k), device="cuda")
+        ops.sweep(dside, ts.cuda(), to.cuda(), got_part, k, ld, acc_rows=got_acc, acc_ld=k)
+        torch.cuda.synchronize()
+        for got, want in ((got_part.cpu(), want_part), (got_acc.cpu(), want_acc)):
+            assert float(((got - want).abs() / want.abs().clamp_min(1e-30)).max()) < 2e-5
+        # no accumulator buffer: everything goes to part[]; bit-reproducible between runs
+        a = torch.zeros((side.nseg, ld), device="cuda")
+        b = torch.zeros((side.nseg, ld), device="cuda")
+        ops.sweep(dside, ts.cuda(), to.cuda(), a, k, ld)
+        ops.sweep(dside, ts.cuda(), to.cuda(), b, k, ld)
+        ref.sweep(side, ts, to, want_part, k, ld)
+        assert torch.equal(a, b)
+        assert float(((a.cpu() - want_part).abs() / want_part.abs().clamp_min(1e-30))[:, :k].max()) < 2e-5
+
+
+@pytest.mark.parametrize("k", [30, 50, 100, 200])
+def test_row_finalize_ranges_op(ops, k):
+    """hpf_hip_row_finalize_ranges_f32 (one launch over the slices a rank owns of several item ranges) ==
+    one dense hpf_hip_row_finalize_f32 launch per range, bit for bit (column sums: to rounding)."""
+    rs = np.random.RandomState(k + 31)
+    ld = _lib.ld_for_k(k)
+    nrows = 900
+    ranges = [(130, 0, 40), (0, 130, 300), (257, 140, 500), (1, 400, 899)]   # (rows, first acc row, first table row)
+    acc = torch.from_numpy(rs.uniform(0, 40, size=(401, k)).astype(np.float32)).cuda()
+    e_old = _rand_tables(rs, nrows, k, ld).cuda()
+    cs = torch.zeros(ld)
+    cs[:k] = torch.from_numpy(rs.uniform(5, 50, size=k).astype(np.float32))
+    cs = cs.cuda()
+    rs0 = torch.from_numpy(rs.uniform(0.5, 30, size=nrows).astype(np.float32))
+
+    def fresh():
+        return ([torch.full((nrows, ld), -1.0, device="cuda") for _ in range(3)], torch.full((401, ld), -1.0, device="cuda"),
+                rs0.clone().cuda(), torch.full((nrows,), -1.0, device="cuda"))
+    (shp, rte, fac), e_new, rsv, rsp = fresh()
+    csp = torch.zeros((ops.finalize_grid(388), ld), device="cuda")
+    ops.row_finalize_ranges(acc, ranges, e_old, e_new, shp, rte, fac, rsv, cs, csp, 0.3, 15.3, 0.3, k, ld, k, rs_prev=rsp)
+    cso = torch.zeros(ld, device="cuda")
+    ops.colsum_reduce(csp, cso, ld)
+    (shp2, rte2, fac2), e_new2, rsv2, rsp2 = fresh()
+    tot = torch.zeros(ld, dtype=torch.float64, device="cuda")
+    for n, t0, r0 in ranges:
+        if n == 0:
+            continue
+        cp = torch.zeros((ops.finalize_grid(n), ld), device="cuda")
+        ops.row_finalize(acc[t0:t0 + n], None, n, e_old[r0:], e_new2[t0:], shp2[r0:], rte2[r0:], fac2[r0:], rsv2[r0:], cs,
+                         cp, 0.3, 15.3, 0.3, k, ld, part_ld=k, rs_prev=rsp2[r0:])
+        tot += cp.double().sum(dim=0)
+    torch.cuda.synchronize()
+    for a, b in ((shp, shp2), (rte, rte2), (fac, fac2), (e_new, e_new2), (rsv, rsv2), (rsp, rsp2)):
+        assert torch.equal(a, b)
+    assert float(((cso.double() - tot).abs() / tot.clamp_min(1e-30))[:k].max()) < 1e-6
+    touched = torch.zeros(nrows, dtype=torch.bool)
+    for n, t0, r0 in ranges:
+        touched[r0:r0 + n] = True
+    assert bool((fac.cpu()[~touched] == -1).all()) and bool((fac.cpu()[touched][:, :k] > 0).all())
+
+
 @pytest.mark.parametrize("k", [30, 50, 100, 300])
 def test_row_finalize_expect_colsum_ops(ops, k):
     rs = np.random.RandomState(k + 1)
@@ -369,7 +450,7 @@ def test_fused_and_split_drivers_agree(hip_backend):
         assert _maxrel(a[n], b[n]) < 2e-6, n
 
 
-@pytest.mark.parametrize("mode", ["scatter", "allreduce"])
+@pytest.mark.parametrize("mode", ["scatter", "allreduce", "scatter-graph", "scatter-item-stream"])
 def test_sharded_path_single_rank_nccl(mode):
     """The multi-GPU code path on one GPU with a real RCCL group: "scatter" = asynchronous reduce-scatter / dense
     finalize of the own slice / all-gather into the E table; "allreduce" = async packed all-reduce + deferred finalize."""
@@ -379,10 +460,16 @@ def test_sharded_path_single_rank_nccl(mode):
         pytest.skip("no GPU")
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-               HPF_SHARD_MODE=mode)
+               HPF_SHARD_MODE=mode.split("-")[0])
+    if mode == "scatter-graph":           # pairs of iterations replayed from a captured hipGraph (RCCL calls included)
+        env["HPF_GRAPH"] = "1"
+    if mode == "scatter-item-stream":     # item sweeps on a third stream
+        env["HPF_ITEM_STREAM"] = "1"
     out = subprocess.run([sys.executable, os.path.join(here, "sharded_single_rank.py")], env=env, capture_output=True,
                          text=True, timeout=600)
     assert "SHARDED_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    if mode == "scatter-graph":
+        assert "GRAPH_PAIRS_REPLAYED" in out.stdout, out.stdout[-2000:]
 
 
 @pytest.mark.parametrize("k", [30, 50, 200])

@@ -108,11 +108,18 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
             for _ in range(3):
                 m.iterate(store)
             torch.cuda.synchronize()
+            many = os.environ.get("HPF_GRAPH") == "1"
+            if many:
+                m.iterate_many(4, store)      # capture
+                torch.cuda.synchronize()
             ops.events, ops.recording = {}, store and os.environ.get('PROBE_EVENTS', '1') == '1'
             t0 = time.perf_counter()
             steps = 30
-            for _ in range(steps):
-                m.iterate(store)
+            if many:
+                m.iterate_many(steps, store)
+            else:
+                for _ in range(steps):
+                    m.iterate(store)
             t_issue = (time.perf_counter() - t0) / steps * 1e3
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps * 1e3
@@ -120,7 +127,9 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
             if store:
                 ks = {n: round(v["total_ms"] / steps, 3) for n, v in ops.summary().items()}
                 print("world %d rank %d: %d users, %d nnz: %.3f ms/iteration (all tables stored; host issue time %.3f ms); "
-                      "kernels ms/iter %s" % (world, r, u1 - u0, m.nnz, dt, t_issue, ks), flush=True)
+                      "kernels ms/iter %s%s" % (world, r, u1 - u0, m.nnz, dt, t_issue, ks,
+                                                " [hipGraph pairs: %s]" % ("ok" if m.__dict__.get("_graphs", {}).get(True) is not None
+                                                                           else getattr(m, "_graph_error", "off")) if many else ""), flush=True)
             else:
                 print("world %d rank %d: %.3f ms/iteration without the output-table stores (host issue time %.3f ms)"
                       % (world, r, dt, t_issue), flush=True)
