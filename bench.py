@@ -300,46 +300,69 @@ def main():
     # first and the fastest one -- by the slowest rank's clock -- is the configuration that is then benchmarked.
     autotune = None
     if dist and world > 1 and not args.no_autotune and not any(
-            v in os.environ for v in ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_RS_ALLTOALL")):
+            v in os.environ for v in ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_RS_ALLTOALL", "HPF_GRAPH")):
         autotune, failed = {}, {}
-        # Safety net: this multi-rank path could only be exercised with gloo ranks on one GPU before the driver's
-        # run.  If anything after a completed candidate stops making progress, rank 0 still reports that candidate's
-        # barrier-bracketed 20-iteration measurement (flagged as a fallback) instead of nothing.
+        # Safety net: this multi-rank path could only be exercised with gloo ranks on one GPU (and a one-rank RCCL
+        # group) before the driver's run.  If anything after a completed candidate stops making progress, rank 0
+        # still reports that candidate's barrier-bracketed 20-iteration measurement (flagged as a fallback).
         watchdog_state["autotune"], watchdog_state["meta"] = autotune, dict(
             workload=label, users=nU, items=nI, nnz=nnz, k=k, world=world, rank=rank, workload_key=args.workload)
         _arm_watchdog(float(os.environ.get("HPF_BENCH_WATCHDOG_S", "240")))
-        # the plain all-reduce configurations go first: they are the most conservative use of RCCL
-        for mode, chunks, istream, a2a in (("allreduce", "3", "1", "0"), ("allreduce", "2", "1", "0"),
-                                           ("scatter", "2", "1", "0"), ("scatter", "3", "1", "0"),
-                                           ("scatter", "2", "0", "0"), ("scatter", "1", "1", "0"),
-                                           ("scatter", "2", "1", "1")):
-            os.environ["HPF_SHARD_MODE"], os.environ["HPF_AR_CHUNKS"], os.environ["HPF_ITEM_STREAM"] = mode, chunks, istream
-            os.environ["HPF_RS_ALLTOALL"] = a2a
-            key = "%s/%s%s%s" % (mode, chunks, "" if istream == "1" else "/items-on-compute-stream",
-                                 "/all-to-all" if a2a == "1" else "")
-            try:        # a configuration that fails on this node (same error on every rank) is skipped, not fatal
+
+        def candidate(mode, chunks, istream, a2a, graph):
+            env = {"HPF_SHARD_MODE": mode, "HPF_AR_CHUNKS": chunks, "HPF_ITEM_STREAM": istream, "HPF_RS_ALLTOALL": a2a,
+                   "HPF_GRAPH": graph}
+            os.environ.update(env)
+            key = "%s/%s%s%s%s" % (mode, chunks, "/item-stream" if istream == "1" else "",
+                                   "/all-to-all" if a2a == "1" else "", "/hipgraph" if graph == "1" else "")
+            t_ms, err, m = None, None, None
+            try:
                 m = build_model()
-                for _ in range(3):
-                    m.iterate(not args.lean)
+                m.iterate_many(4, not args.lean)         # (graph candidates: 2 eager + the capture + 1 replayed pair)
                 dist.barrier()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                for _ in range(20):
-                    m.iterate(not args.lean)
+                m.iterate_many(20, not args.lean)
                 dist.barrier()
                 torch.cuda.synchronize()
-                t = torch.tensor([(time.perf_counter() - t0) / 20 * 1e3], dtype=torch.float64, device=device)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                autotune[key] = float(t.item())
+                t_ms = (time.perf_counter() - t0) / 20 * 1e3
+                if graph == "1" and not any(g is not None for g in m.__dict__.get("_graphs", {}).values()):
+                    err, t_ms = "no hipGraph captured: %s" % getattr(m, "_graph_error", "backend not capturable"), None
                 m.flush_items()
-                del m
             except Exception as exc:   # noqa: BLE001
-                failed[key] = "%s: %s" % (type(exc).__name__, str(exc)[:200])
+                err = "%s: %s" % (type(exc).__name__, str(exc)[:200])
+            # every rank takes the same decision: a candidate counts only if it ran on ALL ranks
+            flag = torch.tensor([0.0 if t_ms is None else 1.0, t_ms or 0.0], dtype=torch.float64, device=device)
+            ok = flag[:1].clone()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            dist.all_reduce(flag[1:], op=dist.ReduceOp.MAX)
+            del m
             torch.cuda.empty_cache()
-        best = min(autotune, key=autotune.get)
-        os.environ["HPF_SHARD_MODE"], os.environ["HPF_AR_CHUNKS"] = best.split("/")[:2]
-        os.environ["HPF_ITEM_STREAM"] = "0" if "items-on-compute-stream" in best else "1"
-        os.environ["HPF_RS_ALLTOALL"] = "1" if best.endswith("all-to-all") else "0"
+            if float(ok.item()) > 0:
+                autotune[key] = float(flag[1].item())
+            else:
+                failed[key] = err or "failed on another rank"
+            return key, env
+
+        envs = {}
+        # the plain all-reduce configurations go first: they are the most conservative use of RCCL
+        for cand in (("allreduce", "3", "0", "0", "0"), ("allreduce", "2", "0", "0", "0"), ("scatter", "2", "0", "0", "0"),
+                     ("scatter", "1", "0", "0", "0"), ("scatter", "3", "0", "0", "0"), ("scatter", "2", "1", "0", "0"),
+                     ("scatter", "2", "0", "1", "0")):
+            key, env = candidate(*cand)
+            envs[key] = env
+        sc = {k_: v for k_, v in autotune.items() if k_.startswith("scatter") and "item-stream" not in k_}
+        if sc:      # the fastest scatter configuration once more, replayed from captured hipGraphs
+            base = envs[min(sc, key=sc.get)]
+            key, env = candidate(base["HPF_SHARD_MODE"], base["HPF_AR_CHUNKS"], "0", base["HPF_RS_ALLTOALL"], "1")
+            envs[key] = env
+        if autotune:
+            best = min(autotune, key=autotune.get)
+            os.environ.update(envs[best])
+        else:       # nothing completed everywhere: the library defaults
+            best = None
+            for v in ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_RS_ALLTOALL", "HPF_GRAPH"):
+                os.environ.pop(v, None)
         autotune = {"ms_per_iteration": autotune, "chosen": best, "failed": failed}
     model = build_model()
     del lu, li, ly, init, Theta, Beta
@@ -357,17 +380,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 1)):   # at least one untimed step: code-object load, first-touch of scratch
-        model.iterate(store)
-    fence()
+    # (iterate_many: plain iterate() calls, or -- N>1 with HPF_GRAPH=1 -- pairs replayed from a captured hipGraph)
+    model.iterate_many(max(args.warmup, 4 if os.environ.get("HPF_GRAPH") == "1" else 1), store)   # untimed: code-object
+    fence()                                                                   # load, first touch, graph capture
     # N=1: every launch of the timed region is bracketed with HIP events (roofline.achieved comes from them).
     # N>1: an iteration is ~10 short launches, and two event records per launch cost ~9 % of it (measured with
     # tools/shard_probe.py), so the event-bracketed iterations are a separate pass right after the timed region.
     events_in_timed = (world == 1)
     ops.recording = events_in_timed and not args.no_events
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        model.iterate(store)
+    if events_in_timed:
+        for _ in range(args.steps):
+            model.iterate(store)
+    else:
+        model.iterate_many(args.steps, store)
     fence()
     dt = time.perf_counter() - t0
     ops.recording = False
@@ -441,10 +467,11 @@ def main():
                 b_launch = n_loc * (4 + 4 * k) + ((model.nU + model.nI) / 2.0) * (8 + 4 * k)
                 t_k = ksum[dom]["avg_ms"] * 1e-3
             ach = b_launch / t_k
+            traffic, traffic_src = _pmc_traffic(args.workload, world)
             roof = {"bound": "hbm", "kernel": "sweep_kernel (%s)" % ("fused with row finalize" if dom == "sweep_finalize"
                                                                      else "unfused"),
                     "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
-                    "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": _pmc_traffic(args.workload, world),
+                    "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": b_launch, "avg_launch_ms": t_k * 1e3,
                     "launches": ksum[dom]["calls"],
                     "iteration": {"algorithmic_bytes": b_iter,
@@ -470,6 +497,7 @@ def main():
                                         "ranges (RCCL), item finalize deferred into the next item sweep"
                                         % (world, len(model.item_chunks)))) if world > 1 else "1 GPU",
                        "exchange_autotune": autotune,
+                       "hipgraph_pairs": any(g is not None for g in model.__dict__.get("_graphs", {}).values()),
                        "seg_cap": cavi.layout.SEG_CAP, "fused_finalize": model.fused and world == 1,
                        "stores_all_state_tables": store, "state_finite": finite},
             "roofline": roof,
@@ -502,16 +530,33 @@ def main():
         print(json.dumps(line), flush=True)
 
 
+def kernel_source_sha16():
+    """Hash of the kernel source + C header the loaded library was built from (what a PMC summary is tied to)."""
+    import hashlib
+    from hpfrec_amd import _lib
+    h = hashlib.sha256()
+    for path in (_lib.SRC_PATH, os.path.join(_lib.INC_PATH, "hpf_hip.h")):
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _pmc_traffic(workload, world):
-    """HBM bytes per sweep launch from the rocprofv3 --pmc passes committed under profiles/
-    (collected separately, never in the timed run); None when no such summary exists."""
-    p = os.path.join(ROOT, "profiles", "pmc_%s_n%d.json" % (workload, world))
-    if os.path.exists(p):
-        try:
-            return json.load(open(p)).get("sweep_kernel_hbm_bytes_per_launch")
-        except Exception:
-            return None
-    return None
+    """(HBM bytes per sweep launch, provenance) from the rocprofv3 --pmc passes committed under profiles/ (collected
+    in separate runs, never in the timed one; tools/gpu_profile.sh + tools/pmc_json.py).  The summary names the
+    kernel source it was measured on: when that is not the source of the library running now, the number is stale
+    and `traffic` is null."""
+    rel = os.path.join("profiles", "pmc_%s_n%d.json" % (workload, world))
+    p = os.path.join(ROOT, rel)
+    if not os.path.exists(p):
+        return None, "no PMC summary for this workload (%s)" % rel
+    try:
+        d = json.load(open(p))
+    except Exception as e:   # noqa: BLE001
+        return None, "%s unreadable: %r" % (rel, e)
+    have, want = d.get("kernel_source_sha16"), kernel_source_sha16()
+    if have != want:
+        return None, "%s was measured on kernel source %s, this run uses %s: stale" % (rel, have, want)
+    return d.get("sweep_kernel_hbm_bytes_per_launch"), "%s (%s; kernel source %s)" % (rel, d.get("source"), have)
 
 
 if __name__ == "__main__":

@@ -101,7 +101,7 @@ class FullBatchCavi:
         # fatter blocks (16 per CU costs 3 % at N=8, gains 1 % at N=1)
         self.sweep_blocks = ops.sweep_blocks
         if self.dist and "HPF_SWEEP_BPC" not in os.environ and hasattr(ops, "cu_count"):
-            self.sweep_blocks = max(1, ops.cu_count) * 8
+            self.sweep_blocks = max(1, ops.cu_count) * int(os.environ.get("HPF_SHARD_SWEEP_BPC", "4"))
         # the sharded item pass is many short rows: more, smaller blocks even out its tail (tools/sweep_micro.py:
         # 203 us at 32 blocks per CU vs 220 at 8 for rank 0 of 8 at C3)
         self.item_sweep_blocks = max(1, getattr(ops, "cu_count", 1)) * int(os.environ.get("HPF_ITEM_SWEEP_BPC", "32")) \
@@ -328,8 +328,8 @@ class FullBatchCavi:
     def _graph_capable(self):
         if not (self.dist and self.shard_mode == "scatter" and self.device.type == "cuda"):
             return False
-        if os.environ.get("HPF_GRAPH", "0") != "1" or getattr(self, "_graph_failed", False):
-            return False
+        if os.environ.get("HPF_GRAPH", "0") != "1" or getattr(self, "_graph_failed", False) or self.item_stream:
+            return False        # (three-stream captures crash the ROCm 7.0 runtime: graphs only with HPF_ITEM_STREAM=0)
         try:
             return self.dist.get_backend() == "nccl"     # gloo collectives run on the host: nothing to capture
         except Exception:   # noqa: BLE001  (stand-ins for torch.distributed in probes: assume capturable)

@@ -13,6 +13,16 @@ for p in (os.path.dirname(HERE), HERE):
 
 
 def run(rank, world, port, out_dir, k, its, case, device="cpu"):
+    try:
+        _run(rank, world, port, out_dir, k, its, case, device)
+    except BaseException:   # noqa: BLE001  (leave the traceback where the parent test can show it)
+        import traceback
+        with open(os.path.join(out_dir, "rank%d.err" % rank), "w") as f:
+            f.write(traceback.format_exc())
+        raise
+
+
+def _run(rank, world, port, out_dir, k, its, case, device="cpu"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

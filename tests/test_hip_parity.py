@@ -638,7 +638,7 @@ def test_tiny_shape_priors(hip_backend):
 
 
 @pytest.mark.parametrize("world,mode,lazy,k", [(2, "scatter", "1", 20), (3, "scatter", "1", 20),
-                                               (2, "scatter", "no-item-stream", 20), (2, "scatter", "1", 100),
+                                               (2, "scatter", "item-stream", 20), (2, "scatter", "1", 100),
                                                (3, "scatter", "a2a", 20),
                                                (2, "allreduce", "1", 20), (3, "allreduce", "1", 20),
                                                (2, "allreduce", "0", 20), (2, "allreduce", "1", 100)])
@@ -650,8 +650,8 @@ def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypat
     import torch.multiprocessing as mp
     import dist_worker
     monkeypatch.setenv("HPF_SHARD_MODE", mode)   # reduce-scatter + sharded finalizer, or all-reduce + replicated one
-    if lazy == "no-item-stream":                  # scatter mode with the item pass on the compute stream
-        monkeypatch.setenv("HPF_ITEM_STREAM", "0")
+    if lazy == "item-stream":                     # scatter mode with the item sweeps on a third stream
+        monkeypatch.setenv("HPF_ITEM_STREAM", "1")
         lazy = "1"
     if lazy == "a2a":                             # scatter mode, reduce-scatter as all-to-all + local sum
         monkeypatch.setenv("HPF_RS_ALLTOALL", "1")
@@ -671,7 +671,13 @@ def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypat
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(dist_worker.run, args=(world, port, str(tmp_path), k, its, "mid", "cuda"), nprocs=world, join=True)
+    try:
+        mp.spawn(dist_worker.run, args=(world, port, str(tmp_path), k, its, "mid", "cuda"), nprocs=world, join=True)
+    except Exception:
+        import glob
+        for f in sorted(glob.glob(os.path.join(str(tmp_path), "rank*.err"))):
+            print(f, open(f).read())
+        raise
     outs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     for r in range(world):
         assert int(outs[r]["niter"]) == i

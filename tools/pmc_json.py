@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""profiles/pmc_<workload>_n1.json from the two rocprofv3 --pmc passes of tools/gpu_profile.sh (FETCH_SIZE and
+WRITE_SIZE, separate runs): HBM-side bytes per launch of the dominant kernel, tied to the kernel source it was
+measured on (bench.py emits roofline.traffic = null when the library running is built from another source).
+
+usage: pmc_json.py <dir with FETCH_SIZE csv> <dir with WRITE_SIZE csv> <workload> <out.json> [kernel substring]"""
+import csv
+import glob
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def avg_counter(d, counter, kern):
+    vals = {}
+    for p in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(p)):
+            if r["Counter_Name"] == counter and kern in r["Kernel_Name"]:
+                vals.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+    if not vals:
+        raise SystemExit("no %s rows for kernel %r under %s" % (counter, kern, d))
+    name = max(vals, key=lambda n: sum(vals[n]))          # the instantiation that moves the most bytes
+    return name, sum(vals[name]) / len(vals[name]), len(vals[name])
+
+
+fetch_dir, write_dir, workload, out = sys.argv[1:5]
+kern = sys.argv[5] if len(sys.argv) > 5 else "sweep_kernel"
+name, fetch_kb, nf = avg_counter(fetch_dir, "FETCH_SIZE", kern)
+_, write_kb, nw = avg_counter(write_dir, "WRITE_SIZE", name.split("(")[0])
+doc = {
+    "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of `python bench.py --workload %s --steps 3 "
+              "--warmup 1 --no-cpu-baseline --no-events --no-extras` (tools/gpu_profile.sh)" % workload,
+    "kernel": name.replace("(anonymous namespace)::", "").split("(")[0],
+    "launches_averaged": [nf, nw],
+    "fetch_size_kb_per_launch": fetch_kb,
+    "write_size_kb_per_launch": write_kb,
+    "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B for wide coalesced reads -> x2 (MI355X_MICROARCH.md "
+                  "section HBM); WRITE_SIZE taken as reported (uncalibrated)",
+    "sweep_kernel_hbm_bytes_per_launch": int((2.0 * fetch_kb + write_kb) * 1024),
+    "kernel_source_sha16": bench.kernel_source_sha16(),
+}
+json.dump(doc, open(out, "w"), indent=2)
+print(json.dumps(doc))
