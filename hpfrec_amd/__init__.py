@@ -23,7 +23,7 @@ import numpy as np
 import pandas as pd
 from scipy.sparse import coo_array, issparse
 
-from . import cython_loops_float
+from . import cython_loops_float, resident
 
 __all__ = ["HPF"]
 
@@ -90,6 +90,17 @@ class HPF:
     Attributes: Theta (nusers,k), Beta (nitems,k), user_mapping_, item_mapping_, user_dict_,
     item_dict_, is_fitted, niter, train_llk.
     """
+
+    # the eight state arrays live in a ResidentState (host copy + device copy with explicit validity, see
+    # hpfrec_amd/resident.py); as attributes they behave like the reference's plain numpy arrays
+    Theta = resident.StateArray("Theta")
+    Beta = resident.StateArray("Beta")
+    Gamma_shp = resident.StateArray("Gamma_shp")
+    Gamma_rte = resident.StateArray("Gamma_rte")
+    Lambda_shp = resident.StateArray("Lambda_shp")
+    Lambda_rte = resident.StateArray("Lambda_rte")
+    k_rte = resident.StateArray("k_rte")
+    t_rte = resident.StateArray("t_rte")
 
     def __init__(self, k=30, a=0.3, a_prime=0.3, b_prime=1.0, c=0.3, c_prime=0.3, d_prime=1.0, ncores=-1,
                  stop_crit='maxiter', check_every=10, stop_thr=1e-3, users_per_batch=None, items_per_batch=None,
@@ -345,8 +356,8 @@ class HPF:
 
     def _cast_before_fit(self):
         be = self._backend()
-        self.Theta = np.empty((self.nusers, self.k), dtype=be.c_real_t)
-        self.Beta = np.empty((self.nitems, self.k), dtype=be.c_real_t)
+        self._state.set_host("Theta", np.empty((self.nusers, self.k), dtype=be.c_real_t), private=True)
+        self._state.set_host("Beta", np.empty((self.nitems, self.k), dtype=be.c_real_t), private=True)
         self.k = be.cast_ind_type(self.k)
         self.nusers = be.cast_ind_type(self.nusers)
         self.nitems = be.cast_ind_type(self.nitems)
@@ -381,7 +392,7 @@ class HPF:
             self._col(self.input_df, "Count", be.c_real_t),
             self._col(self.input_df, "UserId", be.obj_ind_type),
             self._col(self.input_df, "ItemId", be.obj_ind_type),
-            self.Theta, self.Beta,
+            self._state.peek_host("Theta"), self._state.peek_host("Beta"),
             self.maxiter, self.stop_crit, self.check_every, self.stop_thr,
             self.users_per_batch, self.items_per_batch, self.step_size, be.cast_int(self.sum_exp_trick),
             self._st_ix_user.astype(be.obj_ind_type),
@@ -394,8 +405,11 @@ class HPF:
 
         if self.users_per_batch == 0:
             del self._st_ix_user
+        for name in ("Theta", "Beta"):          # filled in place by fit_hpf: the device copies (if any) are old
+            self._state.set_host(name, self._state.host[name], private=not self._state.handed.get(name, True))
         if self.keep_all_objs:
-            (self.Gamma_shp, self.Gamma_rte, self.Lambda_shp, self.Lambda_rte, self.k_rte, self.t_rte) = temp
+            for name, arr in zip(("Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "k_rte", "t_rte"), temp):
+                self._state.set_host(name, arr, private=True)
 
     # ------------------------------------------------------------------------------------------
     def _process_data_single(self, counts_df):
@@ -495,13 +509,15 @@ class HPF:
         items_in_batch = (np.unique(ix_i_batch) if items_in_batch is None
                           else np.require(items_in_batch, dtype=be.obj_ind_type, requirements=req))
 
-        if self.Theta is None or self.Beta is None:
+        if self._state.host.get("Theta") is None or self._state.host.get("Beta") is None:
             self._cast_before_fit()
-            (self.Gamma_shp, self.Gamma_rte, self.Lambda_shp, self.Lambda_rte, self.k_rte,
-             self.t_rte) = be.initialize_parameters(self.Theta, self.Beta, self.random_seed, self.a, self.a_prime,
-                                                    self.b_prime, self.c, self.c_prime, self.d_prime)
-            self.Theta = self.Gamma_shp / self.Gamma_rte
-            self.Beta = self.Lambda_shp / self.Lambda_rte
+            st = self._state
+            temp = be.initialize_parameters(st.host["Theta"], st.host["Beta"], self.random_seed, self.a, self.a_prime,
+                                            self.b_prime, self.c, self.c_prime, self.d_prime)
+            for name, arr in zip(("Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "k_rte", "t_rte"), temp):
+                st.set_host(name, arr, private=True)
+            st.set_host("Theta", temp[0] / temp[1], private=True)
+            st.set_host("Beta", temp[2] / temp[3], private=True)
 
         if new_users:
             n_add = self.nusers - (ix_u_batch.max() + 1)
@@ -523,11 +539,14 @@ class HPF:
         # sic (INIT:912): the multiplier uses the user counts for item batches too
         multiplier_batch = float(nusers) / users_in_batch.shape[0]
 
-        be.partial_fit(Y_batch, ix_u_batch, ix_i_batch, self.Theta, self.Beta, self.Gamma_shp, self.Gamma_rte,
-                       self.Lambda_shp, self.Lambda_rte, self.k_rte, self.t_rte, add_k_rte, add_t_rte, self.a, self.c,
-                       k_shp, t_shp, be.cast_ind_type(self.k), users_in_batch, items_in_batch,
-                       be.cast_int(self.allow_inconsistent_math), be.cast_real_t(step_size),
-                       be.cast_real_t(multiplier_batch), self.ncores, user_batch)
+        # the same step as the extension's partial_fit (be.partial_fit, PXI:423-473), on the state that stays on the
+        # device between calls: only the batch crosses PCIe; host copies are refreshed when somebody reads them
+        from . import svi
+        m = self._state.ensure_model(be._make_ops())
+        svi.partial_fit_device(m, Y_batch, ix_u_batch, ix_i_batch, add_k_rte, add_t_rte, self.a, self.c, k_shp, t_shp,
+                               users_in_batch, items_in_batch, be.cast_real_t(step_size),
+                               be.cast_real_t(multiplier_batch), user_batch)
+        self._state.touched()
         self.niter += 1
         self.is_fitted = True
         return self
@@ -571,12 +590,14 @@ class HPF:
     def _fold_in(self, counts_df, maxiter, ncores, random_seed, stop_thr, return_all):
         be = self._backend()
         Theta = np.empty(self.k, dtype=be.c_real_t)
+        # item tables: the resident device copies (uploaded once, re-used by topN and the next fold-in)
+        m = self._state.ensure_model(be._make_ops(), ("Beta", "Lambda_shp", "Lambda_rte"))
         temp = be.calc_user_factors(
             self.a, self.a_prime, self.b_prime, self.c, self.c_prime, self.d_prime,
             self._col(counts_df, "Count", be.c_real_t), self._col(counts_df, "ItemId", be.obj_ind_type),
-            Theta, self.Beta, self.Lambda_shp, self.Lambda_rte,
+            Theta, None, None, None,
             be.cast_ind_type(counts_df.shape[0]), be.cast_ind_type(self.k), be.cast_int(int(maxiter)),
-            be.cast_int(ncores), be.cast_int(int(random_seed)), stop_thr, be.cast_int(bool(return_all)))
+            be.cast_int(ncores), be.cast_int(int(random_seed)), stop_thr, be.cast_int(bool(return_all)), resident=m)
         if np.isnan(Theta).any():
             raise ValueError("NaNs encountered in the result. Failed to produce latent factors.")
         return Theta, temp
@@ -611,12 +632,13 @@ class HPF:
             counts_df['UserId'] = user_id
             counts_df['UserId'] = np.require(counts_df["UserId"], dtype=be.obj_ind_type)
             self.partial_fit(counts_df, new_users=(not update_existing))
-            Theta_prev = self.Theta[-1].copy()
+            Theta_prev = self._state.rows("Theta", -1)[0].copy()       # (one row: the state stays on the device)
             for _ in range(maxiter - 1):
                 self.partial_fit(counts_df)
-                if np.linalg.norm(self.Theta[-1] - Theta_prev) <= stop_thr:
+                last = self._state.rows("Theta", -1)[0]
+                if np.linalg.norm(last - Theta_prev) <= stop_thr:
                     break
-                Theta_prev = self.Theta[-1].copy()
+                Theta_prev = last.copy()
         else:
             # sic (INIT:1155): the reference passes cast_int(stop_thr) == 0, i.e. never stops early
             Theta, temp = self._fold_in(counts_df, maxiter, ncores, random_seed, float(be.cast_int(stop_thr)),
@@ -685,23 +707,44 @@ class HPF:
         user = self._lookup(user, self.user_mapping_, self.user_dict_)
         item = self._lookup(item, self.item_mapping_, self.item_dict_)
         assert user.shape[0] == item.shape[0]
+        st = self._state
         if user.shape[0] == 1:
             if user[0] == -1 or item[0] == -1:
                 return np.nan
-            return self.Theta[user].dot(self.Beta[item].T).reshape(-1)[0]
-        be = self._backend()
-        req = ["ENSUREARRAY", "C_CONTIGUOUS"]
+            return st.rows("Theta", user).dot(st.rows("Beta", item).T).reshape(-1)[0]
         unknown = (user == -1) | (item == -1)
         if not unknown.any():
-            return be.predict_arr(self.Theta, self.Beta, np.require(user, dtype=be.obj_ind_type, requirements=req),
-                                  np.require(item, dtype=be.obj_ind_type, requirements=req), self.ncores)
-        out = np.full(user.shape[0], np.nan, dtype=self.Theta.dtype)
+            return self._predict_pairs(user, item)
+        out = np.full(user.shape[0], np.nan, dtype=np.float32)
         if (~unknown).any():
-            out[~unknown] = be.predict_arr(self.Theta, self.Beta,
-                                           np.require(user[~unknown], dtype=be.obj_ind_type, requirements=req),
-                                           np.require(item[~unknown], dtype=be.obj_ind_type, requirements=req),
-                                           self.ncores)
+            out[~unknown] = self._predict_pairs(user[~unknown], item[~unknown])
         return out
+
+    def _pair_tables(self, n_pairs):
+        """(Theta, Beta) operands for n_pairs listed pairs: the resident device tables when they are current or the
+        pairs are many, else the host arrays (the backend then ships only the rows the pairs touch)."""
+        st = self._state
+        be = self._backend()
+        if (st.on_device("Theta") and st.on_device("Beta")) or 2 * n_pairs >= self.Theta_rows() + self.Beta_rows():
+            ops = be._make_ops()
+            return st.table(ops, "Theta"), st.table(ops, "Beta"), True
+        return st.peek_host("Theta"), st.peek_host("Beta"), False
+
+    def Theta_rows(self):
+        return int(self._state.host["Theta"].shape[0])
+
+    def Beta_rows(self):
+        return int(self._state.host["Beta"].shape[0])
+
+    def _predict_pairs(self, user, item):
+        be = self._backend()
+        req = ["ENSUREARRAY", "C_CONTIGUOUS"]
+        user = np.require(user, dtype=be.obj_ind_type, requirements=req)
+        item = np.require(item, dtype=be.obj_ind_type, requirements=req)
+        T, B, on_dev = self._pair_tables(user.shape[0])
+        if on_dev:
+            return be.pair_dots_device(T, B, user, item, self.k)
+        return be.predict_arr(T, B, user, item, self.ncores)
 
     def _seen_by(self, user):
         # int(): after an SVI fit the start index is a size_t array, and uint64 + int32 is float64 in numpy
@@ -736,7 +779,9 @@ class HPF:
             # device path: GEMV over the (cached) item table + mask + top-k; same ids as the reference's
             # argpartition/setdiff1d/argsort sequence (INIT:1337-1356), ties aside
             be = self._backend()
-            rec = be.top_items(self.Theta[user], self.Beta, n, self._seen_by(user) if exclude_seen else None)
+            st = self._state
+            rec = be.top_items(st.rows("Theta", user)[0], st.table(be._make_ops(), "Beta"), n,
+                               self._seen_by(user) if exclude_seen else None)
             return back(rec)
 
         items_pool = np.require(items_pool, requirements=["ENSUREARRAY"]).reshape(-1)
@@ -752,13 +797,14 @@ class HPF:
                 raise ValueError("No items to recommend.")
             if pool.shape[0] == 1:
                 raise ValueError("Only 1 item to recommend.")
-        neg = -self.Theta[user].dot(self.Beta[pool].T)
+        theta_u = self._state.rows("Theta", user)[0]
+        neg = -theta_u.dot(self._state.rows("Beta", pool).T)
         n = int(min(n, items_pool.shape[0]))
         if exclude_seen:
             n_ext = int(min(n + self._n_seen_by_user[user], items_pool.shape[0]))
             cand = np.argpartition(neg, n_ext - 1)[:n_ext]
             cand = np.setdiff1d(pool[cand], self._seen_by(user))
-            neg = -self.Theta[user].dot(self.Beta[cand].T)
+            neg = -theta_u.dot(self._state.rows("Beta", cand).T)
             return back(cand[np.argsort(neg)[:n]])
         cand = np.argpartition(neg, n - 1)[:n]
         return items_pool[cand[np.argsort(neg[cand])]]
@@ -771,11 +817,15 @@ class HPF:
         self._process_valset(input_df, valset=False)
         be = self._backend()
         self.ncores = be.cast_int(self.ncores)
-        out = {'llk': be.calc_llk(self._col(self.val_set, "Count", be.c_real_t),
-                                  self._col(self.val_set, "UserId", be.obj_ind_type),
-                                  self._col(self.val_set, "ItemId", be.obj_ind_type),
-                                  self.Theta, self.Beta, self.k, self.ncores, be.cast_int(bool(full_llk))),
-               'nobs': self.val_set.shape[0]}
+        yv = self._col(self.val_set, "Count", be.c_real_t)
+        uv = self._col(self.val_set, "UserId", be.obj_ind_type)
+        iv = self._col(self.val_set, "ItemId", be.obj_ind_type)
+        T, B, on_dev = self._pair_tables(yv.shape[0])
+        if on_dev:
+            llk = be.calc_llk_device(yv, uv, iv, T, B, self.k, bool(full_llk))
+        else:
+            llk = be.calc_llk(yv, uv, iv, T, B, self.k, self.ncores, be.cast_int(bool(full_llk)))
+        out = {'llk': llk, 'nobs': self.val_set.shape[0]}
         del self.val_set
         return out
 

@@ -30,11 +30,22 @@ obj_long_double_type = ctypes.c_longdouble
 _DEVICE = None   # None = torch's current device; a multi-GPU launcher sets the device per rank beforehand
 
 
+_OPS = {}
+
+
 def _make_ops():
-    """The HIP op set.  There is no alternative implementation in this package: HipOps raises when the
-    extension or the GPU is missing.  (tests/ substitute this module's `HipOps` name with a numpy stand-in to
-    exercise the host logic on GPU-less machines.)"""
-    return HipOps(_DEVICE)
+    """The HIP op set (one instance per device, created on first use).  There is no alternative implementation in
+    this package: HipOps raises when the extension or the GPU is missing.  (tests/ substitute this module's
+    `HipOps` name with a numpy stand-in to exercise the host logic on GPU-less machines.)"""
+    dev = _DEVICE
+    if dev is None and torch.cuda.is_available():
+        dev = "cuda:%d" % torch.cuda.current_device()
+    key = (HipOps, dev)
+    ops = _OPS.get(key)
+    if ops is None:
+        _OPS.clear()
+        ops = _OPS[key] = HipOps(dev)
+    return ops
 
 
 # -- helper functions (PXI:11-18) ---------------------------------------------------------
@@ -339,36 +350,18 @@ def _padded(host_arr, ld, dev):
 
 
 # -- not in the reference's extension: the scoring product of HPF.topN (hpfrec/__init__.py:1337-1356) ----
-_ITEM_CACHE = {}
-
-
-def _fingerprint(arr):
-    flat = arr.reshape(-1)
-    step = max(1, flat.shape[0] // 2048)
-    return (id(arr), arr.shape, flat[::step].tobytes())
-
-
-def device_item_table(Beta, ops):
-    """Padded device copy of the host item table, kept between calls (keyed on a fingerprint of the host array:
-    identity, shape and a strided sample of its values), shared by topN and the single-user fold-in."""
-    ld = cavi._lib.ld_for_k(int(Beta.shape[1]))
-    key = _fingerprint(Beta)
-    hit = _ITEM_CACHE.get("Beta")
-    if hit is None or hit[0] != key or hit[1].device != ops.device:
-        _ITEM_CACHE["Beta"] = hit = (key, _padded(Beta, ld, ops.device))
-    return hit[1]
-
-
 def top_items(theta_row, Beta, n, exclude=None):
     """Ids of the n rows of Beta with the largest theta_row . Beta[i], best first, optionally skipping
-    `exclude` (ids).  The item table is kept on the device between calls (keyed on a fingerprint of
-    the host array) so a query costs one GEMV over Beta, a mask and a top-k -- the reference does a host
-    GEMV + argpartition + setdiff1d + argsort per query."""
+    `exclude` (ids).  `Beta`: the padded device table [nitems][ld] (hpfrec_amd.HPF keeps it resident,
+    hpfrec_amd.resident) or a host array [nitems][k] (uploaded for this call: nothing is cached behind the
+    caller's back).  One GEMV over Beta, a mask and a top-k -- the reference does a host GEMV + argpartition +
+    setdiff1d + argsort per query."""
     ops = _make_ops()
     dev = ops.device
-    k = int(Beta.shape[1])
+    k = int(np.asarray(theta_row).reshape(-1).shape[0])
     ld = cavi._lib.ld_for_k(k)
-    tab = device_item_table(Beta, ops)
+    tab = Beta if torch.is_tensor(Beta) else _padded(Beta, ld, dev)
+    assert tab.shape[1] == ld
     vec = torch.zeros(ld, dtype=torch.float32, device=dev)
     vec[:k] = torch.from_numpy(np.ascontiguousarray(theta_row, dtype=np.float32).reshape(-1)).to(dev)
     scores = torch.empty(tab.shape[0], dtype=torch.float32, device=dev)
@@ -384,11 +377,38 @@ def top_items(theta_row, Beta, n, exclude=None):
     return torch.topk(scores, n, largest=True, sorted=True).indices.cpu().numpy()
 
 
+def pair_dots_device(T, B, ix_u, ix_i, k):
+    """predict_arr on tables that are already on the device (padded [rows][ld])."""
+    ops = _make_ops()
+    ld = cavi._lib.ld_for_k(int(k))
+    iu = torch.from_numpy(np.ascontiguousarray(ix_u).astype(np.int64)).to(ops.device).to(torch.int32)
+    ii = torch.from_numpy(np.ascontiguousarray(ix_i).astype(np.int64)).to(ops.device).to(torch.int32)
+    if iu.numel() and (int(iu.max()) >= T.shape[0] or int(ii.max()) >= B.shape[0]):
+        raise ValueError("user/item id out of range")
+    out = torch.zeros(iu.shape[0], dtype=torch.float32, device=ops.device)
+    ops.pair_dot(T, B, iu, ii, out, int(k), ld)
+    return out.cpu().numpy()
+
+
+def calc_llk_device(Y, ix_u, ix_i, T, B, k, full_llk):
+    """calc_llk on tables that are already on the device (padded [rows][ld])."""
+    ops = _make_ops()
+    ld = cavi._lib.ld_for_k(int(k))
+    iu = torch.from_numpy(np.ascontiguousarray(ix_u).astype(np.int64)).to(ops.device).to(torch.int32)
+    ii = torch.from_numpy(np.ascontiguousarray(ix_i).astype(np.int64)).to(ops.device).to(torch.int32)
+    if iu.numel() and (int(iu.max()) >= T.shape[0] or int(ii.max()) >= B.shape[0]):
+        raise ValueError("user/item id out of range")
+    y = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(ops.device)
+    t = ops.pair_llk(T, B, iu, ii, y, int(k), ld, bool(full_llk)).cpu().numpy()
+    return np.longdouble(t[0]) - np.longdouble(t[2])
+
+
 # -- PXI:476-520 --------------------------------------------------------------------------
 def calc_user_factors(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_i, Theta, Beta, Lambda_shp, Lambda_rte, nY, k,
-                      maxiter, nthreads, random_seed, stop_thr, return_all):
-    """Fold-in of one new user with item parameters fixed (HPF.predict_factors / add_user)."""
+                      maxiter, nthreads, random_seed, stop_thr, return_all, resident=None):
+    """Fold-in of one new user with item parameters fixed (HPF.predict_factors / add_user).  `resident` (not in
+    the reference's signature): a DeviceModel already holding the item tables, see svi.calc_user_factors."""
     ops = _make_ops()
     return svi.calc_user_factors(ops, a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_i, Theta, Beta,
                                  Lambda_shp, Lambda_rte, int(nY), int(k), int(maxiter), int(random_seed),
-                                 float(stop_thr), bool(return_all), Beta_dev=device_item_table(Beta, ops))
+                                 float(stop_thr), bool(return_all), resident=resident)

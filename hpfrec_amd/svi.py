@@ -71,24 +71,45 @@ class DeviceModel:
         # full-height accumulator tables: the batch sweeps write a row's phi-sums straight to acc[row]
         self.acc_u = torch.zeros((self.nU, self.ld), **f32)
         self.acc_i = torch.zeros((self.nI, self.ld), **f32)
+        self.csT = torch.zeros(self.ld, **f32)      # Theta.sum(axis=0) / Beta.sum(axis=0): set by put(), kept
+        self.csB = torch.zeros(self.ld, **f32)      # current by every step
 
     def v(self, name):
         return getattr(self, name)[:, : self.k]
 
-    def load(self, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta):
+    def put(self, name, host):
+        """Upload one state array ([n,k] table or [n,1] scalar-rate vector) from the host."""
         dev = self.ops.device
-        for n, a in zip(_NAMES, (Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, Theta, Beta)):
-            self.v(n).copy_(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev))
-        self.k_rte.copy_(torch.from_numpy(np.ascontiguousarray(k_rte, dtype=np.float32).reshape(-1)))
-        self.t_rte.copy_(torch.from_numpy(np.ascontiguousarray(t_rte, dtype=np.float32).reshape(-1)))
-        self.csT = self.colsum("Theta")     # Theta.sum(axis=0) / Beta.sum(axis=0), kept current by every step
-        self.csB = self.colsum("Beta")
+        a = torch.from_numpy(np.ascontiguousarray(host, dtype=np.float32))
+        if name in ("k_rte", "t_rte"):
+            getattr(self, name).copy_(a.reshape(-1))
+        else:
+            self.v(name).copy_(a.to(dev))
+            if name == "Theta":           # Theta.sum(axis=0) / Beta.sum(axis=0) are kept current by every step
+                self.csT = self.colsum("Theta")
+            elif name == "Beta":
+                self.csB = self.colsum("Beta")
+
+    def get(self, name, out=None):
+        """Download one state array; into `out` (in place) when given."""
+        if name in ("k_rte", "t_rte"):
+            a = getattr(self, name).cpu().numpy().reshape(-1, 1)
+        else:
+            a = self.v(name).contiguous().cpu().numpy()
+        if out is None:
+            return a
+        out[...] = a
+        return out
+
+    def load(self, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta):
+        for n, a in zip(_NAMES + ("k_rte", "t_rte"),
+                        (Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, Theta, Beta, k_rte, t_rte)):
+            self.put(n, a)
 
     def store(self, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta):
-        for n, a in zip(_NAMES, (Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, Theta, Beta)):
-            a[:, :] = self.v(n).contiguous().cpu().numpy()
-        k_rte[:, :] = self.k_rte.cpu().numpy().reshape(-1, 1)
-        t_rte[:, :] = self.t_rte.cpu().numpy().reshape(-1, 1)
+        for n, a in zip(_NAMES + ("k_rte", "t_rte"),
+                        (Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, Theta, Beta, k_rte, t_rte)):
+            self.get(n, out=a)
 
     def colsum(self, name):
         """tab.sum(axis=0) -> [ld] (HIP colsum kernels; PXI:300,320,352,372)."""
@@ -162,19 +183,28 @@ def _svi_step(m, hy, su, si, users_tb, items_tb, step, mult, user_batch, all_sca
         ops.svi_rate_rows(I["rows"], None, I["fac"], I["rs"], None, 0.0, I["add"], step, step_prev, 1, k, ld)
 
 
+def gather_rows(side, rows):
+    """COO triplets (row, col, y) of the listed rows of a SparseSide (ascending `rows`: the triplets come grouped)."""
+    st = side.indptr[rows]
+    deg = side.indptr[rows + 1] - st
+    total = int(deg.sum().item())
+    offs = torch.cumsum(deg, 0) - deg
+    pos = torch.repeat_interleave(st - offs, deg, output_size=total) + torch.arange(total, device=rows.device)
+    return (torch.repeat_interleave(rows, deg, output_size=total), side.idx[pos].to(torch.int64), side.y[pos])
+
+
 def _dev_ids(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a).astype(np.int64)).to(dev)
 
 
 # -- PXI:423-473 ------------------------------------------------------------------------------------
-def partial_fit_step(ops, Y_batch, ix_u_batch, ix_i_batch, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp,
-                     Lambda_rte, k_rte, t_rte, add_k_rte, add_t_rte, a, c, k_shp, t_shp, k, users_this_batch,
-                     items_this_batch, step_size_batch, multiplier_batch, user_batch):
-    nU, nI = Theta.shape[0], Beta.shape[0]
-    if ix_u_batch.size and (int(ix_u_batch.max()) >= nU or int(ix_i_batch.max()) >= nI):
+def partial_fit_device(m, Y_batch, ix_u_batch, ix_i_batch, add_k_rte, add_t_rte, a, c, k_shp, t_shp,
+                       users_this_batch, items_this_batch, step_size_batch, multiplier_batch, user_batch):
+    """One partial_fit step on a DeviceModel that already holds the current state: only the batch's triplets and
+    row lists cross PCIe.  Mutates all eight state tables of `m` (as the reference mutates its arrays, PXI:443-473)."""
+    ops = m.ops
+    if ix_u_batch.size and (int(ix_u_batch.max()) >= m.nU or int(ix_i_batch.max()) >= m.nI):
         raise ValueError("partial_fit: user/item id out of range")
-    m = DeviceModel(ops, k, nU, nI)
-    m.load(Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta)
     dev = ops.device
     hy = {"a": float(np.float32(a)), "c": float(np.float32(c)), "k_shp": float(np.float32(k_shp)),
           "t_shp": float(np.float32(t_shp)), "add_k_rte": float(np.float32(add_k_rte)),
@@ -186,6 +216,18 @@ def partial_fit_step(ops, Y_batch, ix_u_batch, ix_i_batch, Theta, Beta, Gamma_sh
     if not (bool(torch.isin(su.rows, users_tb).all()) and bool(torch.isin(si.rows, items_tb).all())):
         raise ValueError("the batch contains users/items that are not in users_in_batch/items_in_batch")
     _svi_step(m, hy, su, si, users_tb, items_tb, step_size_batch, multiplier_batch, user_batch, all_scalar_rows=True)
+
+
+def partial_fit_step(ops, Y_batch, ix_u_batch, ix_i_batch, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp,
+                     Lambda_rte, k_rte, t_rte, add_k_rte, add_t_rte, a, c, k_shp, t_shp, k, users_this_batch,
+                     items_this_batch, step_size_batch, multiplier_batch, user_batch):
+    """The module-level form (drop-in for the extension function): the caller's host arrays are the state, so all
+    eight go up and come back, in place.  hpfrec_amd.HPF keeps the state on the device between calls instead
+    (hpfrec_amd.resident)."""
+    m = DeviceModel(ops, k, Theta.shape[0], Beta.shape[0])
+    m.load(Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta)
+    partial_fit_device(m, Y_batch, ix_u_batch, ix_i_batch, add_k_rte, add_t_rte, a, c, k_shp, t_shp,
+                       users_this_batch, items_this_batch, step_size_batch, multiplier_batch, user_batch)
     m.store(Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta)
 
 
@@ -208,15 +250,6 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
     ti = _dev_ids(ix_i, dev)
     ty = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(dev)
     users, items, u_sorted = layout.build_sides(tu, ti, ty, nU, nI)
-
-    def gather_rows(side, rows):
-        """COO triplets (row, col, y) of the listed rows of a SparseSide."""
-        st = side.indptr[rows]
-        deg = side.indptr[rows + 1] - st
-        total = int(deg.sum().item())
-        offs = torch.cumsum(deg, 0) - deg
-        pos = torch.repeat_interleave(st - offs, deg, output_size=total) + torch.arange(total, device=dev)
-        return (torch.repeat_interleave(rows, deg, output_size=total), side.idx[pos].to(torch.int64), side.y[pos])
 
     val = None
     if has_valset and Yval is not None and Yval.shape[0] > 0:
@@ -317,9 +350,13 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
 
 # -- PXI:476-520 ------------------------------------------------------------------------------------
 def calc_user_factors(ops, a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_i, Theta, Beta, Lambda_shp, Lambda_rte,
-                      nY, k, maxiter, random_seed, stop_thr, return_all, Beta_dev=None):
+                      nY, k, maxiter, random_seed, stop_thr, return_all, resident=None):
     """Local CAVI for ONE user with the item parameters fixed.  Fills `Theta` (k,) in place; returns
-    (Gamma_shp, Gamma_rte, phi/Y) when return_all else None."""
+    (Gamma_shp, Gamma_rte, phi/Y) when return_all else None.
+
+    resident: a DeviceModel holding the current Beta / Lambda_shp / Lambda_rte (then the host arguments of those
+    names are not read at all: the user's item rows are gathered on the device and Beta.sum(axis=0) is the
+    model's resident column sum)."""
     f = np.float32
     dev = ops.device
     ld = _lib.ld_for_k(k)
@@ -330,13 +367,15 @@ def calc_user_factors(ops, a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_i, Th
     rng = np.random.default_rng(seed=random_seed if random_seed > 0 else None)
     Theta[:] = rng.gamma(a, 1 / b_prime, size=k).astype(np.float32)
     k_rte = f(b_prime + Theta.sum())
-    if Beta_dev is None:
+    if resident is not None:
+        cs = resident.csB
+    else:
         Beta_dev = torch.zeros((Beta.shape[0], ld), dtype=torch.float32, device=dev)
         Beta_dev[:, :k] = torch.from_numpy(np.ascontiguousarray(Beta, dtype=np.float32)).to(dev)
-    csp = torch.zeros((ops.finalize_grid(Beta.shape[0]), ld), dtype=torch.float32, device=dev)
-    cs = torch.zeros(ld, dtype=torch.float32, device=dev)
-    ops.colsum(Beta_dev, Beta.shape[0], ld, csp)
-    ops.colsum_reduce(csp, cs, ld)
+        csp = torch.zeros((ops.finalize_grid(Beta.shape[0]), ld), dtype=torch.float32, device=dev)
+        cs = torch.zeros(ld, dtype=torch.float32, device=dev)
+        ops.colsum(Beta_dev, Beta.shape[0], ld, csp)
+        ops.colsum_reduce(csp, cs, ld)
     csB = cs[:k].cpu().numpy()                                   # Beta.sum(axis=0)
     Gamma_rte = rng.gamma(a_prime, b_prime / a_prime, size=1).astype(np.float32) + csB
     Gamma_shp = Gamma_rte * Theta * rng.uniform(low=.85, high=1.15, size=k).astype(np.float32)
@@ -346,10 +385,14 @@ def calc_user_factors(ops, a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_i, Th
     # the user's items, renumbered 0..nY-1; only those rows of the item tables go to the device
     ix = np.ascontiguousarray(ix_i).astype(np.int64)
     n = int(nY)
-    Ls = torch.zeros((n, ld), dtype=torch.float32, device=dev)
-    Lr = torch.zeros((n, ld), dtype=torch.float32, device=dev)
-    Ls[:, :k] = torch.from_numpy(np.ascontiguousarray(Lambda_shp[ix], dtype=np.float32)).to(dev)
-    Lr[:, :k] = torch.from_numpy(np.ascontiguousarray(Lambda_rte[ix], dtype=np.float32)).to(dev)
+    if resident is not None:
+        ixd = torch.from_numpy(ix).to(dev)
+        Ls, Lr = resident.Lambda_shp[ixd].contiguous(), resident.Lambda_rte[ixd].contiguous()
+    else:
+        Ls = torch.zeros((n, ld), dtype=torch.float32, device=dev)
+        Lr = torch.zeros((n, ld), dtype=torch.float32, device=dev)
+        Ls[:, :k] = torch.from_numpy(np.ascontiguousarray(Lambda_shp[ix], dtype=np.float32)).to(dev)
+        Lr[:, :k] = torch.from_numpy(np.ascontiguousarray(Lambda_rte[ix], dtype=np.float32)).to(dev)
     eB = torch.zeros((n, ld), dtype=torch.float32, device=dev)
     ops.expect(Ls, Lr, eB, n, k, ld)
     side = BatchSide(torch.zeros(n, dtype=torch.int64, device=dev), torch.arange(n, dtype=torch.int64, device=dev),

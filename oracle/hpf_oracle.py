@@ -262,5 +262,132 @@ def partial_fit_step(st, hy, Y_batch, ix_u_batch, ix_i_batch, users_this_batch, 
     st.t_rte[:, :] = step * (float(hy.add_t_rte) + st.Beta.sum(axis=1, keepdims=True)) + step_prev * st.t_rte
 
 
+def csc_data(ix_u, ix_i, Y, nU, nI):
+    """get_csc_data, PXI:22-25 (scipy's coo -> csc: rows ascending inside a column, duplicate pairs summed)."""
+    from scipy.sparse import coo_array
+    X = coo_array((Y, (ix_u, ix_i)), shape=(nU, nI)).tocsc()
+    return _ind(X.indptr), _ind(X.indices), _f32(X.data)
+
+
+def svi_inputs_like_reference(Y, ix_u, ix_i, nU, nI):
+    """What HPF.fit hands to fit_hpf in stochastic mode with users_per_batch > 0: the triplets sorted by user with
+    pandas' default (unstable) sort -- twice, INIT:520 and INIT:600 -- and the CSR start indices from scipy's
+    coo -> csr (INIT:589-599).  Returns (Y, ix_u, ix_i, st_ix_u)."""
+    import pandas as pd
+    from scipy.sparse import coo_array
+    df = pd.DataFrame({"UserId": _ind(ix_u), "ItemId": _ind(ix_i), "Count": _f32(Y)})
+    df.sort_values("UserId", inplace=True)
+    X = coo_array((df["Count"].to_numpy(copy=False), (df["UserId"].to_numpy(copy=False), df["ItemId"].to_numpy(copy=False))),
+                  shape=(nU, nI), dtype=np.float32).tocsr()
+    df.sort_values("UserId", inplace=True)
+    return (_f32(df["Count"].to_numpy()), _ind(df["UserId"].to_numpy()), _ind(df["ItemId"].to_numpy()),
+            _ind(X.indptr))
+
+
+def fit_svi(Y, ix_u, ix_i, st_ix_u, nU, nI, k, maxiter, random_seed, users_per_batch, items_per_batch,
+            step_size=None, a=0.3, a_prime=0.3, b_prime=1.0, c=0.3, c_prime=0.3, d_prime=1.0, nthreads=1, state=None,
+            exact_colsums=False):
+    """The stochastic epochs of fit_hpf, PXI:262-377, statement for statement (alloc_full_phi=True form: phi rows
+    indexed by the nonzero's position; the `_small` form only differs in where a phi row is stored).
+
+    Y, ix_u, ix_i: as fit_hpf receives them (sorted by user when users_per_batch > 0, st_ix_u their CSR start
+    indices -- see svi_inputs_like_reference).  The scatter runs serially in batch order: the reference's `prange`
+    over batch rows races on the gathered side (PXI:745-746), nthreads=1 is its only reproducible order and the one
+    the golden vectors were captured with.  `nthreads` here only parallelises phi (race-free).
+
+    exact_colsums=True is NOT the reference (see cavi_iteration): Theta.sum(axis=0) / Beta.sum(axis=0) in float64."""
+    L = lib()
+
+    def colsum(arr, keepdims):
+        if exact_colsums:
+            return arr.sum(axis=0, keepdims=keepdims, dtype=np.float64).astype(np.float32)
+        return arr.sum(axis=0, keepdims=keepdims)
+
+    f = np.float32
+    Y, ix_u, ix_i = _f32(Y), _ind(ix_u), _ind(ix_i)
+    hy = Hyper(k, a, a_prime, b_prime, c, c_prime, d_prime)
+    st = state if state is not None else State(nU, nI, hy, random_seed)
+    if step_size is None:
+        step_size = lambda x: 1 / np.sqrt(x + 2)      # noqa: E731  (INIT:208 default)
+    k_shp, t_shp = float(hy.k_shp), float(hy.t_shp)
+    add_k_rte, add_t_rte = float(hy.add_k_rte), float(hy.add_t_rte)
+    nY = Y.shape[0]
+    phi = np.empty((nY, k), dtype=np.float32)
+    if items_per_batch > 0:
+        items_numeration = np.arange(nI, dtype=obj_ind_type)
+        nbatches_i = int(np.ceil(float(nI) / float(items_per_batch)))
+        st_ix_i_copy, ix_u_copy, Ycopy = csc_data(ix_u, ix_i, Y, nU, nI)
+        phi_i = np.empty((Ycopy.shape[0], k), dtype=np.float32)
+    if users_per_batch != 0:
+        users_numeration = np.arange(nU, dtype=obj_ind_type)
+        nbatches_u = int(np.ceil(float(nU) / float(users_per_batch)))
+        st_ix_u = _ind(st_ix_u)
+    rng = np.random.default_rng(seed=random_seed if random_seed > 0 else None)
+
+    def unique_other(rows, indptr, idx):
+        if rows.shape[0] == 0:
+            return np.empty(0, dtype=obj_ind_type)
+        return np.unique(np.concatenate([idx[indptr[r]: indptr[r + 1]] for r in rows]))
+
+    for i in range(maxiter):
+        step = float(f(step_size(i)))                       # <real_t> step_size(i), boxed back to a Python float
+        step_prev = float(f(1 - step))                      # cdef real_t
+        if users_per_batch > 0 and items_per_batch > 0:
+            user_epoch = ((i + 1) % 2) == 0
+        else:
+            user_epoch = users_per_batch > 0 and items_per_batch == 0
+        if user_epoch:
+            rng.shuffle(users_numeration)
+            for bt in range(nbatches_u):
+                st_b, end_b = bt * users_per_batch, min(nU, (bt + 1) * users_per_batch)
+                users_tb = np.ascontiguousarray(users_numeration[st_b:end_b])
+                mult = float(f(float(nU) / float(end_b - st_b)))
+                items_tb = unique_other(users_tb, st_ix_u, ix_i)
+                L.hpf_oracle_update_phi_csr_f32(_p(st.Gamma_shp), _p(st.Gamma_rte), _p(st.Lambda_shp), _p(st.Lambda_rte),
+                                                _p(phi), _p(Y), _p(ix_i), _p(st_ix_u), _p(users_tb), k,
+                                                users_tb.shape[0], int(nthreads))
+                st.Gamma_rte = k_shp / st.k_rte + colsum(st.Beta, True)
+                Lambda_shp_prev = st.Lambda_shp[items_tb, :].copy()
+                st.Gamma_shp[users_tb, :] = float(hy.a)
+                st.Lambda_shp[items_tb, :] = float(hy.c)
+                L.hpf_oracle_scatter_csr_f32(_p(st.Gamma_shp), _p(st.Lambda_shp), _p(phi), k, users_tb.shape[0], _p(ix_i),
+                                             _p(st_ix_u), _p(users_tb))
+                st.Lambda_shp[items_tb, :] = step * mult * st.Lambda_shp[items_tb, :] + step_prev * Lambda_shp_prev
+                st.Theta[:, :] = st.Gamma_shp / st.Gamma_rte
+                st.Lambda_rte[items_tb, :] = (step * (t_shp / st.t_rte[items_tb] + colsum(st.Theta, False))
+                                              + step_prev * st.Lambda_rte[items_tb, :])
+                st.Beta[:, :] = st.Lambda_shp / st.Lambda_rte
+                st.k_rte[users_tb] = (step * (add_k_rte + st.Theta[users_tb].sum(axis=1, keepdims=True))
+                                      + step_prev * st.k_rte[users_tb])
+                st.t_rte[items_tb] = (step * (add_t_rte + st.Beta[items_tb].sum(axis=1, keepdims=True))
+                                      + step_prev * st.t_rte[items_tb])
+        else:
+            rng.shuffle(items_numeration)
+            for bt in range(nbatches_i):
+                st_b, end_b = bt * items_per_batch, min(nI, (bt + 1) * items_per_batch)
+                items_tb = np.ascontiguousarray(items_numeration[st_b:end_b])
+                mult = float(f(float(nI) / float(end_b - st_b)))
+                users_tb = unique_other(items_tb, st_ix_i_copy, ix_u_copy)
+                L.hpf_oracle_update_phi_csr_f32(_p(st.Lambda_shp), _p(st.Lambda_rte), _p(st.Gamma_shp), _p(st.Gamma_rte),
+                                                _p(phi_i), _p(Ycopy), _p(ix_u_copy), _p(st_ix_i_copy), _p(items_tb), k,
+                                                items_tb.shape[0], int(nthreads))
+                st.Lambda_rte = t_shp / st.t_rte + colsum(st.Theta, True)
+                Gamma_shp_prev = st.Gamma_shp[users_tb, :].copy()
+                st.Gamma_shp[users_tb, :] = float(hy.a)
+                st.Lambda_shp[items_tb, :] = float(hy.c)
+                L.hpf_oracle_scatter_csr_f32(_p(st.Lambda_shp), _p(st.Gamma_shp), _p(phi_i), k, items_tb.shape[0],
+                                             _p(ix_u_copy), _p(st_ix_i_copy), _p(items_tb))
+                st.Gamma_shp[users_tb, :] = step * mult * st.Gamma_shp[users_tb, :] + step_prev * Gamma_shp_prev
+                st.Beta[:, :] = st.Lambda_shp / st.Lambda_rte
+                st.Gamma_rte[users_tb, :] = (step * (k_shp / st.k_rte[users_tb] + colsum(st.Beta, False))
+                                             + step_prev * st.Gamma_rte[users_tb, :])
+                st.Theta[:, :] = st.Gamma_shp / st.Gamma_rte
+                st.k_rte[users_tb] = (step * (add_k_rte + st.Theta[users_tb].sum(axis=1, keepdims=True))
+                                      + step_prev * st.k_rte[users_tb])
+                st.t_rte[items_tb] = (step * (add_t_rte + st.Beta[items_tb].sum(axis=1, keepdims=True))
+                                      + step_prev * st.t_rte[items_tb])
+    return st
+
+
 def max_threads():
     return int(lib().hpf_oracle_max_threads())

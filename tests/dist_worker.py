@@ -35,11 +35,15 @@ def _run(rank, world, port, out_dir, k, its, case, device="cpu"):
     else:
         import torch
         torch.cuda.set_device(0)
-    if case == "c1":
-        df, nU, nI = datagen.readme_counts()
+    if case == "c4small":     # BASELINE C4's shape of problem at 2M nonzeros (tests/test_full_size.py)
+        nU, nI = 100_000, 30_000
+        iu, ii, Y = datagen.synthetic_hpf_shaped(nU, nI, 2_000_000, seed=4)
     else:
-        df, nU, nI = datagen.mid_counts(nusers=600, nitems=400, nobs=20000)
-    Y, iu, ii = datagen.triplets(df)
+        if case == "c1":
+            df, nU, nI = datagen.readme_counts()
+        else:
+            df, nU, nI = datagen.mid_counts(nusers=600, nitems=400, nobs=20000)
+        Y, iu, ii = datagen.triplets(df)
     Theta = np.empty((nU, k), np.float32)
     Beta = np.empty((nI, k), np.float32)
     i, temp, llk = be.fit_hpf(0.3, 0.3, 1.0, 0.3, 0.3, 1.0, Y, iu, ii, Theta, Beta, its, "maxiter", its, 1e-3, 0, 0, None,

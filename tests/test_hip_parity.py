@@ -552,7 +552,7 @@ def test_invariants_at_c3_full_size(ops):
     assert abs(res["fused"][2][0] / res["split"][2][0] - 1) < 1e-7
 
 
-@pytest.mark.parametrize("k", [30, 50, 130])
+@pytest.mark.parametrize("k", [30, 50, 130, 200, 300])
 def test_svi_row_ops(ops, k):
     """svi_shape_rows / svi_refresh / svi_rate_rows against the numpy statements (float32, statement for statement)."""
     rs = np.random.RandomState(k)

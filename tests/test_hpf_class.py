@@ -154,3 +154,85 @@ def test_use_float_false_is_refused():
     df, nU, nI = datagen.readme_counts()
     with pytest.raises(NotImplementedError):
         HPF(use_float=False, verbose=False).fit(df.copy())
+
+
+def test_state_stays_on_the_device_and_never_goes_stale(any_backend):
+    """hpfrec_amd.resident: between calls the state lives on the device; reading / editing / assigning the public
+    attributes is always reflected by the next device operation (no content fingerprints), and a stream of
+    partial_fit calls moves only the batches over PCIe."""
+    import copy
+    import pickle
+    batches, nU, nI = datagen.partial_fit_batches()
+    k = 12
+    m = HPF(k=k, reindex=False, keep_data=False, random_seed=5, verbose=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.partial_fit(batches[0][1].copy(), nusers=nU, nitems=nI)
+        st = m._state
+        up0, down0 = st.stats["h2d_bytes"], st.stats["d2h_bytes"]
+        assert up0 > 0 and down0 == 0                      # first call: everything went up, nothing came back
+        for kind, bdf in batches[1:]:
+            m.partial_fit(bdf.copy(), batch_type=kind)
+    assert st.stats["h2d_bytes"] == up0 and st.stats["d2h_bytes"] == 0     # three more calls: no table crossed PCIe
+    assert not st.host_ok["Theta"] and st.on_device("Theta")
+    # the same sequence through the extension-level entry point (full upload/download per call) gives the same state
+    m2 = HPF(k=k, reindex=False, keep_data=False, random_seed=5, verbose=False)
+    be = m2._backend()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m2.partial_fit(batches[0][1].iloc[:0:1].copy() if False else batches[0][1].copy(), nusers=nU, nitems=nI)
+    ref = {n: getattr(m2, n).copy() for n in NAMES}
+    niter = 1
+    for kind, bdf in batches[1:]:
+        Y, iu, ii = datagen.triplets(bdf)
+        users, items = np.unique(iu), np.unique(ii)
+        be.partial_fit(Y, iu, ii, ref["Theta"], ref["Beta"], ref["Gamma_shp"], ref["Gamma_rte"], ref["Lambda_shp"],
+                       ref["Lambda_rte"], ref["k_rte"], ref["t_rte"], be.cast_real_t(0.3 / 1.0), be.cast_real_t(0.3 / 1.0),
+                       0.3, 0.3, be.cast_real_t(0.3 + k * 0.3), be.cast_real_t(0.3 + k * 0.3), k, users, items, 0,
+                       be.cast_real_t(1 / np.sqrt(niter + 2)), be.cast_real_t(float(nU) / users.shape[0]), 1,
+                       kind == "users")
+        niter += 1
+    for n in NAMES:                                              # reading the attributes downloads the tables ...
+        # (to rounding: the resident model carries its column sums from step to step, a fresh upload recomputes them
+        # with another launch geometry)
+        assert _maxrel(getattr(m, n), ref[n]) < 1e-5, n
+    assert st.stats["d2h_bytes"] > 0 and not st.on_device("Beta")   # ... and hands them out: device copies untrusted
+    # in-place edits of a few rows at ANY later time (a sampled fingerprint would not notice them) reach topN
+    B = m.Beta
+    top = m.topN(user=3, n=5, exclude_seen=False)
+    loser = int(np.setdiff1d(np.arange(nI), top)[0])
+    B[loser] = 1e3
+    assert m.topN(user=3, n=5, exclude_seen=False)[0] == loser
+    B[loser] = 1e-9
+    assert loser not in m.topN(user=3, n=5, exclude_seen=False)
+    # an object whose arrays were never handed out re-uses its device tables
+    m4 = HPF(k=k, reindex=False, keep_data=False, random_seed=5, verbose=False, maxiter=3, check_every=None).fit(batches[0][1].copy())
+    r1 = m4.topN(user=3, n=5, exclude_seen=False)
+    up4 = m4._state.stats["h2d_bytes"]
+    assert up4 > 0 and np.array_equal(m4.topN(user=3, n=5, exclude_seen=False), r1)
+    m4.predict_factors(batches[1][1][["ItemId", "Count"]].iloc[:7].copy())
+    lam = m4._state.host["Lambda_shp"].nbytes * 2
+    assert m4._state.stats["h2d_bytes"] == up4 + lam        # fold-in: Lambda_shp/Lambda_rte went up once, Beta was there
+    m4.predict_factors(batches[1][1][["ItemId", "Count"]].iloc[:7].copy())
+    assert m4._state.stats["h2d_bytes"] == up4 + lam and m4._state.stats["d2h_bytes"] == 0
+    # re-assignment, predict and eval_llk see the current arrays too
+    newB = np.ascontiguousarray(m.Beta[::-1])
+    m.Beta = newB
+    want = (m.Theta[[1, 2, 3]] * newB[[5, 6, 7]]).sum(axis=1)
+    assert np.allclose(m.predict(np.array([1, 2, 3]), np.array([5, 6, 7])), want, rtol=1e-5)
+    assert abs(m.predict(1, 5) / want[0] - 1) < 1e-5
+    pairs = batches[0][1]
+    a = m.eval_llk(pairs.copy())["llk"]
+    m.Beta = newB * np.float32(2.0)
+    assert abs(float(a - m.eval_llk(pairs.copy())["llk"])) > 1e-3
+    # a later partial_fit starts from the edited arrays
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.partial_fit(batches[1][1].copy())
+    assert np.isfinite(m.Theta).all() and m.Beta[loser if False else 0].shape == (k,)
+    # pickling / deep copies carry the host arrays
+    m3 = pickle.loads(pickle.dumps(copy.deepcopy(m._state)))
+    for n in NAMES:
+        assert np.array_equal(m3.host[n], getattr(m, n)), n
+    # attributes that were never assigned behave like missing attributes
+    assert not hasattr(HPF(verbose=False), "Gamma_shp") and HPF(verbose=False).Theta is None

@@ -83,3 +83,18 @@ def test_partial_fit_bit_exact():
         assert niter == int(g["call%d_niter" % (b + 1)])
         for n in O.State.names:
             assert np.array_equal(getattr(st, n), g["call%d_%s" % (b + 1, n)]), (b, n)
+
+
+@pytest.mark.parametrize("tag,upb,ipb", [("both", 20, 25), ("users", 30, 0), ("items", 0, 40), ("both_fullphi", 20, 25)])
+def test_svi_epochs_bit_exact(tag, upb, ipb):
+    """O.fit_svi (the stochastic epochs of fit_hpf, PXI:262-377) against the reference's ncores=1 captures: 4 epochs
+    on the README data, users-only / items-only / alternating."""
+    df, nU, nI = datagen.readme_counts()
+    Y, iu, ii = datagen.triplets(df)
+    g = np.load(os.path.join(GOLDEN, "c1_svi.npz"))
+    st_ix_u = np.zeros(1, np.uint64)
+    if upb > 0:
+        Y, iu, ii, st_ix_u = O.svi_inputs_like_reference(Y, iu, ii, nU, nI)
+    st = O.fit_svi(Y, iu, ii, st_ix_u, nU, nI, 30, 4, 123, upb, ipb)
+    for n in O.State.names:
+        assert np.array_equal(getattr(st, n), g["%s_%s" % (tag, n)]), (tag, n)

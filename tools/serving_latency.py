@@ -14,10 +14,11 @@ from hpfrec_amd import HPF  # noqa: E402
 nU, nI, k = 1_000_000, 380_000, 50
 rs = np.random.RandomState(0)
 m = HPF(k=k, reindex=False, verbose=False)
-m.Theta = rs.gamma(0.3, 1.0, size=(nU, k)).astype(np.float32)
-m.Beta = rs.gamma(0.3, 1.0, size=(nI, k)).astype(np.float32)
-m.Lambda_shp = rs.uniform(0.3, 5, size=(nI, k)).astype(np.float32)
-m.Lambda_rte = rs.uniform(0.3, 5, size=(nI, k)).astype(np.float32)
+# (as a fitted model holds them: arrays the package created itself and never handed out -- an array assigned through
+# the public attribute stays referenced by the caller and is re-uploaded before every device use, hpfrec_amd/resident.py)
+for name, arr in (("Theta", rs.gamma(0.3, 1.0, size=(nU, k))), ("Beta", rs.gamma(0.3, 1.0, size=(nI, k))),
+                  ("Lambda_shp", rs.uniform(0.3, 5, size=(nI, k))), ("Lambda_rte", rs.uniform(0.3, 5, size=(nI, k)))):
+    m._state.set_host(name, arr.astype(np.float32), private=True)
 m.nusers, m.nitems, m.is_fitted, m.niter = nU, nI, True, 1
 m.seen = np.sort(rs.choice(nI, size=48, replace=False))
 m._n_seen_by_user = np.full(nU, 48, dtype=np.int64)
@@ -35,7 +36,7 @@ def timeit(f, n=20):
 print("topN(n=10, exclude_seen=True):   %.2f ms/query" % timeit(lambda: m.topN(user=12345, n=10)))
 print("topN(n=10, exclude_seen=False):  %.2f ms/query" % timeit(lambda: m.topN(user=777, n=10, exclude_seen=False)))
 t0 = time.perf_counter()
-ref = np.argsort(-(m.Theta[777].dot(m.Beta.T)))[:10]
+ref = np.argsort(-(m._state.host["Theta"][777].dot(m._state.host["Beta"].T)))[:10]
 print("  (host numpy GEMV+argsort for the same query: %.1f ms; ids agree: %s)"
       % ((time.perf_counter() - t0) * 1e3, list(ref) == list(m.topN(user=777, n=10, exclude_seen=False))))
 pu, pi = rs.randint(nU, size=1000), rs.randint(nI, size=1000)
