@@ -82,21 +82,159 @@ def initialize_parameters(Theta, Beta, random_seed, a, a_prime, b_prime, c, c_pr
     return Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte
 
 
-def _print_norm_diff(it, check_every, normdiff):
+# -- PXI:830-847 --------------------------------------------------------------------------
+def print_norm_diff(it, check_every, normdiff):
     print("Iteration %d | Norm(Theta_{%d} - Theta_{%d}): %.5f" % (it, it, it - check_every, normdiff))
 
 
-def _print_llk_iter(it, llk, rmse, has_valset):
+def print_llk_iter(it, llk, rmse, has_valset):
     tag = "val" if has_valset else "train"
     print(("Iteration %d | " + tag + " llk: %d | " + tag + " rmse: %.4f") % (it, int(llk), rmse))
 
 
-def _print_final_msg(it, llk, rmse, minutes):
+def print_final_msg(it, llk, rmse, end_tm):
     print("\n\nOptimization finished")
     print("Final log-likelihood: %d" % int(llk))
     print("Final RMSE: %.4f" % rmse)
-    print("Minutes taken (optimization part): %.1f" % minutes)
+    print("Minutes taken (optimization part): %.1f" % end_tm)
     print("")
+
+
+_print_norm_diff, _print_llk_iter, _print_final_msg = print_norm_diff, print_llk_iter, print_final_msg
+
+
+# -- PXI:22-42: helpers the reference exports "for ctpfrec" ---------------------------------
+def get_csc_data(ix_u, ix_i, Y, nU, nI):
+    """COO triplets -> CSC (indptr [nI+1], row indices, values), rows ascending inside a column and duplicate
+    (user, item) pairs summed -- what scipy's coo_array(...).tocsc() gives the reference (PXI:22-25) -- built on the
+    device: one stable sort of the column-major keys, a segmented sum over runs of equal keys, a bincount."""
+    ops = _make_ops()
+    dev = ops.device
+    nU, nI = int(nU), int(nI)
+    u = _as_index_tensor(ix_u, nU, "UserId").to(dev)
+    i = _as_index_tensor(ix_i, nI, "ItemId").to(dev)
+    y = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(dev)
+    key = i * nU + u
+    skey, order = torch.sort(key, stable=True)
+    ukey, counts = torch.unique_consecutive(skey, return_counts=True)
+    # sums over runs of equal keys as differences of a float64 running sum: fixed order (no atomics), exact for the
+    # pairs and triples of small counts that occur
+    run = torch.cumsum(y[order].double(), 0)
+    ends = torch.cumsum(counts, 0) - 1
+    data = run[ends]
+    data[1:] -= run[ends[:-1]]
+    data = data.float()
+    cols = torch.div(ukey, nU, rounding_mode="floor")
+    indptr = torch.zeros(nI + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(torch.bincount(cols, minlength=nI), 0, out=indptr[1:])
+    return (indptr.cpu().numpy().astype(obj_ind_type), (ukey - cols * nU).cpu().numpy().astype(obj_ind_type),
+            data.cpu().numpy().astype(c_real_t))
+
+
+def get_unique_items_batch(users_this_batch, st_ix_u, ix_i, nthreads, return_ix=False):
+    """Sorted unique other-side ids of the listed CSR rows (and, with return_ix, the start of every listed row's
+    nonzeros inside the batch: [0, n_0, n_0+n_1, ...]) -- PXI:27-42 -- gathered on the device."""
+    ops = _make_ops()
+    dev = ops.device
+    rows = torch.from_numpy(np.ascontiguousarray(users_this_batch).astype(np.int64)).to(dev)
+    st = torch.from_numpy(np.ascontiguousarray(st_ix_u).astype(np.int64)).to(dev)
+    idx = torch.from_numpy(np.ascontiguousarray(ix_i).astype(np.int64)).to(dev)
+    beg = st[rows]
+    deg = st[rows + 1] - beg
+    total = int(deg.sum().item())
+    offs = torch.cumsum(deg, 0) - deg
+    pos = torch.repeat_interleave(beg - offs, deg, output_size=total) + torch.arange(total, device=dev)
+    items = torch.unique(idx[pos]).cpu().numpy().astype(np.asarray(ix_i).dtype)
+    if not return_ix:
+        return items
+    st_pos = np.zeros(rows.shape[0] + 1, dtype=np.asarray(users_this_batch).dtype)
+    st_pos[1:] = torch.cumsum(deg, 0).cpu().numpy()
+    return items, st_pos
+
+
+def _llk_terms_host(Theta, Beta, Y, ix_u, ix_i, full_llk):
+    """[sum y*log(yhat) (- lgamma(y+1)), sum (y-yhat)^2, sum yhat] over listed pairs of host tables (float64)."""
+    ops = _make_ops()
+    T, B, iu, ii, k, ld = _pair_operands(Theta, Beta, ix_u, ix_i, ops.device)
+    y = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(ops.device)
+    return ops.pair_llk(T, B, iu, ii, y, k, ld, bool(full_llk)).cpu().numpy()
+
+
+def _colsum_dot_host(Theta, Beta):
+    """Theta.sum(axis=0).dot(Beta.sum(axis=0)) (PXI:78), the column sums taken on the device."""
+    ops = _make_ops()
+    k = int(Theta.shape[1])
+    ld = cavi._lib.ld_for_k(k)
+    sums = []
+    for M in (Theta, Beta):
+        tab = _padded(M, ld, ops.device)
+        part = torch.zeros((ops.finalize_grid(tab.shape[0]), ld), dtype=torch.float32, device=ops.device)
+        out = torch.zeros(ld, dtype=torch.float32, device=ops.device)
+        ops.colsum(tab, tab.shape[0], ld, part)
+        ops.colsum_reduce(part, out, ld)
+        sums.append(out[:k].cpu().numpy())
+    return np.dot(sums[0], sums[1])
+
+
+def _eval_llk_rmse(errs, Theta, Beta, Y, ix_u, ix_i, n, full_llk, verbose, subtract):
+    """llk_plus_rmse (PXI:627-658) + the subtrahend + the square root, into errs[0:2]."""
+    t = _llk_terms_host(Theta, Beta, Y, ix_u, ix_i, full_llk)
+    if subtract == "yhat":                                  # sum_prediction over the listed pairs (PXI:72)
+        sub = t[2]
+    elif subtract == "colsums":                             # all pairs (PXI:78)
+        sub = _colsum_dot_host(Theta, Beta)
+    else:                                                   # PXI:105 (sic): sums over the listed rows only
+        iu = np.ascontiguousarray(ix_u).astype(np.int64)
+        ii = np.ascontiguousarray(ix_i).astype(np.int64)
+        sub = _colsum_dot_host(Theta[iu], Beta[ii])
+    errs[0] = np.longdouble(t[0]) - np.longdouble(sub)
+    # the reference only accumulates the squared error when verbose (add_mse = verbose, PXI:71,77)
+    errs[1] = np.sqrt(np.longdouble(t[1] if verbose else 0.0) / np.longdouble(max(int(n), 1)))
+
+
+# -- PXI:51-92 ----------------------------------------------------------------------------
+def assess_convergence(i, check_every, stop_crit, last_crit, stop_thr, Theta, Theta_prev, Beta, nY, Y, ix_u, ix_i, nYv,
+                       Yval, ix_u_val, ix_i_val, errs, k, nthreads, verbose, full_llk, has_valset):
+    """-> (has_converged, last_crit); fills errs[0] (llk) / errs[1] (rmse), overwrites Theta_prev in 'diff-norm'
+    mode, prints when verbose -- the reference's statements on host arrays, the sums on the device."""
+    if stop_crit == "diff-norm":
+        ops = _make_ops()
+        d = (torch.from_numpy(np.ascontiguousarray(Theta, dtype=np.float32)).to(ops.device).double()
+             - torch.from_numpy(np.ascontiguousarray(Theta_prev, dtype=np.float32)).to(ops.device).double())
+        last_crit = float(np.float32(torch.sqrt((d * d).sum()).item()))
+        if verbose:
+            print_norm_diff(i + 1, check_every, last_crit)
+        if last_crit < stop_thr:
+            return True, last_crit
+        Theta_prev[:, :] = Theta
+    else:
+        if has_valset:
+            _eval_llk_rmse(errs, Theta, Beta, Yval, ix_u_val, ix_i_val, nYv, full_llk, verbose, "yhat")
+        else:
+            _eval_llk_rmse(errs, Theta, Beta, Y, ix_u, ix_i, nY, full_llk, verbose, "colsums")
+        if verbose:
+            print_llk_iter(i + 1, errs[0], float(errs[1]), has_valset)
+        if stop_crit != "maxiter":
+            if (i + 1) == check_every:
+                last_crit = errs[0]
+            else:
+                if (1.0 - errs[0] / last_crit) <= stop_thr:
+                    return True, last_crit
+                last_crit = errs[0]
+    return False, last_crit
+
+
+# -- PXI:94-113 ---------------------------------------------------------------------------
+def eval_after_term(stop_crit, verbose, nthreads, full_llk, k, nY, nYv, has_valset, Theta, Beta, errs, Y, ix_u, ix_i,
+                    Yval, ix_u_val, ix_i_val):
+    """Final llk/rmse for the criteria that do not track llk ('maxiter', 'diff-norm') when verbose; else None."""
+    if stop_crit in ("diff-norm", "maxiter") and verbose > 0:
+        if has_valset:
+            _eval_llk_rmse(errs, Theta, Beta, Yval, ix_u_val, ix_i_val, nYv, full_llk, verbose, "listed-rows")
+        else:
+            _eval_llk_rmse(errs, Theta, Beta, Y, ix_u, ix_i, nY, full_llk, verbose, "colsums")
+        return errs[0]
+    return None
 
 
 def save_parameters(verbose, save_folder, file_names, obj_list):

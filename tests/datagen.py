@@ -72,3 +72,20 @@ def synthetic_hpf_shaped(nusers, nitems, nnz, seed=1, item_power=2.5, sigma=1.0)
     y = (1 + np.floor(rng.gamma(1.0, 1.0, size=u.shape[0]))).astype(np.float32)
     perm = rng.permutation(u.shape[0])
     return u[perm].astype(np.uint64), i[perm].astype(np.uint64), y[perm]
+
+
+def boundary_valset(nusers, nitems, n=400, seed=21):
+    """A small validation set for the llk / RMSE fixtures of tests/golden/c1_boundary.npz."""
+    rs = np.random.RandomState(seed)
+    u = rs.randint(nusers, size=n).astype(np.uint64)
+    i = rs.randint(nitems, size=n).astype(np.uint64)
+    y = (rs.gamma(1, 1, size=n) + 1).astype("int32").astype(np.float32)
+    return y, u, i
+
+
+def sorted_by_user(Y, ix_u, ix_i, nusers, nitems):
+    """Triplets stably sorted by user plus the CSR start indices (what the SVI path of the reference works on)."""
+    order = np.argsort(ix_u, kind="stable")
+    st = np.zeros(nusers + 1, dtype=np.uint64)
+    st[1:] = np.cumsum(np.bincount(ix_u.astype(np.int64), minlength=nusers))
+    return Y[order], ix_u[order], ix_i[order], st

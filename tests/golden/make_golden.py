@@ -167,7 +167,74 @@ def c1_predict():
     print("c1_predict", len(out))
 
 
+def c1_boundary():
+    """The module-level helpers the reference exports "for ctpfrec" (PXI:20-113), called directly on the extension
+    module: train / validation llk and RMSE of assess_convergence (PXI:66-79: errs[0], errs[1]), the val-set
+    expression of eval_after_term (PXI:105), get_csc_data and get_unique_items_batch."""
+    from hpfrec import cython_loops_float as c
+    df, nU, nI = datagen.readme_counts()
+    Y, iu, ii = datagen.triplets(df)
+    m = fit_ref(df, 30, 10)
+    Theta, Beta = np.array(m.Theta), np.array(m.Beta)
+    Yv, iuv, iiv = datagen.boundary_valset(nU, nI)
+    out = {}
+    k = 30
+    for tag, full in (("", 0), ("_full", 1)):
+        for has_val in (0, 1):
+            errs = np.zeros(2, dtype=c.obj_long_double_type)
+            conv, crit = quiet(c.assess_convergence, 9, 10, "train-llk", -1e300, 1e-3, Theta, Theta.copy(), Beta,
+                               Y.shape[0], Y, iu, ii, Yv.shape[0], Yv, iuv, iiv, errs, k, 1, 1, full, has_val)
+            which = "val" if has_val else "train"
+            out["assess_%s_llk%s" % (which, tag)] = np.float64(errs[0])
+            out["assess_%s_rmse%s" % (which, tag)] = np.float64(errs[1])
+            assert not conv and float(crit) == float(errs[0])       # first check only records
+            errs2 = np.zeros(2, dtype=c.obj_long_double_type)
+            last = quiet(c.eval_after_term, "maxiter", 1, 1, full, k, Y.shape[0], Yv.shape[0], has_val, Theta, Beta,
+                         errs2, Y, iu, ii, Yv, iuv, iiv)
+            out["after_term_%s_llk%s" % (which, tag)] = np.float64(last)
+            out["after_term_%s_rmse%s" % (which, tag)] = np.float64(errs2[1])
+    # second check: the stopping rule fires when 1 - llk/last_crit <= stop_thr
+    errs = np.zeros(2, dtype=c.obj_long_double_type)
+    conv, _ = quiet(c.assess_convergence, 19, 10, "train-llk", out["assess_train_llk"] * (1 - 5e-4), 1e-3, Theta,
+                    Theta.copy(), Beta, Y.shape[0], Y, iu, ii, Yv.shape[0], Yv, iuv, iiv, errs, k, 1, 0, 0, 0)
+    out["assess_second_check_converged"] = np.int64(bool(conv))
+    # diff-norm branch
+    Tp = (Theta * np.float32(1.01)).astype(np.float32)
+    conv, crit = quiet(c.assess_convergence, 9, 10, "diff-norm", -1e300, 1e-9, Theta, Tp, Beta, Y.shape[0], Y, iu, ii,
+                       0, Yv, iuv, iiv, np.zeros(2, dtype=c.obj_long_double_type), k, 1, 0, 0, 0)
+    out["assess_diffnorm"] = np.float64(crit)
+    assert np.array_equal(Tp, Theta)                                # Theta_prev is overwritten when not converged
+    # fits that use the validation set
+    vdf = pd.DataFrame({"UserId": iuv.astype(np.int64), "ItemId": iiv.astype(np.int64), "Count": Yv})
+    mv = HPF(k=30, maxiter=200, random_seed=123, ncores=1, reindex=False, verbose=False, stop_crit="val-llk",
+             check_every=5, stop_thr=1e-3, use_float=True)
+    quiet(mv.fit, df.copy(), val_set=vdf.copy())
+    out["valllk_stop_niter"] = np.int64(mv.niter)
+    mv = HPF(k=30, maxiter=10, random_seed=123, ncores=1, reindex=False, verbose=True, stop_crit="maxiter",
+             check_every=10, use_float=True)
+    quiet(mv.fit, df.copy(), val_set=vdf.copy())
+    out["maxiter_valset_last_llk"] = np.float64(mv.train_llk)      # eval_after_term's val expression (PXI:105)
+    # CSC conversion with duplicate pairs (scipy merges them) and the batch helper
+    rs = np.random.RandomState(1)
+    du, di = rs.randint(nU, size=3000).astype(np.uint64), rs.randint(40, size=3000).astype(np.uint64)
+    dy = (rs.gamma(1, 1, size=3000) + 1).astype(np.float32)
+    ptr, ind, dat = c.get_csc_data(du, di, dy, nU, nI)
+    out["csc_indptr"], out["csc_indices"], out["csc_data"] = ptr, ind, dat
+    Ys, ius, iis, st = datagen.sorted_by_user(Y, iu, ii, nU, nI)
+    users_b = np.array([5, 17, 3, 99, 42], dtype=np.uint64)
+    items, st_pos = c.get_unique_items_batch(users_b, st, iis, 1, True)
+    out["batch_items"], out["batch_st_pos"] = items, st_pos
+    out["batch_items_only"] = c.get_unique_items_batch(users_b, st, iis, 1, False)
+    np.savez_compressed(os.path.join(OUT, "c1_boundary.npz"), **out)
+    print("c1_boundary", len(out))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                   # regenerate selected fixtures only: make_golden.py c1_boundary ...
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
+    c1_boundary()
     c1_full()
     c1_trick()
     c1_hyper()

@@ -182,3 +182,77 @@ def test_driver_return_contract(cpu_ops_backend):
     # stopping rules stop at the iteration the reference stops at
     i, _, _ = _fit(cpu_ops_backend, Y, iu, ii, nU, nI, 30, 200, stop_crit="train-llk", check_every=5)
     assert i == int(g["trainllk_stop_niter"])
+
+
+def test_ctpfrec_exports_vs_reference(any_backend, capsys):
+    """The module-level helpers the reference exports "for ctpfrec" (PXI:20-113, 830-847) with the reference's
+    arity, against values the real extension module returned (tests/golden/c1_boundary.npz): train / validation
+    llk and RMSE (errs[0], errs[1]; PXI:66-79), the val-set expression of eval_after_term (PXI:105), the stopping
+    rule, the diff-norm branch, get_csc_data with duplicate pairs, get_unique_items_batch."""
+    import inspect
+    import pandas as pd
+    from hpfrec_amd import HPF
+    be = any_backend
+    g = np.load(os.path.join(GOLDEN, "c1_boundary.npz"))
+    g10 = np.load(os.path.join(GOLDEN, "c1_full.npz"))
+    for name, arity in (("assess_convergence", 22), ("eval_after_term", 17), ("get_csc_data", 5),
+                        ("get_unique_items_batch", 5), ("print_norm_diff", 3), ("print_llk_iter", 4),
+                        ("print_final_msg", 4), ("save_parameters", 4)):
+        assert len(inspect.signature(getattr(be, name)).parameters) == arity, name
+    df, nU, nI = datagen.readme_counts()
+    Y, iu, ii = datagen.triplets(df)
+    Yv, iuv, iiv = datagen.boundary_valset(nU, nI)
+    Theta, Beta, k = g10["it10_Theta"], g10["it10_Beta"], 30
+    for tag, full in (("", 0), ("_full", 1)):
+        for has_val, which in ((0, "train"), (1, "val")):
+            errs = np.zeros(2, dtype=np.longdouble)
+            conv, crit = be.assess_convergence(9, 10, "train-llk", -1e300, 1e-3, Theta, Theta.copy(), Beta, Y.shape[0], Y,
+                                               iu, ii, Yv.shape[0], Yv, iuv, iiv, errs, k, 1, 1, full, has_val)
+            assert not conv and float(crit) == float(errs[0])
+            assert abs(float(errs[0]) / g["assess_%s_llk%s" % (which, tag)] - 1) < 2e-6
+            assert abs(float(errs[1]) / g["assess_%s_rmse%s" % (which, tag)] - 1) < 2e-6          # errs[1], PXI:73,79
+            errs2 = np.zeros(2, dtype=np.longdouble)
+            last = be.eval_after_term("maxiter", 1, 1, full, k, Y.shape[0], Yv.shape[0], has_val, Theta, Beta, errs2,
+                                      Y, iu, ii, Yv, iuv, iiv)
+            assert abs(float(last) / g["after_term_%s_llk%s" % (which, tag)] - 1) < 2e-6          # PXI:105 for "val"
+            assert abs(float(errs2[1]) / g["after_term_%s_rmse%s" % (which, tag)] - 1) < 2e-6
+    assert be.eval_after_term("train-llk", 1, 1, 0, k, Y.shape[0], 0, 0, Theta, Beta, np.zeros(2, np.longdouble), Y, iu,
+                              ii, Yv, iuv, iiv) is None
+    out = capsys.readouterr().out
+    assert "Iteration 10 | train llk: -9871 | train rmse: 1.0955" in out and "val llk: -408 | val rmse: 1.2016" in out
+    # not verbose: no squared-error accumulation (add_mse = verbose), nothing printed
+    errs = np.zeros(2, dtype=np.longdouble)
+    conv, _ = be.assess_convergence(19, 10, "train-llk", float(g["assess_train_llk"]) * (1 - 5e-4), 1e-3, Theta,
+                                    Theta.copy(), Beta, Y.shape[0], Y, iu, ii, Yv.shape[0], Yv, iuv, iiv, errs, k, 1, 0, 0, 0)
+    assert bool(conv) == bool(g["assess_second_check_converged"]) and errs[1] == 0 and capsys.readouterr().out == ""
+    Tp = (Theta * np.float32(1.01)).astype(np.float32)
+    conv, crit = be.assess_convergence(9, 10, "diff-norm", -1e300, 1e-9, Theta, Tp, Beta, Y.shape[0], Y, iu, ii, 0, Yv,
+                                       iuv, iiv, np.zeros(2, np.longdouble), k, 1, 0, 0, 0)
+    assert not conv and abs(crit / g["assess_diffnorm"] - 1) < 1e-5 and np.array_equal(Tp, Theta)
+    conv, _ = be.assess_convergence(9, 10, "diff-norm", -1e300, 1e-3, Theta, Theta.copy(), Beta, Y.shape[0], Y, iu, ii, 0,
+                                    Yv, iuv, iiv, np.zeros(2, np.longdouble), k, 1, 0, 0, 0)
+    assert conv
+    # CSC conversion: duplicates merged, rows ascending; the batch helper
+    rs = np.random.RandomState(1)
+    du, di = rs.randint(nU, size=3000).astype(np.uint64), rs.randint(40, size=3000).astype(np.uint64)
+    dy = (rs.gamma(1, 1, size=3000) + 1).astype(np.float32)
+    ptr, ind, dat = be.get_csc_data(du, di, dy, nU, nI)
+    for got, want in ((ptr, g["csc_indptr"]), (ind, g["csc_indices"])):
+        assert got.dtype == want.dtype and np.array_equal(got, want)
+    assert dat.dtype == g["csc_data"].dtype and np.allclose(dat, g["csc_data"], rtol=1e-6, atol=0)   # (sum order of triples)
+    Ys, ius, iis, st = datagen.sorted_by_user(Y, iu, ii, nU, nI)
+    users_b = np.array([5, 17, 3, 99, 42], dtype=np.uint64)
+    items, st_pos = be.get_unique_items_batch(users_b, st, iis, 1, True)
+    assert np.array_equal(items, g["batch_items"]) and np.array_equal(st_pos, g["batch_st_pos"])
+    assert items.dtype == g["batch_items"].dtype and st_pos.dtype == g["batch_st_pos"].dtype
+    assert np.array_equal(be.get_unique_items_batch(users_b, st, iis, 1, False), g["batch_items_only"])
+    # the class with a validation set: where 'val-llk' stops, and the final expression of a verbose 'maxiter' run
+    vdf = pd.DataFrame({"UserId": iuv.astype(np.int64), "ItemId": iiv.astype(np.int64), "Count": Yv})
+    mv = HPF(k=30, maxiter=200, random_seed=123, reindex=False, verbose=False, stop_crit="val-llk", check_every=5,
+             stop_thr=1e-3).fit(df.copy(), val_set=vdf.copy())
+    assert mv.niter == int(g["valllk_stop_niter"])
+    mv = HPF(k=30, maxiter=10, random_seed=123, reindex=False, verbose=True, stop_crit="maxiter", check_every=10)
+    mv.fit(df.copy(), val_set=vdf.copy())
+    assert abs(float(mv.train_llk) / g["maxiter_valset_last_llk"] - 1) < 1e-4
+    out = capsys.readouterr().out
+    assert "Final RMSE: %.4f" % g["after_term_val_rmse"] in out
