@@ -23,7 +23,7 @@ import numpy as np
 import pandas as pd
 from scipy.sparse import coo_array, issparse
 
-from . import cython_loops_float, resident
+from . import cython_loops_float, ingest, resident
 
 __all__ = ["HPF"]
 
@@ -210,6 +210,8 @@ class HPF:
             raise ValueError("If 'stop_crit' is set to 'val-llk', must provide a validation set.")
         if self.verbose:
             self._print_st_msg()
+        self.__dict__.pop("_tick_t", None)
+        self._tick("start")
         self._process_data(counts_df)
         if self.verbose:
             self._print_data_info()
@@ -219,13 +221,16 @@ class HPF:
             self.val_set = None
 
         self._cast_before_fit()
+        self._tick("validation set, casts")
         self._fit()
+        self._tick("fit_hpf (init, layout, iterations, outputs to host)")
 
         if self.keep_data:
             if self.users_per_batch == 0:
                 self._store_metadata()
             else:
                 self._st_ix_user = self._st_ix_user[:-1]
+        self._dev_triplets = None
         if self.produce_dicts and self.reindex:
             self.user_dict_ = {uid: pos for pos, uid in enumerate(self.user_mapping_)}
             self.item_dict_ = {iid: pos for pos, iid in enumerate(self.item_mapping_)}
@@ -250,20 +255,51 @@ class HPF:
 
         # llk-based criteria need counts >= 1 (log of the rate); the others only positive ones (INIT:462-475)
         thr = 0 if self.stop_crit in ('maxiter', 'diff-norm') else 0.9
-        drop = frame["Count"] <= thr
-        if drop.any():
-            warnings.warn("'counts_df' contains observations with a count value less than 1, these will be ignored."
-                          " Any user or item associated exclusively with zero-value observations will be excluded."
-                          " If using 'reindex=False', make sure that your data still meets the necessary criteria."
-                          " If you still want to use these observations, set 'stop_crit' to 'diff-norm' or 'maxiter'.")
-            frame = frame.loc[~drop]
+        zero_msg = ("'counts_df' contains observations with a count value less than 1, these will be ignored."
+                    " Any user or item associated exclusively with zero-value observations will be excluded."
+                    " If using 'reindex=False', make sure that your data still meets the necessary criteria."
+                    " If you still want to use these observations, set 'stop_crit' to 'diff-norm' or 'maxiter'.")
+        self._dev_triplets = None
+        tick = self._tick
+        # numeric ids: filter, renumbering and (later) the seen-items index run on the device (hpfrec_amd/ingest.py);
+        # the triplets stay there for the fit.  Other id types (strings, objects): pandas, as the reference does.
+        import torch
+        dev = be._make_ops().device
+        du = ingest.to_device_ids(frame["UserId"].to_numpy(copy=False), dev)
+        di = ingest.to_device_ids(frame["ItemId"].to_numpy(copy=False), dev) if du is not None else None
+        on_device = di is not None and frame["Count"].dtype.kind in "iuf"
+        tick("ids to device")
+        if on_device:
+            cnt = torch.from_numpy(np.ascontiguousarray(frame["Count"].to_numpy(copy=False))).to(dev)
+            drop = cnt <= thr
+            if bool(drop.any()):
+                warnings.warn(zero_msg)
+                keep = ~drop
+                du, di, cnt = du[keep], di[keep], cnt[keep]
+                frame = frame.loc[keep.cpu().numpy()]
+            dy = cnt.to(torch.float32)
+            tick("count filter")
+        else:
+            drop = frame["Count"] <= thr
+            if drop.any():
+                warnings.warn(zero_msg)
+                frame = frame.loc[~drop]
         self.input_df = frame
 
         if self.reindex:
             # first-appearance numbering, exactly pd.factorize (INIT:478-479)
-            ucodes, umap = pd.factorize(frame["UserId"])
-            icodes, imap = pd.factorize(frame["ItemId"])
-            frame["UserId"], frame["ItemId"] = ucodes, icodes
+            if on_device:
+                du, umap_d = ingest.factorize(du)
+                di, imap_d = ingest.factorize(di)
+                umap = umap_d.cpu().numpy().astype(frame["UserId"].dtype, copy=False)
+                imap = imap_d.cpu().numpy().astype(frame["ItemId"].dtype, copy=False)
+                tick("factorize")
+                frame["UserId"], frame["ItemId"] = du.cpu().numpy(), di.cpu().numpy()
+                tick("codes to host")
+            else:
+                ucodes, umap = pd.factorize(frame["UserId"])
+                icodes, imap = pd.factorize(frame["ItemId"])
+                frame["UserId"], frame["ItemId"] = ucodes, icodes
             self.user_mapping_ = np.require(umap, requirements=["ENSUREARRAY"]).reshape(-1)
             self.item_mapping_ = np.require(imap, requirements=["ENSUREARRAY"]).reshape(-1)
             self.nusers = self.user_mapping_.shape[0]
@@ -285,13 +321,32 @@ class HPF:
                 fh.write("random seed: %s\n" % ("None" if self.random_seed is None else "%d" % self.random_seed))
 
         self._cast_frame(self.input_df, be)
+        if on_device:
+            if du.numel() and (int(du.min()) < 0 or int(di.min()) < 0):
+                raise ValueError("user/item ids must be non-negative")
+            self._dev_triplets = (du, di, dy)
+        tick("cast")
 
         if self.users_per_batch != 0:
             if self.nusers < self.users_per_batch:
                 warnings.warn("Batch size passed is larger than number of users. Will set it to nusers/10.")
                 self.users_per_batch = int(np.ceil(self.nusers / 10))
-            self.input_df.sort_values('UserId', inplace=True)
+            if not on_device:      # (the engine groups the triplets by user itself, on the device: no host sort)
+                self.input_df.sort_values('UserId', inplace=True)
             self._store_metadata(for_partial_fit=True)
+
+    def _tick(self, phase):
+        """HPF_TIMING=1: wall time per phase of fit() in self.timings_ (device work synchronised at phase ends)."""
+        if os.environ.get("HPF_TIMING") != "1":
+            return
+        import time
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        now = time.perf_counter()
+        t = self.__dict__.setdefault("timings_", {})
+        t[phase] = t.get(phase, 0.0) + now - self.__dict__.get("_tick_t", now)
+        self._tick_t = now
 
     @staticmethod
     def _cast_frame(frame, be):
@@ -343,6 +398,20 @@ class HPF:
         be = self._backend()
         if self.verbose and for_partial_fit:
             print("Creating user indices for stochastic optimization...")
+        trip = getattr(self, "_dev_triplets", None)
+        if trip is not None:
+            # the same three arrays as scipy's coo -> csr below, from one device sort of the pair keys
+            n_seen, indptr, seen = ingest.seen_metadata(trip[0], trip[1], self.nusers, self.nitems)
+            idt = ingest.SEEN_INDEX_DTYPE
+            indptr = indptr.cpu().numpy().astype(idt)
+            self._n_seen_by_user = n_seen.cpu().numpy().astype(idt)
+            self.seen = seen.cpu().numpy().astype(idt)
+            if for_partial_fit:
+                self._st_ix_user = np.require(indptr, dtype=be.obj_ind_type, requirements=["ENSUREARRAY", "C_CONTIGUOUS"])
+            else:
+                self._st_ix_user = indptr[:-1]
+            self._tick("seen-items index")
+            return
         X = coo_array((self.input_df["Count"].to_numpy(copy=False),
                        (self.input_df["UserId"].to_numpy(copy=False), self.input_df["ItemId"].to_numpy(copy=False))),
                       shape=(self.nusers, self.nitems), dtype=ctypes.c_float).tocsr()
@@ -401,7 +470,8 @@ class HPF:
             self._col(self.val_set, "Count", be.c_real_t),
             self._col(self.val_set, "UserId", be.obj_ind_type),
             self._col(self.val_set, "ItemId", be.obj_ind_type),
-            be.cast_int(self.full_llk), be.cast_int(self.keep_all_objs), be.cast_int(self.alloc_full_phi))
+            be.cast_int(self.full_llk), be.cast_int(self.keep_all_objs), be.cast_int(self.alloc_full_phi),
+            device_triplets=getattr(self, "_dev_triplets", None))
 
         if self.users_per_batch == 0:
             del self._st_ix_user

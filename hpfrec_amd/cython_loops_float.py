@@ -255,7 +255,7 @@ def _as_index_tensor(a, n_max, what):
 class _Engine:
     """Glue between the reference-shaped host arrays and cavi.FullBatchCavi (handles sharding)."""
 
-    def __init__(self, hyper, Y, ix_u, ix_i, nU, nI, Yval=None, ix_u_val=None, ix_i_val=None):
+    def __init__(self, hyper, Y, ix_u, ix_i, nU, nI, Yval=None, ix_u_val=None, ix_i_val=None, device_triplets=None):
         self.ops = _make_ops()
         self.device = self.ops.device
         dist = cavi._dist()
@@ -263,9 +263,14 @@ class _Engine:
         self.rank = dist.get_rank() if dist else 0
         self.world = dist.get_world_size() if dist else 1
         dev = self.device
-        tu = _as_index_tensor(ix_u, nU, "UserId").to(dev)
-        ti = _as_index_tensor(ix_i, nI, "ItemId").to(dev)
-        ty = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(dev)
+        if device_triplets is not None:      # the caller's triplets are on the device already (hpfrec_amd.HPF.fit)
+            tu, ti, ty = (t.to(dev) for t in device_triplets)
+            if tu.numel() and (int(tu.max()) >= nU or int(ti.max()) >= nI):
+                raise ValueError("UserId / ItemId contains an id out of range")
+        else:
+            tu = _as_index_tensor(ix_u, nU, "UserId").to(dev)
+            ti = _as_index_tensor(ix_i, nI, "ItemId").to(dev)
+            ty = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(dev)
         lu, li, ly, (self.u0, self.u1) = cavi.shard_users(tu, ti, ty, nU, self.rank, self.world)
         self.nU_global, self.nI = int(nU), int(nI)
         self.model = cavi.FullBatchCavi(self.ops, dev, lu, li, ly, self.u1 - self.u0, nI, hyper)
@@ -305,7 +310,7 @@ class _Engine:
 def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta, maxiter, stop_crit,
             check_every, stop_thr, users_per_batch, items_per_batch, step_size, sum_exp_trick, st_ix_u,
             save_folder, random_seed, verbose, nthreads, par_sh, has_valset, Yval, ix_u_val, ix_i_val,
-            full_llk, keep_all_objs, alloc_full_phi):
+            full_llk, keep_all_objs, alloc_full_phi, device_triplets=None):
     """Same contract as the reference's fit_hpf (PXI:147-162, returns PXI:413-418):
     fills Theta/Beta in place, returns (i, (Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte,
     t_rte) or None, last_llk) with i the 0-based index of the last iteration run.
@@ -313,6 +318,8 @@ def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta
     `nthreads`, `par_sh` (allow_inconsistent_math) and `alloc_full_phi` are accepted and ignored:
     the device path is always parallel, always reproducible and never materialises phi.
     `sum_exp_trick` is honoured implicitly: E rows are rescaled per row (power of two) in every mode.
+    `device_triplets` (not in the reference's signature): (ix_u, ix_i, Y) as device tensors equal to the host
+    arrays, when the caller has them there already -- they are then not uploaded again.
     """
     nU, k = Theta.shape
     nI = Beta.shape[0]
@@ -329,7 +336,8 @@ def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=1) as pool:
             fut = pool.submit(initialize_parameters, *init_args)
-            eng = _Engine(hy, Y, ix_u, ix_i, nU, nI, Yval if has_valset else None, ix_u_val, ix_i_val)
+            eng = _Engine(hy, Y, ix_u, ix_i, nU, nI, Yval if has_valset else None, ix_u_val, ix_i_val,
+                          device_triplets=device_triplets)
             Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte = fut.result()
     else:
         Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte = initialize_parameters(*init_args)
@@ -337,7 +345,7 @@ def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta
         return svi.fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte,
                                t_rte, maxiter, stop_crit, check_every, stop_thr, users_per_batch, items_per_batch,
                                step_size, save_folder, random_seed, verbose, has_valset, Yval, ix_u_val, ix_i_val,
-                               full_llk, keep_all_objs, _make_ops)
+                               full_llk, keep_all_objs, _make_ops, device_triplets=device_triplets)
 
     eng.upload(Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta)
     model = eng.model

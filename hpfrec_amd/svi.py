@@ -234,7 +234,8 @@ def partial_fit_step(ops, Y_batch, ix_u_batch, ix_i_batch, Theta, Beta, Gamma_sh
 # -- PXI:262-377 (+ the shared convergence tail PXI:380-418) ---------------------------------------------
 def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, maxiter,
                 stop_crit, check_every, stop_thr, users_per_batch, items_per_batch, step_size, save_folder,
-                random_seed, verbose, has_valset, Yval, ix_u_val, ix_i_val, full_llk, keep_all_objs, make_ops):
+                random_seed, verbose, has_valset, Yval, ix_u_val, ix_i_val, full_llk, keep_all_objs, make_ops,
+                device_triplets=None):
     from . import cython_loops_float as be   # printing helpers and save_parameters
     import time
     ops = make_ops()
@@ -246,9 +247,12 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
     hyd = {"a": float(hy.a), "c": float(hy.c), "k_shp": float(hy.k_shp), "t_shp": float(hy.t_shp),
            "add_k_rte": float(hy.add_k_rte), "add_t_rte": float(hy.add_t_rte)}
 
-    tu = _dev_ids(ix_u, dev)
-    ti = _dev_ids(ix_i, dev)
-    ty = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(dev)
+    if device_triplets is not None:
+        tu, ti, ty = (t.to(dev) for t in device_triplets)
+    else:
+        tu = _dev_ids(ix_u, dev)
+        ti = _dev_ids(ix_i, dev)
+        ty = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(dev)
     users, items, u_sorted = layout.build_sides(tu, ti, ty, nU, nI)
 
     val = None

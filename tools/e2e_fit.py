@@ -32,3 +32,27 @@ dt = time.time() - t0
 print("E2E %s: nnz=%d k=%d maxiter=%d (llk every 10, verbose) wall=%.2fs -> %.1f it/s incl. init, H2D, CSR/CSC build, "
       "llk checks, D2H of 8 arrays; last_llk=%.6g finite=%s" % (wl, Y.shape[0], k, maxiter, dt, maxiter / dt, float(llk),
                                                                 bool(np.isfinite(Theta).all() and np.isfinite(Beta).all())))
+
+# ---- the class-level path: HPF.fit on a DataFrame with raw ids (filter, renumbering, seen-items index included) ----
+import pandas as pd  # noqa: E402
+from hpfrec_amd import HPF  # noqa: E402
+
+os.environ["HPF_TIMING"] = "1"
+rs = np.random.RandomState(0)
+perm_u, perm_i = rs.permutation(nU).astype(np.int64) * 3 + 5, rs.permutation(nI).astype(np.int64) * 2 + 1
+df = pd.DataFrame({"UserId": perm_u[IU.astype(np.int64)], "ItemId": perm_i[II.astype(np.int64)], "Count": Y})
+del Theta, Beta
+for rep in range(2):        # second pass: warm allocator / code objects
+    m = HPF(k=k, maxiter=maxiter, check_every=10, stop_crit="maxiter", verbose=False, random_seed=123)
+    t0 = time.time()
+    m.fit(df.copy())
+    dt = time.time() - t0
+print("E2E class %s: HPF(k=%d, maxiter=%d, reindex=True, keep_data=True).fit(DataFrame of %d rows with raw ids): "
+      "wall=%.2fs (%.1f it/s incl. everything); phases [s]: %s"
+      % (wl, k, maxiter, df.shape[0], dt, maxiter / dt, {p: round(v, 3) for p, v in m.timings_.items()}))
+t0 = time.time()
+rec = m.topN(user=int(df["UserId"].iloc[0]), n=10)
+print("first topN after the fit (uploads the item table once): %.1f ms; second: " % ((time.time() - t0) * 1e3), end="")
+t0 = time.time()
+m.topN(user=int(df["UserId"].iloc[1]), n=10)
+print("%.2f ms" % ((time.time() - t0) * 1e3))
