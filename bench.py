@@ -230,7 +230,6 @@ def main():
                     help="skip the untimed extras (lean-iteration and llk-pass timings); used under rocprofv3 so that "
                          "per-kernel averages cover exactly the warm-up + timed iterations")
     ap.add_argument("--no-fuse", action="store_true", help="separate sweep and row-finalize launches")
-    ap.add_argument("--atomic", action="store_true", help="experimental one-pass variant with fp32 atomics")
     ap.add_argument("--no-autotune", action="store_true",
                     help="N>1: do not try the exchange configurations first, use the defaults of hpfrec_amd.cavi")
     ap.add_argument("--lean", action="store_true",
@@ -371,9 +370,6 @@ def main():
     if args.no_fuse:
         model.set_fused(False)
     store = not args.lean
-    if args.atomic:
-        model.set_fused(False)
-        model.iterate = model.iterate_one_pass_atomic
 
     def fence():
         if dist:

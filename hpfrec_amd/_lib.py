@@ -21,7 +21,7 @@ SO_PATH = os.environ.get("HPF_HIP_SO") or os.path.join(_PKG, "libhpf_hip.so")
 SRC_PATH = os.path.join(_PKG, "csrc", "hpf_hip.hip")
 INC_PATH = os.path.join(_ROOT, "include")
 
-HPF_HIP_ABI_VERSION = 6
+HPF_HIP_ABI_VERSION = 7
 
 #: every symbol include/hpf_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = (
@@ -68,7 +68,7 @@ def lib():
     L.hpf_hip_abi_version.argtypes = []
     L.hpf_hip_ld_for_k.argtypes = [ci]
     L.hpf_hip_device_info.argtypes = [ctypes.POINTER(ci), ctypes.c_char_p, ci]
-    L.hpf_hip_sweep_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+    L.hpf_hip_sweep_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
     L.hpf_hip_sweep_finalize_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, ci,
                                              ci, ci, vp]
     L.hpf_hip_sweep_prefinalize_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, cf,

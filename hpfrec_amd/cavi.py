@@ -262,28 +262,6 @@ class FullBatchCavi:
             ops.row_finalize(part, side.row_seg_ptr, nrows, e_self, e_new, shp, None, fac, rs, cs_other,
                              cs_part[gs:], prior, top, add, k, ld, rs_prev=rs_prev)
 
-    def iterate_one_pass_atomic(self, store=True):
-        """Experimental one-pass variant: the user sweep also scatters w*eT_u into the item accumulators
-        with fp32 atomics (hpf_hip_sweep_f32 scatter_acc), so the CSC pass disappears.  Not
-        bit-reproducible; kept for measurement and for the stochastic paths."""
-        ops, hy, k, ld = self.ops, self.hy, self.k, self.ld
-        if not hasattr(self, "acc_atomic"):
-            self.acc_atomic = torch.zeros((self.nI, ld), dtype=torch.float32, device=self.device)
-        self.acc_atomic.zero_()
-        ops.sweep(self.users, self.eT, self.eB, self.part_u, k, ld, scatter_acc=self.acc_atomic)
-        ops.row_finalize(self.part_u, self.users.row_seg_ptr, self.nU, self.eT, self.eT_next,
-                         self.Gamma_shp if store else None, None, self.Theta,
-                         self.k_rte, self.csB, self.csT_part[self.gsu:], hy.a, hy.k_shp, hy.add_k_rte, k, ld,
-                         rs_prev=self.k_rte_prev)
-        ops.colsum_reduce(self.csT_part, self.csT, ld)
-        self._keep_csB(store)
-        ops.row_finalize(self.acc_atomic, None, self.nI, self.eB, self.eB, self.Lambda_shp if store else None,
-                         None, self.Beta, self.t_rte, self.csT,
-                         self.csB_part[self.gsi:], hy.c, hy.t_shp, hy.add_t_rte, k, ld, rs_prev=self.t_rte_prev)
-        ops.colsum_reduce(self.csB_part, self.csB, ld)
-        self.eT, self.eT_next = self.eT_next, self.eT
-        self.niter_done += 1
-
     def iterate(self, store=True):
         """One CAVI iteration.  store=False skips writing the Gamma/Lambda shape and rate tables AND the mean
         tables Theta/Beta: all six are outputs (and llk inputs) only -- the iteration itself runs on the E

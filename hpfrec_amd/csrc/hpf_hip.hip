@@ -199,15 +199,14 @@ struct FinalizeArgs {  // the row-finalize operands when it is fused into the sw
 //       2 = row finalize fused as PROLOGUE of whole-row segments from an already reduced accumulator row
 //           (sharded path: the previous iteration's all-reduced item statistics are turned into this
 //           iteration's E row by the very wave that then sweeps the row -- "deferred item finalize")
-template <int LPR, int VPL, bool SCATTER, int MODE, int UU = HPF_U>
+template <int LPR, int VPL, int MODE, int UU = HPF_U>
 __global__ __launch_bounds__(BLOCK)
 __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUSED_MAX_WAVES : 8))) void sweep_kernel(const hpf_segment *__restrict__ segs, int64_t nseg,
                                                       const int32_t *__restrict__ idx,
                                                       const float *__restrict__ y,
                                                       const float *tab_self,  // may alias fa.e_new
                                                       const float *__restrict__ tab_other,
-                                                      float *__restrict__ part, float *scatter_acc,
-                                                      const FinalizeArgs fa) {
+                                                      float *__restrict__ part, const FinalizeArgs fa) {
     constexpr int LD = 4 * LPR * VPL;
     constexpr int NG = WAVE / LPR;  // nonzeros per step
     constexpr int U = UU;           // gathers in flight per wavefront (WAVE/NG = LPR >= 8 is a multiple)
@@ -348,19 +347,6 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
                         acc[v].y = fmaf(w, o[u][v].y, acc[v].y);
                         acc[v].z = fmaf(w, o[u][v].z, acc[v].z);
                         acc[v].w = fmaf(w, o[u][v].w, acc[v].w);
-                    }
-                    if constexpr (SCATTER) {
-                        if (yy[u] > 0.f) {
-                            float *sp = scatter_acc + (size_t)cc[u] * LD;
-#pragma unroll
-                            for (int v = 0; v < VPL; v++) {
-                                float *q = sp + (v * LPR + j) * 4;
-                                unsafeAtomicAdd(q + 0, w * rv[v].x);
-                                unsafeAtomicAdd(q + 1, w * rv[v].y);
-                                unsafeAtomicAdd(q + 2, w * rv[v].z);
-                                unsafeAtomicAdd(q + 3, w * rv[v].w);
-                            }
-                        }
                     }
                 }
             }
@@ -1268,8 +1254,8 @@ int hpf_hip_device_info(int *cu_count, char *arch, int arch_len) {
 }
 
 int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
-                      const float *tab_self, const float *tab_other, float *part, float *scatter_acc,
-                      float *acc_rows, int acc_ld, int k, int ld, int short_rows, int grid_blocks, void *stream) {
+                      const float *tab_self, const float *tab_other, float *part, float *acc_rows, int acc_ld, int k,
+                      int ld, int short_rows, int grid_blocks, void *stream) {
     if (nseg == 0) return 0;
     if (!segs || !idx || !y || !tab_self || !tab_other || !part || nseg < 0 || k <= 0 || ld != hpf_hip_ld_for_k(k))
         return HPF_EINVAL;
@@ -1282,7 +1268,7 @@ int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx,
     // short rows (a batch or a shard of a many-rank run: ~16 nonzeros per row): half the gathers in flight per wave
     // fill just as well and the smaller register file buys occupancy (-15 % at N=8)
     constexpr int US = (HPF_U >= 8) ? HPF_U / 2 : HPF_U;
-    if (short_rows == 2 && !scatter_acc && ld <= 128) {
+    if (short_rows == 2 && ld <= 128) {
         // one segment per lane group (sweep_groups_kernel): 8 / 4 / 2 segments per wavefront at ld = 32 / 64 / 128
         const int per_block = WPB * (WAVE / (ld / 4));
         const int ggrid = clamp_grid((nseg + per_block - 1) / per_block, grid_blocks);
@@ -1298,15 +1284,12 @@ int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx,
         return last_error();
     }
 #define CALL(LPR, VPL)                                                                                              \
-    if (scatter_acc)                                                                                                \
-        hipLaunchKernelGGL((sweep_kernel<LPR, VPL, true, 0>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg, idx, \
-                           y, tab_self, tab_other, part, scatter_acc, fa);                                          \
-    else if (short_rows)                                                                                            \
-        hipLaunchKernelGGL((sweep_kernel<LPR, VPL, false, 0, US>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg,     \
-                           idx, y, tab_self, tab_other, part, scatter_acc, fa);                                     \
+    if (short_rows)                                                                                                 \
+        hipLaunchKernelGGL((sweep_kernel<LPR, VPL, 0, US>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg, idx, y,     \
+                           tab_self, tab_other, part, fa);                                                          \
     else                                                                                                            \
-        hipLaunchKernelGGL((sweep_kernel<LPR, VPL, false, 0>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg,     \
-                           idx, y, tab_self, tab_other, part, scatter_acc, fa);
+        hipLaunchKernelGGL((sweep_kernel<LPR, VPL, 0>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg, idx, y,         \
+                           tab_self, tab_other, part, fa);
     HPF_DISPATCH_LD(ld, CALL)
 #undef CALL
     return last_error();
@@ -1325,8 +1308,8 @@ int hpf_hip_sweep_finalize_f32(const hpf_segment *segs, int64_t nseg, const int3
     const FinalizeArgs fa = {cs_other, cs_partial, e_new, shp, rte, fac, rs, prior_shp, top_shp, add_rte, k, rs_prev,
                              nullptr, 0};
 #define CALL(LPR, VPL)                                                                                            \
-    hipLaunchKernelGGL((sweep_kernel<LPR, VPL, false, 1>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg, \
-                       idx, y, tab_self, tab_other, part, (float *)nullptr, fa);
+    hipLaunchKernelGGL((sweep_kernel<LPR, VPL, 1>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg, idx, y,    \
+                       tab_self, tab_other, part, fa);
     HPF_DISPATCH_LD(ld, CALL)
 #undef CALL
     return last_error();
@@ -1345,8 +1328,8 @@ int hpf_hip_sweep_prefinalize_f32(const hpf_segment *segs, int64_t nseg, const i
     const FinalizeArgs fa = {cs_other, cs_partial, tab_self, shp, rte, fac, rs, prior_shp, top_shp, add_rte, k,
                              rs_prev, acc_rows, acc_ld};
 #define CALL(LPR, VPL)                                                                                          \
-    hipLaunchKernelGGL((sweep_kernel<LPR, VPL, false, 2>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg, idx, \
-                       y, (const float *)tab_self, tab_other, part, (float *)nullptr, fa);
+    hipLaunchKernelGGL((sweep_kernel<LPR, VPL, 2>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg, idx, y,    \
+                       (const float *)tab_self, tab_other, part, fa);
     HPF_DISPATCH_LD(ld, CALL)
 #undef CALL
     return last_error();

@@ -37,10 +37,10 @@ class HipOps:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     # -- every method mirrors one C entry point ------------------------------------------
-    def sweep(self, side, tab_self, tab_other, part, k, ld, scatter_acc=None, acc_rows=None, acc_ld=0, grid_blocks=None):
+    def sweep(self, side, tab_self, tab_other, part, k, ld, acc_rows=None, acc_ld=0, grid_blocks=None):
         _lib.check(self.L.hpf_hip_sweep_f32(_ptr(side.segs), side.nseg, _ptr(side.idx), _ptr(side.y),
-                                            _ptr(tab_self), _ptr(tab_other), _ptr(part), _ptr(scatter_acc),
-                                            _ptr(acc_rows), int(acc_ld), k, ld, int(getattr(side, "short_rows", 0)),
+                                            _ptr(tab_self), _ptr(tab_other), _ptr(part), _ptr(acc_rows), int(acc_ld),
+                                            k, ld, int(getattr(side, "short_rows", 0)),
                                             grid_blocks or self.sweep_blocks, self._stream()),
                    "hpf_hip_sweep_f32")
 

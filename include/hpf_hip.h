@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 6
+#define HPF_HIP_ABI_VERSION 7
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -64,12 +64,12 @@ int hpf_hip_device_info(int *cu_count, char *arch, int arch_len);
  *   for every segment g, nonzero n in g (other-side row c = idx[n], count y[n]):
  *       s = <tab_self[row(g)], tab_other[c]>;   w = y[n] / s
  *       part[g][:] += w * tab_other[c][:]
- *       (optional) scatter_acc[c][:] += w * tab_self[row(g)][:]   -- atomicAdd
  *
  * with tab_self/tab_other holding E = exp(psi(shape) - log(rate)) rows (row-scaled,
  * see hpf_hip_row_finalize_f32), so that shape_row = prior + tab_self[row] (*) sum of
- * that row's part[] entries.  One wavefront per segment, 64/(ld/4) nonzeros per step.
- * scatter_acc may be NULL (the deterministic two-pass scheme: call once per side).
+ * that row's part[] entries.  One wavefront per segment, 64/(ld/4) nonzeros per step.  Call once per side (the
+ * deterministic two-pass scheme; a one-pass form with fp32 atomics for the other side was measured at 4x the time
+ * of the second pass and removed, profiles/r02_atomic_one_pass.txt).
  * acc_rows (optional): segments flagged HPF_SEG_WHOLE_ROW write their accumulator to
  * acc_rows[row][0:acc_ld] (k <= acc_ld <= ld, packed) instead of part[g] -- the multi-GPU exchange buffer.
  * short_rows: tuning hint for rows that average a few dozen nonzeros at most.  1: the wave-per-segment kernel with
@@ -78,8 +78,8 @@ int hpf_hip_device_info(int *cu_count, char *arch, int arch_len);
  * row sequentially instead of in 64/(ld/4) interleaved partial sums).
  */
 int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
-                      const float *tab_self, const float *tab_other, float *part, float *scatter_acc,
-                      float *acc_rows, int acc_ld, int k, int ld, int short_rows, int grid_blocks, void *stream);
+                      const float *tab_self, const float *tab_other, float *part, float *acc_rows, int acc_ld, int k,
+                      int ld, int short_rows, int grid_blocks, void *stream);
 
 /*
  * hpf_hip_sweep_f32 with the row finalizer (next entry) fused in: a segment flagged

@@ -64,7 +64,7 @@ class CpuOps:
                           rs_prev=rs_prev)
         self.sweep(side, tab_self, tab_other, part, k, ld, acc_rows=acc_rows, acc_ld=acc_ld)
 
-    def sweep(self, side, tab_self, tab_other, part, k, ld, scatter_acc=None, acc_rows=None, acc_ld=0, grid_blocks=None):
+    def sweep(self, side, tab_self, tab_other, part, k, ld, acc_rows=None, acc_ld=0, grid_blocks=None):
         if side.nseg == 0:
             return
         begin, length, row = _decode_segs(side)
@@ -86,10 +86,6 @@ class CpuOps:
             _np(part)[: side.nseg][~whole] = out[~whole].astype(np.float32)
         else:
             _np(part)[: side.nseg] = out.astype(np.float32)
-        if scatter_acc is not None:
-            acc = _np(scatter_acc).astype(np.float64)
-            np.add.at(acc, idx, w[:, None] * S)
-            _np(scatter_acc)[:] = acc.astype(np.float32)
 
     def row_finalize(self, part, row_seg_ptr, nrows, e_old, e_new, shp, rte, fac, rs, cs_other, cs_partial,
                      prior_shp, top_shp, add_rte, k, ld, row_list=None, part_ld=None, rs_prev=None):

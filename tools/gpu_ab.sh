@@ -15,7 +15,7 @@ V=$PWD/hpfrec_amd/variants
 run
 run --no-fuse
 run --lean
-run --atomic
+
 ENVV="HPF_FORCE_SHARDED=1" run
 run --workload c2
 run --workload c4
