@@ -43,10 +43,13 @@ WORKLOADS = {
     "tiny": (2_000, 1_000, 50_000, 50, "tiny synthetic 2k x 1k, 50k nnz, k=50 (host-overhead probe)"),
     "k30": (1_000_000, 380_000, 48_000_000, 30, "C3 matrix with k=30 (ld=32: 8 nonzeros per wave step)"),
     "k200": (1_000_000, 380_000, 48_000_000, 200, "C3 matrix with k=200 (ld=256: 1 nonzero per wave step)"),
+    # probes for the hot/cold split of the gathers: the nonzeros of C3 that fall on its 16k most
+    # popular items (4 MB of E rows: L2-resident in every XCD), and the rest
+    "hot": (1_000_000, 16_000, 13_500_000, 50, "probe: 1M x 16k, 13.5M nnz, k=50 (item table = 4 MB)"),
 }
 
 
-POWER = {"c3u": 1.0}   # item-popularity exponent per workload (default 2.5)
+POWER = {"c3u": 1.0, "hot": 1.0}   # item-popularity exponent per workload (default 2.5)
 
 
 def synth_on_device(nU, nI, nnz_target, device, seed=1, item_power=2.5, sigma=1.0):
