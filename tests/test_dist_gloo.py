@@ -1,4 +1,4 @@
-"""The N>1 path on CPU: world_size 2 and 3 over gloo (user-sharded driver, both exchange modes), numpy stand-in ops.  Every rank must end with
+"""The N>1 path on CPU: world_size 2, 3, 4 and 8 over gloo (user-sharded driver, both exchange modes), numpy stand-in ops.  Every rank must end with
 the full, identical model, equal (to rounding: the sum order changes) to the single-process run."""
 import os
 import socket
@@ -23,11 +23,13 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,case,mode", [(2, "c1", "scatter"), (3, "mid", "scatter"), (3, "c1", "scatter"),
+                                             (8, "c1", "scatter"), (4, "mid", "scatter"), (8, "mid", "allreduce"),
                                              (3, "c1", "scatter-a2a"), (3, "c1", "scatter-one-range"),
                                              (2, "c1", "allreduce"), (3, "mid", "allreduce")])
 def test_sharded_equals_single(tmp_path, cpu_ops_backend, monkeypatch, world, case, mode):
     """mode: "scatter" = reduce-scatter / sharded item finalizer / all-gather (default); "allreduce" = all-reduce +
-    replicated deferred finalizer.  (3, c1): 100 items over 3 ranks -> pad rows in the item tables."""
+    replicated deferred finalizer.  (3, c1): 100 items over 3 ranks -> pad rows in the item tables; (8, c1): the
+    driver's largest rank count, 12-13 users and 100 items (ranges padded to multiples of 8) per rank."""
     if mode == "scatter-a2a":                     # reduce-scatter as all-to-all + local sum
         mode = "scatter"
         monkeypatch.setenv("HPF_RS_ALLTOALL", "1")
