@@ -705,9 +705,11 @@ def test_rank1_rate_tables_expand_bit_identically(ops):
     assert torch.all(rte[:, k:] == 0)
 
 
-def test_bench_multi_rank_path_selftest():
-    """bench.py's N>1 path (rank-0 generation + broadcast, sharding, exchange autotune, separate event pass, one JSON
-    line from rank 0) with two gloo ranks sharing the GPU -- a code-path test, not a measurement."""
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_bench_multi_rank_path_selftest(ranks):
+    """bench.py's N>1 path (rank-0 generation + broadcast, sharding, exchange autotune incl. the hipGraph candidate --
+    which gloo cannot capture and must be reported as such --, separate event pass, one JSON line from rank 0) with
+    2 and with 8 gloo ranks sharing the GPU -- a code-path test, not a measurement."""
     import json
     import subprocess
     import sys
@@ -717,16 +719,21 @@ def test_bench_multi_rank_path_selftest():
     env = dict(os.environ, HPF_BENCH_SELFTEST_GLOO="1")
     for v in ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_FORCE_SHARDED"):
         env.pop(v, None)
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29588", os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "small"],
+    for v in ("HPF_RS_ALLTOALL", "HPF_GRAPH"):
+        env.pop(v, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+                          "--master-addr", "127.0.0.1", "--master-port", str(29588 + ranks), os.path.join(root, "bench.py"),
+                          "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--workload", "small"],
                          env=env, capture_output=True, text=True, timeout=900, cwd=root)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["state_finite"] is True
-    assert {"scatter/2", "scatter/3", "allreduce/3"} <= set(d["config"]["exchange_autotune"]["ms_per_iteration"])
-    assert d["config"]["exchange_autotune"]["chosen"] in d["config"]["exchange_autotune"]["ms_per_iteration"]
+    assert d["n_gpus"] == ranks and d["steps"] == 2 and d["config"]["state_finite"] is True
+    at = d["config"]["exchange_autotune"]
+    assert {"scatter/2", "scatter/1", "scatter/3", "allreduce/3", "scatter/2/item-stream", "scatter/2/all-to-all"} \
+        <= set(at["ms_per_iteration"]), at
+    assert at["chosen"] in at["ms_per_iteration"]
+    assert any(key.endswith("/hipgraph") for key in at["failed"]) and d["config"]["hipgraph_pairs"] is False
     assert d["roofline"]["events"].startswith("separate pass") and d["cpu_baseline"] is None
 
 
