@@ -77,13 +77,18 @@ class TimedOps(HipOps):
     """HipOps that brackets every launch with HIP events on the launch stream (torch's current
     stream is the stream the C ABI launches on)."""
 
+    #: the launches bracketed in the timed region: the dominant kernel only (two event records per launch cost
+    #: 1.4 % of a C3 iteration when all six launches of an iteration are bracketed); recording = "all" brackets every
+    #: launch (the untimed breakdown pass)
+    DOMINANT = ("sweep", "sweep_finalize", "sweep_prefinalize")
+
     def __init__(self, device):
         super().__init__(device)
         self.recording = False
         self.events = {}
 
     def _timed(self, name, fn, *a, **kw):
-        if not self.recording:
+        if not self.recording or (self.recording != "all" and name not in self.DOMINANT):
             return fn(*a, **kw)
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
@@ -399,7 +404,7 @@ def main():
     ev_steps = args.steps
     if not events_in_timed and not args.no_events:
         ev_steps = min(args.steps, 10)
-        ops.recording = True
+        ops.recording = "all"
         for _ in range(ev_steps):
             model.iterate(store)
         fence()
@@ -411,6 +416,16 @@ def main():
 
     # what fit_hpf actually does between checks: the six [n,k] output tables (shapes, rates, Theta/Beta) are
     # not written.  Reported as an extra field; `value` above is the conservative all-tables-stored figure.
+    # per-kernel breakdown of an iteration (every launch bracketed), outside the timed region
+    breakdown = None
+    if events_in_timed and not args.no_events and not args.no_extras:
+        timed_events, ops.events, ops.recording = ops.events, {}, "all"
+        for _ in range(4):
+            model.iterate(store)
+        fence()
+        ops.recording = False
+        breakdown = {n: v["total_ms"] / 4 for n, v in ops.summary().items()}
+        ops.events = timed_events
     lean_ms = None
     if store and not args.no_extras:
         for _ in range(2):
@@ -475,8 +490,11 @@ def main():
                     "launches": ksum[dom]["calls"],
                     "iteration": {"algorithmic_bytes": b_iter,
                                   "frac_of_hbm_peak": b_iter / (ms * 1e-3) / HBM_PEAK if world == 1 else None},
-                    "kernels_ms_per_step": {n: v["total_ms"] / ev_steps for n, v in ksum.items()},
-                    "events": "timed region" if events_in_timed else "separate pass of %d iterations after the timed region" % ev_steps}
+                    "kernels_ms_per_step": breakdown if breakdown is not None else
+                    {n: v["total_ms"] / ev_steps for n, v in ksum.items()},
+                    "events": ("timed region (dominant kernel; the per-kernel breakdown is a separate pass of 4 "
+                               "iterations)") if events_in_timed
+                    else "separate pass of %d iterations after the timed region" % ev_steps}
             if roof["frac"] > 1.0:
                 roof["note"] = ("algorithmic bytes exceed what HBM delivers: at this size the gathered tables stay in "
                                 "L2 / Infinity Cache (each gather is still counted at face value, SURVEY.md section 8d)")

@@ -29,7 +29,8 @@ def avg_counter(d, counter, kern):
 fetch_dir, write_dir, workload, out = sys.argv[1:5]
 kern = sys.argv[5] if len(sys.argv) > 5 else "sweep_kernel"
 name, fetch_kb, nf = avg_counter(fetch_dir, "FETCH_SIZE", kern)
-_, write_kb, nw = avg_counter(write_dir, "WRITE_SIZE", name.split("(")[0])
+inst = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")    # e.g. sweep_kernel<16, 1, 1, 8>
+_, write_kb, nw = avg_counter(write_dir, "WRITE_SIZE", inst)
 doc = {
     "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of `python bench.py --workload %s --steps 3 "
               "--warmup 1 --no-cpu-baseline --no-events --no-extras` (tools/gpu_profile.sh)" % workload,
