@@ -322,6 +322,10 @@ class FullBatchCavi:
         try:
             self._sync_scatter_streams()
             torch.cuda.synchronize(self.device)
+            # let torch's RCCL watchdog thread retire the eager collectives issued so far before events start being
+            # recorded into a capture (it polls every 100 ms)
+            import time
+            time.sleep(float(os.environ.get("HPF_GRAPH_DRAIN_S", "0.35")))
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.iterate(store)

@@ -723,7 +723,7 @@ def test_bench_multi_rank_path_selftest(ranks):
         env.pop(v, None)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
                           "--master-addr", "127.0.0.1", "--master-port", str(29588 + ranks), os.path.join(root, "bench.py"),
-                          "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--workload", "small"],
+                          "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--workload", "small", "--try-hipgraph"],
                          env=env, capture_output=True, text=True, timeout=900, cwd=root)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]

@@ -23,5 +23,13 @@ has e2e && run e2e_fit.txt python tools/e2e_fit.py c3 100
 if has shard; then
   run shard_probe_c3.txt env HPF_SHARD_MODE=scatter PROBE_EVENTS=0 python tools/shard_probe.py 8
   run shard_probe_c4.txt env PROBE_WORKLOAD=c4 HPF_SHARD_MODE=scatter PROBE_EVENTS=0 python tools/shard_probe.py 8
+  run shard_probe_c3_graph1.txt env HPF_GRAPH=1 HPF_AR_CHUNKS=1 HPF_SHARD_MODE=scatter PROBE_EVENTS=0 python tools/shard_probe.py 8
+  run shard_probe_c4_graph1.txt env PROBE_WORKLOAD=c4 HPF_GRAPH=1 HPF_AR_CHUNKS=1 HPF_SHARD_MODE=scatter PROBE_EVENTS=0 python tools/shard_probe.py 8
+  run shard_probe_c3_graph2.txt env HPF_GRAPH=1 HPF_AR_CHUNKS=2 HPF_SHARD_MODE=scatter PROBE_EVENTS=0 python tools/shard_probe.py 8
+  run shard_probe_c3_all_n.txt env HPF_GRAPH=1 PROBE_EVENTS=0 python tools/shard_probe.py 1 2 4 8
+  run shard_probe_c3_allreduce_n.txt env HPF_SHARD_MODE=allreduce PROBE_EVENTS=0 python tools/shard_probe.py 2 4
+fi
+if has default; then
+  run bench_c3_default.json python bench.py
 fi
 tail -n 3 $OUT/*
