@@ -103,3 +103,58 @@ def test_svi_on_gpu(hip_backend):
 @pytest.mark.gpu
 def test_fold_in_on_gpu(hip_backend):
     _fold_in()
+
+
+def _partial_fit_growing_model():
+    """partial_fit with new_users / new_items (INIT:933-963: fresh rows appended from a default_rng stream) on the
+    resident state: the appended host rows and the device tables stay in step (shape change -> tables rebuilt), and
+    the result equals replaying the same steps through the extension-level partial_fit on plain arrays."""
+    batches, nU, nI = datagen.partial_fit_batches()
+    k = 8
+    m = HPF(k=k, reindex=False, keep_data=False, random_seed=3, verbose=False)
+    first = batches[0][1]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.partial_fit(first.copy(), nusers=nU, nitems=nI)
+        m.partial_fit(batches[1][1].copy())
+    snap = {n: getattr(m, n).copy() for n in NAMES}
+    extra = pd.DataFrame({"UserId": [nU, nU, nU + 1], "ItemId": [3, nI, 7], "Count": [2, 1, 4]})
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # (the reference's new_users / new_items arithmetic, INIT:889-905, wants nusers to exceed the batch's largest id
+        # by the number of rows to add; the row-appending helpers are what matters here)
+        m._initialize_extra_users(2, 11)
+        m._initialize_extra_items(1, 11)
+        m.nusers, m.nitems = nU + 2, nI + 1
+        m.partial_fit(extra.copy())
+    assert m.Theta.shape == (nU + 2, k) and m.Beta.shape == (nI + 1, k) and m.k_rte.shape == (nU + 2, 1)
+    assert m._state.model.nU == nU + 2 and m._state.model.nI == nI + 1
+    # the same step on plain arrays through the module-level entry point
+    be = m._backend()
+    ref = dict(snap)
+    rng_rows = HPF(k=k, reindex=False, keep_data=False, random_seed=3, verbose=False)
+    rng_rows.k, rng_rows.a_prime, rng_rows.b_prime, rng_rows.c_prime, rng_rows.d_prime = k, 0.3, 1.0, 0.3, 1.0
+    shp, rte, fac, sc = rng_rows._fresh_rows(2, 11, 0.3, 1.0)
+    ref["Gamma_shp"], ref["Gamma_rte"] = np.r_[ref["Gamma_shp"], shp], np.r_[ref["Gamma_rte"], rte]
+    ref["Theta"], ref["k_rte"] = np.r_[ref["Theta"], fac], np.r_[ref["k_rte"], sc]
+    shp, rte, fac, sc = rng_rows._fresh_rows(1, 11, 0.3, 1.0)
+    ref["Lambda_shp"], ref["Lambda_rte"] = np.r_[ref["Lambda_shp"], shp], np.r_[ref["Lambda_rte"], rte]
+    ref["Beta"], ref["t_rte"] = np.r_[ref["Beta"], fac], np.r_[ref["t_rte"], sc]
+    Y = extra["Count"].to_numpy().astype(np.float32)
+    iu, ii = extra["UserId"].to_numpy().astype(np.uint64), extra["ItemId"].to_numpy().astype(np.uint64)
+    users, items = np.unique(iu), np.unique(ii)
+    f = be.cast_real_t
+    be.partial_fit(Y, iu, ii, ref["Theta"], ref["Beta"], ref["Gamma_shp"], ref["Gamma_rte"], ref["Lambda_shp"],
+                   ref["Lambda_rte"], ref["k_rte"], ref["t_rte"], f(0.3 / 1.0), f(0.3 / 1.0), 0.3, 0.3, f(0.3 + k * 0.3),
+                   f(0.3 + k * 0.3), k, users, items, 0, f(1 / np.sqrt(2 + 2)), f(float(nU + 2) / users.shape[0]), 1, True)
+    for n in NAMES:
+        assert _maxrel(getattr(m, n), ref[n]) < 1e-5, n
+
+
+def test_partial_fit_growing_model_on_standin(cpu_ops_backend):
+    _partial_fit_growing_model()
+
+
+@pytest.mark.gpu
+def test_partial_fit_growing_model_on_gpu(hip_backend):
+    _partial_fit_growing_model()
