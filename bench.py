@@ -308,8 +308,9 @@ def main():
     # deliver on this node, so (unless the environment pins them) each candidate runs a few untimed iterations
     # first and the fastest one -- by the slowest rank's clock -- is the configuration that is then benchmarked.
     autotune = None
-    if dist and world > 1 and not args.no_autotune and not any(
-            v in os.environ for v in ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_RS_ALLTOALL", "HPF_GRAPH")):
+    TUNED = ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_RS_ALLTOALL", "HPF_GRAPH", "HPF_RCCL_DIRECT")
+    sharded = dist is not None and (world > 1 or os.environ.get("HPF_FORCE_SHARDED") == "1")
+    if sharded and not args.no_autotune and not any(v in os.environ for v in TUNED):
         autotune, failed = {}, {}
         # Safety net: this multi-rank path could only be exercised with gloo ranks on one GPU (and a one-rank RCCL
         # group) before the driver's run.  If anything after a completed candidate stops making progress, rank 0
@@ -318,12 +319,13 @@ def main():
             workload=label, users=nU, items=nI, nnz=nnz, k=k, world=world, rank=rank, workload_key=args.workload)
         _arm_watchdog(float(os.environ.get("HPF_BENCH_WATCHDOG_S", "240")))
 
-        def candidate(mode, chunks, istream, a2a, graph):
+        def candidate(mode, chunks, istream, a2a, graph, direct="0"):
             env = {"HPF_SHARD_MODE": mode, "HPF_AR_CHUNKS": chunks, "HPF_ITEM_STREAM": istream, "HPF_RS_ALLTOALL": a2a,
-                   "HPF_GRAPH": graph}
+                   "HPF_GRAPH": graph, "HPF_RCCL_DIRECT": direct}
             os.environ.update(env)
-            key = "%s/%s%s%s%s" % (mode, chunks, "/item-stream" if istream == "1" else "",
-                                   "/all-to-all" if a2a == "1" else "", "/hipgraph" if graph == "1" else "")
+            key = "%s/%s%s%s%s%s" % (mode, chunks, "/item-stream" if istream == "1" else "",
+                                     "/all-to-all" if a2a == "1" else "", "/direct-rccl" if direct == "1" else "",
+                                     "/hipgraph" if graph == "1" else "")
             t_ms, err, m = None, None, None
             try:
                 m = build_model()
@@ -337,6 +339,8 @@ def main():
                 t_ms = (time.perf_counter() - t0) / 20 * 1e3
                 if graph == "1" and not any(g is not None for g in m.__dict__.get("_graphs", {}).values()):
                     err, t_ms = "no hipGraph captured: %s" % getattr(m, "_graph_error", "backend not capturable"), None
+                if direct == "1" and getattr(m, "comm", None) is None:
+                    err, t_ms = "no communicator of our own (backend is not RCCL)", None
                 m.flush_items()
             except Exception as exc:   # noqa: BLE001
                 err = "%s: %s" % (type(exc).__name__, str(exc)[:200])
@@ -360,8 +364,19 @@ def main():
                      ("scatter", "2", "0", "1", "0")):
             key, env = candidate(*cand)
             envs[key] = env
-        sc = {k_: v for k_, v in autotune.items() if k_.startswith("scatter") and "item-stream" not in k_}
-        # The fastest scatter configuration once more, replayed from captured hipGraphs -- only on request
+        # the collectives on an RCCL communicator of our own (hpfrec_amd/rccl.py): eager, then -- the fastest of the two
+        # -- replayed from captured hipGraphs (nothing of torch's polls that communicator's work, so the capture is safe)
+        for cand in (("scatter", "2", "0", "0", "0", "1"), ("scatter", "1", "0", "0", "0", "1")):
+            key, env = candidate(*cand)
+            envs[key] = env
+        dr = {k_: v for k_, v in autotune.items() if "direct-rccl" in k_}
+        if dr:
+            base = envs[min(dr, key=dr.get)]
+            key, env = candidate("scatter", base["HPF_AR_CHUNKS"], "0", "0", "1", "1")
+            envs[key] = env
+        sc = {k_: v for k_, v in autotune.items() if k_.startswith("scatter") and "item-stream" not in k_
+              and "direct-rccl" not in k_}
+        # The fastest torch.distributed scatter configuration replayed from captured hipGraphs -- only on request
         # (--try-hipgraph): in ~1 of 50 captures on this image torch's RCCL watchdog thread queried an event recorded
         # into the capture (hipErrorCapturedEvent) and aborted the process (profiles/r02_hipgraph_watchdog_abort.txt); a
         # benchmark line must not depend on that.
@@ -374,7 +389,7 @@ def main():
             os.environ.update(envs[best])
         else:       # nothing completed everywhere: the library defaults
             best = None
-            for v in ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_RS_ALLTOALL", "HPF_GRAPH"):
+            for v in TUNED:
                 os.environ.pop(v, None)
         autotune = {"ms_per_iteration": autotune, "chosen": best, "failed": failed}
     model = build_model()
@@ -387,6 +402,8 @@ def main():
 
     def fence():
         if dist:
+            if getattr(model, "shard_mode", None) == "scatter":
+                model._sync_scatter_streams()     # (exchange stream joined before another communicator's barrier)
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -521,6 +538,7 @@ def main():
                                         % (world, len(model.item_chunks)))) if world > 1 else "1 GPU",
                        "exchange_autotune": autotune,
                        "hipgraph_pairs": any(g is not None for g in model.__dict__.get("_graphs", {}).values()),
+                       "direct_rccl_communicator": getattr(model, "comm", None) is not None,
                        "seg_cap": cavi.layout.SEG_CAP, "fused_finalize": model.fused and world == 1,
                        "stores_all_state_tables": store, "state_finite": finite},
             "roofline": roof,

@@ -55,6 +55,28 @@ def _dist():
     return None
 
 
+_DIRECT_COMMS = {}
+
+
+def _direct_comm(dist, device, rank, world):
+    """The process-wide DirectComm for (device, world) when HPF_RCCL_DIRECT=1 and the job runs on RCCL; else None
+    (torch.distributed carries the collectives).  A stand-in for torch.distributed may bring its own (`direct_comm`)."""
+    if dist is None or os.environ.get("HPF_RCCL_DIRECT", "0") != "1" or torch.device(device).type != "cuda":
+        return None
+    if hasattr(dist, "direct_comm"):
+        return dist.direct_comm(device)
+    try:
+        if dist.get_backend() != "nccl":
+            return None
+    except Exception:   # noqa: BLE001
+        return None
+    key = (str(device), world, rank)
+    if key not in _DIRECT_COMMS:
+        from . import rccl
+        _DIRECT_COMMS[key] = rccl.DirectComm(device, dist, rank, world)
+    return _DIRECT_COMMS[key]
+
+
 def shard_users(ix_u, ix_i, y, nU, rank, world):
     """Keep the nonzeros of this rank's contiguous, nnz-balanced user range.
     Returns (local ix_u, ix_i, y, (u0, u1))."""
@@ -162,6 +184,10 @@ class FullBatchCavi:
         self.niter_done = 0
         self._chunk_views = None
         self.rs_alltoall = os.environ.get("HPF_RS_ALLTOALL", "0") == "1"   # scatter mode: all-to-all + local sum
+        # scatter mode, opt-in: the per-iteration collectives on an RCCL communicator of our own (hpfrec_amd/rccl.py)
+        # instead of torch.distributed -- no Work objects, no watchdog polls, capturable into hipGraphs
+        self.comm = _direct_comm(self.dist, self.device, self.rank, self.world) \
+            if (self.shard_mode == "scatter" and not self.rs_alltoall) else None
         self.item_stream = os.environ.get("HPF_ITEM_STREAM", "0") == "1"   # scatter mode: item pass on its own stream
         self.lazy_items = os.environ.get("HPF_LAZY_ITEMS", "1") == "1"
         self.item_pending = False   # sharded path: acc_i holds reduced statistics not yet applied to the item tables
@@ -308,6 +334,8 @@ class FullBatchCavi:
             return False
         if os.environ.get("HPF_GRAPH", "0") != "1" or getattr(self, "_graph_failed", False) or self.item_stream:
             return False        # (three-stream captures crash the ROCm 7.0 runtime: graphs only with HPF_ITEM_STREAM=0)
+        if self.comm is not None:
+            return True         # our own communicator: plain stream work, nothing of torch's polls it
         try:
             return self.dist.get_backend() == "nccl"     # gloo collectives run on the host: nothing to capture
         except Exception:   # noqa: BLE001  (stand-ins for torch.distributed in probes: assume capturable)
@@ -504,6 +532,8 @@ class FullBatchCavi:
                     # once), which then adds up the N slices it received, in rank order
                     dist.all_to_all_single(c["a2a_recv"], c["acc"])
                     torch.sum(c["a2a_recv"].view(self.world, c["m"], k), dim=0, out=c["acc_own"])
+                elif self.comm is not None:
+                    self.comm.reduce_scatter(c["acc_own"], c["acc"])
                 else:
                     dist.reduce_scatter_tensor(c["acc_own"], c["acc"])
         if cuda and not fresh:
@@ -518,8 +548,9 @@ class FullBatchCavi:
         if cuda:
             self._csT_ready.record(cs)
             xs.wait_event(self._csT_ready)
+        ar = self.comm.all_reduce if self.comm is not None else dist.all_reduce
         with on(xs):
-            dist.all_reduce(self.csT)
+            ar(self.csT)
             if self._fin_ranges:
                 ops.row_finalize_ranges(self.acc_own_all, self._fin_ranges, self.eB, self.e_own_all,
                                         self.Lambda_shp if store else None, None, self.Beta if store else None,
@@ -530,8 +561,11 @@ class FullBatchCavi:
                     # colsum(Beta) -- read by the next USER side only -- goes ahead of the last all-gather (which the
                     # user side waits for anyway) and behind the first one (which the next item sweep is waiting for)
                     ops.colsum_reduce(self.csB_part_sc, self.csB, ld)      # this rank's partial colsum(Beta) ...
-                    dist.all_reduce(self.csB)                              # ... summed over ranks
-                dist.all_gather_into_tensor(c["eB_range"], c["e_own"])
+                    ar(self.csB)                                           # ... summed over ranks
+                if self.comm is not None:
+                    self.comm.all_gather(c["eB_range"], c["e_own"])
+                else:
+                    dist.all_gather_into_tensor(c["eB_range"], c["e_own"])
                 if cuda:
                     c["ag_done"].record(xs)
         self._sc_fresh = False

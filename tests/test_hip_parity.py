@@ -443,7 +443,8 @@ def test_fused_and_split_drivers_agree(hip_backend):
         assert _maxrel(a[n], b[n]) < 2e-6, n
 
 
-@pytest.mark.parametrize("mode", ["scatter", "allreduce", "scatter-graph", "scatter-item-stream"])
+@pytest.mark.parametrize("mode", ["scatter", "allreduce", "scatter-graph", "scatter-item-stream", "scatter-direct",
+                                  "scatter-direct-graph"])
 def test_sharded_path_single_rank_nccl(mode):
     """The multi-GPU code path on one GPU with a real RCCL group: "scatter" = asynchronous reduce-scatter / dense
     finalize of the own slice / all-gather into the E table; "allreduce" = async packed all-reduce + deferred finalize."""
@@ -454,15 +455,19 @@ def test_sharded_path_single_rank_nccl(mode):
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                HPF_SHARD_MODE=mode.split("-")[0])
-    if mode == "scatter-graph":           # pairs of iterations replayed from a captured hipGraph (RCCL calls included)
+    if mode.endswith("graph"):            # pairs of iterations replayed from a captured hipGraph (RCCL calls included)
         env["HPF_GRAPH"] = "1"
+    if "direct" in mode:                  # the collectives on an RCCL communicator of our own (hpfrec_amd/rccl.py)
+        env["HPF_RCCL_DIRECT"] = "1"
     if mode == "scatter-item-stream":     # item sweeps on a third stream
         env["HPF_ITEM_STREAM"] = "1"
     out = subprocess.run([sys.executable, os.path.join(here, "sharded_single_rank.py")], env=env, capture_output=True,
                          text=True, timeout=600)
     assert "SHARDED_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
-    if mode == "scatter-graph":
+    if mode.endswith("graph"):
         assert "GRAPH_PAIRS_REPLAYED" in out.stdout, out.stdout[-2000:]
+    if "direct" in mode:
+        assert "DIRECT_RCCL_USED" in out.stdout, out.stdout[-2000:]
 
 
 @pytest.mark.parametrize("k", [30, 50, 200])
@@ -733,8 +738,37 @@ def test_bench_multi_rank_path_selftest(ranks):
     assert {"scatter/2", "scatter/1", "scatter/3", "allreduce/3", "scatter/2/item-stream", "scatter/2/all-to-all"} \
         <= set(at["ms_per_iteration"]), at
     assert at["chosen"] in at["ms_per_iteration"]
+    # gloo: no communicator of our own, nothing to capture -- reported as failed candidates, not as timings
     assert any(key.endswith("/hipgraph") for key in at["failed"]) and d["config"]["hipgraph_pairs"] is False
+    assert any("direct-rccl" in key for key in at["failed"]) and d["config"]["direct_rccl_communicator"] is False
     assert d["roofline"]["events"].startswith("separate pass") and d["cpu_baseline"] is None
+
+
+def test_bench_autotune_on_a_one_rank_rccl_group():
+    """The exchange autotune of bench.py on REAL RCCL (one rank, HPF_FORCE_SHARDED=1): every candidate completes,
+    including the ones on the communicator of our own and its hipGraph replay."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HPF_FORCE_SHARDED="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29577")
+    for v in ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_RS_ALLTOALL", "HPF_GRAPH", "HPF_RCCL_DIRECT",
+              "HPF_BENCH_SELFTEST_GLOO"):
+        env.pop(v, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
+                          "--workload", "small", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                         timeout=900, cwd=root)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    at = d["config"]["exchange_autotune"]
+    assert at["failed"] == {}, at
+    assert {"scatter/2/direct-rccl", "scatter/1/direct-rccl"} <= set(at["ms_per_iteration"])
+    assert any(key.endswith("direct-rccl/hipgraph") for key in at["ms_per_iteration"])
+    assert d["config"]["state_finite"] is True and d["value"] > 0
 
 
 def test_long_horizon_ends_at_the_same_optimum(hip_backend):

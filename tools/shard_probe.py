@@ -71,6 +71,28 @@ class EmulatedRank:
             return _EvWork(e1) if async_op else torch.cuda.current_stream().wait_event(e1) or _Done()
         return dist.all_reduce(t, async_op=async_op) or _Done()
 
+    def direct_comm(self, device):
+        """HPF_RCCL_DIRECT=1: the collectives as calls on a one-rank communicator of our own + the same local copies."""
+        emu = self
+        if not hasattr(EmulatedRank, "_comm"):
+            from hpfrec_amd import rccl
+            EmulatedRank._comm = rccl.DirectComm(device)
+
+        class Direct:
+            def all_reduce(self, t):
+                EmulatedRank._comm.all_reduce(t)
+
+            def reduce_scatter(self, out, inp):
+                m = out.shape[0]
+                out.copy_(inp[emu.rank * m: (emu.rank + 1) * m])
+                EmulatedRank._comm.all_reduce(emu.tiny)
+
+            def all_gather(self, out, inp):
+                m = inp.shape[0]
+                out[emu.rank * m: (emu.rank + 1) * m].copy_(inp)
+                EmulatedRank._comm.all_reduce(emu.tiny)
+        return Direct()
+
     def all_reduce(self, t, op=None, async_op=False):
         return self._call(t, async_op)
 
