@@ -12,9 +12,13 @@ HBM before the timed region.  With N>1 the SAME matrix is sharded by users (stro
 
 Prints ONE JSON line on rank 0 (see the bench contract in the task): metric/value/unit ... plus
   "roofline":     the dominant kernel (sweep_kernel) priced against HBM peak, timed with HIP events
-                  on the launch stream inside the timed region;
+                  on the launch stream inside the timed region; `traffic` = HBM-side bytes per launch from the
+                  committed rocprofv3 --pmc passes, null when they were measured on another kernel source;
   "cpu_baseline": the CPU oracle (oracle/, a port of the reference's Cython loops) timed on this
                   node's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+N>1: the exchange configuration (all-reduce / reduce-scatter form, item ranges, streams, torch.distributed or an
+RCCL communicator of our own, hipGraph replay) is autotuned first, every rank taking the same decision
+(config.exchange_autotune); a watchdog reports the best completed candidate should a later one hang.
 """
 import argparse
 import json
