@@ -236,3 +236,23 @@ def test_state_stays_on_the_device_and_never_goes_stale(any_backend):
         assert np.array_equal(m3.host[n], getattr(m, n)), n
     # attributes that were never assigned behave like missing attributes
     assert not hasattr(HPF(verbose=False), "Gamma_shp") and HPF(verbose=False).Theta is None
+
+
+def test_refit_and_mixed_calls(any_backend):
+    """fit -> topN -> partial_fit -> predict -> fit on a smaller problem (tables rebuilt) -> topN / eval_llk: the
+    resident state follows every change of shape and owner."""
+    df, nU, nI = datagen.readme_counts()
+    m = HPF(k=6, maxiter=3, reindex=False, verbose=False, check_every=None, random_seed=1)
+    m.fit(df.copy())
+    assert len(m.topN(user=3, n=5)) == 5
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.partial_fit(df.loc[df.UserId.isin([1, 2, 3])].copy())
+    assert m.niter == 3 and not m._state.host_ok["Beta"]
+    p = m.predict(np.array([1, 2]), np.array([3, 4]))
+    assert np.allclose(p, (m.Theta[[1, 2]] * m.Beta[[3, 4]]).sum(axis=1), rtol=1e-5)
+    df2 = df.loc[(df.UserId < 40) & (df.ItemId < 50)].copy()
+    m.fit(df2.copy())
+    assert m.Theta.shape == (int(df2.UserId.max()) + 1, 6)
+    assert len(m.topN(user=3, n=5)) == 5 and m._state.model.nU == m.Theta.shape[0]
+    assert np.isfinite(float(m.eval_llk(df2.copy())["llk"]))
