@@ -51,6 +51,35 @@ def factorize(ids):
     return codes, uniq[by_appearance]
 
 
+class IdLookup:
+    """pd.Categorical(values, mapping).codes for numeric ids on the device: position of each value in `mapping`
+    (the first-appearance numbering of the fit), -1 for values that are not in it (INIT:561-563, 1221-1269).
+    The mapping is sorted once; a query is a searchsorted + an equality check."""
+
+    def __init__(self, mapping, device):
+        m = to_device_ids(mapping, device)
+        if m is None:
+            raise ValueError("mapping is not numeric")
+        self.sorted_vals, order = torch.sort(m)
+        self.codes = order                       # position in the original (first-appearance) order
+        self.device = device
+
+    def __call__(self, values):
+        v = to_device_ids(values, self.device)
+        if v is None:
+            return None
+        if v.dtype != self.sorted_vals.dtype:
+            v = v.to(self.sorted_vals.dtype) if self.sorted_vals.dtype.is_floating_point else None
+            if v is None:
+                return None
+        n = self.sorted_vals.shape[0]
+        if n == 0:
+            return torch.full(v.shape, -1, dtype=torch.int64, device=self.device)
+        pos = torch.searchsorted(self.sorted_vals, v).clamp_(max=n - 1)
+        hit = self.sorted_vals[pos] == v
+        return torch.where(hit, self.codes[pos], torch.full_like(pos, -1))
+
+
 def seen_metadata(ix_u, ix_i, nU, nI):
     """(n_seen_by_user [nU], st_ix_user = indptr [nU+1], seen) of scipy's coo_array((.., (ix_u, ix_i))).tocsr():
     duplicate pairs counted once, item ids ascending inside a user's slice (INIT:589-605).  int64 device tensors."""

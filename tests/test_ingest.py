@@ -116,3 +116,50 @@ def test_ingest_at_24m_triplets_vs_pandas_scipy():
     assert np.array_equal(ptr.cpu().numpy(), X.indptr) and np.array_equal(seen.cpu().numpy(), X.indices)
     assert X.indices.dtype == ingest.SEEN_INDEX_DTYPE
     assert int(nseen.sum()) == X.nnz < pcu.shape[0]            # repeated pairs were merged
+
+
+def test_id_lookup_equals_categorical_codes():
+    rs = np.random.RandomState(0)
+    for dt in (np.int64, np.int32, np.float64, np.uint64):
+        mapping = pd.unique((rs.randint(0, 10 ** 6, size=50_000) * 3).astype(dt))
+        q = (rs.randint(0, 10 ** 6, size=120_000) * 3 + rs.randint(0, 2, size=120_000)).astype(dt)
+        got = ingest.IdLookup(mapping, "cpu")(q).numpy()
+        assert np.array_equal(got, pd.Categorical(q, mapping).codes), dt
+    assert np.array_equal(ingest.IdLookup(np.empty(0, np.int64), "cpu")(np.array([1, 2])).numpy(), [-1, -1])
+
+
+def _big_valset_and_predict():
+    """A validation set / predict query large enough for the device lookup (>= 200k ids): same codes, same results
+    as the pandas path (forced by lowering / raising the threshold)."""
+    import hpfrec_amd
+    rs = np.random.RandomState(4)
+    n = 260_000
+    df = pd.DataFrame({"UserId": rs.randint(0, 3000, size=n) * 7 + 1, "ItemId": rs.randint(0, 800, size=n) * 3 + 2,
+                       "Count": (rs.gamma(1, 1, size=n) + 1).astype("int32")})
+    df = df.loc[~df[["UserId", "ItemId"]].duplicated()].reset_index(drop=True)
+    val = df.sample(n=210_000, random_state=1).reset_index(drop=True)
+    val.loc[::1000, "UserId"] = 10 ** 7                      # ids the model never saw
+    res = {}
+    for thr in (200_000, 10 ** 9):
+        old = hpfrec_amd._BIG_LOOKUP
+        hpfrec_amd._BIG_LOOKUP = thr
+        try:
+            m = HPF(k=8, maxiter=4, random_seed=1, verbose=False, stop_crit="val-llk", check_every=2).fit(df.copy(), val.copy())
+            p = m.predict(val["UserId"].to_numpy(), val["ItemId"].to_numpy())
+            res[thr] = (m.niter, m.Theta.copy(), p, m.eval_llk(val.copy())["llk"])
+            assert ("_id_lookup" in m.__dict__) == (thr == 200_000)
+        finally:
+            hpfrec_amd._BIG_LOOKUP = old
+    a, b = res[200_000], res[10 ** 9]
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(np.isnan(a[2]), np.isnan(b[2]))
+    assert np.isnan(a[2]).sum() == 210 and np.allclose(a[2][~np.isnan(a[2])], b[2][~np.isnan(b[2])], rtol=1e-6)
+    assert abs(float(a[3]) / float(b[3]) - 1) < 1e-9
+
+
+def test_big_valset_lookup_standin(cpu_ops_backend):
+    _big_valset_and_predict()
+
+
+@pytest.mark.gpu
+def test_big_valset_lookup_gpu(hip_backend):
+    _big_valset_and_predict()
