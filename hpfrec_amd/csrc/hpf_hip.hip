@@ -914,6 +914,110 @@ __global__ __launch_bounds__(BLOCK) void svi_refresh_kernel(int64_t nrows, const
     }
 }
 
+// One pass over ALL rows of a side that applies everything an SVI step does to that side (the statements of
+// svi_shape_rows + svi_rate_rows + svi_refresh, row-local, same float32 operations in the same order):
+//   flagged rows (flag[r] != 0: the batch's rows / the rows the batch touched):
+//       shp = w_new*(prior + e (*) acc[r]) + w_old*shp                                  PXI:304-316, 356-368
+//   rate_mode 0 (batch side), every row:   rte = top/rs + cs_other                      PXI:300 / 352
+//   rate_mode 1 (other side), flagged:     rte = step*(top/rs + cs_other) + step_prev*rte      PXI:320 / 372
+//   every row:                             fac = shp/rte ; per-block column sums        PXI:318,322 / 370,374
+//   rs_mode 2: every row, 1: flagged rows: rs = step*(add + sum_k fac) + step_prev*rs   PXI:324-325,376-377,472-473
+template <int LD>
+__global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const uint8_t *__restrict__ flag,
+                                                         const float *__restrict__ acc, const float *__restrict__ e,
+                                                         float *__restrict__ shp, float *__restrict__ rte,
+                                                         float *__restrict__ fac, float *__restrict__ rs,
+                                                         const float *__restrict__ cs_other,
+                                                         float *__restrict__ cs_partial, float prior, float w_new,
+                                                         float w_old, float top, float add, float step,
+                                                         float step_prev, int rate_mode, int rs_mode, int k) {
+    constexpr int CPL = (LD + WAVE - 1) / WAVE;
+    __shared__ float red[WPB][LD];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WPB;
+    float csl[CPL], csacc[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; q++) {
+        const int c = lane + WAVE * q;
+        csl[q] = (c < k) ? cs_other[c] : 0.f;
+        csacc[q] = 0.f;
+    }
+    constexpr int R = (CPL <= 4) ? 2 : 1;   // rows in flight per wavefront
+    for (int64_t r0 = (int64_t)blockIdx.x * WPB + wid; r0 < nrows; r0 += R * nwaves) {
+        float sv[R][CPL], rv[R][CPL], av[R][CPL], ev[R][CPL], rs_old[R];
+        bool fl[R];
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int64_t r = r0 + i * nwaves;
+            const bool live = r < nrows;
+            fl[i] = live && flag && flag[r] != 0;
+            rs_old[i] = live ? rs[r] : 1.f;
+#pragma unroll
+            for (int q = 0; q < CPL; q++) {
+                const int c = lane + WAVE * q;
+                const size_t o = (size_t)r * LD + c;
+                const bool lc = live && c < k;
+                sv[i][q] = lc ? shp[o] : 0.f;
+                rv[i][q] = (lc && rate_mode != 0) ? rte[o] : 1.f;
+                av[i][q] = (lc && fl[i]) ? acc[o] : 0.f;
+                ev[i][q] = (lc && fl[i]) ? e[o] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int64_t r = r0 + i * nwaves;
+            if (r >= nrows) break;
+            const float base = top / rs_old[i];
+            float fsum = 0.f;
+#pragma unroll
+            for (int q = 0; q < CPL; q++) {
+                const int c = lane + WAVE * q;
+                if (c < LD) {
+                    const size_t o = (size_t)r * LD + c;
+                    float f = 0.f;
+                    if (c < k) {
+                        float s = sv[i][q];
+                        if (fl[i]) {
+                            const float fresh = fmaf(ev[i][q], av[i][q], prior);
+                            s = (w_old == 0.f) ? w_new * fresh : w_new * fresh + w_old * s;
+                            shp[o] = s;
+                        }
+                        float rt = rv[i][q];
+                        if (rate_mode == 0) {
+                            rt = base + csl[q];
+                            rte[o] = rt;
+                        } else if (fl[i]) {
+                            rt = step * (base + csl[q]) + step_prev * rt;
+                            rte[o] = rt;
+                        }
+                        f = s / rt;
+                    }
+                    fac[o] = f;
+                    fsum += f;
+                    csacc[q] += f;
+                }
+            }
+            if (rs_mode == 2 || (rs_mode == 1 && fl[i])) {
+                fsum = wave_sum(fsum);
+                if (lane == 0) rs[r] = step * (add + fsum) + step_prev * rs_old[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < CPL; q++) {
+        const int c = lane + WAVE * q;
+        if (c < LD) red[wid][c] = csacc[q];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < LD; c += BLOCK) {
+        float t = red[0][c];
+#pragma unroll
+        for (int w2 = 1; w2 < WPB; w2++) t += red[w2][c];
+        cs_partial[(size_t)blockIdx.x * LD + c] = t;
+    }
+}
+
 // listed rows: mode 0: rte[r] = step*(top/rs[r] + cs_other) + (1-step)*rte[r]       (PXI:320 / PXI:372)
 //              mode 1: rs[r]  = step*(add + sum_k fac[r]) + (1-step)*rs[r]          (PXI:324-325, 376-377)
 template <int LD>
@@ -1506,6 +1610,25 @@ int hpf_hip_svi_refresh_f32(int64_t nrows, const float *shp, float *rte, float *
 #define CALL(LD)                                                                                                    \
     hipLaunchKernelGGL((svi_refresh_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, nrows, shp, rte, fac, rs,  \
                        cs_other, cs_partial, top, add, step, step_prev, refresh_rte, blend_rs, k);
+    HPF_DISPATCH_LD1(ld, CALL)
+#undef CALL
+    return last_error();
+}
+
+int hpf_hip_svi_side_f32(int64_t nrows, const uint8_t *flag, const float *acc, const float *e, float *shp, float *rte,
+                         float *fac, float *rs, const float *cs_other, float *cs_partial, float prior, float w_new,
+                         float w_old, float top, float add, float step, float step_prev, int rate_mode, int rs_mode,
+                         int k, int ld, int grid_blocks, void *stream) {
+    if (!shp || !rte || !fac || !rs || !cs_other || !cs_partial || (flag && (!acc || !e)) || nrows <= 0 || k <= 0 ||
+        ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0 || (rate_mode != 0 && rate_mode != 1) || rs_mode < 0 ||
+        rs_mode > 2)
+        return HPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    // grid not clamped: every block writes its cs_partial row
+#define CALL(LD)                                                                                                    \
+    hipLaunchKernelGGL((svi_side_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, nrows, flag, acc, e, shp, rte, \
+                       fac, rs, cs_other, cs_partial, prior, w_new, w_old, top, add, step, step_prev, rate_mode,    \
+                       rs_mode, k);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
     return last_error();

@@ -156,6 +156,14 @@ class HipOps:
                                                   float(step_prev), int(bool(refresh_rte)), int(bool(blend_rs)), k,
                                                   ld, cs_partial.shape[0], self._stream()), "hpf_hip_svi_refresh_f32")
 
+    def svi_side(self, nrows, flag, acc, e, shp, rte, fac, rs, cs_other, cs_partial, prior, w_new, w_old, top, add, step,
+                 step_prev, rate_mode, rs_mode, k, ld):
+        _lib.check(self.L.hpf_hip_svi_side_f32(nrows, _ptr(flag), _ptr(acc), _ptr(e), _ptr(shp), _ptr(rte), _ptr(fac),
+                                               _ptr(rs), _ptr(cs_other), _ptr(cs_partial), float(prior), float(w_new),
+                                               float(w_old), float(top), float(add), float(step), float(step_prev),
+                                               int(rate_mode), int(rs_mode), k, ld, cs_partial.shape[0], self._stream()),
+                   "hpf_hip_svi_side_f32")
+
     def svi_rate_rows(self, row_list, rte, fac, rs, cs_other, top, add, step, step_prev, mode, k, ld):
         _lib.check(self.L.hpf_hip_svi_rate_rows_f32(_ptr(row_list), int(row_list.shape[0]), _ptr(rte), _ptr(fac),
                                                     _ptr(rs), _ptr(cs_other), float(top), float(add), float(step),

@@ -71,6 +71,8 @@ class DeviceModel:
         # full-height accumulator tables: the batch sweeps write a row's phi-sums straight to acc[row]
         self.acc_u = torch.zeros((self.nU, self.ld), **f32)
         self.acc_i = torch.zeros((self.nI, self.ld), **f32)
+        self.flag_u = torch.zeros(self.nU, dtype=torch.uint8, device=dev)   # rows of the current step, per side
+        self.flag_i = torch.zeros(self.nI, dtype=torch.uint8, device=dev)
         self.csT = torch.zeros(self.ld, **f32)      # Theta.sum(axis=0) / Beta.sum(axis=0): set by put(), kept
         self.csB = torch.zeros(self.ld, **f32)      # current by every step
 
@@ -153,34 +155,30 @@ def _svi_step(m, hy, su, si, users_tb, items_tb, step, mult, user_batch, all_sca
         if tb.shape[0] != side.nrows:        # listed rows without any nonzero in the batch
             acc.index_fill_(0, tb, 0.0)
     m.batch_phi_sums(su, si)                                      # phi from the OLD parameters
-    utb, acc_utb, itb, acc_itb = users_tb, m.acc_u, items_tb, m.acc_i
-
-    U = dict(n=m.nU, shp=m.Gamma_shp, rte=m.Gamma_rte, fac=m.Theta, rs=m.k_rte, e=m.eT, rows=utb, acc=acc_utb,
+    for flag, tb in ((m.flag_u, users_tb), (m.flag_i, items_tb)):
+        flag.zero_()
+        flag.index_fill_(0, tb, 1)
+    U = dict(n=m.nU, flag=m.flag_u, shp=m.Gamma_shp, rte=m.Gamma_rte, fac=m.Theta, rs=m.k_rte, e=m.eT, acc=m.acc_u,
              prior=hy["a"], top=hy["k_shp"], add=hy["add_k_rte"], cs="csT")
-    I = dict(n=m.nI, shp=m.Lambda_shp, rte=m.Lambda_rte, fac=m.Beta, rs=m.t_rte, e=m.eB, rows=itb, acc=acc_itb,
+    I = dict(n=m.nI, flag=m.flag_i, shp=m.Lambda_shp, rte=m.Lambda_rte, fac=m.Beta, rs=m.t_rte, e=m.eB, acc=m.acc_i,
              prior=hy["c"], top=hy["t_shp"], add=hy["add_t_rte"], cs="csB")
     B, O = (U, I) if user_batch else (I, U)     # batch side, other side
-
-    # shapes: batch side = prior + phi ; other side blended with its previous value
-    ops.svi_shape_rows(B["rows"], B["acc"], B["e"], B["shp"], B["prior"], 1.0, 0.0, k, ld, acc_by_row=True)
-    ops.svi_shape_rows(O["rows"], O["acc"], O["e"], O["shp"], O["prior"], w_other, step_prev, k, ld, acc_by_row=True)
-    # batch side: rate for ALL its rows from the other side's current column sums, then its means
-    cs_other = getattr(m, O["cs"])
-    ops.svi_refresh(B["n"], B["shp"], B["rte"], B["fac"], B["rs"], cs_other, m._cs_part, B["top"], B["add"], step,
-                    step_prev, True, all_scalar_rows, k, ld)
+    # SVI epochs blend the scalar rates of the step's rows only (PXI:324-325, 376-377), partial_fit of all (PXI:472-473)
+    rs_mode = 2 if all_scalar_rows else 1
+    # One pass per side (hpf_hip_svi_side_f32).  Batch side: shapes of its rows reset to prior + phi, the rate of
+    # EVERY row from the other side's current column sums, means, scalar rates, column sums ...
+    ops.svi_side(B["n"], B["flag"], B["acc"], B["e"], B["shp"], B["rte"], B["fac"], B["rs"], getattr(m, O["cs"]),
+                 m._cs_part, B["prior"], 1.0, 0.0, B["top"], B["add"], step, step_prev, 0, rs_mode, k, ld)
     cs_batch = torch.zeros(ld, dtype=torch.float32, device=ops.device)
     ops.colsum_reduce(m._cs_part, cs_batch, ld)
     setattr(m, B["cs"], cs_batch)
-    # other side: rate of the touched rows blended towards top/rs + colsum(batch-side means), then its means
-    ops.svi_rate_rows(O["rows"], O["rte"], None, O["rs"], cs_batch, O["top"], 0.0, step, step_prev, 0, k, ld)
-    ops.svi_refresh(O["n"], O["shp"], O["rte"], O["fac"], O["rs"], None, m._cs_part, O["top"], O["add"], step,
-                    step_prev, False, all_scalar_rows, k, ld)
+    # ... other side: shapes and rates of the touched rows blended towards the step's estimate (the rates with the
+    # batch side's NEW column sums), means of every row, scalar rates, column sums
+    ops.svi_side(O["n"], O["flag"], O["acc"], O["e"], O["shp"], O["rte"], O["fac"], O["rs"], cs_batch, m._cs_part,
+                 O["prior"], w_other, step_prev, O["top"], O["add"], step, step_prev, 1, rs_mode, k, ld)
     cs_o = torch.zeros(ld, dtype=torch.float32, device=ops.device)
     ops.colsum_reduce(m._cs_part, cs_o, ld)
     setattr(m, O["cs"], cs_o)
-    if not all_scalar_rows:   # SVI epochs blend the scalar rates of the batch rows only (PXI:324-325, 376-377)
-        ops.svi_rate_rows(U["rows"], None, U["fac"], U["rs"], None, 0.0, U["add"], step, step_prev, 1, k, ld)
-        ops.svi_rate_rows(I["rows"], None, I["fac"], I["rs"], None, 0.0, I["add"], step, step_prev, 1, k, ld)
 
 
 def gather_rows(side, rows):

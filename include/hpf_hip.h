@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 7
+#define HPF_HIP_ABI_VERSION 8
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -210,6 +210,20 @@ int hpf_hip_svi_shape_rows_f32(const int64_t *row_list, int64_t nrows, const flo
 int hpf_hip_svi_refresh_f32(int64_t nrows, const float *shp, float *rte, float *fac, float *rs, const float *cs_other,
                             float *cs_partial, float top, float add, float step, float step_prev, int refresh_rte,
                             int blend_rs, int k, int ld, int grid_blocks, void *stream);
+/*
+ * The three statements groups above for ONE side in ONE pass over all of its rows (what the drivers use): flag[r] != 0
+ * marks the rows of the step (the batch's rows / the rows the batch touched; flag == NULL: none),
+ *   flagged:        shp[r] = w_new*(prior + e[r] (*) acc[r]) + w_old*shp[r]          (acc, e: full-height tables)
+ *   rate_mode 0:    rte[r] = top/rs[r] + cs_other for every row   (the batch side, PXI:300 / 352)
+ *   rate_mode 1:    rte[r] = step*(top/rs[r] + cs_other) + step_prev*rte[r] for flagged rows   (PXI:320 / 372)
+ *   every row:      fac[r] = shp[r]/rte[r];  cs_partial = per-block column sums of fac
+ *   rs_mode 0/1/2:  rs[r] = step*(add + sum_k fac[r]) + step_prev*rs[r] for no / flagged / all rows
+ * Row-local, the same float32 operations in the same order as the separate kernels.
+ */
+int hpf_hip_svi_side_f32(int64_t nrows, const uint8_t *flag, const float *acc, const float *e, float *shp, float *rte,
+                         float *fac, float *rs, const float *cs_other, float *cs_partial, float prior, float w_new,
+                         float w_old, float top, float add, float step, float step_prev, int rate_mode, int rs_mode,
+                         int k, int ld, int grid_blocks, void *stream);
 int hpf_hip_svi_rate_rows_f32(const int64_t *row_list, int64_t nrows, float *rte, const float *fac, float *rs,
                               const float *cs_other, float top, float add, float step, float step_prev, int mode,
                               int k, int ld, void *stream);

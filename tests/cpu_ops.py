@@ -239,6 +239,20 @@ class CpuOps:
         cp[:] = 0
         cp[0] = F.astype(np.float64).sum(axis=0).astype(np.float32)
 
+    def svi_side(self, nrows, flag, acc, e, shp, rte, fac, rs, cs_other, cs_partial, prior, w_new, w_old, top, add, step,
+                 step_prev, rate_mode, rs_mode, k, ld):
+        """hpf_hip_svi_side_f32 = the separate stand-in statements in the reference's order."""
+        rows = torch.nonzero(flag[:nrows] != 0).reshape(-1) if flag is not None else torch.empty(0, dtype=torch.int64)
+        self.svi_shape_rows(rows, acc, e, shp, prior, w_new, w_old, k, ld, acc_by_row=True)
+        if rate_mode == 1:
+            self.svi_rate_rows(rows, rte, None, rs, cs_other, top, 0.0, step, step_prev, 0, k, ld)
+        rs_before = rs.clone()
+        self.svi_refresh(nrows, shp, rte, fac, rs, cs_other if rate_mode == 0 else None, cs_partial, top, add, step,
+                         step_prev, rate_mode == 0, rs_mode == 2, k, ld)
+        if rs_mode == 1:
+            assert torch.equal(rs, rs_before)
+            self.svi_rate_rows(rows, None, fac, rs, None, 0.0, add, step, step_prev, 1, k, ld)
+
     def svi_rate_rows(self, row_list, rte, fac, rs, cs_other, top, add, step, step_prev, mode, k, ld):
         rows = _np(row_list).astype(np.int64)
         if rows.shape[0] == 0:

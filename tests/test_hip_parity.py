@@ -600,6 +600,71 @@ def test_svi_row_ops(ops, k):
     assert float(((g2 - w2).abs() / w2.abs().clamp_min(1e-30))[:k].max()) < 2e-6
 
 
+@pytest.mark.parametrize("k", [30, 50, 130, 200, 300])
+@pytest.mark.parametrize("rate_mode,rs_mode,w", [(0, 1, (1.0, 0.0)), (1, 1, (0.35, 0.55)), (0, 2, (1.0, 0.0)),
+                                                  (1, 2, (0.6, 0.4)), (1, 0, (0.6, 0.4))])
+def test_svi_side_op(ops, k, rate_mode, rs_mode, w):
+    """hpf_hip_svi_side_f32 (one pass per side) == the separate svi_shape_rows / svi_rate_rows / svi_refresh launches
+    it stands for, on the device (1e-6: same operations, possibly contracted differently) and against the numpy
+    statements."""
+    rs = np.random.RandomState(7 * k + 3 * rate_mode + rs_mode)
+    ld = _lib.ld_for_k(k)
+    n, nb = 900, 210
+    shp = _rand_tables(rs, n, k, ld) + 0.3
+    rte = _rand_tables(rs, n, k, ld) + 0.5
+    shp[:, k:] = 0
+    rte[:, k:] = 0
+    e = _rand_tables(rs, n, k, ld)
+    rsc = torch.from_numpy(rs.uniform(0.5, 20, size=n).astype(np.float32))
+    rows = torch.from_numpy(np.sort(rs.choice(n, size=nb, replace=False)).astype(np.int64))
+    flag = torch.zeros(n, dtype=torch.uint8)
+    flag[rows] = 1
+    acc = torch.zeros((n, ld))
+    acc[rows] = torch.from_numpy(rs.gamma(1, 2, size=(nb, ld)).astype(np.float32))
+    cs = torch.zeros(ld)
+    cs[:k] = torch.from_numpy(rs.uniform(3, 30, size=k).astype(np.float32))
+
+    def run(o, dev, fused):
+        T = dict(shp=shp.clone().to(dev), rte=rte.clone().to(dev), fac=torch.zeros((n, ld), device=dev),
+                 rsc=rsc.clone().to(dev))
+        csp = torch.zeros((o.finalize_grid(n), ld), device=dev)
+        a_, e_, c_, r_, f_ = acc.to(dev), e.to(dev), cs.to(dev), rows.to(dev), flag.to(dev)
+        if fused:
+            o.svi_side(n, f_, a_, e_, T["shp"], T["rte"], T["fac"], T["rsc"], c_, csp, 0.3, w[0], w[1], 15.3, 0.3, 0.7, 0.3,
+                       rate_mode, rs_mode, k, ld)
+        else:
+            o.svi_shape_rows(r_, a_, e_, T["shp"], 0.3, w[0], w[1], k, ld, acc_by_row=True)
+            if rate_mode == 1:
+                o.svi_rate_rows(r_, T["rte"], None, T["rsc"], c_, 15.3, 0.0, 0.7, 0.3, 0, k, ld)
+            o.svi_refresh(n, T["shp"], T["rte"], T["fac"], T["rsc"], c_ if rate_mode == 0 else None, csp, 15.3, 0.3, 0.7,
+                          0.3, rate_mode == 0, rs_mode == 2, k, ld)
+            if rs_mode == 1:
+                o.svi_rate_rows(r_, None, T["fac"], T["rsc"], None, 0.0, 0.3, 0.7, 0.3, 1, k, ld)
+        cso = torch.zeros(ld, device=dev)
+        o.colsum_reduce(csp, cso, ld)
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        return {a: v.cpu() for a, v in T.items()}, cso.cpu()
+
+    got, g = run(ops, "cuda", True)
+    for want, wc in (run(ops, "cuda", False), run(cpu_ops.CpuOps(), "cpu", False)):
+        for name in ("shp", "rte", "fac", "rsc"):
+            a, b = got[name], want[name]
+            if a.dim() == 2:
+                assert torch.all(a[:, k:] == b[:, k:]), name
+                a, b = a[:, :k], b[:, :k]
+            assert float(((a - b).abs() / b.abs().clamp_min(1e-30)).max()) < 2e-6, name
+        assert float(((g - wc).abs() / wc.abs().clamp_min(1e-30))[:k].max()) < 2e-6
+    untouched = flag == 0
+    assert torch.equal(got["shp"][untouched], shp[untouched])
+    if rate_mode == 1:
+        assert torch.equal(got["rte"][untouched], rte[untouched])
+    if rs_mode == 0:
+        assert torch.equal(got["rsc"], rsc)
+    if rs_mode == 1:
+        assert torch.equal(got["rsc"][untouched], rsc[untouched])
+
+
 def test_c2_size_vs_oracle(hip_backend):
     """BASELINE config C2 shape at full size (138k x 27k, ~19.4M unique nonzeros, k=50): every array against the
     CPU oracle after 1 and 2 iterations.  At this size the reference's own arithmetic is the noisier side
