@@ -52,6 +52,9 @@ class BatchSide:
         self.multi_local = torch.nonzero(nseg_row > 1).reshape(-1)              # rows cut into several segments
         self.nmulti = int(self.multi_local.shape[0])
 
+    def tensors(self):
+        return [self.rows, self.idx, self.y, self.row_seg_ptr, self.segs, self.multi_local]
+
 
 class DeviceModel:
     """The variational state as padded device tables; `v(name)` is the [:, :k] view used by the dense algebra."""
@@ -264,6 +267,29 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
     nbatches_i = int(np.ceil(float(nI) / float(items_per_batch))) if items_per_batch > 0 else 0
     rng = np.random.default_rng(seed=random_seed if random_seed > 0 else None)   # PXI:207
 
+    prep_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+    if prep_stream is not None:
+        prep_stream.wait_stream(torch.cuda.current_stream(dev))      # the CSR / CSC built above
+
+    def prepare(ids, user_epoch):
+        """-> ((su, si, users_tb, items_tb), ready event): the batch of the listed rows grouped by user and by item."""
+        import contextlib
+        with (torch.cuda.stream(prep_stream) if prep_stream is not None else contextlib.nullcontext()):
+            rows = torch.sort(_dev_ids(ids, dev)).values             # ascending: the gathered triplets come grouped
+            if user_epoch:
+                bu, bi, by = gather_rows(users, rows)
+                su, si = BatchSide(bu, bi, by, grouped=True), BatchSide(bi, bu, by)
+                out = (su, si, rows, si.rows)
+            else:
+                bi, bu, by = gather_rows(items, rows)
+                su, si = BatchSide(bu, bi, by), BatchSide(bi, bu, by, grouped=True)
+                out = (su, si, su.rows, rows)
+            ready = None
+            if prep_stream is not None:
+                ready = torch.cuda.Event()
+                ready.record(prep_stream)
+        return out, ready
+
     errs = np.zeros(2, dtype=np.longdouble)
     last_crit = -np.inf
     Theta_prev = m.Theta.clone() if stop_crit == "diff-norm" else None
@@ -296,22 +322,26 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
             user_epoch = users_per_batch > 0
         if user_epoch:
             rng.shuffle(users_numeration)
-            for bt in range(nbatches_u):
-                ids = users_numeration[bt * users_per_batch: min(nU, (bt + 1) * users_per_batch)]
-                mult = float(nU) / float(ids.shape[0])
-                rows = torch.sort(_dev_ids(ids, dev)).values       # ascending: the gathered triplets come grouped
-                bu, bi, by = gather_rows(users, rows)
-                su, si = BatchSide(bu, bi, by, grouped=True), BatchSide(bi, bu, by)
-                _svi_step(m, hyd, su, si, rows, si.rows, step, mult, True, all_scalar_rows=False)
+            chunks = [users_numeration[bt * users_per_batch: min(nU, (bt + 1) * users_per_batch)].copy()
+                      for bt in range(nbatches_u)]
         else:
             rng.shuffle(items_numeration)
-            for bt in range(nbatches_i):
-                ids = items_numeration[bt * items_per_batch: min(nI, (bt + 1) * items_per_batch)]
-                mult = float(nI) / float(ids.shape[0])
-                rows = torch.sort(_dev_ids(ids, dev)).values
-                bi, bu, by = gather_rows(items, rows)
-                su, si = BatchSide(bu, bi, by), BatchSide(bi, bu, by, grouped=True)
-                _svi_step(m, hyd, su, si, su.rows, rows, step, mult, False, all_scalar_rows=False)
+            chunks = [items_numeration[bt * items_per_batch: min(nI, (bt + 1) * items_per_batch)].copy()
+                      for bt in range(nbatches_i)]
+        n_side = nU if user_epoch else nI
+        # a batch's index structures (its rows gathered from the CSR / CSC, grouped by both sides, cut into segments)
+        # are data-only: batch j+1 is prepared on a second stream -- with the host-side size queries that entails --
+        # while the kernels of batch j run
+        pending = prepare(chunks[0], user_epoch)
+        for j in range(len(chunks)):
+            (su, si, utb, itb), ready = pending
+            if ready is not None:
+                torch.cuda.current_stream(dev).wait_event(ready)
+                for t in su.tensors() + si.tensors() + [utb, itb]:
+                    t.record_stream(torch.cuda.current_stream(dev))
+            _svi_step(m, hyd, su, si, utb, itb, step, float(n_side) / float(chunks[j].shape[0]), user_epoch,
+                      all_scalar_rows=False)
+            pending = prepare(chunks[j + 1], user_epoch) if j + 1 < len(chunks) else None
 
         if check_every > 0 and ((i + 1) % check_every) == 0:
             if stop_crit == "diff-norm":
