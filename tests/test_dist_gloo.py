@@ -10,6 +10,7 @@ import torch.multiprocessing as mp
 
 import datagen
 import dist_worker
+from conftest import spawn_ranks
 
 NAMES = ("Theta", "Beta", "Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "k_rte", "t_rte")
 
@@ -49,7 +50,7 @@ def test_sharded_equals_single(tmp_path, cpu_ops_backend, monkeypatch, world, ca
                                            0, 0, None, 0, np.zeros(1, np.uint64), "", 123, 1, 1, 0, 0,
                                            np.empty(0, np.float32), np.empty(0, np.uint64), np.empty(0, np.uint64), 0, 1, 0)
     single = dict(zip(NAMES, (Theta, Beta) + tuple(temp)))
-    mp.spawn(dist_worker.run, args=(world, _free_port(), str(tmp_path), k, its, case), nprocs=world, join=True)
+    spawn_ranks(dist_worker.run, lambda port: (world, port, str(tmp_path), k, its, case), world, str(tmp_path))
     outs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     for r in range(world):
         assert int(outs[r]["niter"]) == i

@@ -125,17 +125,8 @@ def test_c4_two_ranks_sharded_vs_oracle(tmp_path, monkeypatch, mode):
     nU, nI = 100_000, 30_000
     st, _ = O.fit_full_batch(Y, iu, ii, nU, nI, k, its, 123, nthreads=O.max_threads())
     ref_llk = float(O.train_llk(st, Y, iu, ii, O.max_threads())[0])
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    try:
-        mp.spawn(dist_worker.run, args=(world, port, str(tmp_path), k, its, "c4small", "cuda"), nprocs=world, join=True)
-    except Exception:
-        import glob
-        for f in sorted(glob.glob(os.path.join(str(tmp_path), "rank*.err"))):
-            print(f, open(f).read())
-        raise
+    from conftest import spawn_ranks
+    spawn_ranks(dist_worker.run, lambda port: (world, port, str(tmp_path), k, its, "c4small", "cuda"), world, str(tmp_path))
     outs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     assert Y.shape[0] >= 1_900_000
     for r in range(world):

@@ -730,17 +730,8 @@ def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypat
                                        np.empty(0, np.float32), np.empty(0, np.uint64), np.empty(0, np.uint64), 0, 1, 0)
     names = ("Theta", "Beta", "Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "k_rte", "t_rte")
     single = dict(zip(names, (Theta, Beta) + tuple(temp)))
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    try:
-        mp.spawn(dist_worker.run, args=(world, port, str(tmp_path), k, its, "mid", "cuda"), nprocs=world, join=True)
-    except Exception:
-        import glob
-        for f in sorted(glob.glob(os.path.join(str(tmp_path), "rank*.err"))):
-            print(f, open(f).read())
-        raise
+    from conftest import spawn_ranks
+    spawn_ranks(dist_worker.run, lambda port: (world, port, str(tmp_path), k, its, "mid", "cuda"), world, str(tmp_path))
     outs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     for r in range(world):
         assert int(outs[r]["niter"]) == i
