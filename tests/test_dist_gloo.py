@@ -2,11 +2,9 @@
 the full, identical model, equal (to rounding: the sum order changes) to the single-process run."""
 import os
 import socket
-import sys
 
 import numpy as np
 import pytest
-import torch.multiprocessing as mp
 
 import datagen
 import dist_worker

@@ -3,7 +3,6 @@ size-independent invariants and a 2-rank sharded fit against the oracle, C5 (sto
 k=200) through per-batch identities, a subsample against the oracle's SVI restatement, and the cost of a
 partial_fit call on a C5-sized resident model.  All `-m gpu`; the oracle legs use every host core."""
 import os
-import socket
 import time
 import warnings
 
@@ -117,7 +116,6 @@ def test_c4_invariants_full_size(ops):
 def test_c4_two_ranks_sharded_vs_oracle(tmp_path, monkeypatch, mode):
     """C4's configuration -- k=100, users sharded, item statistics exchanged per iteration -- on 2 ranks sharing the
     GPU (gloo), 2M nonzeros, 3 iterations, against the oracle (PXI:227-259) and between replicas."""
-    import torch.multiprocessing as mp
     import dist_worker
     monkeypatch.setenv("HPF_SHARD_MODE", mode)
     k, its, world = 100, 3, 2

@@ -709,8 +709,6 @@ def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypat
     """The N>1 path on the REAL kernels: `world` processes, all on cuda:0, gloo backend (it stages the CUDA tensors
     through the host), user-sharded fit with the pipelined item exchange and the deferred item finalize; every
     rank must end with the same full model as the single-process HIP fit."""
-    import socket
-    import torch.multiprocessing as mp
     import dist_worker
     monkeypatch.setenv("HPF_SHARD_MODE", mode)   # reduce-scatter + sharded finalizer, or all-reduce + replicated one
     if lazy == "item-stream":                     # scatter mode with the item sweeps on a third stream
