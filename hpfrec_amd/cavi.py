@@ -103,6 +103,23 @@ class _SideView:
                                                    nnz / self.nseg < layout.SHORT_ROW_NNZ) else 0
 
 
+def mt19937_state_words(random_seed):
+    """numpy's MT19937 state for this seed (seed <= 0 / None: OS entropy, PXI:127) as int32[625]: key + pos."""
+    bg = np.random.MT19937(seed=random_seed if (random_seed is not None and random_seed > 0) else None)
+    st = bg.state["state"]
+    words = np.concatenate([st["key"].astype(np.uint32), np.array([st["pos"]], dtype=np.uint32)])
+    return torch.from_numpy(words.view(np.int32).copy())
+
+
+def draw_init_words(ops, mt_state, nU, nI, k):
+    """The 2*(nU + nI)*k stream words initialize_parameters consumes (PXI:127-138), on the current stream; `mt_state`
+    (device int32[625]) is advanced.  One workgroup walks the recurrence (67 ms at C3): callers start it on a side
+    stream before the CSR/CSC build."""
+    raw = torch.empty(2 * (int(nU) + int(nI)) * int(k), dtype=torch.int32, device=mt_state.device)
+    ops.mt19937_words(mt_state, raw)
+    return raw
+
+
 class FullBatchCavi:
     """Device-resident state + one-iteration step for (a shard of) the HPF model."""
 
@@ -212,6 +229,35 @@ class FullBatchCavi:
         self._tables_split = False
         if self.shard_mode == "scatter":
             self._sync_scatter()      # only waits for exchanges still in flight
+        self.rte_factored = False
+        self.refresh_expectations()
+
+    def init_state(self, raw, u0=0, nU_global=None):
+        """initialize_parameters (PXI:117-143) without the host: the four tables are prior + 0.01*U drawn from ONE
+        MT19937 stream in the reference's order -- user rates, item rates, user shapes, item shapes, all with a'/c'
+        -- bit-identical to numpy's Generator.random(dtype=float32); the means are the ratios, k_rte = b', t_rte = d'.
+        `raw`: the stream's first 2*(nU_global + nI)*k state words (`draw_init_words`).  A rank of a sharded fit
+        keeps rows u0 <= r < u0 + nU of the user tables of nU_global rows (every rank walks the whole stream: it is
+        sequential)."""
+        ops, hy, k, ld = self.ops, self.hy, self.k, self.ld
+        nUg = self.nU if nU_global is None else int(nU_global)
+        for t in (self.Gamma_shp, self.Gamma_rte, self.Lambda_shp, self.Lambda_rte, self.Theta, self.Beta):
+            t.zero_()
+        nI, nU = self.nI, self.nU
+        assert raw.numel() == 2 * (nUg + nI) * k
+        mine = slice(u0 * k, (u0 + nU) * k)          # this rank's rows of a user table's words
+        draws = (raw[: nUg * k][mine], raw[nUg * k: (nUg + nI) * k],
+                 raw[(nUg + nI) * k: (2 * nUg + nI) * k][mine], raw[(2 * nUg + nI) * k:])
+        ops.uniform_rows(draws[0], self.Gamma_rte, nU, k, ld, hy.a_prime, 0.01)
+        ops.uniform_rows(draws[1], self.Lambda_rte, nI, k, ld, hy.c_prime, 0.01)
+        ops.uniform_rows(draws[2], self.Gamma_shp, nU, k, ld, hy.a_prime, 0.01, den=self.Gamma_rte, ratio=self.Theta)
+        ops.uniform_rows(draws[3], self.Lambda_shp, nI, k, ld, hy.c_prime, 0.01, den=self.Lambda_rte, ratio=self.Beta)
+        self.k_rte.fill_(float(hy.b_prime))
+        self.t_rte[: self.nI].fill_(float(hy.d_prime))
+        self.item_pending = False
+        self._tables_split = False
+        if self.shard_mode == "scatter":
+            self._sync_scatter()
         self.rte_factored = False
         self.refresh_expectations()
 

@@ -1294,6 +1294,87 @@ __global__ __launch_bounds__(BLOCK) void gather_probe_kernel(const int32_t *__re
     if (r == 123.456f) sink[0] = r;  // keeps the loads alive without a store stream
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// initialize_parameters (PXI:127-138): the reference fills its four [n,k] tables from ONE MT19937 stream
+// (numpy Generator.random(dtype=float32): one 32-bit output per value, (y >> 8) * 2^-24), as prior + 0.01*U.
+// Two kernels.  (1) The recurrence x[n+624] = x[n+397] ^ A(x[n], x[n+1]) is sequential with 227-word strides, so ONE
+// workgroup walks it: thread t of 227 produces words t, 227+t and 454+t of every 624-word state -- each depends on
+// the OLD state and on the word the SAME thread produced just before (x[i-227]) -- and stores them, untempered, as a
+// linear stream; the state is double-buffered in LDS, one barrier per 624 words.  The stream position carries over
+// between launches (state[624], numpy's `pos`).  (2) Everything else -- tempering, the float conversion, the
+// affine map, the padded table layout, the ratio -- is a chip-wide elementwise pass over the stored words.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mt_twist(uint32_t hi, uint32_t lo) {
+    const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+__global__ __launch_bounds__(256) void mt19937_words_kernel(uint32_t *__restrict__ state, uint32_t *__restrict__ raw,
+                                                            long long n) {
+    __shared__ uint32_t buf[2][624];
+    const int t = threadIdx.x;
+    for (int i = t; i < 624; i += 256) buf[0][i] = state[i];
+    const int pos = (int)state[624];
+    __syncthreads();
+    for (int i = t; i < 624; i += 256) {             // words left in the current state
+        const long long j = (long long)i - pos;
+        if (j >= 0 && j < n) raw[j] = buf[0][i];
+    }
+    const long long rest = n - (624 - pos);
+    if (rest <= 0) {
+        if (t == 0) state[624] = (uint32_t)(pos + n);
+        return;
+    }
+    const long long nblk = (rest + 623) / 624;
+    uint32_t *dst = raw + (624 - pos) + t;           // this thread's word of the current block, first of three
+    long long left = rest - t;                       // words of the stream from dst on
+    for (long long b = 0; b < nblk; ++b) {
+        const uint32_t *old = buf[b & 1];
+        uint32_t *nw = buf[(b & 1) ^ 1];
+        if (t < 227) {
+            const uint32_t nA = old[t + 397] ^ mt_twist(old[t], old[t + 1]);
+            const uint32_t nB = nA ^ mt_twist(old[227 + t], old[228 + t]);
+            nw[t] = nA;
+            nw[227 + t] = nB;
+            if (left > 0) dst[0] = nA;
+            if (left > 227) dst[227] = nB;
+            if (t < 170) {
+                // word 623 wraps around to the NEW word 0 (recomputed here instead of waiting for thread 0)
+                const uint32_t nxt = (t < 169) ? old[455 + t] : (old[397] ^ mt_twist(old[0], old[1]));
+                const uint32_t nC = nB ^ mt_twist(old[454 + t], nxt);
+                nw[454 + t] = nC;
+                if (left > 454) dst[454] = nC;
+            }
+            dst += 624;
+            left -= 624;
+        }
+        __syncthreads();
+    }
+    const uint32_t *fin = buf[nblk & 1];
+    for (int i = t; i < 624; i += 256) state[i] = fin[i];
+    if (t == 0) state[624] = (uint32_t)(rest - 624 * (nblk - 1));
+}
+
+__global__ __launch_bounds__(BLOCK) void uniform_rows_kernel(const uint32_t *__restrict__ raw, float *__restrict__ out,
+                                                             const float *__restrict__ den, float *__restrict__ ratio,
+                                                             long long nrows, int k, int ld, float base, float scale) {
+#pragma clang fp contract(off)
+    const long long total = nrows * k;
+    for (long long j = (long long)blockIdx.x * BLOCK + threadIdx.x; j < total; j += (long long)gridDim.x * BLOCK) {
+        uint32_t y = raw[j];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        const float u = (float)(y >> 8) * (1.0f / 16777216.0f);
+        const float sc = scale * u;                  // two roundings, as numpy's `prior + 0.01 * draw`
+        const float v = base + sc;
+        const long long at = (j / k) * ld + (j % k);
+        out[at] = v;
+        if (ratio) ratio[at] = __fdiv_rn(v, den[at]);   // Theta = Gamma_shp / Gamma_rte (PXI:140-141)
+    }
+}
+
 inline int clamp_grid(int64_t want, int grid_blocks) {
     int64_t g = grid_blocks > 0 ? grid_blocks : 2048;
     if (want < g) g = want;
@@ -1670,6 +1751,23 @@ int hpf_hip_score_rows_f32(const float *vec, const float *tab, int64_t nrows, fl
     }
     HPF_DISPATCH_LD(ld, CALL)
 #undef CALL
+    return last_error();
+}
+
+int hpf_hip_mt19937_words(uint32_t *state, uint32_t *raw, int64_t n, void *stream) {
+    if (!state || n < 0 || (n > 0 && !raw)) return HPF_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mt19937_words_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, state, raw, (long long)n);
+    return last_error();
+}
+
+int hpf_hip_uniform_rows_f32(const uint32_t *raw, float *out, const float *den, float *ratio, int64_t nrows, float base,
+                             float scale, int k, int ld, void *stream) {
+    if (nrows == 0) return 0;
+    if (!raw || !out || nrows < 0 || k <= 0 || ld < k || (ratio && !den)) return HPF_EINVAL;
+    const int grid = clamp_grid((nrows * k + BLOCK - 1) / BLOCK, 8192);
+    hipLaunchKernelGGL(uniform_rows_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, raw, out, den, ratio,
+                       (long long)nrows, k, ld, base, scale);
     return last_error();
 }
 

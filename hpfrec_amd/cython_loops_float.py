@@ -255,7 +255,8 @@ def _as_index_tensor(a, n_max, what):
 class _Engine:
     """Glue between the reference-shaped host arrays and cavi.FullBatchCavi (handles sharding)."""
 
-    def __init__(self, hyper, Y, ix_u, ix_i, nU, nI, Yval=None, ix_u_val=None, ix_i_val=None, device_triplets=None):
+    def __init__(self, hyper, Y, ix_u, ix_i, nU, nI, Yval=None, ix_u_val=None, ix_i_val=None, device_triplets=None,
+                 random_seed=None, draw_init=False):
         self.ops = _make_ops()
         self.device = self.ops.device
         dist = cavi._dist()
@@ -263,6 +264,8 @@ class _Engine:
         self.rank = dist.get_rank() if dist else 0
         self.world = dist.get_world_size() if dist else 1
         dev = self.device
+        if draw_init:
+            self.start_init_draw(random_seed, nU, nI, hyper.k)
         if device_triplets is not None:      # the caller's triplets are on the device already (hpfrec_amd.HPF.fit)
             tu, ti, ty = (t.to(dev) for t in device_triplets)
             if tu.numel() and (int(tu.max()) >= nU or int(ti.max()) >= nI):
@@ -284,9 +287,31 @@ class _Engine:
             self.val = ((vu[keep] - self.u0).to(torch.int32), vi[keep].to(torch.int32), vy[keep])
             self.nval_global = int(Yval.shape[0])
 
-    def upload(self, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta):
-        s = slice(self.u0, self.u1)
-        self.model.load_state(Gamma_shp[s], Gamma_rte[s], Lambda_shp, Lambda_rte, k_rte[s], t_rte, Theta[s], Beta)
+    def start_init_draw(self, random_seed, nU, nI, k):
+        """Starts the reference's random initialisation (PXI:127-141) on the device: the MT19937 recurrence for this seed
+        (seed <= 0: OS entropy -- every rank then takes rank 0's state) on a side stream, under the CSR/CSC build."""
+        dev = self.device
+        mt_state = cavi.mt19937_state_words(random_seed).to(dev)
+        if self.dist:
+            self.dist.broadcast(mt_state, 0)
+        if dev.type != "cuda":
+            self._init_raw, self._init_done = cavi.draw_init_words(self.ops, mt_state, nU, nI, k), None
+            return
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        mt_state.record_stream(side)      # (the kernel leaves the stream's new position in it when it ends)
+        with torch.cuda.stream(side):
+            self._init_raw = cavi.draw_init_words(self.ops, mt_state, nU, nI, k)
+            self._init_done = torch.cuda.Event()
+            self._init_done.record(side)
+
+    def init_state(self):
+        raw, self._init_raw = self._init_raw, None
+        if self._init_done is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(self._init_done)
+            raw.record_stream(cur)
+        self.model.init_state(raw, self.u0, self.nU_global)
 
     def gather_users(self, name):
         """Full (all users) host copy of a user-side array."""
@@ -304,6 +329,25 @@ class _Engine:
         if self.dist:
             self.dist.all_reduce(sq)
         return float(np.sqrt(sq.item()))
+
+
+FIT_TIMINGS = {}
+
+
+def _phase_clock():
+    """HPF_TIMING=1: wall time per phase of the last fit_hpf call in FIT_TIMINGS (device synchronised at phase ends)."""
+    if os.environ.get("HPF_TIMING") != "1":
+        return lambda phase: None
+    FIT_TIMINGS.clear()
+    last = [time.perf_counter()]
+
+    def tick(phase):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        now = time.perf_counter()
+        FIT_TIMINGS[phase] = FIT_TIMINGS.get(phase, 0.0) + now - last[0]
+        last[0] = now
+    return tick
 
 
 # -- PXI:147-418 --------------------------------------------------------------------------
@@ -324,30 +368,27 @@ def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta
     nU, k = Theta.shape
     nI = Beta.shape[0]
     hy = cavi.Hyper(k, a, a_prime, b_prime, c, c_prime, d_prime)
+    tick = _phase_clock()
     if verbose > 0:
         print("Initializing parameters...")
     init_args = (Theta, Beta, random_seed, float(hy.a), float(hy.a_prime), float(hy.b_prime), float(hy.c),
                  float(hy.c_prime), float(hy.d_prime))
     full_updates = (users_per_batch == 0) and (items_per_batch == 0)
-    eng = None
-    if full_updates:
-        # the reference's initialisation is 4 numpy RNG passes over (nU+nI)*k floats (0.3 s at C3; the generator's
-        # fill loops release the GIL): it runs beside the upload + CSR/CSC build of the engine
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=1) as pool:
-            fut = pool.submit(initialize_parameters, *init_args)
-            eng = _Engine(hy, Y, ix_u, ix_i, nU, nI, Yval if has_valset else None, ix_u_val, ix_i_val,
-                          device_triplets=device_triplets)
-            Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte = fut.result()
-    else:
-        Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte = initialize_parameters(*init_args)
     if not full_updates:
+        Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte = initialize_parameters(*init_args)
         return svi.fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte,
                                t_rte, maxiter, stop_crit, check_every, stop_thr, users_per_batch, items_per_batch,
                                step_size, save_folder, random_seed, verbose, has_valset, Yval, ix_u_val, ix_i_val,
                                full_llk, keep_all_objs, _make_ops, device_triplets=device_triplets)
 
-    eng.upload(Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta)
+    # the reference's initialisation (4 numpy RNG passes over (nU+nI)*k floats, 0.36 s on the host at C3) is drawn on
+    # the device from the same MT19937 stream, bit for bit: the sequential recurrence on a side stream under the
+    # CSR/CSC build, the tables from its words afterwards (cavi.init_state); nothing of the state is uploaded
+    eng = _Engine(hy, Y, ix_u, ix_i, nU, nI, Yval if has_valset else None, ix_u_val, ix_i_val,
+                  device_triplets=device_triplets, random_seed=random_seed, draw_init=True)
+    tick("triplets to the device, CSR/CSC layout (+ the MT19937 recurrence)")
+    eng.init_state()
+    tick("initial tables from the drawn words")
     model = eng.model
     errs = np.zeros(2, dtype=np.longdouble)
     last_crit = -np.inf
@@ -412,6 +453,7 @@ def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta
     minutes = (time.time() - st_time) / 60.0
     if verbose:
         _print_final_msg(i + 1, errs[0], float(errs[1]), minutes)
+    tick("iterations and checks")
 
     Theta[:, :] = eng.gather_users("Theta")
     Beta[:, :] = model.fetch("Beta")
@@ -425,6 +467,7 @@ def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta
                         [Theta, Beta] + list(temp))
     if not keep_all_objs:
         temp = None
+    tick("outputs to the host")
     return i, temp, last_llk
 
 

@@ -139,6 +139,19 @@ class HipOps:
         _lib.check(self.L.hpf_hip_score_rows_f32(_ptr(vec), _ptr(tab), int(tab.shape[0]), _ptr(out), k, ld,
                                                  self._stream()), "hpf_hip_score_rows_f32")
 
+    def mt19937_words(self, state, raw):
+        """raw[:] = the next raw.numel() state words of the MT19937 stream in `state` (int32[625] device tensor:
+        numpy's key + pos, advanced in place); the sequential half of initialize_parameters' draws (PXI:127-138)."""
+        _lib.check(self.L.hpf_hip_mt19937_words(_ptr(state), _ptr(raw), int(raw.numel()), self._stream()),
+                   "hpf_hip_mt19937_words")
+
+    def uniform_rows(self, raw, out, nrows, k, ld, base, scale, den=None, ratio=None):
+        """out[r, :k] = base + scale*U for the nrows*k stored words `raw` (numpy's float32 uniforms, bit for bit);
+        ratio = out / den when given."""
+        assert raw.numel() >= nrows * k
+        _lib.check(self.L.hpf_hip_uniform_rows_f32(_ptr(raw), _ptr(out), _ptr(den), _ptr(ratio), int(nrows), float(base),
+                                                   float(scale), k, ld, self._stream()), "hpf_hip_uniform_rows_f32")
+
     # -- stochastic-VI row kernels ------------------------------------------------------------
     def svi_shape_rows(self, row_list, acc, e, shp, prior, w_new, w_old, k, ld, acc_by_row=False):
         _lib.check(self.L.hpf_hip_svi_shape_rows_f32(_ptr(row_list), int(row_list.shape[0]), _ptr(acc), _ptr(e),

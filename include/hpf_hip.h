@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 8
+#define HPF_HIP_ABI_VERSION 9
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -227,6 +227,23 @@ int hpf_hip_svi_side_f32(int64_t nrows, const uint8_t *flag, const float *acc, c
 int hpf_hip_svi_rate_rows_f32(const int64_t *row_list, int64_t nrows, float *rte, const float *fac, float *rs,
                               const float *cs_other, float top, float add, float step, float step_prev, int mode,
                               int k, int ld, void *stream);
+
+/*
+ * initialize_parameters (PXI:127-141) without the host, in two steps.
+ * hpf_hip_mt19937_words: the next n words of an MT19937 stream, raw[0..n) -- the recurrence's state words, before the
+ *   tempering that turns a word into an output.  `state` is uint32[625] in device memory: numpy's 624 key words + its
+ *   `pos` (bit_generator.state); it is left at the stream's new position, so consecutive calls continue one stream like
+ *   consecutive numpy draws.  One workgroup: the recurrence is sequential (timing in DESIGN.md).
+ * hpf_hip_uniform_rows_f32: nrows*k stored words -> numpy's Generator.random(dtype=float32) values (tempering, then
+ *   (y >> 8) * 2^-24), laid out row-major with leading dimension ld:
+ *     out[r*ld + j] = base + scale*U[r*k + j]       (two float32 roundings, like `a_prime + 0.01 * draw`)
+ *   and, when `ratio` is given, ratio[...] = out[...] / den[...] correctly rounded (Theta = Gamma_shp / Gamma_rte,
+ *   PXI:140-141; den and ratio are laid out like out).  Pad columns are not written.  A rank of a sharded fit passes
+ *   the words of its own rows (raw + row0*k).
+ */
+int hpf_hip_mt19937_words(uint32_t *state, uint32_t *raw, int64_t n, void *stream);
+int hpf_hip_uniform_rows_f32(const uint32_t *raw, float *out, const float *den, float *ratio, int64_t nrows, float base,
+                             float scale, int k, int ld, void *stream);
 
 /* Measurement aid, not part of the replaced path: the sweep's gather pattern (256-byte rows of a [rows][64]
  * table, row ids from idx[], 4 rows per wave step, 8 steps in flight) with the arithmetic stripped; used by

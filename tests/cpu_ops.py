@@ -204,6 +204,37 @@ class CpuOps:
     def score_rows(self, vec, tab, out, k, ld):
         _np(out)[:] = (_np(tab).astype(np.float64) @ _np(vec).astype(np.float64)).astype(np.float32)
 
+    def mt19937_words(self, state, raw):
+        """numpy's own generator positioned at `state`; its outputs, un-tempered, are the stream's state words."""
+        st = _np(state).view(np.uint32)
+        bg = np.random.MT19937()
+        bg.state = {"bit_generator": "MT19937", "state": {"key": st[:624].copy(), "pos": int(st[624])}}
+        y = bg.random_raw(raw.numel()).astype(np.uint32)
+        new = bg.state["state"]
+        st[:624] = new["key"]
+        st[624] = new["pos"]
+        y ^= y >> 18
+        y ^= (y << 15) & np.uint32(0xefc60000)
+        t = y.copy()
+        for _ in range(5):
+            t = y ^ ((t << 7) & np.uint32(0x9d2c5680))
+        y = t
+        for _ in range(3):
+            t = y ^ (t >> 11)
+        _np(raw).view(np.uint32)[:] = t
+
+    def uniform_rows(self, raw, out, nrows, k, ld, base, scale, den=None, ratio=None):
+        y = _np(raw).view(np.uint32)[: nrows * k].copy()
+        y ^= y >> 11
+        y ^= (y << 7) & np.uint32(0x9d2c5680)
+        y ^= (y << 15) & np.uint32(0xefc60000)
+        y ^= y >> 18
+        u = (y >> 8).astype(np.float32) * np.float32(1.0 / 16777216.0)
+        vals = (np.float32(base) + np.float32(scale) * u).reshape(nrows, k)
+        _np(out)[:nrows, :k] = vals
+        if ratio is not None:
+            _np(ratio)[:nrows, :k] = vals / _np(den)[:nrows, :k]
+
     # -- stochastic-VI row kernels (float32 arithmetic, statement for statement) ------------------
     def refresh_grid(self, nrows):
         return self.finalize_grid(nrows)

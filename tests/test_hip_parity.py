@@ -872,3 +872,68 @@ def test_odd_shapes_against_the_float64_sums_reference(hip_backend):
         # (the HIP path's own float32 noise on a 2*10^4-nonzero row is ~1e-5: 1024-nonzero segments, tree-folded)
         assert w_exact < 5e-5 and (noise < 2e-5 or w_exact < 0.3 * noise), (c, nU, nI, k, nnz, w_exact, noise)
         assert w_oracle < 1e-5 + 1.5 * noise, (c, nU, nI, k, nnz, w_oracle, noise)
+
+
+def _mt_state_tensor(bg, dev):
+    st = bg.state["state"]
+    words = np.concatenate([st["key"].astype(np.uint32), np.array([st["pos"]], dtype=np.uint32)])
+    return torch.from_numpy(words.view(np.int32)).to(dev)
+
+
+@pytest.mark.parametrize("seed,skip,shapes", [
+    (123, 0, [(100, 30), (100, 30), (37, 30)]),         # C1's draws; fresh state (pos = 624)
+    (1, 5, [(3, 7), (1, 1), (0, 9), (211, 50), (5, 700)]),   # mid-state start, n < what is left, no rows, k > 624
+    (77, 623, [(1, 2), (624, 1), (1, 624), (1000, 130)]),
+    (5, 1000, [(40000, 50), (3000, 100), (40000, 50)]),
+])
+def test_mt19937_stream_is_numpys(ops, seed, skip, shapes):
+    """hpf_hip_mt19937_words + hpf_hip_uniform_rows_f32 == numpy's Generator(MT19937).random(dtype=float32) stream, bit
+    for bit, draw after draw on one state (initialize_parameters, PXI:127-138), with the affine map and the ratio as
+    numpy rounds them, for a row window of the table too (a rank's shard), and the state is left where numpy's is."""
+    dev = ops.device
+    bg = np.random.MT19937(seed)
+    gen = np.random.Generator(bg)
+    if skip:
+        gen.random(size=skip, dtype=np.float32)
+    state = _mt_state_tensor(bg, dev)
+    base, scale = np.float32(0.3), np.float32(0.01)
+    for t, (rows, k) in enumerate(shapes):
+        ld = _lib.ld_for_k(k)
+        want = base + scale * gen.random(size=(rows, k), dtype=np.float32)
+        raw = torch.full((rows * k + 3,), 0x5a5a5a5a, dtype=torch.int32, device=dev)
+        ops.mt19937_words(state, raw[: rows * k])
+        assert torch.all(raw[rows * k:] == 0x5a5a5a5a)                                # nothing past the end
+        assert np.array_equal(state.cpu().numpy(), _mt_state_tensor(bg, "cpu").numpy()), (t, rows, k)
+        row0 = rows // 3 if t % 2 else 0
+        nout = (rows - row0) // 2 if t % 2 else rows
+        out = torch.full((max(nout, 1), ld), -7.0, dtype=torch.float32, device=dev)
+        den = torch.from_numpy(np.random.RandomState(t).rand(max(nout, 1), ld).astype(np.float32) + 0.5).to(dev)
+        ratio = torch.full_like(out, -7.0)
+        ops.uniform_rows(raw[row0 * k: (row0 + nout) * k], out, nout, k, ld, base, scale, den=den, ratio=ratio)
+        got = out.cpu().numpy()
+        assert np.array_equal(got[:nout, :k], want[row0: row0 + nout]), (t, rows, k)
+        assert np.all(got[:nout, k:] == -7.0) and np.all(got[nout:] == -7.0)          # pads are not written
+        assert np.array_equal(ratio.cpu().numpy()[:nout, :k], want[row0: row0 + nout] / den.cpu().numpy()[:nout, :k])
+
+
+def test_device_initialisation_is_the_reference_draw(ops):
+    """cavi.init_state == the host initialize_parameters (the reference's draw order, PXI:127-141), bit for bit, for a
+    whole model and for a rank's user shard."""
+    from hpfrec_amd import cavi
+    from hpfrec_amd import cython_loops_float as be
+    nU, nI, k = 700, 450, 50
+    iu, ii, y = datagen.synthetic_hpf_shaped(nU, nI, 9000, seed=4)
+    iu, ii = iu.astype(np.int64), ii.astype(np.int64)
+    hy = cavi.Hyper(k, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
+    Theta, Beta = np.empty((nU, k), np.float32), np.empty((nI, k), np.float32)
+    want = dict(zip(NAMES, (Theta, Beta) + tuple(be.initialize_parameters(Theta, Beta, 123, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0))))
+    dev = ops.device
+    for u0, u1 in ((0, nU), (200, 530)):
+        keep = (iu >= u0) & (iu < u1)
+        m = cavi.FullBatchCavi(ops, dev, torch.from_numpy((iu[keep] - u0).astype(np.int64)).to(dev),
+                               torch.from_numpy(ii[keep].astype(np.int64)).to(dev), torch.from_numpy(y[keep]).to(dev),
+                               u1 - u0, nI, hy)
+        m.init_state(cavi.draw_init_words(ops, cavi.mt19937_state_words(123).to(dev), nU, nI, k), u0, nU)
+        for name in NAMES:
+            w = want[name][u0:u1] if name in ("Theta", "Gamma_shp", "Gamma_rte", "k_rte") else want[name]
+            assert np.array_equal(m.fetch(name), w), (name, u0)

@@ -24,14 +24,19 @@ del iu, ii, y
 torch.cuda.empty_cache()
 Theta = np.empty((nU, k), np.float32)
 Beta = np.empty((nI, k), np.float32)
-t0 = time.time()
-i, temp, llk = be.fit_hpf(0.3, 0.3, 1.0, 0.3, 0.3, 1.0, Y, IU, II, Theta, Beta, maxiter, "maxiter", 10, 1e-3, 0, 0, None, 0,
-                          np.zeros(1, np.uint64), "", 123, 1, 1, 0, 0, np.empty(0, np.float32), np.empty(0, np.uint64),
-                          np.empty(0, np.uint64), 0, 1, 0)
-dt = time.time() - t0
+os.environ["HPF_TIMING"] = os.environ.get("HPF_TIMING", "1")
+reps = int(os.environ.get("E2E_REPS", "2"))
+for rep in range(reps):       # second pass: warm allocator / code objects
+  t0 = time.time()
+  i, temp, llk = be.fit_hpf(0.3, 0.3, 1.0, 0.3, 0.3, 1.0, Y, IU, II, Theta, Beta, maxiter, "maxiter", 10, 1e-3, 0, 0, None, 0,
+                            np.zeros(1, np.uint64), "", 123, 1 if rep == reps - 1 else 0, 1, 0, 0, np.empty(0, np.float32),
+                            np.empty(0, np.uint64), np.empty(0, np.uint64), 0, 1, 0)
+  dt = time.time() - t0
+  print("fit_hpf pass %d: wall %.3f s; phases [s]: %s" % (rep, dt, {p: round(v, 3) for p, v in be.FIT_TIMINGS.items()}))
 print("E2E %s: nnz=%d k=%d maxiter=%d (llk every 10, verbose) wall=%.2fs -> %.1f it/s incl. init, H2D, CSR/CSC build, "
       "llk checks, D2H of 8 arrays; last_llk=%.6g finite=%s" % (wl, Y.shape[0], k, maxiter, dt, maxiter / dt, float(llk),
                                                                 bool(np.isfinite(Theta).all() and np.isfinite(Beta).all())))
+
 
 # ---- the class-level path: HPF.fit on a DataFrame with raw ids (filter, renumbering, seen-items index included) ----
 import pandas as pd  # noqa: E402
