@@ -113,7 +113,7 @@ def mt19937_state_words(random_seed):
 
 def draw_init_words(ops, mt_state, nU, nI, k):
     """The 2*(nU + nI)*k stream words initialize_parameters consumes (PXI:127-138), on the current stream; `mt_state`
-    (device int32[625]) is advanced.  One workgroup walks the recurrence (67 ms at C3): callers start it on a side
+    (device int32[625]) is advanced.  One workgroup walks the recurrence (60 ms at C3): callers start it on a side
     stream before the CSR/CSC build."""
     raw = torch.empty(2 * (int(nU) + int(nI)) * int(k), dtype=torch.int32, device=mt_state.device)
     ops.mt19937_words(mt_state, raw)

@@ -1328,23 +1328,26 @@ __global__ __launch_bounds__(256) void mt19937_words_kernel(uint32_t *__restrict
     const long long nblk = (rest + 623) / 624;
     uint32_t *dst = raw + (624 - pos) + t;           // this thread's word of the current block, first of three
     long long left = rest - t;                       // words of the stream from dst on
+    const int tc = t < 170 ? t : 0;                  // (all ten LDS reads of a step are issued together, unconditionally)
     for (long long b = 0; b < nblk; ++b) {
         const uint32_t *old = buf[b & 1];
         uint32_t *nw = buf[(b & 1) ^ 1];
         if (t < 227) {
-            const uint32_t nA = old[t + 397] ^ mt_twist(old[t], old[t + 1]);
-            const uint32_t nB = nA ^ mt_twist(old[227 + t], old[228 + t]);
+            const uint32_t a0 = old[t], a1 = old[t + 1], am = old[t + 397];
+            const uint32_t b0 = old[227 + t], b1 = old[228 + t];
+            const uint32_t c0 = old[454 + tc], c1 = old[455 + (t < 169 ? t : 0)];
+            const uint32_t w0 = old[0], w1 = old[1], wm = old[397];
+            asm volatile("" ::"v"(w0), "v"(w1), "v"(wm));      // (keeps these reads out of the t == 169 branch: one LDS latency)
+            const uint32_t nA = am ^ mt_twist(a0, a1);
+            const uint32_t nB = nA ^ mt_twist(b0, b1);
+            // word 623 wraps around to the NEW word 0 (recomputed here instead of waiting for thread 0)
+            const uint32_t nC = nB ^ mt_twist(c0, t < 169 ? c1 : (wm ^ mt_twist(w0, w1)));
             nw[t] = nA;
             nw[227 + t] = nB;
+            if (t < 170) nw[454 + t] = nC;
             if (left > 0) dst[0] = nA;
             if (left > 227) dst[227] = nB;
-            if (t < 170) {
-                // word 623 wraps around to the NEW word 0 (recomputed here instead of waiting for thread 0)
-                const uint32_t nxt = (t < 169) ? old[455 + t] : (old[397] ^ mt_twist(old[0], old[1]));
-                const uint32_t nC = nB ^ mt_twist(old[454 + t], nxt);
-                nw[454 + t] = nC;
-                if (left > 454) dst[454] = nC;
-            }
+            if (t < 170 && left > 454) dst[454] = nC;
             dst += 624;
             left -= 624;
         }

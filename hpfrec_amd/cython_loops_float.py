@@ -252,6 +252,36 @@ def _as_index_tensor(a, n_max, what):
     return torch.from_numpy(a.astype(np.int64, copy=False))
 
 
+def start_init_draw(ops, dist, random_seed, nU, nI, k):
+    """Starts the reference's random initialisation (PXI:127-141) on the device: the MT19937 recurrence for this seed
+    (seed <= 0: OS entropy -- every rank of a sharded fit then takes rank 0's state) on a side stream, so that it runs
+    under the caller's uploads and CSR/CSC build.  -> (words, done event or None) for finish_init_draw."""
+    dev = ops.device
+    mt_state = cavi.mt19937_state_words(random_seed).to(dev)
+    if dist:
+        dist.broadcast(mt_state, 0)
+    if dev.type != "cuda":
+        return cavi.draw_init_words(ops, mt_state, nU, nI, k), None
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    mt_state.record_stream(side)          # (the kernel leaves the stream's new position in it when it ends)
+    with torch.cuda.stream(side):
+        raw = cavi.draw_init_words(ops, mt_state, nU, nI, k)
+        done = torch.cuda.Event()
+        done.record(side)
+    return raw, done
+
+
+def finish_init_draw(dev, draw):
+    """The drawn words, usable on the current stream."""
+    raw, done = draw
+    if done is not None:
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_event(done)
+        raw.record_stream(cur)
+    return raw
+
+
 class _Engine:
     """Glue between the reference-shaped host arrays and cavi.FullBatchCavi (handles sharding)."""
 
@@ -265,7 +295,7 @@ class _Engine:
         self.world = dist.get_world_size() if dist else 1
         dev = self.device
         if draw_init:
-            self.start_init_draw(random_seed, nU, nI, hyper.k)
+            self._init_draw = start_init_draw(self.ops, dist, random_seed, nU, nI, hyper.k)
         if device_triplets is not None:      # the caller's triplets are on the device already (hpfrec_amd.HPF.fit)
             tu, ti, ty = (t.to(dev) for t in device_triplets)
             if tu.numel() and (int(tu.max()) >= nU or int(ti.max()) >= nI):
@@ -287,31 +317,9 @@ class _Engine:
             self.val = ((vu[keep] - self.u0).to(torch.int32), vi[keep].to(torch.int32), vy[keep])
             self.nval_global = int(Yval.shape[0])
 
-    def start_init_draw(self, random_seed, nU, nI, k):
-        """Starts the reference's random initialisation (PXI:127-141) on the device: the MT19937 recurrence for this seed
-        (seed <= 0: OS entropy -- every rank then takes rank 0's state) on a side stream, under the CSR/CSC build."""
-        dev = self.device
-        mt_state = cavi.mt19937_state_words(random_seed).to(dev)
-        if self.dist:
-            self.dist.broadcast(mt_state, 0)
-        if dev.type != "cuda":
-            self._init_raw, self._init_done = cavi.draw_init_words(self.ops, mt_state, nU, nI, k), None
-            return
-        side = torch.cuda.Stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        mt_state.record_stream(side)      # (the kernel leaves the stream's new position in it when it ends)
-        with torch.cuda.stream(side):
-            self._init_raw = cavi.draw_init_words(self.ops, mt_state, nU, nI, k)
-            self._init_done = torch.cuda.Event()
-            self._init_done.record(side)
-
     def init_state(self):
-        raw, self._init_raw = self._init_raw, None
-        if self._init_done is not None:
-            cur = torch.cuda.current_stream(self.device)
-            cur.wait_event(self._init_done)
-            raw.record_stream(cur)
-        self.model.init_state(raw, self.u0, self.nU_global)
+        self.model.init_state(finish_init_draw(self.device, self._init_draw), self.u0, self.nU_global)
+        self._init_draw = None
 
     def gather_users(self, name):
         """Full (all users) host copy of a user-side array."""
@@ -371,15 +379,14 @@ def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta
     tick = _phase_clock()
     if verbose > 0:
         print("Initializing parameters...")
-    init_args = (Theta, Beta, random_seed, float(hy.a), float(hy.a_prime), float(hy.b_prime), float(hy.c),
-                 float(hy.c_prime), float(hy.d_prime))
     full_updates = (users_per_batch == 0) and (items_per_batch == 0)
     if not full_updates:
-        Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte = initialize_parameters(*init_args)
-        return svi.fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte,
-                               t_rte, maxiter, stop_crit, check_every, stop_thr, users_per_batch, items_per_batch,
-                               step_size, save_folder, random_seed, verbose, has_valset, Yval, ix_u_val, ix_i_val,
-                               full_llk, keep_all_objs, _make_ops, device_triplets=device_triplets)
+        draw = start_init_draw(_make_ops(), None, random_seed, nU, nI, k)
+        outs = [np.empty((n, w), dtype=np.float32) for n, w in ((nU, k), (nU, k), (nI, k), (nI, k), (nU, 1), (nI, 1))]
+        return svi.fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, *outs, maxiter, stop_crit, check_every, stop_thr,
+                               users_per_batch, items_per_batch, step_size, save_folder, random_seed, verbose,
+                               has_valset, Yval, ix_u_val, ix_i_val, full_llk, keep_all_objs, _make_ops,
+                               device_triplets=device_triplets, init_draw=draw)
 
     # the reference's initialisation (4 numpy RNG passes over (nU+nI)*k floats, 0.36 s on the host at C3) is drawn on
     # the device from the same MT19937 stream, bit for bit: the sequential recurrence on a side stream under the

@@ -111,6 +111,24 @@ class DeviceModel:
                         (Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, Theta, Beta, k_rte, t_rte)):
             self.put(n, a)
 
+    def init_state(self, raw, hy):
+        """initialize_parameters (PXI:127-141) from the MT19937 stream's first 2*(nU + nI)*k words (cavi.draw_init_words):
+        the four tables in the reference's draw order, bit-identical to its numpy draws; see cavi.init_state."""
+        ops, k, ld, nU, nI = self.ops, self.k, self.ld, self.nU, self.nI
+        assert raw.numel() == 2 * (nU + nI) * k
+        for n in _NAMES:
+            getattr(self, n).zero_()
+        ops.uniform_rows(raw[: nU * k], self.Gamma_rte, nU, k, ld, hy.a_prime, 0.01)
+        ops.uniform_rows(raw[nU * k: (nU + nI) * k], self.Lambda_rte, nI, k, ld, hy.c_prime, 0.01)
+        ops.uniform_rows(raw[(nU + nI) * k: (2 * nU + nI) * k], self.Gamma_shp, nU, k, ld, hy.a_prime, 0.01,
+                         den=self.Gamma_rte, ratio=self.Theta)
+        ops.uniform_rows(raw[(2 * nU + nI) * k:], self.Lambda_shp, nI, k, ld, hy.c_prime, 0.01, den=self.Lambda_rte,
+                         ratio=self.Beta)
+        self.k_rte.fill_(float(hy.b_prime))
+        self.t_rte.fill_(float(hy.d_prime))
+        self.csT = self.colsum("Theta")
+        self.csB = self.colsum("Beta")
+
     def store(self, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta):
         for n, a in zip(_NAMES + ("k_rte", "t_rte"),
                         (Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, Theta, Beta, k_rte, t_rte)):
@@ -236,7 +254,9 @@ def partial_fit_step(ops, Y_batch, ix_u_batch, ix_i_batch, Theta, Beta, Gamma_sh
 def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, maxiter,
                 stop_crit, check_every, stop_thr, users_per_batch, items_per_batch, step_size, save_folder,
                 random_seed, verbose, has_valset, Yval, ix_u_val, ix_i_val, full_llk, keep_all_objs, make_ops,
-                device_triplets=None):
+                device_triplets=None, init_draw=None):
+    """`init_draw`: the running device draw of the initial state (cython_loops_float.start_init_draw); the eight host
+    arrays are then outputs only.  Without it they hold the initial state (initialize_parameters)."""
     from . import cython_loops_float as be   # printing helpers and save_parameters
     import time
     ops = make_ops()
@@ -244,7 +264,8 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
     nU, k = Theta.shape
     nI = Beta.shape[0]
     m = DeviceModel(ops, k, nU, nI)
-    m.load(Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta)
+    if init_draw is None:
+        m.load(Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta)
     hyd = {"a": float(hy.a), "c": float(hy.c), "k_shp": float(hy.k_shp), "t_shp": float(hy.t_shp),
            "add_k_rte": float(hy.add_k_rte), "add_t_rte": float(hy.add_t_rte)}
 
@@ -255,6 +276,8 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
         ti = _dev_ids(ix_i, dev)
         ty = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(dev)
     users, items, u_sorted = layout.build_sides(tu, ti, ty, nU, nI)
+    if init_draw is not None:        # (the MT19937 recurrence ran on its own stream under the uploads and sorts above)
+        m.init_state(be.finish_init_draw(dev, init_draw), hy)
 
     val = None
     if has_valset and Yval is not None and Yval.shape[0] > 0:
