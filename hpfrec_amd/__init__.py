@@ -297,7 +297,9 @@ class HPF:
                 umap = umap_d.cpu().numpy().astype(frame["UserId"].dtype, copy=False)
                 imap = imap_d.cpu().numpy().astype(frame["ItemId"].dtype, copy=False)
                 tick("factorize")
-                frame["UserId"], frame["ItemId"] = du.cpu().numpy(), di.cpu().numpy()
+                # (the codes are >= 0: handed over as the index type _cast_frame would convert them to, INIT:508-514)
+                ind_t = np.dtype(be.obj_ind_type)
+                frame["UserId"], frame["ItemId"] = du.cpu().numpy().view(ind_t), di.cpu().numpy().view(ind_t)
                 tick("codes to host")
             else:
                 ucodes, umap = pd.factorize(frame["UserId"])

@@ -750,14 +750,22 @@ class FullBatchCavi:
         self.Lambda_rte[:nI, :k] = (float(self.hy.t_shp) / self.t_rte_prev[:nI])[:, None] + self.csT[None, :k]
         self.rte_factored = False
 
-    def fetch(self, name):
-        """Unpadded host copy of one state array (this rank's rows)."""
+    def fetch(self, name, out=None):
+        """Unpadded host copy of one state array (this rank's rows); into `out` -- a C-contiguous float32 host array
+        of that shape -- when given (one device-to-host copy, no second pass on the host)."""
         self.flush_items()
         if name in ("Gamma_rte", "Lambda_rte"):
             self.materialize_rates()
         t = getattr(self, name)
         if name in ("Lambda_shp", "Lambda_rte", "Beta", "t_rte", "eB"):
             t = t[: self.nI]          # scatter mode keeps pad rows at the end of the item tables
-        if t.dim() == 1:
-            return t.cpu().numpy().reshape(-1, 1).copy()
-        return t[:, : self.k].contiguous().cpu().numpy()
+        t = t.reshape(-1, 1) if t.dim() == 1 else t[:, : self.k]
+        if out is not None and out.flags.c_contiguous and out.flags.writeable and out.dtype == np.float32 \
+                and tuple(out.shape) == tuple(t.shape):
+            torch.from_numpy(out).copy_(t)
+            return out
+        host = t.contiguous().cpu().numpy()
+        if out is not None:
+            out[...] = host
+            return out
+        return host

@@ -20,7 +20,7 @@ import time
 import numpy as np
 import torch
 
-from . import cavi, svi
+from . import cavi, layout, svi
 from .ops_hip import HipOps
 
 c_real_t = ctypes.c_float          # hpfrec/cython_float.pxi:9
@@ -111,8 +111,8 @@ def get_csc_data(ix_u, ix_i, Y, nU, nI):
     ops = _make_ops()
     dev = ops.device
     nU, nI = int(nU), int(nI)
-    u = _as_index_tensor(ix_u, nU, "UserId").to(dev)
-    i = _as_index_tensor(ix_i, nI, "ItemId").to(dev)
+    u = _as_index_tensor(ix_u, nU, "UserId", dev)
+    i = _as_index_tensor(ix_i, nI, "ItemId", dev)
     y = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(dev)
     key = i * nU + u
     skey, order = torch.sort(key, stable=True)
@@ -245,11 +245,14 @@ def save_parameters(verbose, save_folder, file_names, obj_list):
         np.savetxt(os.path.join(save_folder, name), obj, fmt="%.10f", delimiter=",")
 
 
-def _as_index_tensor(a, n_max, what):
-    a = np.ascontiguousarray(a)
-    if a.size and (int(a.max()) >= n_max):
-        raise ValueError("%s contains an id >= %d" % (what, n_max))
-    return torch.from_numpy(a.astype(np.int64, copy=False))
+def _as_index_tensor(a, n_max, what, dev):
+    """Ids on the device (int64), range-checked there: no pass over the host array besides the copy itself."""
+    t = layout.ids_to_device(a, dev)
+    if t.numel():
+        lo, hi = torch.aminmax(t)
+        if int(lo) < 0 or int(hi) >= n_max:
+            raise ValueError("%s contains an id outside [0, %d)" % (what, n_max))
+    return t
 
 
 def start_init_draw(ops, dist, random_seed, nU, nI, k):
@@ -301,8 +304,8 @@ class _Engine:
             if tu.numel() and (int(tu.max()) >= nU or int(ti.max()) >= nI):
                 raise ValueError("UserId / ItemId contains an id out of range")
         else:
-            tu = _as_index_tensor(ix_u, nU, "UserId").to(dev)
-            ti = _as_index_tensor(ix_i, nI, "ItemId").to(dev)
+            tu = _as_index_tensor(ix_u, nU, "UserId", dev)
+            ti = _as_index_tensor(ix_i, nI, "ItemId", dev)
             ty = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(dev)
         lu, li, ly, (self.u0, self.u1) = cavi.shard_users(tu, ti, ty, nU, self.rank, self.world)
         self.nU_global, self.nI = int(nU), int(nI)
@@ -310,8 +313,8 @@ class _Engine:
         self.nnz_global = int(Y.shape[0])
         self.val = None
         if Yval is not None and Yval.shape[0] > 0:
-            vu = _as_index_tensor(ix_u_val, nU, "val UserId").to(dev)
-            vi = _as_index_tensor(ix_i_val, nI, "val ItemId").to(dev)
+            vu = _as_index_tensor(ix_u_val, nU, "val UserId", dev)
+            vi = _as_index_tensor(ix_i_val, nI, "val ItemId", dev)
             vy = torch.from_numpy(np.ascontiguousarray(Yval, dtype=np.float32)).to(dev)
             keep = (vu >= self.u0) & (vu < self.u1)
             self.val = ((vu[keep] - self.u0).to(torch.int32), vi[keep].to(torch.int32), vy[keep])
@@ -321,15 +324,18 @@ class _Engine:
         self.model.init_state(finish_init_draw(self.device, self._init_draw), self.u0, self.nU_global)
         self._init_draw = None
 
-    def gather_users(self, name):
-        """Full (all users) host copy of a user-side array."""
-        local = self.model.fetch(name)
+    def gather_users(self, name, out=None):
+        """Full (all users) host copy of a user-side array (written into `out` when given)."""
         if not self.dist:
-            return local
+            return self.model.fetch(name, out)
+        local = self.model.fetch(name)
         full = torch.zeros((self.nU_global, local.shape[1]), dtype=torch.float32, device=self.device)
         full[self.u0: self.u1] = torch.from_numpy(local).to(self.device)
         self.dist.all_reduce(full)
-        return full.cpu().numpy()
+        if out is None:
+            return full.cpu().numpy()
+        torch.from_numpy(out).copy_(full)
+        return out
 
     def theta_norm_diff(self, prev):
         d = self.model.Theta - prev
@@ -462,8 +468,8 @@ def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta
         _print_final_msg(i + 1, errs[0], float(errs[1]), minutes)
     tick("iterations and checks")
 
-    Theta[:, :] = eng.gather_users("Theta")
-    Beta[:, :] = model.fetch("Beta")
+    eng.gather_users("Theta", out=Theta)        # (straight into the caller's arrays, PXI:140-141,251,256)
+    model.fetch("Beta", out=Beta)
     temp = None
     if keep_all_objs or save_folder != "":
         temp = (eng.gather_users("Gamma_shp"), eng.gather_users("Gamma_rte"), model.fetch("Lambda_shp"),

@@ -11,6 +11,7 @@ Everything here is index plumbing on torch tensors (any device, incl. CPU for th
 """
 import os
 
+import numpy as np
 import torch
 
 # nonzeros per segment (256 steps of 4 nonzeros at ld=64).  Measured at C3, ms/iteration: 64: 4.09, 128: 3.87,
@@ -69,6 +70,19 @@ def _indptr(sorted_rows, nrows):
     indptr = torch.zeros(nrows + 1, dtype=torch.int64, device=sorted_rows.device)
     torch.cumsum(counts, 0, out=indptr[1:])
     return indptr
+
+
+def ids_to_device(a, dev):
+    """Host id array -> int64 device tensor, without a host-side conversion pass when the ids are 64-bit already:
+    the reference's size_t ids are reinterpreted (an id >= 2^63 comes out negative and fails the range checks)."""
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.uint64:
+        a = a.view(np.int64)
+    elif a.dtype != np.int64:
+        a = a.astype(np.int64)
+    if not a.flags.writeable:
+        a = a.copy()            # (torch.from_numpy wants a writable buffer; never written here)
+    return torch.from_numpy(a).to(dev)
 
 
 def build_sides(ix_u, ix_i, y, nU, nI, seg_cap=SEG_CAP):

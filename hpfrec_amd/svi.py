@@ -213,7 +213,7 @@ def gather_rows(side, rows):
 
 
 def _dev_ids(a, dev):
-    return torch.from_numpy(np.ascontiguousarray(a).astype(np.int64)).to(dev)
+    return layout.ids_to_device(a, dev)
 
 
 # -- PXI:423-473 ------------------------------------------------------------------------------------
