@@ -256,3 +256,21 @@ def test_ctpfrec_exports_vs_reference(any_backend, capsys):
     assert abs(float(mv.train_llk) / g["maxiter_valset_last_llk"] - 1) < 1e-4
     out = capsys.readouterr().out
     assert "Final RMSE: %.4f" % g["after_term_val_rmse"] in out
+
+
+@pytest.mark.parametrize("dtype,bad", [(np.uint64, 100), (np.uint64, 2 ** 63 + 5), (np.int64, -1), (np.int32, 100)])
+def test_fit_rejects_ids_outside_the_tables(cpu_ops_backend, dtype, bad):
+    """The reference indexes without bounds checks (PXI:547-550: UB); here an id outside [0, n) -- also one that only
+    looks valid after the 64-bit reinterpretation of size_t ids -- is an error before anything is launched, for every
+    id dtype, and valid ids of every dtype give the same fit."""
+    df, nU, nI = datagen.readme_counts()
+    Y, iu, ii = datagen.triplets(df)
+    base = _fit(cpu_ops_backend, Y, iu, ii, nU, nI, 8, 2)[1]
+    same = _fit(cpu_ops_backend, Y, iu.astype(np.int64).astype(dtype), ii.astype(np.int64).astype(dtype), nU, nI, 8, 2)[1]
+    assert all(np.array_equal(base[n], same[n]) for n in NAMES)
+    for side in (0, 1):
+        ids = [iu.astype(np.int64).astype(dtype), ii.astype(np.int64).astype(dtype)]
+        ids[side] = ids[side].copy()
+        ids[side][17] = np.array(bad).astype(dtype)
+        with pytest.raises(ValueError):
+            _fit(cpu_ops_backend, Y, ids[0], ids[1], nU, nI, 8, 2)
