@@ -22,7 +22,19 @@ _NCCL_SUM = 0         # ncclRedOp_t
 
 
 class _UniqueId(ctypes.Structure):
-    _fields_ = [("internal", ctypes.c_char * 128)]
+    _fields_ = [("internal", ctypes.c_byte * 128)]     # (not c_char: ctypes cuts a c_char array at its first NUL)
+
+
+def _uid_bytes(uid):
+    """All 128 bytes of an ncclUniqueId (it is binary: a socket address and a magic number, zeros included)."""
+    return ctypes.string_at(ctypes.byref(uid), ctypes.sizeof(uid))
+
+
+def _uid_from(raw):
+    assert len(raw) == ctypes.sizeof(_UniqueId)
+    uid = _UniqueId()
+    ctypes.memmove(ctypes.byref(uid), raw, len(raw))
+    return uid
 
 
 def _lib():
@@ -61,10 +73,10 @@ class DirectComm:
                 self._check(self.L.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
             if self.world > 1:
                 # the id travels through torch.distributed (as a byte tensor on the communicator's device type)
-                buf = torch.frombuffer(bytearray(bytes(uid.internal)) if self.rank == 0 else bytearray(128), dtype=torch.uint8)
+                buf = torch.frombuffer(bytearray(_uid_bytes(uid)), dtype=torch.uint8)      # (zeros on the other ranks)
                 buf = buf.to(self.device) if dist.get_backend() == "nccl" else buf
                 dist.broadcast(buf, 0)
-                ctypes.memmove(ctypes.byref(uid), bytes(buf.cpu().numpy().tobytes()), 128)
+                uid = _uid_from(buf.cpu().numpy().tobytes())
             comm = ctypes.c_void_p()
             self._check(self.L.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank), "ncclCommInitRank")
         self.comm = comm

@@ -274,3 +274,17 @@ def test_fit_rejects_ids_outside_the_tables(cpu_ops_backend, dtype, bad):
         ids[side][17] = np.array(bad).astype(dtype)
         with pytest.raises(ValueError):
             _fit(cpu_ops_backend, Y, ids[0], ids[1], nU, nI, 8, 2)
+
+
+def test_rccl_unique_id_travels_whole():
+    """The ncclUniqueId rank 0 hands to the others (hpfrec_amd/rccl.py) is 128 BINARY bytes: zeros inside it must
+    survive the trip through a byte tensor (a c_char array field would be cut at the first NUL)."""
+    import ctypes
+    from hpfrec_amd import rccl
+    raw = bytes([7, 0, 0, 9] + [0] * 60 + list(range(64)))
+    uid = rccl._uid_from(raw)
+    assert ctypes.sizeof(uid) == 128 and rccl._uid_bytes(uid) == raw
+    buf = torch.frombuffer(bytearray(rccl._uid_bytes(uid)), dtype=torch.uint8)
+    assert buf.numel() == 128
+    assert rccl._uid_bytes(rccl._uid_from(buf.numpy().tobytes())) == raw
+    assert rccl._uid_bytes(rccl._UniqueId()) == bytes(128)
