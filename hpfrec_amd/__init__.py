@@ -297,10 +297,11 @@ class HPF:
                 umap = umap_d.cpu().numpy().astype(frame["UserId"].dtype, copy=False)
                 imap = imap_d.cpu().numpy().astype(frame["ItemId"].dtype, copy=False)
                 tick("factorize")
-                # (the codes are >= 0: handed over as the index type _cast_frame would convert them to, INIT:508-514)
-                ind_t = np.dtype(be.obj_ind_type)
-                frame["UserId"], frame["ItemId"] = du.cpu().numpy().view(ind_t), di.cpu().numpy().view(ind_t)
-                tick("codes to host")
+                # The renumbered ids stay on the device (self._dev_triplets): the fit, the seen-items index and the
+                # batches read them there, and input_df is deleted when fit() ends (INIT:688), so the frame's id
+                # columns -- still the caller's raw ids -- are dropped instead of being overwritten with 2 x nnz codes
+                # brought back over PCIe (0.2 s at 48M rows).
+                frame = self.input_df = frame[["Count"]]
             else:
                 ucodes, umap = pd.factorize(frame["UserId"])
                 icodes, imap = pd.factorize(frame["ItemId"])
@@ -358,7 +359,7 @@ class HPF:
         if frame['Count'].dtype != be.c_real_t:
             frame['Count'] = frame["Count"].astype(be.c_real_t)
         for col in ("UserId", "ItemId"):
-            if frame[col].dtype != be.obj_ind_type:
+            if col in frame.columns and frame[col].dtype != be.obj_ind_type:   # (absent: the ids live on the device)
                 frame[col] = frame[col].astype(be.obj_ind_type)
 
     def _process_valset(self, val_set, valset=True):
@@ -465,6 +466,14 @@ class HPF:
     def _col(frame, col, dtype):
         return np.require(frame[col].to_numpy(copy=False), dtype=dtype, requirements=["ENSUREARRAY", "C_CONTIGUOUS"])
 
+    def _ids_for_fit(self, col, be):
+        """The host id column handed to fit_hpf; empty when the (renumbered) ids are on the device only -- fit_hpf
+        does not read the host ids when it gets `device_triplets`."""
+        if col not in self.input_df.columns:
+            assert getattr(self, "_dev_triplets", None) is not None
+            return np.empty(0, dtype=be.obj_ind_type)
+        return self._col(self.input_df, col, be.obj_ind_type)
+
     def _fit(self):
         be = self._backend()
         if self.val_set is None:
@@ -480,8 +489,7 @@ class HPF:
         self.niter, temp, self.train_llk = be.fit_hpf(
             self.a, self.a_prime, self.b_prime, self.c, self.c_prime, self.d_prime,
             self._col(self.input_df, "Count", be.c_real_t),
-            self._col(self.input_df, "UserId", be.obj_ind_type),
-            self._col(self.input_df, "ItemId", be.obj_ind_type),
+            self._ids_for_fit("UserId", be), self._ids_for_fit("ItemId", be),
             self._state.peek_host("Theta"), self._state.peek_host("Beta"),
             self.maxiter, self.stop_crit, self.check_every, self.stop_thr,
             self.users_per_batch, self.items_per_batch, self.step_size, be.cast_int(self.sum_exp_trick),

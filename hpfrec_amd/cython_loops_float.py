@@ -376,8 +376,9 @@ def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta
     `nthreads`, `par_sh` (allow_inconsistent_math) and `alloc_full_phi` are accepted and ignored:
     the device path is always parallel, always reproducible and never materialises phi.
     `sum_exp_trick` is honoured implicitly: E rows are rescaled per row (power of two) in every mode.
-    `device_triplets` (not in the reference's signature): (ix_u, ix_i, Y) as device tensors equal to the host
-    arrays, when the caller has them there already -- they are then not uploaded again.
+    `device_triplets` (not in the reference's signature): (ix_u, ix_i, Y) as device tensors, when the caller has the
+    triplets there already -- the host arrays `ix_u`, `ix_i` are then not read (they may be empty) and of `Y` only the
+    length is used.
     """
     nU, k = Theta.shape
     nI = Beta.shape[0]
