@@ -500,10 +500,12 @@ class HPF:
             self._col(self.val_set, "UserId", be.obj_ind_type),
             self._col(self.val_set, "ItemId", be.obj_ind_type),
             be.cast_int(self.full_llk), be.cast_int(self.keep_all_objs), be.cast_int(self.alloc_full_phi),
-            device_triplets=getattr(self, "_dev_triplets", None))
+            device_triplets=getattr(self, "_dev_triplets", None), resident=self._state)
 
         if self.users_per_batch == 0:
             del self._st_ix_user
+        if self.keep_all_objs and temp is None:
+            return          # the fit ended on the device and handed its tables to self._state (fit_hpf: `resident`)
         for name in ("Theta", "Beta"):          # filled in place by fit_hpf: the device copies (if any) are old
             self._state.set_host(name, self._state.host[name], private=not self._state.handed.get(name, True))
         if self.keep_all_objs:

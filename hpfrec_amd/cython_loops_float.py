@@ -368,7 +368,7 @@ def _phase_clock():
 def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta, maxiter, stop_crit,
             check_every, stop_thr, users_per_batch, items_per_batch, step_size, sum_exp_trick, st_ix_u,
             save_folder, random_seed, verbose, nthreads, par_sh, has_valset, Yval, ix_u_val, ix_i_val,
-            full_llk, keep_all_objs, alloc_full_phi, device_triplets=None):
+            full_llk, keep_all_objs, alloc_full_phi, device_triplets=None, resident=None):
     """Same contract as the reference's fit_hpf (PXI:147-162, returns PXI:413-418):
     fills Theta/Beta in place, returns (i, (Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte,
     t_rte) or None, last_llk) with i the 0-based index of the last iteration run.
@@ -379,6 +379,10 @@ def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta
     `device_triplets` (not in the reference's signature): (ix_u, ix_i, Y) as device tensors, when the caller has the
     triplets there already -- the host arrays `ix_u`, `ix_i` are then not read (they may be empty) and of `Y` only the
     length is used.
+    `resident` (not in the reference's signature): a resident.ResidentState.  A single-process fit with
+    keep_all_objs and no save_folder then ENDS ON THE DEVICE: the state tables are handed to it (`adopt`), `Theta` /
+    `Beta` are NOT filled and None is returned in place of the six arrays -- hpfrec_amd.HPF reads its attributes
+    through that object, which makes host copies when somebody asks for them.
     """
     nU, k = Theta.shape
     nI = Beta.shape[0]
@@ -393,7 +397,7 @@ def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta
         return svi.fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, *outs, maxiter, stop_crit, check_every, stop_thr,
                                users_per_batch, items_per_batch, step_size, save_folder, random_seed, verbose,
                                has_valset, Yval, ix_u_val, ix_i_val, full_llk, keep_all_objs, _make_ops,
-                               device_triplets=device_triplets, init_draw=draw)
+                               device_triplets=device_triplets, init_draw=draw, resident=resident)
 
     # the reference's initialisation (4 numpy RNG passes over (nU+nI)*k floats, 0.36 s on the host at C3) is drawn on
     # the device from the same MT19937 stream, bit for bit: the sequential recurrence on a side stream under the
@@ -468,6 +472,13 @@ def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta
     if verbose:
         _print_final_msg(i + 1, errs[0], float(errs[1]), minutes)
     tick("iterations and checks")
+
+    if resident is not None and eng.dist is None and keep_all_objs and save_folder == "":
+        model.materialize_rates()         # (also flushes a deferred item side)
+        names = ("Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "Theta", "Beta", "eT", "eB", "k_rte", "t_rte")
+        resident.adopt(svi.DeviceModel(eng.ops, k, nU, nI, tables={n: getattr(model, n) for n in names}))
+        tick("state handed over on the device")
+        return i, None, last_llk
 
     eng.gather_users("Theta", out=Theta)        # (straight into the caller's arrays, PXI:140-141,251,256)
     model.fetch("Beta", out=Beta)

@@ -86,6 +86,8 @@ class ResidentState:
     def _shapes(self):
         th, be = self.host.get("Theta"), self.host.get("Beta")
         if th is None or be is None:
+            if self.model is not None:
+                return self.model.nU, self.model.nI, self.model.k
             raise ValueError("the model has no Theta/Beta yet")
         return int(th.shape[0]), int(be.shape[0]), int(th.shape[1])
 
@@ -110,6 +112,18 @@ class ResidentState:
                 self.stats["h2d_bytes"] += int(a.nbytes)
                 self.dev_ok[n] = True
         return m
+
+    def adopt(self, model, names=NAMES):
+        """`model` (a DeviceModel of this state's shape, built on the ops object later calls will use) holds the
+        CURRENT values of `names` -- a fit that finished on the device.  The host copies become stale; they are
+        brought up to date, in place, when somebody reads them."""
+        self.model = model
+        for n in names:
+            self.host.setdefault(n, None)
+            self.handed.setdefault(n, False)
+            self.host_ok[n] = False
+            self.dev_ok[n] = True
+        self.version += 1
 
     def touched(self, names=NAMES):
         """The device copies of `names` were just mutated."""

@@ -59,17 +59,25 @@ class BatchSide:
 class DeviceModel:
     """The variational state as padded device tables; `v(name)` is the [:, :k] view used by the dense algebra."""
 
-    def __init__(self, ops, k, nU, nI):
+    def __init__(self, ops, k, nU, nI, tables=None):
+        """`tables`: padded device tensors ([n, ld] tables, [n] scalar rates; zero pad columns) to take over instead of
+        allocating -- the state a full-batch fit leaves on the device (the arrays it names must all be given)."""
         self.ops, self.k, self.ld = ops, int(k), _lib.ld_for_k(int(k))
         self.nU, self.nI = int(nU), int(nI)
         dev = ops.device
         f32 = dict(dtype=torch.float32, device=dev)
-        for n in ("Gamma_shp", "Gamma_rte", "Theta", "eT"):
-            setattr(self, n, torch.zeros((self.nU, self.ld), **f32))
-        for n in ("Lambda_shp", "Lambda_rte", "Beta", "eB"):
-            setattr(self, n, torch.zeros((self.nI, self.ld), **f32))
-        self.k_rte = torch.zeros(self.nU, **f32)
-        self.t_rte = torch.zeros(self.nI, **f32)
+        tables = tables or {}
+        for names, rows in ((("Gamma_shp", "Gamma_rte", "Theta", "eT"), self.nU),
+                            (("Lambda_shp", "Lambda_rte", "Beta", "eB"), self.nI)):
+            for n in names:
+                t = tables.get(n)
+                if t is None:
+                    t = torch.zeros((rows, self.ld), **f32)
+                assert tuple(t.shape) == (rows, self.ld) and t.dtype == torch.float32 and t.is_contiguous(), n
+                setattr(self, n, t)
+        self.k_rte = tables["k_rte"] if "k_rte" in tables else torch.zeros(self.nU, **f32)
+        self.t_rte = tables["t_rte"] if "t_rte" in tables else torch.zeros(self.nI, **f32)
+        assert tuple(self.k_rte.shape) == (self.nU,) and tuple(self.t_rte.shape) == (self.nI,)
         self._cs_part = torch.zeros((ops.refresh_grid(max(self.nU, self.nI)), self.ld), **f32)
         # full-height accumulator tables: the batch sweeps write a row's phi-sums straight to acc[row]
         self.acc_u = torch.zeros((self.nU, self.ld), **f32)
@@ -78,6 +86,10 @@ class DeviceModel:
         self.flag_i = torch.zeros(self.nI, dtype=torch.uint8, device=dev)
         self.csT = torch.zeros(self.ld, **f32)      # Theta.sum(axis=0) / Beta.sum(axis=0): set by put(), kept
         self.csB = torch.zeros(self.ld, **f32)      # current by every step
+        if "Theta" in tables:
+            self.csT = self.colsum("Theta")
+        if "Beta" in tables:
+            self.csB = self.colsum("Beta")
 
     def v(self, name):
         return getattr(self, name)[:, : self.k]
@@ -254,9 +266,10 @@ def partial_fit_step(ops, Y_batch, ix_u_batch, ix_i_batch, Theta, Beta, Gamma_sh
 def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, maxiter,
                 stop_crit, check_every, stop_thr, users_per_batch, items_per_batch, step_size, save_folder,
                 random_seed, verbose, has_valset, Yval, ix_u_val, ix_i_val, full_llk, keep_all_objs, make_ops,
-                device_triplets=None, init_draw=None):
+                device_triplets=None, init_draw=None, resident=None):
     """`init_draw`: the running device draw of the initial state (cython_loops_float.start_init_draw); the eight host
-    arrays are then outputs only.  Without it they hold the initial state (initialize_parameters)."""
+    arrays are then outputs only.  Without it they hold the initial state (initialize_parameters).
+    `resident`: see cython_loops_float.fit_hpf."""
     from . import cython_loops_float as be   # printing helpers and save_parameters
     import time
     ops = make_ops()
@@ -394,6 +407,9 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
     if verbose:
         be._print_final_msg(i + 1, errs[0], float(errs[1]), (time.time() - st_time) / 60.0)
 
+    if resident is not None and keep_all_objs and save_folder == "":
+        resident.adopt(m)              # the state stays on the device; host copies are made when somebody reads them
+        return i, None, last_llk
     m.store(Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta)
     temp = (Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte)
     if save_folder != "":

@@ -57,7 +57,7 @@ print("E2E class %s: HPF(k=%d, maxiter=%d, reindex=True, keep_data=True).fit(Dat
       % (wl, k, maxiter, df.shape[0], dt, maxiter / dt, {p: round(v, 3) for p, v in m.timings_.items()}))
 t0 = time.time()
 rec = m.topN(user=int(df["UserId"].iloc[0]), n=10)
-print("first topN after the fit (uploads the item table once): %.1f ms; second: " % ((time.time() - t0) * 1e3), end="")
+print("first topN after the fit (the fit left the state on the device: nothing is uploaded): %.1f ms; second: " % ((time.time() - t0) * 1e3), end="")
 t0 = time.time()
 m.topN(user=int(df["UserId"].iloc[1]), n=10)
 print("%.2f ms" % ((time.time() - t0) * 1e3))
