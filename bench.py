@@ -321,7 +321,7 @@ def main():
         # still reports that candidate's barrier-bracketed 20-iteration measurement (flagged as a fallback).
         watchdog_state["autotune"], watchdog_state["meta"] = autotune, dict(
             workload=label, users=nU, items=nI, nnz=nnz, k=k, world=world, rank=rank, workload_key=args.workload)
-        _arm_watchdog(float(os.environ.get("HPF_BENCH_WATCHDOG_S", "240")))
+        _arm_watchdog(float(os.environ.get("HPF_BENCH_WATCHDOG_S", "150")))
 
         def candidate(mode, chunks, istream, a2a, graph, direct="0"):
             env = {"HPF_SHARD_MODE": mode, "HPF_AR_CHUNKS": chunks, "HPF_ITEM_STREAM": istream, "HPF_RS_ALLTOALL": a2a,
