@@ -775,7 +775,8 @@ def test_bench_multi_rank_path_selftest(ranks):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HPF_BENCH_SELFTEST_GLOO="1")
+    env = dict(os.environ, HPF_BENCH_SELFTEST_GLOO="1",
+               HPF_BENCH_WATCHDOG_S="600")     # (8 gloo ranks SHARING one GPU are slow: not what the watchdog is for)
     for v in ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_FORCE_SHARDED"):
         env.pop(v, None)
     for v in ("HPF_RS_ALLTOALL", "HPF_GRAPH"):
