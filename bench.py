@@ -214,14 +214,15 @@ def _arm_watchdog(seconds):
             print(json.dumps({
                 "metric": "full-batch CAVI iters/sec (48M nnz, k=50)" if meta["workload_key"] == "c3" else
                           "full-batch CAVI iters/sec (%s)" % meta["workload_key"],
-                "value": 1e3 / at[best], "unit": "iters/s", "n_gpus": meta["world"], "steps": 20, "warmup": 3,
+                "value": 1e3 / at[best], "unit": "iters/s", "n_gpus": meta["world"], "steps": meta.get("tune_iters", 20), "warmup": 3,
                 "ms_per_step": at[best], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                 "dtype": "f32", "data": "synthetic",
                 "config": {"workload": meta["workload"], "users": meta["users"], "items": meta["items"],
                            "nnz": meta["nnz"], "k": meta["k"], "parallelism": "users sharded x%d, %s" % (meta["world"], best),
                            "exchange_autotune": {"ms_per_iteration": dict(at), "chosen": best},
                            "fallback": "watchdog: a later configuration or phase made no progress; this is the "
-                                       "barrier-bracketed 20-iteration measurement of the best completed candidate"},
+                                       "barrier-bracketed %d-iteration measurement of the best completed candidate"
+                                       % meta.get("tune_iters", 20)},
                 "roofline": None, "cpu_baseline": None}), flush=True)
         os._exit(0 if (at or meta["rank"] != 0) else 3)
 
@@ -323,6 +324,10 @@ def main():
             workload=label, users=nU, items=nI, nnz=nnz, k=k, world=world, rank=rank, workload_key=args.workload)
         _arm_watchdog(float(os.environ.get("HPF_BENCH_WATCHDOG_S", "150")))
 
+        # (the one-GPU self-test of this code path -- N gloo ranks sharing a GPU -- times 6 iterations per candidate)
+        tune_iters = 6 if os.environ.get("HPF_BENCH_SELFTEST_GLOO") == "1" else 20
+        watchdog_state["meta"]["tune_iters"] = tune_iters
+
         def candidate(mode, chunks, istream, a2a, graph, direct="0"):
             env = {"HPF_SHARD_MODE": mode, "HPF_AR_CHUNKS": chunks, "HPF_ITEM_STREAM": istream, "HPF_RS_ALLTOALL": a2a,
                    "HPF_GRAPH": graph, "HPF_RCCL_DIRECT": direct}
@@ -337,10 +342,10 @@ def main():
                 dist.barrier()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                m.iterate_many(20, not args.lean)
+                m.iterate_many(tune_iters, not args.lean)
                 dist.barrier()
                 torch.cuda.synchronize()
-                t_ms = (time.perf_counter() - t0) / 20 * 1e3
+                t_ms = (time.perf_counter() - t0) / tune_iters * 1e3
                 if graph == "1" and not any(g is not None for g in m.__dict__.get("_graphs", {}).values()):
                     err, t_ms = "no hipGraph captured: %s" % getattr(m, "_graph_error", "backend not capturable"), None
                 if direct == "1" and getattr(m, "comm", None) is None:
