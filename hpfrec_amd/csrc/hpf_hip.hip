@@ -336,9 +336,9 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
                 }
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    float p = 0.f;
+                    float p = dot4(rv[0], o[u][0]);   // (not 0.f + ...: an add the compiler must keep for -0)
 #pragma unroll
-                    for (int v = 0; v < VPL; v++) p += dot4(rv[v], o[u][v]);
+                    for (int v = 1; v < VPL; v++) p += dot4(rv[v], o[u][v]);
                     const float s = group_sum<LPR>(p);
                     const float w = (yy[u] > 0.f) ? yy[u] * __builtin_amdgcn_rcpf(s) : 0.f;
 #pragma unroll
@@ -1065,9 +1065,9 @@ __device__ __forceinline__ float pair_dot(const float *__restrict__ T, const flo
     constexpr int LD = 4 * LPR * VPL;
     const float4 *tp = reinterpret_cast<const float4 *>(T + (size_t)u * LD);
     const float4 *bp = reinterpret_cast<const float4 *>(B + (size_t)i * LD);
-    float p = 0.f;
+    float p = dot4(tp[0 * LPR + j], bp[0 * LPR + j]);   // (not 0.f + ...: an add the compiler must keep for -0)
 #pragma unroll
-    for (int v = 0; v < VPL; v++) p += dot4(tp[v * LPR + j], bp[v * LPR + j]);
+    for (int v = 1; v < VPL; v++) p += dot4(tp[v * LPR + j], bp[v * LPR + j]);
     return group_sum<LPR>(p);
 }
 
@@ -1174,9 +1174,9 @@ __global__ __launch_bounds__(BLOCK) void llk_sweep_kernel(const hpf_segment *__r
                 }
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    float p = 0.f;
+                    float p = dot4(rv[0], o[u][0]);   // (not 0.f + ...: an add the compiler must keep for -0)
 #pragma unroll
-                    for (int v = 0; v < VPL; v++) p += dot4(rv[v], o[u][v]);
+                    for (int v = 1; v < VPL; v++) p += dot4(rv[v], o[u][v]);
                     const float yhat = group_sum<LPR>(p);
                     if (j == 0 && (t0 + u) * NG + g < n) {  // slots past the chunk's n entries are padding
                         if constexpr (FULL)
@@ -1251,9 +1251,9 @@ __global__ __launch_bounds__(BLOCK) void score_rows_kernel(const float *__restri
         const int64_t r = it * ngroups + gid;
         const bool live = r < nrows;
         const float4 *tp = reinterpret_cast<const float4 *>(tab + (size_t)(live ? r : 0) * LD);
-        float p = 0.f;
+        float p = dot4(v[0], tp[0 * LPR + j]);   // (not 0.f + ...: an add the compiler must keep for -0)
 #pragma unroll
-        for (int q = 0; q < VPL; q++) p += dot4(v[q], tp[q * LPR + j]);
+        for (int q = 1; q < VPL; q++) p += dot4(v[q], tp[q * LPR + j]);
         p = group_sum<LPR>(p);
         if (live && j == 0) out[r] = p;
     }
