@@ -527,6 +527,10 @@ def main():
                     "events": ("timed region (dominant kernel; the per-kernel breakdown is a separate pass of 4 "
                                "iterations)") if events_in_timed
                     else "separate pass of %d iterations after the timed region" % ev_steps}
+            if traffic:
+                # the PMC bytes over the live launch duration: what the memory side actually moved per second
+                roof["traffic_rate"] = {"GB/s": traffic / t_k / 1e9, "frac_of_peak": traffic / t_k / HBM_PEAK,
+                                        "over_algorithmic": traffic / b_launch}
             if roof["frac"] > 1.0:
                 roof["note"] = ("algorithmic bytes exceed what HBM delivers: at this size the gathered tables stay in "
                                 "L2 / Infinity Cache (each gather is still counted at face value, SURVEY.md section 8d)")
