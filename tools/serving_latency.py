@@ -43,3 +43,6 @@ pu, pi = rs.randint(nU, size=1000), rs.randint(nI, size=1000)
 print("predict(1000 pairs):             %.2f ms" % timeit(lambda: m.predict(pu, pi)))
 new = pd.DataFrame({"ItemId": rs.choice(nI, size=40, replace=False), "Count": rs.randint(1, 5, size=40)})
 print("predict_factors(40 items):       %.2f ms" % timeit(lambda: m.predict_factors(new.copy()), n=5))
+big = pd.DataFrame({"ItemId": rs.choice(nI, size=1000, replace=False), "Count": rs.randint(1, 5, size=1000)})
+print("predict_factors(1000 items):     %.2f ms   (reference, 8 CPU threads, k=50, smaller model: 3.5 ms for 40 items, "
+      "27 ms for 1000 -- profiles/r02_cpu_calibration.txt)" % timeit(lambda: m.predict_factors(big.copy()), n=5))
