@@ -797,6 +797,56 @@ __global__ __launch_bounds__(BLOCK) void segsum_kernel(const float *__restrict__
 }
 
 // ----------------------------------------------------------------------------------------
+// index plumbing of a stochastic batch (svi.py: the batch's rows gathered out of the CSR / CSC, the other side's
+// segments): two launches in place of the ~150 tensor-library launches a batch took -- the batches were bound by
+// the host's launch rate, not by their kernels (profiles/r02_svi_c5_timeline.txt)
+// ----------------------------------------------------------------------------------------
+// row t of the list: its nonzeros src_idx/src_y[src_begin[t] ...) copied to out[dst_begin[t] .. dst_begin[t+1]),
+// out_row = the row's id (one wavefront per row)
+__global__ __launch_bounds__(BLOCK) void gather_rows_kernel(const int64_t *__restrict__ src_begin,
+                                                            const int64_t *__restrict__ dst_begin,
+                                                            const int64_t *__restrict__ row_ids, int64_t nrows,
+                                                            const int32_t *__restrict__ src_idx,
+                                                            const float *__restrict__ src_y,
+                                                            int32_t *__restrict__ out_idx, float *__restrict__ out_y,
+                                                            int32_t *__restrict__ out_row) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t nwaves = (int64_t)gridDim.x * WPB;
+    for (int64_t t = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); t < nrows; t += nwaves) {
+        const int64_t s = src_begin[t], d = dst_begin[t];
+        const int64_t n = dst_begin[t + 1] - d;
+        const int32_t r = (int32_t)row_ids[t];
+        for (int64_t i = lane; i < n; i += WAVE) {
+            out_idx[d + i] = src_idx[s + i];
+            out_y[d + i] = src_y[s + i];
+            out_row[d + i] = r;
+        }
+    }
+}
+
+// row t (count[t] > 0 nonzeros from start[t] on, id row_ids[t]) cut into ceil(count/cap) segments, written at
+// segs[row_seg_ptr[t] ...): the layout of layout.build_segments, with the GLOBAL row id in the descriptor
+__global__ __launch_bounds__(BLOCK) void fill_segments_kernel(const int64_t *__restrict__ start,
+                                                              const int64_t *__restrict__ count,
+                                                              const int64_t *__restrict__ row_seg_ptr,
+                                                              const int64_t *__restrict__ row_ids, int64_t nrows,
+                                                              int cap, hpf_segment *__restrict__ segs) {
+    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < nrows; t += (int64_t)gridDim.x * BLOCK) {
+        const int64_t s0 = row_seg_ptr[t], ns = row_seg_ptr[t + 1] - s0;
+        const int64_t b = start[t], c = count[t];
+        const int32_t r = (int32_t)row_ids[t];
+        for (int64_t q = 0; q < ns; ++q) {
+            const int64_t left = c - q * cap;
+            hpf_segment sg;
+            sg.begin = b + q * cap;
+            sg.len = (int32_t)(left < cap ? left : cap) | (ns == 1 ? HPF_SEG_WHOLE_ROW : 0);
+            sg.row = r;
+            segs[s0 + q] = sg;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
 // stochastic-VI row kernels (one wavefront per row, lane <-> factor): the numpy statements the reference
 // executes around update_phi_csr in an SVI batch / partial_fit (PXI:300-325, 352-377, 443-473)
 // ----------------------------------------------------------------------------------------
@@ -1754,6 +1804,30 @@ int hpf_hip_score_rows_f32(const float *vec, const float *tab, int64_t nrows, fl
     }
     HPF_DISPATCH_LD(ld, CALL)
 #undef CALL
+    return last_error();
+}
+
+int hpf_hip_gather_rows(const int64_t *src_begin, const int64_t *dst_begin, const int64_t *row_ids, int64_t nrows,
+                        const int32_t *src_idx, const float *src_y, int32_t *out_idx, float *out_y, int32_t *out_row,
+                        void *stream) {
+    if (nrows == 0) return 0;
+    if (!src_begin || !dst_begin || !row_ids || !src_idx || !src_y || !out_idx || !out_y || !out_row || nrows < 0)
+        return HPF_EINVAL;
+    const int grid = clamp_grid((nrows + WPB - 1) / WPB, 4096);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, src_begin, dst_begin,
+                       row_ids, nrows, src_idx, src_y, out_idx, out_y, out_row);
+    return last_error();
+}
+
+int hpf_hip_fill_segments(const int64_t *start, const int64_t *count, const int64_t *row_seg_ptr,
+                          const int64_t *row_ids, int64_t nrows, int seg_cap, hpf_segment *segs, void *stream) {
+    if (nrows == 0) return 0;
+    if (!start || !count || !row_seg_ptr || !row_ids || !segs || nrows < 0 || seg_cap <= 0 ||
+        seg_cap > HPF_SEG_LEN_MASK)
+        return HPF_EINVAL;
+    const int grid = clamp_grid((nrows + BLOCK - 1) / BLOCK, 2048);
+    hipLaunchKernelGGL(fill_segments_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, start, count,
+                       row_seg_ptr, row_ids, nrows, seg_cap, segs);
     return last_error();
 }
 

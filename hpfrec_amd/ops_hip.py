@@ -139,6 +139,19 @@ class HipOps:
         _lib.check(self.L.hpf_hip_score_rows_f32(_ptr(vec), _ptr(tab), int(tab.shape[0]), _ptr(out), k, ld,
                                                  self._stream()), "hpf_hip_score_rows_f32")
 
+    # -- index plumbing of a stochastic batch ---------------------------------------------------
+    def gather_rows(self, src_begin, dst_begin, row_ids, src_idx, src_y, out_idx, out_y, out_row):
+        """Nonzeros of the listed rows (row t: src[src_begin[t] ...) -> out[dst_begin[t] .. dst_begin[t+1]))."""
+        _lib.check(self.L.hpf_hip_gather_rows(_ptr(src_begin), _ptr(dst_begin), _ptr(row_ids), int(row_ids.shape[0]),
+                                              _ptr(src_idx), _ptr(src_y), _ptr(out_idx), _ptr(out_y), _ptr(out_row),
+                                              self._stream()), "hpf_hip_gather_rows")
+
+    def fill_segments(self, start, count, row_seg_ptr, row_ids, seg_cap, segs):
+        """hpf_segment descriptors (int64 [nseg,2] image) of rows (start, count, id) cut at seg_cap nonzeros."""
+        _lib.check(self.L.hpf_hip_fill_segments(_ptr(start), _ptr(count), _ptr(row_seg_ptr), _ptr(row_ids),
+                                                int(row_ids.shape[0]), int(seg_cap), _ptr(segs), self._stream()),
+                   "hpf_hip_fill_segments")
+
     def mt19937_words(self, state, raw):
         """raw[:] = the next raw.numel() state words of the MT19937 stream in `state` (int32[625] device tensor:
         numpy's key + pos, advanced in place); the sequential half of initialize_parameters' draws (PXI:127-138)."""

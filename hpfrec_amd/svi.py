@@ -13,12 +13,15 @@ Division of labour in this round:
 torch is used for index plumbing only (grouping a batch by row, aligning accumulators with row lists).
 No numerics run on the host; shuffles and seeds use numpy's generators so batches are the reference's.
 """
+import os
+
 import numpy as np
 import torch
 
 from . import _lib, layout
 
 _NAMES = ("Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "Theta", "Beta")
+SVI_TIMINGS = {}      # HPF_TIMING=1: {"epochs": n, "seconds": wall time of the last fit's epoch loop}
 
 
 class BatchSide:
@@ -52,8 +55,165 @@ class BatchSide:
         self.multi_local = torch.nonzero(nseg_row > 1).reshape(-1)              # rows cut into several segments
         self.nmulti = int(self.multi_local.shape[0])
 
+    @classmethod
+    def from_parts(cls, rows, idx, y, row_seg_ptr, segs, multi_local, nseg, nmulti):
+        """The same object from ready-made pieces (no device work, no host synchronisation)."""
+        self = cls.__new__(cls)
+        self.rows, self.idx, self.y, self.row_seg_ptr, self.segs, self.multi_local = rows, idx, y, row_seg_ptr, segs, multi_local
+        self.nseg, self.nmulti, self.nrows = int(nseg), int(nmulti), int(rows.shape[0])
+        self.short_rows = layout.SHORT_VARIANT if (self.nseg > 0 and
+                                                   int(y.shape[0]) / self.nseg < layout.SHORT_ROW_NNZ) else 0
+        return self
+
     def tensors(self):
         return [self.rows, self.idx, self.y, self.row_seg_ptr, self.segs, self.multi_local]
+
+
+class PinnedStaging:
+    """Page-locked host memory for the small int64 arrays a batch sends to the device (row lists, offsets, segment
+    descriptors), allocated ONCE: a copy from pageable memory makes the host wait for everything queued on the stream
+    before it, and pinning per copy costs milliseconds on this platform.  All arrays of a batch go up in ONE
+    asynchronous copy.  A few slots are used round-robin; a slot is re-used only after its copy has completed."""
+
+    def __init__(self, device, words=1 << 20, slots=4):
+        self.device = device
+        self.bufs = [torch.empty(words, dtype=torch.int64, pin_memory=True) for _ in range(slots)]
+        self.events = [None] * slots
+        self.turn = -1
+
+    def upload(self, arrays):
+        """int64 numpy arrays -> device tensors of the same shapes (one transfer)."""
+        arrays = [np.ascontiguousarray(a, dtype=np.int64) for a in arrays]
+        total = sum(int(a.size) for a in arrays)
+        self.turn = (self.turn + 1) % len(self.bufs)
+        slot, buf = self.turn, self.bufs[self.turn]
+        if total > buf.shape[0]:                                  # (does not fit: plain synchronous copies)
+            return [torch.from_numpy(a).to(self.device) for a in arrays]
+        if self.events[slot] is not None:
+            self.events[slot].synchronize()
+        host, at = buf.numpy(), 0
+        for a in arrays:
+            host[at: at + a.size] = a.reshape(-1)
+            at += a.size
+        dev_all = buf[:total].to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[slot] = ev
+        out, at = [], 0
+        for a in arrays:
+            out.append(dev_all[at: at + a.size].reshape(a.shape))
+            at += a.size
+        return out
+
+
+class _BatchInFlight:
+    """A batch whose device work has been launched (batch_sides_start) but whose data-dependent sizes -- how many rows
+    of the other side it touches, into how many segments they are cut -- have not been read yet."""
+    pass
+
+
+def batch_sides_start(ops, side, indptr_host, ids, n_other, seg_cap=layout.SEG_CAP, staging=None):
+    """First half of `batch_sides`: everything that needs no data-dependent size on the host.  The batch's own side is
+    complete after it (numpy on the host copy of the row pointers -- whose sizes the host therefore knows -- and ONE
+    gather launch); the other side is sorted (int32 keys) and its three sizes (rows, segments, split rows) are on
+    their way to pinned host memory.  No host synchronisation."""
+    dev = ops.device
+    b = _BatchInFlight()
+    b.ops, b.cap = ops, int(seg_cap)
+    rows_h = np.sort(np.ascontiguousarray(ids).astype(np.int64, copy=False))
+    st = indptr_host[rows_h]
+    deg = indptr_host[rows_h + 1] - st
+    keep = deg > 0
+    rk, stk, dk = (rows_h, st, deg) if keep.all() else (rows_h[keep], st[keep], deg[keep])
+    nr = int(rk.shape[0])
+    dst = np.zeros(nr + 1, dtype=np.int64)
+    np.cumsum(dk, out=dst[1:])
+    total = b.total = int(dst[-1])
+    nsr = (dk + (seg_cap - 1)) // seg_cap
+    rsp = np.zeros(nr + 1, dtype=np.int64)
+    np.cumsum(nsr, out=rsp[1:])
+    nseg = int(rsp[-1])
+    if nseg == nr:                       # no row of the batch is longer than a segment
+        begin, length = dst[:-1], dk | layout.SEG_WHOLE_ROW
+        row_of = rk
+    else:
+        local = np.repeat(np.arange(nr, dtype=np.int64), nsr)
+        within = np.arange(nseg, dtype=np.int64) - rsp[local]
+        begin = dst[local] + within * seg_cap
+        length = np.minimum(dk[local] - within * seg_cap, seg_cap) | np.where(nsr[local] == 1, layout.SEG_WHOLE_ROW, 0)
+        row_of = rk[local]
+    segs_h = np.stack([begin, length | (row_of << 32)], axis=1)
+    multi_h = np.nonzero(nsr > 1)[0]
+
+    host_arrays = [rows_h, rk, stk, dst, rsp, segs_h, multi_h]
+    if staging is not None:
+        d_rows, d_rk, d_stk, d_dst, d_rsp, d_segs, d_multi = staging.upload(host_arrays)
+    else:
+        d_rows, d_rk, d_stk, d_dst, d_rsp, d_segs, d_multi = (torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+                                                              for a in host_arrays)
+    b.rows_all = d_rows
+    rows_own = d_rows if nr == rows_h.shape[0] else d_rk
+    out_idx = torch.empty(total, dtype=torch.int32, device=dev)
+    out_y = torch.empty(total, dtype=torch.float32, device=dev)
+    out_row = torch.empty(total, dtype=torch.int32, device=dev)
+    if total:
+        ops.gather_rows(d_stk, d_dst, rows_own, side.idx, side.y, out_idx, out_y, out_row)
+    b.own = BatchSide.from_parts(rows_own, out_idx, out_y, d_rsp, d_segs.reshape(-1, 2), d_multi, nseg,
+                                 multi_h.shape[0])
+    # the other side: a stable sort of the gathered ids groups the batch by them (ties keep the order of the own side)
+    order = torch.sort(out_idx, stable=True).indices
+    b.o_idx, b.o_y = out_row[order], out_y[order]
+    b.sizes_host = b.sizes_ready = None
+    if total:
+        # nonzeros per row of the other side (a histogram over ALL its rows: integer atomics, exact) and, from it, the
+        # three sizes the second half needs: rows present, segments, rows cut into several segments
+        b.per_row = torch.zeros(int(n_other), dtype=torch.int32, device=dev)
+        b.per_row.index_add_(0, out_idx, torch.ones(total, dtype=torch.int32, device=dev))
+        sizes = torch.stack([(b.per_row > 0).sum(), ((b.per_row + (seg_cap - 1)) // seg_cap).sum(),
+                             (b.per_row > seg_cap).sum()])
+        if dev.type == "cuda":
+            b.sizes_host = torch.empty(3, dtype=torch.int64, pin_memory=True)
+            b.sizes_host.copy_(sizes, non_blocking=True)
+            b.sizes_ready = torch.cuda.Event()
+            b.sizes_ready.record()
+        else:
+            b.sizes_host = sizes
+    return b
+
+
+def batch_sides_finish(b):
+    """Second half: reads the three sizes (long since on the host when the first half ran a batch earlier) and lays out
+    the other side's row list and segment descriptors.  -> (rows of the list, ascending, on the device; own BatchSide;
+    other BatchSide)."""
+    ops, cap, dev = b.ops, b.cap, b.ops.device
+    if not b.total:
+        e = torch.empty(0, dtype=torch.int64, device=dev)
+        other = BatchSide.from_parts(e, b.o_idx, b.o_y, torch.zeros(1, dtype=torch.int64, device=dev),
+                                     torch.empty((0, 2), dtype=torch.int64, device=dev), e, 0, 0)
+        return b.rows_all, b.own, other
+    if b.sizes_ready is not None:
+        b.sizes_ready.synchronize()
+    R, nseg, nmulti = (int(v) for v in b.sizes_host.tolist())
+    o_rows = torch.nonzero_static(b.per_row > 0, size=R).reshape(-1)            # ascending = the sorted keys' runs
+    counts = b.per_row[o_rows].to(torch.int64)
+    starts = torch.cumsum(counts, 0) - counts
+    o_nsr = (counts + (cap - 1)) // cap
+    o_rsp = torch.zeros(R + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(o_nsr, 0, out=o_rsp[1:])
+    o_segs = torch.empty((nseg, 2), dtype=torch.int64, device=dev)
+    ops.fill_segments(starts, counts, o_rsp, o_rows, cap, o_segs)
+    o_multi = torch.nonzero_static(o_nsr > 1, size=nmulti).reshape(-1)
+    other = BatchSide.from_parts(o_rows, b.o_idx, b.o_y, o_rsp, o_segs, o_multi, nseg, nmulti)
+    return b.rows_all, b.own, other
+
+
+def batch_sides(ops, side, indptr_host, ids, n_other, seg_cap=layout.SEG_CAP):
+    """The two BatchSides of the batch made of the listed rows of `side` (the users' CSR for a user batch, the items'
+    CSC for an item batch) -> (rows of the list, ascending, on the device; the batch grouped by those rows; the batch
+    grouped by the other side's rows).  Same structures as BatchSide(gather_rows(...)) builds with ~150 tensor-library
+    launches and four host synchronisations per batch -- a batch was bound by the host, not by its kernels.  In two
+    halves, so that a driver can run the first one a batch ahead and never waits for a size."""
+    return batch_sides_finish(batch_sides_start(ops, side, indptr_host, ids, n_other, seg_cap))
 
 
 class DeviceModel:
@@ -303,23 +463,45 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
     nbatches_i = int(np.ceil(float(nI) / float(items_per_batch))) if items_per_batch > 0 else 0
     rng = np.random.default_rng(seed=random_seed if random_seed > 0 else None)   # PXI:207
 
-    prep_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+    # HPF_SVI_PREP=torch: the batch structures built with tensor-library calls only (the round-1 path; A/B and tests)
+    fast_prep = os.environ.get("HPF_SVI_PREP", "fast") != "torch"
+    indptr_host = (users.indptr.cpu().numpy(), items.indptr.cpu().numpy()) if fast_prep else None
+    # (HPF_SVI_PREP_STREAM=0: the preparation on the compute stream, between the batches -- measured slower, 4.7 vs 4.2 ms
+    # per C5 batch)
+    own_stream = os.environ.get("HPF_SVI_PREP_STREAM", "1") == "1"
+    prep_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and own_stream) else None
+    staging = PinnedStaging(dev) if (fast_prep and dev.type == "cuda") else None
     if prep_stream is not None:
         prep_stream.wait_stream(torch.cuda.current_stream(dev))      # the CSR / CSC built above
 
-    def prepare(ids, user_epoch):
-        """-> ((su, si, users_tb, items_tb), ready event): the batch of the listed rows grouped by user and by item."""
-        import contextlib
-        with (torch.cuda.stream(prep_stream) if prep_stream is not None else contextlib.nullcontext()):
+    import contextlib
+
+    def on_prep_stream():
+        return torch.cuda.stream(prep_stream) if prep_stream is not None else contextlib.nullcontext()
+
+    def prepare_start(ids, user_epoch):
+        """Launches the index work of a batch (the listed rows gathered from the CSR / CSC, the other side sorted) on the
+        preparation stream; nothing here waits for the device (fast path)."""
+        with on_prep_stream():
+            if fast_prep:
+                return batch_sides_start(ops, users if user_epoch else items, indptr_host[0 if user_epoch else 1], ids,
+                                         nI if user_epoch else nU, staging=staging)
             rows = torch.sort(_dev_ids(ids, dev)).values             # ascending: the gathered triplets come grouped
             if user_epoch:
                 bu, bi, by = gather_rows(users, rows)
-                su, si = BatchSide(bu, bi, by, grouped=True), BatchSide(bi, bu, by)
-                out = (su, si, rows, si.rows)
+                return BatchSide(bu, bi, by, grouped=True), BatchSide(bi, bu, by), rows
+            bi, bu, by = gather_rows(items, rows)
+            return BatchSide(bu, bi, by), BatchSide(bi, bu, by, grouped=True), rows
+
+    def prepare_finish(started, user_epoch):
+        """-> ((su, si, users_tb, items_tb), ready event): the batch grouped by user and by item."""
+        with on_prep_stream():
+            if fast_prep:
+                rows, own, other = batch_sides_finish(started)
+                su, si = (own, other) if user_epoch else (other, own)
             else:
-                bi, bu, by = gather_rows(items, rows)
-                su, si = BatchSide(bu, bi, by), BatchSide(bi, bu, by, grouped=True)
-                out = (su, si, su.rows, rows)
+                su, si, rows = started
+            out = (su, si, rows, si.rows) if user_epoch else (su, si, su.rows, rows)
             ready = None
             if prep_stream is not None:
                 ready = torch.cuda.Event()
@@ -349,6 +531,11 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
     if verbose > 0:
         print("Initializing optimization procedure...")
     st_time = time.time()
+    timing = os.environ.get("HPF_TIMING") == "1"      # SVI_TIMINGS: device-synchronised wall time of the epoch loop
+    if timing and dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    t_loop = time.perf_counter()
+    host_s = [0.0, 0.0]       # host time spent preparing batches / issuing their kernels
     i = -1
     for i in range(maxiter):
         step = float(np.float32(step_size(i)))
@@ -366,10 +553,21 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
                       for bt in range(nbatches_i)]
         n_side = nU if user_epoch else nI
         # a batch's index structures (its rows gathered from the CSR / CSC, grouped by both sides, cut into segments)
-        # are data-only: batch j+1 is prepared on a second stream -- with the host-side size queries that entails --
-        # while the kernels of batch j run
-        pending = prepare(chunks[0], user_epoch)
+        # are data-only and are prepared on a second stream in two halves (batch_sides_start / _finish): before batch j
+        # is issued, batch j+1 -- started one batch ago, so the sizes it needs from the device are on the host by now
+        # -- is finished and batch j+2 is started, so a batch's structures are ready long before its turn.  What is
+        # left of the preparation in a C5 batch is ~0.7 ms of 4.0 (3.3 ms with every batch re-using the first one's
+        # structures): its ~50 small launches run between / beside the batch's long whole-GPU kernels
+        # (profiles/r02_svi_c5_timeline.txt)
+        pending = prepare_finish(prepare_start(chunks[0], user_epoch), user_epoch)
+        started = prepare_start(chunks[1], user_epoch) if len(chunks) > 1 else None
         for j in range(len(chunks)):
+            t_h = time.perf_counter()
+            # batch j+1 was started one batch ago: its sizes are on the host by now; batch j+2 is started
+            nxt = prepare_finish(started, user_epoch) if started is not None else None
+            started = prepare_start(chunks[j + 2], user_epoch) if j + 2 < len(chunks) else None
+            host_s[0] += time.perf_counter() - t_h
+            t_h = time.perf_counter()
             (su, si, utb, itb), ready = pending
             if ready is not None:
                 torch.cuda.current_stream(dev).wait_event(ready)
@@ -377,7 +575,8 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
                     t.record_stream(torch.cuda.current_stream(dev))
             _svi_step(m, hyd, su, si, utb, itb, step, float(n_side) / float(chunks[j].shape[0]), user_epoch,
                       all_scalar_rows=False)
-            pending = prepare(chunks[j + 1], user_epoch) if j + 1 < len(chunks) else None
+            pending = nxt
+            host_s[1] += time.perf_counter() - t_h
 
         if check_every > 0 and ((i + 1) % check_every) == 0:
             if stop_crit == "diff-norm":
@@ -400,6 +599,12 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
                             break
                         last_crit = errs[0]
 
+    if timing:
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        SVI_TIMINGS.clear()
+        SVI_TIMINGS.update(epochs=i + 1, seconds=time.perf_counter() - t_loop, host_prepare_s=host_s[0],
+                           host_issue_s=host_s[1])
     last_llk = None
     if stop_crit in ("diff-norm", "maxiter") and verbose > 0:
         evaluate(final=True)

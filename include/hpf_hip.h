@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 9
+#define HPF_HIP_ABI_VERSION 10
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -227,6 +227,22 @@ int hpf_hip_svi_side_f32(int64_t nrows, const uint8_t *flag, const float *acc, c
 int hpf_hip_svi_rate_rows_f32(const int64_t *row_list, int64_t nrows, float *rte, const float *fac, float *rs,
                               const float *cs_other, float top, float add, float step, float step_prev, int mode,
                               int k, int ld, void *stream);
+
+/*
+ * Index plumbing of a stochastic batch (the reference slices its CSR / CSC per batch with numpy fancy indexing,
+ * PXI:280-290, 332-342, and scipy; here the batch's structures are built on the device).
+ * hpf_hip_gather_rows: the nonzeros of the listed rows of a CSR (or CSC): row t's entries
+ *   src_idx / src_y [src_begin[t] ...) are copied to out_idx / out_y [dst_begin[t], dst_begin[t+1]) and out_row there is
+ *   row_ids[t] (dst_begin has nrows+1 entries).
+ * hpf_hip_fill_segments: hpf_segment descriptors of rows given by (start, count > 0, id): row t is cut into
+ *   row_seg_ptr[t+1]-row_seg_ptr[t] = ceil(count[t]/seg_cap) segments written from segs[row_seg_ptr[t]] on; a row
+ *   with one segment carries HPF_SEG_WHOLE_ROW; `row` of the descriptor is row_ids[t].
+ */
+int hpf_hip_gather_rows(const int64_t *src_begin, const int64_t *dst_begin, const int64_t *row_ids, int64_t nrows,
+                        const int32_t *src_idx, const float *src_y, int32_t *out_idx, float *out_y, int32_t *out_row,
+                        void *stream);
+int hpf_hip_fill_segments(const int64_t *start, const int64_t *count, const int64_t *row_seg_ptr,
+                          const int64_t *row_ids, int64_t nrows, int seg_cap, hpf_segment *segs, void *stream);
 
 /*
  * initialize_parameters (PXI:127-141) without the host, in two steps.

@@ -204,6 +204,23 @@ class CpuOps:
     def score_rows(self, vec, tab, out, k, ld):
         _np(out)[:] = (_np(tab).astype(np.float64) @ _np(vec).astype(np.float64)).astype(np.float32)
 
+    def gather_rows(self, src_begin, dst_begin, row_ids, src_idx, src_y, out_idx, out_y, out_row):
+        sb, db, ids = _np(src_begin), _np(dst_begin), _np(row_ids)
+        for t in range(ids.shape[0]):
+            n = int(db[t + 1] - db[t])
+            _np(out_idx)[db[t]: db[t] + n] = _np(src_idx)[sb[t]: sb[t] + n]
+            _np(out_y)[db[t]: db[t] + n] = _np(src_y)[sb[t]: sb[t] + n]
+            _np(out_row)[db[t]: db[t] + n] = ids[t]
+
+    def fill_segments(self, start, count, row_seg_ptr, row_ids, seg_cap, segs):
+        st, cn, rsp, ids, out = _np(start), _np(count), _np(row_seg_ptr), _np(row_ids), _np(segs)
+        for t in range(ids.shape[0]):
+            ns = int(rsp[t + 1] - rsp[t])
+            for q in range(ns):
+                ln = min(int(cn[t]) - q * seg_cap, seg_cap)
+                out[rsp[t] + q, 0] = st[t] + q * seg_cap
+                out[rsp[t] + q, 1] = ln | (0x40000000 if ns == 1 else 0) | (int(ids[t]) << 32)
+
     def mt19937_words(self, state, raw):
         """numpy's own generator positioned at `state`; its outputs, un-tempered, are the stream's state words."""
         st = _np(state).view(np.uint32)

@@ -158,3 +158,43 @@ def test_partial_fit_growing_model_on_standin(cpu_ops_backend):
 @pytest.mark.gpu
 def test_partial_fit_growing_model_on_gpu(hip_backend):
     _partial_fit_growing_model()
+
+
+@pytest.mark.parametrize("case", ["ragged", "hubs", "empty-rows", "no-nonzeros"])
+def test_batch_structures_fast_path_equals_the_tensor_library_path(any_backend, case):
+    """svi.batch_sides (numpy on the host row pointers + hpf_hip_gather_rows + one sort + hpf_hip_fill_segments) builds
+    exactly the structures BatchSide(gather_rows(...)) builds with tensor-library calls: same row lists, same nonzero
+    order, same segment descriptors, for both sides of user and item batches -- incl. rows longer than a segment, listed
+    rows without nonzeros and a batch without any nonzero."""
+    import torch
+    from hpfrec_amd import layout, svi
+    ops = any_backend._make_ops()
+    dev = ops.device
+    rs = np.random.RandomState({"ragged": 1, "hubs": 2, "empty-rows": 3, "no-nonzeros": 4}[case])
+    nU, nI, cap = 700, 300, 16
+    nnz = 9000 if case != "empty-rows" else 900
+    iu = (nU * rs.random_sample(nnz) ** (3 if case == "hubs" else 1.3)).astype(np.int64)
+    ii = (nI * rs.random_sample(nnz) ** (4 if case == "hubs" else 1.5)).astype(np.int64)
+    y = (1 + rs.poisson(1.0, size=nnz)).astype(np.float32)
+    users, items, _ = layout.build_sides(torch.from_numpy(iu).to(dev), torch.from_numpy(ii).to(dev),
+                                         torch.from_numpy(y).to(dev), nU, nI, seg_cap=cap)
+    for side, n_rows in ((users, nU), (items, nI)):
+        ids = rs.permutation(n_rows)[: n_rows // 3].astype(np.uint64)
+        if case == "no-nonzeros":
+            deg = (side.indptr[1:] - side.indptr[:-1]).cpu().numpy()
+            ids = np.nonzero(deg == 0)[0].astype(np.uint64)
+            if ids.size == 0:
+                ids = np.array([], dtype=np.uint64)
+        rows_t = torch.sort(svi._dev_ids(ids, dev)).values
+        br, bc, by = svi.gather_rows(side, rows_t)
+        want_own = svi.BatchSide(br, bc, by, seg_cap=cap, grouped=True)
+        want_other = svi.BatchSide(bc, br, by, seg_cap=cap)
+        rows, own, other = svi.batch_sides(ops, side, side.indptr.cpu().numpy(), ids, nI if side is users else nU,
+                                           seg_cap=cap)
+        assert torch.equal(rows, rows_t)
+        for got, want in ((own, want_own), (other, want_other)):
+            assert (got.nseg, got.nmulti, got.nrows, got.short_rows) == (want.nseg, want.nmulti, want.nrows, want.short_rows)
+            for a, b, name in zip(got.tensors(), want.tensors(), ("rows", "idx", "y", "row_seg_ptr", "segs", "multi_local")):
+                assert a.dtype == b.dtype and torch.equal(a.reshape(-1), b.reshape(-1)), (case, name)
+        if case == "hubs":
+            assert own.nmulti > 0 and other.nmulti > 0

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of the last N kernels of a rocprofv3 kernel trace (csv): start offset, duration, queue, name -- to see
 which launches of a multi-stream iteration overlap and where the device idles.
-usage: prof_timeline.py <dir with *_kernel_trace.csv> [N=60]"""
+usage: prof_timeline.py <dir with *_kernel_trace.csv> [N=60] [skip the last M=0 kernels]"""
 import csv
 import glob
 import os
@@ -17,6 +17,9 @@ def short(n):
 path = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)[0]
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+if skip:
+    rows = rows[:-skip]
 rows = rows[-(int(sys.argv[2]) if len(sys.argv) > 2 else 60):]
 t0 = int(rows[0]["Start_Timestamp"])
 qs = {}

@@ -35,10 +35,19 @@ def run(n):
     return dt, float(llk)
 
 
+os.environ["HPF_TIMING"] = "1"
+from hpfrec_amd import svi  # noqa: E402
+
 run(2)                      # warm: code objects, allocator
 t_a, _ = run(2)
 t_b, llk = run(2 + epochs)
+loop = dict(svi.SVI_TIMINGS)
 print("C5 SVI (C3 matrix, k=%d, %d user batches / %d item batches of 65536 rows per epoch, nnz=%d): %d epochs in %.2f s wall "
       "incl. upload/layout/download; steady state %.1f ms per epoch (%.2f ms per batch); llk=%.6g"
       % (k, -(-nU // 65536), -(-nI // 65536), Y.shape[0], 2 + epochs, t_b, (t_b - t_a) / epochs * 1e3,
          (t_b - t_a) / epochs * 1e3 / ((-(-nU // 65536) + -(-nI // 65536)) / 2.0), llk))
+per_epoch = loop["seconds"] / loop["epochs"] * 1e3
+print("epoch loop of the last fit alone (device-synchronised; includes the one llk check at the last epoch): %d epochs in "
+      "%.3f s = %.1f ms per epoch, %.2f ms per batch; host time in it: %.3f s preparing batches, %.3f s issuing their kernels"
+      % (loop["epochs"], loop["seconds"], per_epoch, per_epoch / ((-(-nU // 65536) + -(-nI // 65536)) / 2.0),
+         loop["host_prepare_s"], loop["host_issue_s"]))
