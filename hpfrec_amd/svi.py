@@ -470,7 +470,9 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
     # per C5 batch)
     own_stream = os.environ.get("HPF_SVI_PREP_STREAM", "1") == "1"
     prep_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and own_stream) else None
-    staging = PinnedStaging(dev) if (fast_prep and dev.type == "cuda") else None
+    # (a batch sends ~7 words per listed row; a batch that needs more falls back to plain copies)
+    staging = PinnedStaging(dev, words=8 * max(int(users_per_batch), int(items_per_batch), 1) + 4096, slots=3) \
+        if (fast_prep and dev.type == "cuda") else None
     if prep_stream is not None:
         prep_stream.wait_stream(torch.cuda.current_stream(dev))      # the CSR / CSC built above
 
