@@ -21,7 +21,7 @@ SO_PATH = os.environ.get("HPF_HIP_SO") or os.path.join(_PKG, "libhpf_hip.so")
 SRC_PATH = os.path.join(_PKG, "csrc", "hpf_hip.hip")
 INC_PATH = os.path.join(_ROOT, "include")
 
-HPF_HIP_ABI_VERSION = 10
+HPF_HIP_ABI_VERSION = 11
 
 #: every symbol include/hpf_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = (
@@ -29,7 +29,7 @@ SYMBOLS = (
     "hpf_hip_sweep_finalize_f32", "hpf_hip_sweep_prefinalize_f32",
     "hpf_hip_row_finalize_f32", "hpf_hip_row_finalize_ranges_f32", "hpf_hip_colsum_reduce_f32", "hpf_hip_colsum_f32", "hpf_hip_expect_f32",
     "hpf_hip_segsum_f32", "hpf_hip_pair_llk_f32", "hpf_hip_llk_sweep_f32", "hpf_hip_pair_dot_f32", "hpf_hip_score_rows_f32", "hpf_hip_gather_probe_f32",
-    "hpf_hip_svi_shape_rows_f32", "hpf_hip_svi_refresh_f32", "hpf_hip_svi_rate_rows_f32", "hpf_hip_svi_side_f32", "hpf_hip_mt19937_words", "hpf_hip_uniform_rows_f32", "hpf_hip_gather_rows", "hpf_hip_fill_segments",
+    "hpf_hip_svi_shape_rows_f32", "hpf_hip_svi_refresh_f32", "hpf_hip_svi_rate_rows_f32", "hpf_hip_svi_side_f32", "hpf_hip_mt19937_words", "hpf_hip_uniform_rows_f32", "hpf_hip_gather_rows", "hpf_hip_fill_segments", "hpf_hip_fold_in_f32",
 )
 
 _lib = None
@@ -87,6 +87,7 @@ def lib():
     L.hpf_hip_score_rows_f32.argtypes = [vp, vp, i64, vp, ci, ci, vp]
     L.hpf_hip_mt19937_words.argtypes = [vp, vp, i64, vp]
     L.hpf_hip_gather_rows.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp]
+    L.hpf_hip_fold_in_f32.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, cf, ci, ci, ci, vp]
     L.hpf_hip_fill_segments.argtypes = [vp, vp, vp, vp, i64, ci, vp, vp]
     L.hpf_hip_uniform_rows_f32.argtypes = [vp, vp, vp, vp, i64, cf, cf, ci, ci, vp]
     L.hpf_hip_gather_probe_f32.argtypes = [vp, i64, vp, vp, ci, vp]

@@ -139,6 +139,15 @@ class HipOps:
         _lib.check(self.L.hpf_hip_score_rows_f32(_ptr(vec), _ptr(tab), int(tab.shape[0]), _ptr(out), k, ld,
                                                  self._stream()), "hpf_hip_score_rows_f32")
 
+    def fold_in(self, idx, y, e_items, cs_other, shp, rte, fac, e_last, rounds, prior, top, add, rs, stop_thr, maxiter,
+                k, ld):
+        """The local coordinate ascent of one user (calc_user_factors, PXI:505-513) as one launch; shp / rte / fac are
+        [ld] vectors updated in place, e_last the E row of the last round, rounds[0] the rounds executed."""
+        _lib.check(self.L.hpf_hip_fold_in_f32(_ptr(idx), _ptr(y), int(y.shape[0]), _ptr(e_items), _ptr(cs_other),
+                                              _ptr(shp), _ptr(rte), _ptr(fac), _ptr(e_last), _ptr(rounds), float(prior),
+                                              float(top), float(add), float(rs), float(stop_thr), int(maxiter), k, ld,
+                                              self._stream()), "hpf_hip_fold_in_f32")
+
     # -- index plumbing of a stochastic batch ---------------------------------------------------
     def gather_rows(self, src_begin, dst_begin, row_ids, src_idx, src_y, out_idx, out_y, out_row):
         """Nonzeros of the listed rows (row t: src[src_begin[t] ...) -> out[dst_begin[t] .. dst_begin[t+1]))."""

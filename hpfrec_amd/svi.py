@@ -654,15 +654,63 @@ def calc_user_factors(ops, a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_i, Th
         cs = torch.zeros(ld, dtype=torch.float32, device=dev)
         ops.colsum(Beta_dev, Beta.shape[0], ld, csp)
         ops.colsum_reduce(csp, cs, ld)
+    g1 = rng.gamma(a_prime, b_prime / a_prime, size=1).astype(np.float32)
+    unif = rng.uniform(low=.85, high=1.15, size=k).astype(np.float32)
+    ix = np.ascontiguousarray(ix_i).astype(np.int64)
+    n = int(nY)
+    if os.environ.get("HPF_FOLD_IN") == "launches":       # the round-1 path: three launches + a host check per round
+        return _fold_in_launches(ops, resident, cs, g1, unif, ix, n, Y, Theta, Lambda_shp, Lambda_rte, a, k_shp,
+                                 add_k_rte, k_rte, k, ld, maxiter, stop_thr, return_all)
+    # Gamma_rte = g + Beta.sum(axis=0); Gamma_shp = Gamma_rte * Theta * U(0.85, 1.15) (PXI:493-497), on the device
+    init = np.zeros((3, ld), dtype=np.float32)
+    init[0, :k], init[1, :k], init[2, 0] = Theta, unif, g1[0]
+    init_d = torch.from_numpy(init).to(dev)
+    Gr = torch.zeros(ld, dtype=torch.float32, device=dev)
+    Gs = torch.zeros(ld, dtype=torch.float32, device=dev)
+    Gr[:k] = init_d[2, 0] + cs[:k]
+    Gs[:k] = Gr[:k] * init_d[0, :k] * init_d[1, :k]
+    torch.nan_to_num_(Gs)
+    torch.nan_to_num_(Gr)
+    th = init_d[0].clone()
+    # E rows of the user's items: in place in the resident model's scratch table, or of the uploaded rows
+    y_d = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(dev)
+    if resident is not None:
+        ixd = torch.from_numpy(ix).to(dev)
+        ops.expect(resident.Lambda_shp, resident.Lambda_rte, resident.eB, n, k, ld, row_list=ixd)
+        e_items, idx32 = resident.eB, ixd.to(torch.int32)
+    else:
+        Ls = torch.zeros((n, ld), dtype=torch.float32, device=dev)
+        Lr = torch.zeros((n, ld), dtype=torch.float32, device=dev)
+        Ls[:, :k] = torch.from_numpy(np.ascontiguousarray(Lambda_shp[ix], dtype=np.float32)).to(dev)
+        Lr[:, :k] = torch.from_numpy(np.ascontiguousarray(Lambda_rte[ix], dtype=np.float32)).to(dev)
+        e_items = torch.zeros((n, ld), dtype=torch.float32, device=dev)
+        ops.expect(Ls, Lr, e_items, n, k, ld)
+        idx32 = torch.arange(n, dtype=torch.int32, device=dev)
+    e_last = torch.zeros(ld, dtype=torch.float32, device=dev)
+    rounds = torch.zeros(1, dtype=torch.int32, device=dev)
+    # the whole local coordinate ascent (PXI:505-517) is one launch
+    ops.fold_in(idx32, y_d, e_items, cs, Gs, Gr, th, e_last, rounds, a, k_shp, add_k_rte, k_rte, stop_thr, maxiter, k, ld)
+    Theta[:] = th[:k].cpu().numpy()
+    if not return_all:
+        return None
+    # phi / Y: the multinomial probabilities of the LAST phi (computed from the Gamma before its final update)
+    prob = e_last[None, :] * e_items[idx32.long()]
+    prob = (prob / prob.sum(dim=1, keepdim=True))[:, :k]
+    return Gs[:k].cpu().numpy(), Gr[:k].cpu().numpy(), prob.contiguous().cpu().numpy()
+
+
+def _fold_in_launches(ops, resident, cs, g1, unif, ix, n, Y, Theta, Lambda_shp, Lambda_rte, a, k_shp, add_k_rte, k_rte, k,
+                      ld, maxiter, stop_thr, return_all):
+    """calc_user_factors with one {expect, sweep, segsum} round trip and a host-side convergence check per round
+    (HPF_FOLD_IN=launches; kept to hold the fused kernel against)."""
+    dev = ops.device
     csB = cs[:k].cpu().numpy()                                   # Beta.sum(axis=0)
-    Gamma_rte = rng.gamma(a_prime, b_prime / a_prime, size=1).astype(np.float32) + csB
-    Gamma_shp = Gamma_rte * Theta * rng.uniform(low=.85, high=1.15, size=k).astype(np.float32)
+    Gamma_rte = g1 + csB
+    Gamma_shp = Gamma_rte * Theta * unif
     np.nan_to_num(Gamma_shp, copy=False)
     np.nan_to_num(Gamma_rte, copy=False)
 
     # the user's items, renumbered 0..nY-1; only those rows of the item tables go to the device
-    ix = np.ascontiguousarray(ix_i).astype(np.int64)
-    n = int(nY)
     if resident is not None:
         ixd = torch.from_numpy(ix).to(dev)
         Ls, Lr = resident.Lambda_shp[ixd].contiguous(), resident.Lambda_rte[ixd].contiguous()

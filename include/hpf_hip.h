@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 10
+#define HPF_HIP_ABI_VERSION 11
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -227,6 +227,20 @@ int hpf_hip_svi_side_f32(int64_t nrows, const uint8_t *flag, const float *acc, c
 int hpf_hip_svi_rate_rows_f32(const int64_t *row_list, int64_t nrows, float *rte, const float *fac, float *rs,
                               const float *cs_other, float top, float add, float step, float step_prev, int mode,
                               int k, int ld, void *stream);
+
+/*
+ * calc_user_factors (PXI:476-520): the local coordinate ascent of ONE user against fixed item parameters, looping on
+ * the device.  The user's n items are rows idx[t] of the items' E table `e_items` ([rows][ld], hpf_hip_expect_f32 of
+ * Lambda_shp / Lambda_rte), with counts y[t]; cs_other = Beta.sum(axis=0).  shp / rte / fac ([ld] each) hold the
+ * user's initial Gamma_shp, Gamma_rte and Theta (PXI:490-497) and return the final ones; rs is the initial k_rte.
+ * Per round (PXI:505-513): E row from (shp, rte); acc = sum_t y_t * e_items[idx_t] / <E, e_items[idx_t]>;
+ * rte = top/rs + cs_other; shp = prior + E (*) acc; fac = shp/rte; rs = add + sum_k fac; stop when
+ * ||fac - fac_prev||_2 < stop_thr, after at most maxiter rounds.  e_last ([ld]) = the E row of the LAST round (the
+ * reference returns phi/Y of that round), rounds[0] = rounds executed.  One workgroup.
+ */
+int hpf_hip_fold_in_f32(const int32_t *idx, const float *y, int64_t n, const float *e_items, const float *cs_other,
+                        float *shp, float *rte, float *fac, float *e_last, int32_t *rounds, float prior, float top,
+                        float add, float rs, float stop_thr, int maxiter, int k, int ld, void *stream);
 
 /*
  * Index plumbing of a stochastic batch (the reference slices its CSR / CSC per batch with numpy fancy indexing,

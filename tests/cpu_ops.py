@@ -204,6 +204,35 @@ class CpuOps:
     def score_rows(self, vec, tab, out, k, ld):
         _np(out)[:] = (_np(tab).astype(np.float64) @ _np(vec).astype(np.float64)).astype(np.float32)
 
+    def fold_in(self, idx, y, e_items, cs_other, shp, rte, fac, e_last, rounds, prior, top, add, rs, stop_thr, maxiter,
+                k, ld):
+        """hpf_hip_fold_in_f32: the rounds of PXI:505-513 in float32 numpy (phi-sums accumulated in float64)."""
+        f = np.float32
+        ids, yv = _np(idx).astype(np.int64), _np(y).astype(np.float64)
+        EB = _np(e_items)[ids].astype(np.float64)[:, :k]
+        gs, gr, th_prev = _np(shp), _np(rte), _np(fac)[:k].copy()
+        cs = _np(cs_other)[:k]
+        rs, it = f(rs), 0
+        e_row = torch.zeros((1, ld), dtype=torch.float32)
+        th = th_prev.copy()
+        while it < maxiter:
+            self.expect(shp.reshape(1, -1), rte.reshape(1, -1), e_row, 1, k, ld)
+            et = _np(e_row)[0, :k].astype(np.float64)
+            s = EB @ et
+            w = np.where(yv > 0, yv / s, 0.0)
+            acc = (w[:, None] * EB).sum(axis=0).astype(np.float32)
+            gr[:k] = f(top) / rs + cs
+            gs[:k] = f(prior) + _np(e_row)[0, :k] * acc
+            th = gs[:k] / gr[:k]
+            rs = f(add) + th.sum(dtype=np.float32)
+            it += 1
+            if float(np.sqrt(((th - th_prev).astype(np.float32) ** 2).sum(dtype=np.float32))) < stop_thr:
+                break
+            th_prev = th.copy()
+        _np(fac)[:k] = th
+        _np(e_last)[:] = _np(e_row)[0]
+        _np(rounds)[0] = it
+
     def gather_rows(self, src_begin, dst_begin, row_ids, src_idx, src_y, out_idx, out_y, out_row):
         sb, db, ids = _np(src_begin), _np(dst_begin), _np(row_ids)
         for t in range(ids.shape[0]):

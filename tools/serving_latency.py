@@ -42,7 +42,10 @@ print("  (host numpy GEMV+argsort for the same query: %.1f ms; ids agree: %s)"
 pu, pi = rs.randint(nU, size=1000), rs.randint(nI, size=1000)
 print("predict(1000 pairs):             %.2f ms" % timeit(lambda: m.predict(pu, pi)))
 new = pd.DataFrame({"ItemId": rs.choice(nI, size=40, replace=False), "Count": rs.randint(1, 5, size=40)})
-print("predict_factors(40 items):       %.2f ms" % timeit(lambda: m.predict_factors(new.copy()), n=5))
+for _ in range(3):
+    m.predict_factors(new.copy())
+print("predict_factors(40 items):       %.2f ms" % timeit(lambda: m.predict_factors(new.copy()), n=20))
 big = pd.DataFrame({"ItemId": rs.choice(nI, size=1000, replace=False), "Count": rs.randint(1, 5, size=1000)})
 print("predict_factors(1000 items):     %.2f ms   (reference, 8 CPU threads, k=50, smaller model: 3.5 ms for 40 items, "
-      "27 ms for 1000 -- profiles/r02_cpu_calibration.txt)" % timeit(lambda: m.predict_factors(big.copy()), n=5))
+      "27 ms for 1000 -- profiles/r02_cpu_calibration.txt)" % timeit(lambda: m.predict_factors(big.copy()), n=20))
+print("predict_factors(40 items) again: %.2f ms" % timeit(lambda: m.predict_factors(new.copy()), n=20))
