@@ -397,7 +397,7 @@ def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta
         return svi.fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, *outs, maxiter, stop_crit, check_every, stop_thr,
                                users_per_batch, items_per_batch, step_size, save_folder, random_seed, verbose,
                                has_valset, Yval, ix_u_val, ix_i_val, full_llk, keep_all_objs, _make_ops,
-                               device_triplets=device_triplets, init_draw=draw, resident=resident)
+                               device_triplets=device_triplets, init_draw=draw, resident=resident, tick=tick)
 
     # the reference's initialisation (4 numpy RNG passes over (nU+nI)*k floats, 0.36 s on the host at C3) is drawn on
     # the device from the same MT19937 stream, bit for bit: the sequential recurrence on a side stream under the

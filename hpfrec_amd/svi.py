@@ -269,10 +269,12 @@ class DeviceModel:
 
     def get(self, name, out=None):
         """Download one state array; into `out` (in place) when given."""
-        if name in ("k_rte", "t_rte"):
-            a = getattr(self, name).cpu().numpy().reshape(-1, 1)
-        else:
-            a = self.v(name).contiguous().cpu().numpy()
+        t = getattr(self, name).reshape(-1, 1) if name in ("k_rte", "t_rte") else self.v(name)
+        if out is not None and isinstance(out, np.ndarray) and out.flags.c_contiguous and out.flags.writeable \
+                and out.dtype == np.float32 and tuple(out.shape) == tuple(t.shape):
+            torch.from_numpy(out).copy_(t)       # one device-to-host copy, no second pass on the host
+            return out
+        a = t.contiguous().cpu().numpy()
         if out is None:
             return a
         out[...] = a
@@ -426,17 +428,19 @@ def partial_fit_step(ops, Y_batch, ix_u_batch, ix_i_batch, Theta, Beta, Gamma_sh
 def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, maxiter,
                 stop_crit, check_every, stop_thr, users_per_batch, items_per_batch, step_size, save_folder,
                 random_seed, verbose, has_valset, Yval, ix_u_val, ix_i_val, full_llk, keep_all_objs, make_ops,
-                device_triplets=None, init_draw=None, resident=None):
+                device_triplets=None, init_draw=None, resident=None, tick=None):
     """`init_draw`: the running device draw of the initial state (cython_loops_float.start_init_draw); the eight host
     arrays are then outputs only.  Without it they hold the initial state (initialize_parameters).
     `resident`: see cython_loops_float.fit_hpf."""
     from . import cython_loops_float as be   # printing helpers and save_parameters
     import time
+    tick = tick or (lambda phase: None)
     ops = make_ops()
     dev = ops.device
     nU, k = Theta.shape
     nI = Beta.shape[0]
     m = DeviceModel(ops, k, nU, nI)
+    tick("state tables allocated")
     if init_draw is None:
         m.load(Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta)
     hyd = {"a": float(hy.a), "c": float(hy.c), "k_shp": float(hy.k_shp), "t_shp": float(hy.t_shp),
@@ -449,8 +453,10 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
         ti = _dev_ids(ix_i, dev)
         ty = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(dev)
     users, items, u_sorted = layout.build_sides(tu, ti, ty, nU, nI)
+    tick("triplets to the device, CSR/CSC layout")
     if init_draw is not None:        # (the MT19937 recurrence ran on its own stream under the uploads and sorts above)
         m.init_state(be.finish_init_draw(dev, init_draw), hy)
+        tick("initial tables (incl. waiting for the MT19937 recurrence)")
 
     val = None
     if has_valset and Yval is not None and Yval.shape[0] > 0:
@@ -601,6 +607,7 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
                             break
                         last_crit = errs[0]
 
+    tick("epochs and checks")
     if timing:
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
@@ -618,6 +625,7 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
         resident.adopt(m)              # the state stays on the device; host copies are made when somebody reads them
         return i, None, last_llk
     m.store(Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta)
+    tick("outputs to the host")
     temp = (Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte)
     if save_folder != "":
         be.save_parameters(verbose, save_folder,

@@ -51,3 +51,4 @@ print("epoch loop of the last fit alone (device-synchronised; includes the one l
       "%.3f s = %.1f ms per epoch, %.2f ms per batch; host time in it: %.3f s preparing batches, %.3f s issuing their kernels"
       % (loop["epochs"], loop["seconds"], per_epoch, per_epoch / ((-(-nU // 65536) + -(-nI // 65536)) / 2.0),
          loop["host_prepare_s"], loop["host_issue_s"]))
+print("phases of the last fit [s]: %s" % {p: round(v, 3) for p, v in be.FIT_TIMINGS.items()})
