@@ -440,7 +440,7 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
     nU, k = Theta.shape
     nI = Beta.shape[0]
     m = DeviceModel(ops, k, nU, nI)
-    tick("state tables allocated")
+    tick("state tables allocated (the phase clock also waits for the MT19937 recurrence on its side stream here)")
     if init_draw is None:
         m.load(Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta)
     hyd = {"a": float(hy.a), "c": float(hy.c), "k_shp": float(hy.k_shp), "t_shp": float(hy.t_shp),
