@@ -264,3 +264,35 @@ def test_refit_and_mixed_calls(any_backend):
     assert m.Theta.shape == (int(df2.UserId.max()) + 1, 6)
     assert len(m.topN(user=3, n=5)) == 5 and m._state.model.nU == m.Theta.shape[0]
     assert np.isfinite(float(m.eval_llk(df2.copy())["llk"]))
+
+
+def test_partial_fit_continues_from_the_tables_a_fit_left_on_the_device(any_backend):
+    """fit() hands its device tables to the resident state (no download); a partial_fit / add_user right after it must
+    see exactly the state a host round trip of all eight arrays would give it (pad columns, scratch tables and column
+    sums of the adopted tables included)."""
+    batches, nU, nI = datagen.partial_fit_batches()
+    k = 12
+    full = pd.concat([b for _, b in batches[:2]]).drop_duplicates(["UserId", "ItemId"])
+
+    def fitted():
+        m = HPF(k=k, reindex=False, keep_data=False, random_seed=9, verbose=False, maxiter=4, check_every=None)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m.fit(full.copy())
+        return m
+
+    a, b = fitted(), fitted()
+    assert b._state.stats["d2h_bytes"] == 0
+    for n in NAMES:                        # b: every array is read (downloaded and handed out: re-uploaded on next use)
+        getattr(b, n)
+    assert b._state.stats["d2h_bytes"] > 0 and a._state.stats["d2h_bytes"] == 0
+    nxt = batches[2][1]
+    nxt = nxt[(nxt["UserId"] < a.nusers) & (nxt["ItemId"] < a.nitems)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for m in (a, b):
+            m.partial_fit(nxt.copy(), batch_type=batches[2][0])
+    for n in NAMES:
+        assert _maxrel(getattr(a, n), getattr(b, n)) < 2e-6, n
+    new = nxt[["ItemId", "Count"]].iloc[:9]
+    assert np.allclose(a.predict_factors(new.copy()), b.predict_factors(new.copy()), rtol=1e-5)
