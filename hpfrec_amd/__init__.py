@@ -104,6 +104,7 @@ class HPF:
     Lambda_rte = resident.StateArray("Lambda_rte")
     k_rte = resident.StateArray("k_rte")
     t_rte = resident.StateArray("t_rte")
+    seen = resident.DeviceBackedArray("seen")          # (48M ids at C3: produced on the device, downloaded when read)
 
     def __init__(self, k=30, a=0.3, a_prime=0.3, b_prime=1.0, c=0.3, c_prime=0.3, d_prime=1.0, ncores=-1,
                  stop_crit='maxiter', check_every=10, stop_thr=1e-3, users_per_batch=None, items_per_batch=None,
@@ -427,7 +428,8 @@ class HPF:
             idt = ingest.SEEN_INDEX_DTYPE
             indptr = indptr.cpu().numpy().astype(idt)
             self._n_seen_by_user = n_seen.cpu().numpy().astype(idt)
-            self.seen = seen.cpu().numpy().astype(idt)
+            assert seen.dtype.itemsize == np.dtype(idt).itemsize       # (int64, as scipy's indices for 64-bit ids)
+            type(self).seen.set_device(self, seen)       # stays on the device until somebody reads `model.seen`
             if for_partial_fit:
                 self._st_ix_user = np.require(indptr, dtype=be.obj_ind_type, requirements=["ENSUREARRAY", "C_CONTIGUOUS"])
             else:
@@ -847,10 +849,16 @@ class HPF:
             return be.pair_dots_device(T, B, user, item, self.k)
         return be.predict_arr(T, B, user, item, self.ncores)
 
-    def _seen_by(self, user):
+    def _seen_by(self, user, device=False):
+        """The items `user` had in the training data; device=True: as a device tensor when the list lives there."""
         # int(): after an SVI fit the start index is a size_t array, and uint64 + int32 is float64 in numpy
         st = int(self._st_ix_user[user])
-        return self.seen[st: st + int(self._n_seen_by_user[user])]
+        en = st + int(self._n_seen_by_user[user])
+        if device:
+            on_dev = type(self).seen.device_of(self)
+            if on_dev is not None:
+                return on_dev[st:en]
+        return self.seen[st:en]
 
     def topN(self, user, n=10, exclude_seen=True, items_pool=None):
         """The n items with the highest predicted count for `user`, best first; optionally without
@@ -881,8 +889,10 @@ class HPF:
             # argpartition/setdiff1d/argsort sequence (INIT:1337-1356), ties aside
             be = self._backend()
             st = self._state
-            rec = be.top_items(st.rows("Theta", user)[0], st.table(be._make_ops(), "Beta"), n,
-                               self._seen_by(user) if exclude_seen else None)
+            # (the user's row and her seen items are taken on the device when they are there: no round trip)
+            row = st.device_row("Theta", user)
+            rec = be.top_items(st.rows("Theta", user)[0] if row is None else row, st.table(be._make_ops(), "Beta"), n,
+                               self._seen_by(user, device=True) if exclude_seen else None)
             return back(rec)
 
         items_pool = np.require(items_pool, requirements=["ENSUREARRAY"]).reshape(-1)

@@ -572,17 +572,26 @@ def top_items(theta_row, Beta, n, exclude=None):
     setdiff1d + argsort per query."""
     ops = _make_ops()
     dev = ops.device
-    k = int(np.asarray(theta_row).reshape(-1).shape[0])
-    ld = cavi._lib.ld_for_k(k)
+    if torch.is_tensor(theta_row):                    # a padded row [ld] of the resident user table (pads are zero)
+        assert torch.is_tensor(Beta)
+        ld = int(Beta.shape[1])
+        k, vec = ld, theta_row.contiguous()
+        assert vec.shape[0] == ld
+    else:
+        k = int(np.asarray(theta_row).reshape(-1).shape[0])
+        ld = cavi._lib.ld_for_k(k)
+        vec = torch.zeros(ld, dtype=torch.float32, device=dev)
+        vec[:k] = torch.from_numpy(np.ascontiguousarray(theta_row, dtype=np.float32).reshape(-1)).to(dev)
     tab = Beta if torch.is_tensor(Beta) else _padded(Beta, ld, dev)
     assert tab.shape[1] == ld
-    vec = torch.zeros(ld, dtype=torch.float32, device=dev)
-    vec[:k] = torch.from_numpy(np.ascontiguousarray(theta_row, dtype=np.float32).reshape(-1)).to(dev)
     scores = torch.empty(tab.shape[0], dtype=torch.float32, device=dev)
     ops.score_rows(vec, tab, scores, k, ld)
     n_avail = int(tab.shape[0])
     if exclude is not None and len(exclude) > 0:
-        ex = torch.from_numpy(np.unique(np.asarray(exclude).astype(np.int64))).to(dev)
+        if torch.is_tensor(exclude):                  # (a slice of the seen-items list: no duplicates, on the device)
+            ex = exclude.to(torch.int64)
+        else:
+            ex = torch.from_numpy(np.unique(np.asarray(exclude).astype(np.int64))).to(dev)
         scores[ex] = -float("inf")
         n_avail -= int(ex.shape[0])
     n = int(max(0, min(n, n_avail)))

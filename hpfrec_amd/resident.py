@@ -140,6 +140,12 @@ class ResidentState:
     def on_device(self, name):
         return self.model is not None and self._device_current(name)
 
+    def device_row(self, name, idx):
+        """Padded device row [ld] of a table whose device copy is current, else None (never uploads)."""
+        if not self.on_device(name) or idx < 0:
+            return None
+        return getattr(self.model, name)[int(idx)]
+
     def rows(self, name, idx):
         """Host copy of a few rows, from whichever copy is current, without handing the array out."""
         idx = np.atleast_1d(np.asarray(idx, dtype=np.int64))
@@ -196,3 +202,38 @@ class StateArray:
 
 def ld_for(k):
     return _lib.ld_for_k(int(k))
+
+
+class DeviceBackedArray:
+    """Descriptor for a plain host-array attribute of the reference (`HPF.seen`) that the package produces on the
+    device: it stays there until somebody reads the attribute (then it is downloaded once and cached); assigning the
+    attribute -- the class itself does, INIT:1186-1196 -- drops the device copy.  Package code that can work on the
+    device copy asks `device_of(obj)`."""
+
+    def __init__(self, name):
+        self.name, self.slot = name, "_devbacked_" + name
+
+    def __get__(self, obj, objtype=None):
+        if obj is None:
+            return self
+        cell = obj.__dict__.get(self.slot)
+        if cell is None:
+            raise AttributeError(self.name)
+        if cell[0] is None:
+            cell[0] = cell[1].cpu().numpy()
+        return cell[0]
+
+    def __set__(self, obj, value):
+        obj.__dict__[self.slot] = [value, None]
+
+    def __delete__(self, obj):
+        if obj.__dict__.pop(self.slot, None) is None:
+            raise AttributeError(self.name)
+
+    def set_device(self, obj, tensor):
+        """The attribute's value, as a device tensor of the dtype the host array must have."""
+        obj.__dict__[self.slot] = [None, tensor]
+
+    def device_of(self, obj):
+        cell = obj.__dict__.get(self.slot)
+        return None if cell is None else cell[1]

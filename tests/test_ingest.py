@@ -60,6 +60,16 @@ def _fit_pair(backend_name):
         assert any("less than 1" in str(x.message) for x in w)
         out.append(m)
     a, b = out
+    # with numeric ids the seen-items list is produced on the device and stays there until it is read: topN takes the
+    # user's row and her seen items on the device, and answers the same before and after the list came down
+    assert HPF.seen.device_of(a) is not None and HPF.seen.device_of(b) is None
+    users5 = [a.user_mapping_[j] for j in (0, 3, 7, 11, 19)]
+    on_device = [list(a.topN(user=u, n=6)) for u in users5]
+    assert a._state.stats["d2h_bytes"] == 0                     # (neither Theta nor Beta came down for those queries)
+    assert a.seen.shape[0] == b.seen.shape[0] and HPF.seen.device_of(a) is not None
+    a.seen = a.seen.copy()                                      # an assigned list is the host's: device copy dropped
+    assert HPF.seen.device_of(a) is None
+    assert [list(a.topN(user=u, n=6)) for u in users5] == on_device
     assert a.nusers == b.nusers and a.nitems == b.nitems
     assert np.array_equal(np.array(["u%d" % x for x in a.user_mapping_]), b.user_mapping_.astype(str))
     assert np.array_equal(np.array(["i%d" % x for x in a.item_mapping_]), b.item_mapping_.astype(str))
