@@ -70,6 +70,68 @@ def _codes(values, mapping):
 _BIG_LOOKUP = 200_000    # from this many ids on, numeric id lookups run on the device (hpfrec_amd.ingest.IdLookup)
 
 
+class IdTable(dict):
+    """`user_dict_` / `item_dict_`: external id -> internal position (INIT:529-531), as the plain dict the reference
+    builds -- but filled from the mapping only when something needs the whole table (iteration, len, ==, repr).  A
+    single lookup, which is all the package itself does, is a binary search in the sorted ids the device renumbering
+    produced anyway; entries added later (add_user) live in the dict part.  Building the 1.4 million dict entries of a
+    C3-sized model took a quarter of a one-second fit.  Without sorted ids (string ids: the pandas path) the dict is
+    filled at once, as before."""
+
+    def __init__(self, mapping, sorted_ids=None, codes=None):
+        super().__init__()
+        self._mapping, self._sorted, self._codes, self._filled = mapping, sorted_ids, codes, False
+        if sorted_ids is None:
+            self._fill()
+
+    def _fill(self):
+        if not self._filled:
+            later = dict(dict.items(self))                         # entries assigned since (they win)
+            dict.update(self, zip(self._mapping.tolist(), range(self._mapping.shape[0])))
+            dict.update(self, later)
+            self._filled = True
+
+    def _search(self, key):
+        try:
+            pos = int(np.searchsorted(self._sorted, key))
+            if pos < self._sorted.shape[0] and self._sorted[pos] == key:
+                return int(self._codes[pos])
+        except (TypeError, ValueError):
+            pass
+        return None
+
+    def __missing__(self, key):
+        if not self._filled:
+            pos = self._search(key)
+            if pos is not None:
+                return pos
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or (not self._filled and self._search(key) is not None)
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    __hash__ = None
+
+
+def _whole_table(name):
+    def method(self, *args, **kwargs):
+        self._fill()
+        return getattr(dict, name)(self, *args, **kwargs)
+    method.__name__ = name
+    return method
+
+
+for _n in ("__len__", "__iter__", "__eq__", "__ne__", "__repr__", "keys", "values", "items", "copy", "pop", "popitem",
+           "__delitem__", "__reversed__", "__or__", "__ror__"):
+    setattr(IdTable, _n, _whole_table(_n))
+
+
 class HPF:
     """Hierarchical Poisson Factorization (Gopalan, Hofman & Blei 2015) fitted by mean-field
     coordinate-ascent variational inference, full-batch or stochastic.
@@ -236,8 +298,9 @@ class HPF:
                 self._st_ix_user = self._st_ix_user[:-1]
         self._dev_triplets = None
         if self.produce_dicts and self.reindex:
-            self.user_dict_ = {uid: pos for pos, uid in enumerate(self.user_mapping_)}
-            self.item_dict_ = {iid: pos for pos, iid in enumerate(self.item_mapping_)}
+            srt = self.__dict__.pop("_sorted_ids", None) or {}
+            self.user_dict_ = IdTable(self.user_mapping_, *srt.get("user", ()))
+            self.item_dict_ = IdTable(self.item_mapping_, *srt.get("item", ()))
         self.is_fitted = True
         del self.input_df
         del self.val_set
@@ -293,10 +356,13 @@ class HPF:
         if self.reindex:
             # first-appearance numbering, exactly pd.factorize (INIT:478-479)
             if on_device:
-                du, umap_d = ingest.factorize(du)
-                di, imap_d = ingest.factorize(di)
+                du, umap_d, us, uc = ingest.factorize(du, with_sorted=True)
+                di, imap_d, is_, ic = ingest.factorize(di, with_sorted=True)
                 umap = umap_d.cpu().numpy().astype(frame["UserId"].dtype, copy=False)
                 imap = imap_d.cpu().numpy().astype(frame["ItemId"].dtype, copy=False)
+                # (id -> position tables for user_dict_ / item_dict_: the sort of the renumbering is one already)
+                self._sorted_ids = {"user": (us.cpu().numpy().astype(umap.dtype, copy=False), uc.cpu().numpy()),
+                                    "item": (is_.cpu().numpy().astype(imap.dtype, copy=False), ic.cpu().numpy())}
                 tick("factorize")
                 # The renumbered ids stay on the device (self._dev_triplets): the fit, the seen-items index and the
                 # batches read them there, and input_df is deleted when fit() ends (INIT:688), so the frame's id

@@ -31,14 +31,15 @@ def to_device_ids(values, device):
     return None
 
 
-def factorize(ids):
+def factorize(ids, with_sorted=False):
     """pd.factorize(ids) for a numeric device vector: (codes int64, uniques) with uniques in order of first
     appearance and codes[n] = position of ids[n] in uniques.  One stable sort + run detection + a sort of the runs'
-    first positions."""
+    first positions.  with_sorted: also (the unique ids ascending, the code of each) -- a ready-made lookup table."""
     n = ids.shape[0]
     dev = ids.device
     if n == 0:
-        return torch.empty(0, dtype=torch.int64, device=dev), ids.clone()
+        e = torch.empty(0, dtype=torch.int64, device=dev)
+        return (e, ids.clone(), ids.clone(), e) if with_sorted else (e, ids.clone())
     sval, order = torch.sort(ids, stable=True)                   # equal ids keep their input order
     uniq, inverse, counts = torch.unique_consecutive(sval, return_inverse=True, return_counts=True)
     run_start = torch.cumsum(counts, 0) - counts
@@ -48,6 +49,8 @@ def factorize(ids):
     code_of_run[by_appearance] = torch.arange(by_appearance.shape[0], device=dev)
     codes = torch.empty(n, dtype=torch.int64, device=dev)
     codes[order] = code_of_run[inverse]
+    if with_sorted:
+        return codes, uniq[by_appearance], uniq, code_of_run
     return codes, uniq[by_appearance]
 
 

@@ -71,6 +71,17 @@ def _fit_pair(backend_name):
     assert HPF.seen.device_of(a) is None
     assert [list(a.topN(user=u, n=6)) for u in users5] == on_device
     assert a.nusers == b.nusers and a.nitems == b.nitems
+    # user_dict_ / item_dict_: the reference's plain dicts.  With numeric ids they answer single lookups from the sorted
+    # renumbering and are only filled when something needs the whole table
+    ud = a.user_dict_
+    assert isinstance(ud, dict) and dict.__len__(ud) == 0
+    assert all(ud[u] == j and u in ud for j, u in enumerate(a.user_mapping_[:50]))
+    assert ud.get(-5) is None and -5 not in ud and dict.__len__(ud) == 0
+    with pytest.raises(KeyError):
+        ud[10 ** 9]
+    assert ud == {u: j for j, u in enumerate(a.user_mapping_)} and len(ud) == a.nusers         # (filled now)
+    assert a.item_dict_ == {i: j for j, i in enumerate(a.item_mapping_)}
+    assert b.user_dict_ == {u: j for j, u in enumerate(b.user_mapping_)} and dict.__len__(b.item_dict_) == b.nitems
     assert np.array_equal(np.array(["u%d" % x for x in a.user_mapping_]), b.user_mapping_.astype(str))
     assert np.array_equal(np.array(["i%d" % x for x in a.item_mapping_]), b.item_mapping_.astype(str))
     assert a.user_mapping_.dtype == df["UserId"].dtype
