@@ -35,6 +35,9 @@ def _run(rank, world, port, out_dir, k, its, case, device="cpu"):
     else:
         import torch
         torch.cuda.set_device(0)
+    seed = 123
+    if case.endswith("-entropy"):       # random_seed <= 0: OS entropy (PXI:127) -- every rank must end up with rank 0's
+        case, seed = case[: -len("-entropy")], 0
     if case == "c4small":     # BASELINE C4's shape of problem at 2M nonzeros (tests/test_full_size.py)
         nU, nI = 100_000, 30_000
         iu, ii, Y = datagen.synthetic_hpf_shaped(nU, nI, 2_000_000, seed=4)
@@ -47,7 +50,7 @@ def _run(rank, world, port, out_dir, k, its, case, device="cpu"):
     Theta = np.empty((nU, k), np.float32)
     Beta = np.empty((nI, k), np.float32)
     i, temp, llk = be.fit_hpf(0.3, 0.3, 1.0, 0.3, 0.3, 1.0, Y, iu, ii, Theta, Beta, its, "maxiter", its, 1e-3, 0, 0, None,
-                              0, np.zeros(1, np.uint64), "", 123, 1, 1, 0, 0, np.empty(0, np.float32),
+                              0, np.zeros(1, np.uint64), "", seed, 1, 1, 0, 0, np.empty(0, np.float32),
                               np.empty(0, np.uint64), np.empty(0, np.uint64), 0, 1, 0)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), Theta=Theta, Beta=Beta, Gamma_shp=temp[0], Gamma_rte=temp[1],
              Lambda_shp=temp[2], Lambda_rte=temp[3], k_rte=temp[4], t_rte=temp[5], llk=np.float64(llk), niter=i)

@@ -57,3 +57,16 @@ def test_sharded_equals_single(tmp_path, cpu_ops_backend, monkeypatch, world, ca
             assert outs[r][n].shape == single[n].shape
             assert np.max(np.abs(outs[r][n] - single[n]) / np.abs(single[n])) < 1e-5, (r, n)
             assert np.array_equal(outs[r][n], outs[0][n]), (r, n)  # replicas agree bit for bit
+
+
+@pytest.mark.parametrize("world,mode", [(3, "scatter"), (2, "allreduce")])
+def test_unseeded_ranks_start_from_the_same_draw(tmp_path, cpu_ops_backend, monkeypatch, world, mode):
+    """random_seed <= 0 means OS entropy (PXI:127): each rank would draw its own initial item tables and the replicas
+    would drift apart; the sharded fit broadcasts rank 0's generator state, so all ranks still agree bit for bit."""
+    monkeypatch.setenv("HPF_SHARD_MODE", mode)
+    k, its = 12, 3
+    spawn_ranks(dist_worker.run, lambda port: (world, port, str(tmp_path), k, its, "c1-entropy"), world, str(tmp_path))
+    outs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    for r in range(1, world):
+        for n in NAMES:
+            assert np.isfinite(outs[r][n]).all() and np.array_equal(outs[r][n], outs[0][n]), (r, n)
