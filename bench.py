@@ -198,6 +198,18 @@ def cpu_baseline(nU, nI, k, nnz_full, sample_users=200_000, iters=4, device=None
 
 
 watchdog_state = {"done": False, "autotune": None, "meta": None}
+_LINE_FD = [None]
+
+
+def emit(line):
+    """The ONE line of this run, on the process's original stdout (libraries that print banners to stdout -- RCCL does
+    when a communicator is created -- have been pointed at stderr meanwhile, see main())."""
+    data = (json.dumps(line) + "\n").encode()
+    if _LINE_FD[0] is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_LINE_FD[0], data)
 
 
 def _arm_watchdog(seconds):
@@ -211,7 +223,7 @@ def _arm_watchdog(seconds):
         at, meta = watchdog_state["autotune"], watchdog_state["meta"]
         if meta["rank"] == 0 and at:
             best = min(at, key=at.get)
-            print(json.dumps({
+            emit({
                 "metric": "full-batch CAVI iters/sec (48M nnz, k=50)" if meta["workload_key"] == "c3" else
                           "full-batch CAVI iters/sec (%s)" % meta["workload_key"],
                 "value": 1e3 / at[best], "unit": "iters/s", "n_gpus": meta["world"], "steps": meta.get("tune_iters", 20), "warmup": 3,
@@ -223,7 +235,7 @@ def _arm_watchdog(seconds):
                            "fallback": "watchdog: a later configuration or phase made no progress; this is the "
                                        "barrier-bracketed %d-iteration measurement of the best completed candidate"
                                        % meta.get("tune_iters", 20)},
-                "roofline": None, "cpu_baseline": None}), flush=True)
+                "roofline": None, "cpu_baseline": None})
         os._exit(0 if (at or meta["rank"] != 0) else 3)
 
     t = threading.Timer(seconds, fire)
@@ -258,6 +270,12 @@ def main():
         # only rank 0 reports: whatever another rank's libraries leave in stdio at exit (RCCL banners ...) must not
         # trail rank 0's JSON line on the shared stdout
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    else:
+        # stdout carries exactly one line, the JSON: whatever a library prints to fd 1 meanwhile (RCCL's version banner
+        # at communicator creation) goes to stderr
+        sys.stdout.flush()
+        _LINE_FD[0] = os.dup(1)
+        os.dup2(2, 1)
     if os.environ.get("HPF_BENCH_SELFTEST_GLOO") == "1":
         local_rank = 0      # code-path self-test on a ONE-GPU box: all ranks on cuda:0, gloo instead of RCCL (not a benchmark)
     if world > 1 or os.environ.get("HPF_FORCE_SHARDED") == "1":
@@ -581,7 +599,7 @@ def main():
         except Exception:
             pass
         sys.stdout.flush()
-        print(json.dumps(line), flush=True)
+        emit(line)
 
 
 def kernel_source_sha16():
