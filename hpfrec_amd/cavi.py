@@ -99,7 +99,7 @@ class _SideView:
         self.nseg = seg_hi - seg_lo
         self.idx, self.y = side.idx, side.y
         # launch hint (hpf_hip_sweep_f32): a shard of a many-rank run leaves ~16 nonzeros per item row
-        self.short_rows = layout.SHORT_VARIANT if (nnz is not None and self.nseg > 0 and
+        self.short_rows = 1 if (nnz is not None and self.nseg > 0 and
                                                    nnz / self.nseg < layout.SHORT_ROW_NNZ) else 0
 
 

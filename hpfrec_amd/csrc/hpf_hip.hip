@@ -35,9 +35,6 @@ constexpr int WPB = BLOCK / WAVE;
 #ifndef HPF_U
 #define HPF_U 8  // gathers in flight per wavefront (U=4: -3%, U=2: -11%, U=16: -12% at C3)
 #endif
-#ifndef HPF_UG
-#define HPF_UG 4  // gathers in flight per lane group of sweep_groups_kernel (short rows)
-#endif
 #ifndef HPF_NT
 #define HPF_NT 0  // 1: non-temporal hints on the streamed operands (idx, y, part)
 #endif
@@ -417,97 +414,6 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
 #pragma unroll
             for (int w2 = 1; w2 < WPB; w2++) t += red[w2][c];
             fa.cs_partial[(size_t)blockIdx.x * LD + c] = t;
-        }
-    }
-}
-
-// Short rows (a shard of a many-rank run leaves ~16 nonzeros per item row; SVI batches): ONE SEGMENT PER LANE GROUP
-// instead of one per wavefront -- the NG = 64/LPR groups of a wave each own a segment (its E row, its accumulator),
-// so a wave's pass over the segment list carries NG rows through the descriptor -> idx/y -> gather latency chain
-// at once and no lane idles while a 16-nonzero row is 4 steps long.  Same arithmetic per nonzero as sweep_kernel
-// (MODE 0); the accumulation order inside a row is sequential here (one group), so sums differ from the
-// wave-per-segment kernel in rounding only.  Fixed order -> bit-reproducible.
-template <int LPR, int UU>
-__global__ __launch_bounds__(BLOCK) void sweep_groups_kernel(const hpf_segment *__restrict__ segs, int64_t nseg,
-                                                             const int32_t *__restrict__ idx,
-                                                             const float *__restrict__ y,
-                                                             const float *__restrict__ tab_self,
-                                                             const float *__restrict__ tab_other,
-                                                             float *__restrict__ part, float *__restrict__ acc_rows,
-                                                             int acc_ld) {
-    constexpr int LD = 4 * LPR;
-    constexpr int NG = WAVE / LPR;
-    constexpr int U = UU;
-    static_assert(LPR % UU == 0, "a chunk of LPR nonzeros is a whole number of batches");
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int gbase = lane & ~(LPR - 1);
-    const int g = lane / LPR;
-    const int j = lane % LPR;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * WPB;
-    for (int64_t s0 = ((int64_t)blockIdx.x * WPB + wid) * NG; s0 < nseg; s0 += nwaves * NG) {
-        const int64_t sg = s0 + g;
-        const bool live = sg < nseg;
-        hpf_segment sgm;
-        sgm.begin = 0;
-        sgm.len = 0;
-        sgm.row = 0;
-        if (live) sgm = segs[sg];
-        const int len = sgm.len & HPF_SEG_LEN_MASK;
-        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f), acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live) rv = reinterpret_cast<const float4 *>(tab_self + (size_t)sgm.row * LD)[j];
-        const int32_t *ip = idx + sgm.begin;
-        const float *yp = y + sgm.begin;
-        int maxlen = len;
-#pragma unroll
-        for (int m = LPR; m < WAVE; m <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m));
-        maxlen = __builtin_amdgcn_readfirstlane(maxlen);
-        for (int base = 0; base < maxlen; base += LPR) {
-            const int n = len - base;   // this group's remaining nonzeros (may be <= 0)
-            int myc = 0;
-            float myy = 0.f;
-            if (j < n) {
-                myc = ip[base + j];
-                myy = yp[base + j];
-            }
-            int nsteps = min(LPR, maxlen - base);
-            nsteps = (nsteps + U - 1) & ~(U - 1);
-            for (int t0 = 0; t0 < nsteps; t0 += U) {
-                float4 o[U];
-                float yy[U];
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int src = gbase + t0 + u;
-                    const int cc = __shfl(myc, src);
-                    yy[u] = __shfl(myy, src);
-                    o[u] = reinterpret_cast<const float4 *>(tab_other + (size_t)cc * LD)[j];
-                }
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const float s = group_sum<LPR>(dot4(rv, o[u]));
-                    const float w = (yy[u] > 0.f) ? yy[u] * __builtin_amdgcn_rcpf(s) : 0.f;
-                    acc.x = fmaf(w, o[u].x, acc.x);
-                    acc.y = fmaf(w, o[u].y, acc.y);
-                    acc.z = fmaf(w, o[u].z, acc.z);
-                    acc.w = fmaf(w, o[u].w, acc.w);
-                }
-            }
-        }
-        if (live) {
-            if ((sgm.len & HPF_SEG_WHOLE_ROW) && acc_rows) {
-                float *ar = acc_rows + (size_t)sgm.row * acc_ld;
-                const int c = j * 4;
-                if (acc_ld == LD) {
-                    reinterpret_cast<float4 *>(ar)[j] = acc;
-                } else {
-                    if (c + 0 < acc_ld) ar[c + 0] = acc.x;
-                    if (c + 1 < acc_ld) ar[c + 1] = acc.y;
-                    if (c + 2 < acc_ld) ar[c + 2] = acc.z;
-                    if (c + 3 < acc_ld) ar[c + 3] = acc.w;
-                }
-            } else {
-                reinterpret_cast<float4 *>(part + (size_t)sg * LD)[j] = acc;
-            }
         }
     }
 }
@@ -1628,21 +1534,6 @@ int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx,
     // short rows (a batch or a shard of a many-rank run: ~16 nonzeros per row): half the gathers in flight per wave
     // fill just as well and the smaller register file buys occupancy (-15 % at N=8)
     constexpr int US = (HPF_U >= 8) ? HPF_U / 2 : HPF_U;
-    if (short_rows == 2 && ld <= 128) {
-        // one segment per lane group (sweep_groups_kernel): 8 / 4 / 2 segments per wavefront at ld = 32 / 64 / 128
-        const int per_block = WPB * (WAVE / (ld / 4));
-        const int ggrid = clamp_grid((nseg + per_block - 1) / per_block, grid_blocks);
-        if (ld == 32)
-            hipLaunchKernelGGL((sweep_groups_kernel<8, HPF_UG>), dim3(ggrid), dim3(BLOCK), 0, st, segs, nseg, idx, y,
-                               tab_self, tab_other, part, acc_rows, acc_ld);
-        else if (ld == 64)
-            hipLaunchKernelGGL((sweep_groups_kernel<16, HPF_UG>), dim3(ggrid), dim3(BLOCK), 0, st, segs, nseg, idx, y,
-                               tab_self, tab_other, part, acc_rows, acc_ld);
-        else
-            hipLaunchKernelGGL((sweep_groups_kernel<32, HPF_UG>), dim3(ggrid), dim3(BLOCK), 0, st, segs, nseg, idx, y,
-                               tab_self, tab_other, part, acc_rows, acc_ld);
-        return last_error();
-    }
 #define CALL(LPR, VPL)                                                                                              \
     if (short_rows)                                                                                                 \
         hipLaunchKernelGGL((sweep_kernel<LPR, VPL, 0, US>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg, idx, y,     \

@@ -18,9 +18,6 @@ import torch
 # 256: 3.77, 512: 3.74, 1024: 3.70-3.72, 2048-4096: 3.73-3.74, 16384: 3.84 (tail imbalance).
 SEG_CAP = int(os.environ.get("HPF_SEG_CAP", "1024"))
 SHORT_ROW_NNZ = int(os.environ.get("HPF_SHORT_ROW_NNZ", "24"))      # average nonzeros per segment below which the plain sweep is launched with its short-row hint
-# how short rows are swept (hpf_hip_sweep_f32 `short_rows`): 2 = one segment per lane group, 1 = wave per segment with
-# half the gathers in flight, 0 = no hint
-SHORT_VARIANT = int(os.environ.get("HPF_SHORT_VARIANT", "1"))
 SEG_LEN_MASK = 0x00FFFFFF    # include/hpf_hip.h: HPF_SEG_LEN_MASK
 SEG_WHOLE_ROW = 0x40000000   # include/hpf_hip.h: HPF_SEG_WHOLE_ROW
 

@@ -49,7 +49,7 @@ class BatchSide:
         self.segs = segs
         self.nseg = int(segs.shape[0])
         self.nrows = int(self.rows.shape[0])
-        self.short_rows = layout.SHORT_VARIANT if (self.nseg > 0 and
+        self.short_rows = 1 if (self.nseg > 0 and
                                                    int(self.y.shape[0]) / self.nseg < layout.SHORT_ROW_NNZ) else 0
         nseg_row = self.row_seg_ptr[1:] - self.row_seg_ptr[:-1]
         self.multi_local = torch.nonzero(nseg_row > 1).reshape(-1)              # rows cut into several segments
@@ -61,7 +61,7 @@ class BatchSide:
         self = cls.__new__(cls)
         self.rows, self.idx, self.y, self.row_seg_ptr, self.segs, self.multi_local = rows, idx, y, row_seg_ptr, segs, multi_local
         self.nseg, self.nmulti, self.nrows = int(nseg), int(nmulti), int(rows.shape[0])
-        self.short_rows = layout.SHORT_VARIANT if (self.nseg > 0 and
+        self.short_rows = 1 if (self.nseg > 0 and
                                                    int(y.shape[0]) / self.nseg < layout.SHORT_ROW_NNZ) else 0
         return self
 
@@ -666,9 +666,6 @@ def calc_user_factors(ops, a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_i, Th
     unif = rng.uniform(low=.85, high=1.15, size=k).astype(np.float32)
     ix = np.ascontiguousarray(ix_i).astype(np.int64)
     n = int(nY)
-    if os.environ.get("HPF_FOLD_IN") == "launches":       # the round-1 path: three launches + a host check per round
-        return _fold_in_launches(ops, resident, cs, g1, unif, ix, n, Y, Theta, Lambda_shp, Lambda_rte, a, k_shp,
-                                 add_k_rte, k_rte, k, ld, maxiter, stop_thr, return_all)
     # Gamma_rte = g + Beta.sum(axis=0); Gamma_shp = Gamma_rte * Theta * U(0.85, 1.15) (PXI:493-497), on the device
     init = np.zeros((3, ld), dtype=np.float32)
     init[0, :k], init[1, :k], init[2, 0] = Theta, unif, g1[0]
@@ -705,58 +702,3 @@ def calc_user_factors(ops, a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_i, Th
     prob = e_last[None, :] * e_items[idx32.long()]
     prob = (prob / prob.sum(dim=1, keepdim=True))[:, :k]
     return Gs[:k].cpu().numpy(), Gr[:k].cpu().numpy(), prob.contiguous().cpu().numpy()
-
-
-def _fold_in_launches(ops, resident, cs, g1, unif, ix, n, Y, Theta, Lambda_shp, Lambda_rte, a, k_shp, add_k_rte, k_rte, k,
-                      ld, maxiter, stop_thr, return_all):
-    """calc_user_factors with one {expect, sweep, segsum} round trip and a host-side convergence check per round
-    (HPF_FOLD_IN=launches; kept to hold the fused kernel against)."""
-    dev = ops.device
-    csB = cs[:k].cpu().numpy()                                   # Beta.sum(axis=0)
-    Gamma_rte = g1 + csB
-    Gamma_shp = Gamma_rte * Theta * unif
-    np.nan_to_num(Gamma_shp, copy=False)
-    np.nan_to_num(Gamma_rte, copy=False)
-
-    # the user's items, renumbered 0..nY-1; only those rows of the item tables go to the device
-    if resident is not None:
-        ixd = torch.from_numpy(ix).to(dev)
-        Ls, Lr = resident.Lambda_shp[ixd].contiguous(), resident.Lambda_rte[ixd].contiguous()
-    else:
-        Ls = torch.zeros((n, ld), dtype=torch.float32, device=dev)
-        Lr = torch.zeros((n, ld), dtype=torch.float32, device=dev)
-        Ls[:, :k] = torch.from_numpy(np.ascontiguousarray(Lambda_shp[ix], dtype=np.float32)).to(dev)
-        Lr[:, :k] = torch.from_numpy(np.ascontiguousarray(Lambda_rte[ix], dtype=np.float32)).to(dev)
-    eB = torch.zeros((n, ld), dtype=torch.float32, device=dev)
-    ops.expect(Ls, Lr, eB, n, k, ld)
-    side = BatchSide(torch.zeros(n, dtype=torch.int64, device=dev), torch.arange(n, dtype=torch.int64, device=dev),
-                     torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(dev))
-    Gs = torch.zeros((1, ld), dtype=torch.float32, device=dev)
-    Gr = torch.zeros((1, ld), dtype=torch.float32, device=dev)
-    eT = torch.zeros((1, ld), dtype=torch.float32, device=dev)
-    part = torch.zeros((max(1, side.nseg), ld), dtype=torch.float32, device=dev)
-    acc = torch.zeros((1, ld), dtype=torch.float32, device=dev)
-    Gs[0, :k] = torch.from_numpy(Gamma_shp).to(dev)
-    Gr[0, :k] = torch.from_numpy(Gamma_rte).to(dev)
-    th = torch.from_numpy(Theta.copy()).to(dev)
-    th_prev = th.clone()
-    csB_dev = cs[:k]
-    k_rte_d = torch.tensor(float(k_rte), dtype=torch.float32, device=dev)
-    for _ in range(maxiter):
-        ops.expect(Gs, Gr, eT, 1, k, ld)                          # phi from the current Gamma (PXI:505)
-        ops.sweep(side, eT, eB, part, k, ld)
-        ops.segsum(part, side.row_seg_ptr, 1, acc, ld)
-        Gr[0, :k] = float(k_shp) / k_rte_d + csB_dev              # PXI:507
-        Gs[0, :k] = float(a) + (eT[0] * acc[0])[:k]               # PXI:508: a + phi.sum(axis=0)
-        th = Gs[0, :k] / Gr[0, :k]
-        k_rte_d = float(add_k_rte) + th.sum()
-        if float(torch.linalg.norm(th - th_prev)) < stop_thr:
-            break
-        th_prev = th.clone()
-    Theta[:] = th.cpu().numpy()
-    if not return_all:
-        return None
-    # phi / Y: the multinomial probabilities of the LAST phi (computed from the Gamma before its final update)
-    prob = eT[0][None, :] * eB
-    prob = (prob / prob.sum(dim=1, keepdim=True))[:, :k]
-    return Gs[0, :k].cpu().numpy(), Gr[0, :k].cpu().numpy(), prob.contiguous().cpu().numpy()

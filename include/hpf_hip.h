@@ -72,10 +72,8 @@ int hpf_hip_device_info(int *cu_count, char *arch, int arch_len);
  * of the second pass and removed, profiles/r02_atomic_one_pass.txt).
  * acc_rows (optional): segments flagged HPF_SEG_WHOLE_ROW write their accumulator to
  * acc_rows[row][0:acc_ld] (k <= acc_ld <= ld, packed) instead of part[g] -- the multi-GPU exchange buffer.
- * short_rows: tuning hint for rows that average a few dozen nonzeros at most.  1: the wave-per-segment kernel with
- * half the gathers in flight per wavefront (more wavefronts resident); 2: one segment per LANE GROUP (64/(ld/4)
- * segments per wavefront, ld <= 128; wider tables fall back to 1).  Results agree to rounding (2 accumulates a
- * row sequentially instead of in 64/(ld/4) interleaved partial sums).
+ * short_rows: tuning hint (0/1) for rows that average a few dozen nonzeros at most: the same kernel with half the
+ * gathers in flight per wavefront (smaller register file, more wavefronts resident).  Results are identical.
  */
 int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
                       const float *tab_self, const float *tab_other, float *part, float *acc_rows, int acc_ld, int k,

@@ -163,11 +163,11 @@ def test_sweep_op(ops, k):
 
 
 @pytest.mark.parametrize("k", [20, 30, 50, 100, 200])
-@pytest.mark.parametrize("variant", [1, 2])
-def test_short_row_sweep_variants(ops, k, variant):
-    """hpf_hip_sweep_f32 with the short-row hints (1: wave per segment, half the gathers in flight; 2: one segment
-    per lane group) against the numpy reference: ragged short rows, a few long (split) ones, rows without data,
-    whole-row accumulators written packed (acc_ld = k) into the exchange buffer, the rest into part[]."""
+def test_short_row_sweep_hint(ops, k):
+    """hpf_hip_sweep_f32 with the short-row hint (half the gathers in flight per wavefront) against the numpy
+    reference: ragged short rows, a few long (split) ones, rows without data, whole-row accumulators written packed
+    (acc_ld = k) into the exchange buffer, the rest into part[]."""
+    variant = 1
     rs = np.random.RandomState(100 * k + variant)
     ld = _lib.ld_for_k(k)
     nU, nI, n = 5000, 700, 40000

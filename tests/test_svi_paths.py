@@ -202,10 +202,11 @@ def test_batch_structures_fast_path_equals_the_tensor_library_path(any_backend, 
 
 @pytest.mark.parametrize("k,n,stop_thr,maxiter", [(30, 40, 1e-3, 10), (50, 7, 0.0, 6), (50, 2500, 1e-2, 12),
                                                  (130, 300, 1e-3, 10), (200, 64, 0.5, 10), (5, 1, 1e-3, 3)])
-def test_fold_in_one_launch_equals_the_round_trip_path(any_backend, monkeypatch, k, n, stop_thr, maxiter):
-    """hpf_hip_fold_in_f32 (the whole local coordinate ascent of PXI:505-517 looping on the device) gives what the
-    round-1 path gives with an {expect, sweep, segsum} round trip and a host-side check per round: same Theta, Gamma
-    and phi/Y, same stopping round (early stop, stop_thr = 0, more items than one segment holds, k up to 200)."""
+def test_fold_in_one_launch_equals_the_round_trip_path(any_backend, k, n, stop_thr, maxiter):
+    """hpf_hip_fold_in_f32 (the whole local coordinate ascent of PXI:505-517 looping on the device) gives what an
+    {expect, sweep, segsum} round trip with a host-side check per round gives (tests/fold_in_rounds.py): same Theta,
+    Gamma and phi/Y, same stopping round (early stop, stop_thr = 0, more items than one segment holds, k up to 200)."""
+    import fold_in_rounds
     be = any_backend
     rs = np.random.RandomState(k + n)
     nI = max(n, 3000)
@@ -214,13 +215,11 @@ def test_fold_in_one_launch_equals_the_round_trip_path(any_backend, monkeypatch,
     Lr = rs.uniform(0.3, 4.0, size=(nI, k)).astype(np.float32)
     ix = rs.choice(nI, size=n, replace=False).astype(np.uint64)
     Y = (1 + rs.poisson(1.5, size=n)).astype(np.float32)
-    out = {}
-    for mode in ("fused", "launches"):
-        if mode == "launches":
-            monkeypatch.setenv("HPF_FOLD_IN", "launches")
-        Theta = np.empty(k, dtype=np.float32)
-        res = be.calc_user_factors(0.3, 0.3, 1.0, 0.3, 0.3, 1.0, Y, ix, Theta, Beta, Ls, Lr, n, k, maxiter, 1, 7, stop_thr, 1)
-        out[mode] = (Theta,) + tuple(res)
-    for a, b, name in zip(out["fused"], out["launches"], ("Theta", "Gamma_shp", "Gamma_rte", "phi/Y")):
+    Theta = np.empty(k, dtype=np.float32)
+    res = be.calc_user_factors(0.3, 0.3, 1.0, 0.3, 0.3, 1.0, Y, ix, Theta, Beta, Ls, Lr, n, k, maxiter, 1, 7, stop_thr, 1)
+    fused = (Theta,) + tuple(res)
+    rounds = fold_in_rounds.calc_user_factors_round_trips(be._make_ops(), 0.3, 0.3, 1.0, Y, ix, Beta, Ls, Lr, n, k, maxiter,
+                                                          7, stop_thr)
+    for a, b, name in zip(fused, rounds, ("Theta", "Gamma_shp", "Gamma_rte", "phi/Y")):
         assert a.shape == b.shape and np.isfinite(a).all()
         assert _maxrel(a, b) < 2e-5, (name, _maxrel(a, b))

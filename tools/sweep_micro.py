@@ -52,13 +52,13 @@ acc = torch.zeros((m.nI, k), device=dev)
 gb = m.nnz * ld * 4 / 1e9
 for bpc in (4, 8, 16, 32):
     blocks = ops.cu_count * bpc
-    for variant in (0, 1, 2):
+    for variant in (0, 1):
         m.items.short_rows = variant
         t = timed(lambda: ops.sweep(m.items, m.eB, m.eT, m.part_i, k, ld, acc_rows=acc, acc_ld=k, grid_blocks=blocks))
         print("item sweep  bpc=%2d short_rows=%d: %7.1f us  (%.2f TB/s gathered)" % (bpc, variant, t, gb / t * 1e3))
 for bpc in (4, 8, 16, 32):
     blocks = ops.cu_count * bpc
-    for variant in (0, 1, 2):
+    for variant in (0, 1):
         m.users.short_rows = variant
         t = timed(lambda: ops.sweep(m.users, m.eT, m.eB, m.part_u, k, ld, grid_blocks=blocks))
         print("user sweep (plain) bpc=%2d short_rows=%d: %7.1f us  (%.2f TB/s gathered)" % (bpc, variant, t, gb / t * 1e3))
