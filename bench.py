@@ -331,7 +331,14 @@ def main():
     # deliver on this node, so (unless the environment pins them) each candidate runs a few untimed iterations
     # first and the fastest one -- by the slowest rank's clock -- is the configuration that is then benchmarked.
     autotune = None
-    TUNED = ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_RS_ALLTOALL", "HPF_GRAPH", "HPF_RCCL_DIRECT")
+    TUNED = ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_RS_ALLTOALL", "HPF_GRAPH", "HPF_RCCL_DIRECT",
+             "HPF_NATIVE_SHARD", "HPF_AG_PACKED")
+    if os.environ.get("HPF_BENCH_SELFTEST_GLOO") == "1" and dist is not None:
+        # the one-GPU self-test has no RCCL between its ranks: gloo stands in for it behind the C-issued iteration's
+        # collective callback (tests/dist_worker.py), so that the native path and the `collective` block are exercised
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from dist_worker import gloo_collective
+        dist.native_collective = lambda model_: gloo_collective(dist, model_)
     sharded = dist is not None and (world > 1 or os.environ.get("HPF_FORCE_SHARDED") == "1")
     if sharded and not args.no_autotune and not any(v in os.environ for v in TUNED):
         autotune, failed = {}, {}
@@ -340,34 +347,44 @@ def main():
         # still reports that candidate's barrier-bracketed 20-iteration measurement (flagged as a fallback).
         watchdog_state["autotune"], watchdog_state["meta"] = autotune, dict(
             workload=label, users=nU, items=nI, nnz=nnz, k=k, world=world, rank=rank, workload_key=args.workload)
-        _arm_watchdog(float(os.environ.get("HPF_BENCH_WATCHDOG_S", "150")))
+        _arm_watchdog(float(os.environ.get("HPF_BENCH_WATCHDOG_S", "240")))
 
         # (the one-GPU self-test of this code path -- N gloo ranks sharing a GPU -- times 6 iterations per candidate)
         tune_iters = 6 if os.environ.get("HPF_BENCH_SELFTEST_GLOO") == "1" else 20
         watchdog_state["meta"]["tune_iters"] = tune_iters
 
-        def candidate(mode, chunks, istream, a2a, graph, direct="0"):
+        def candidate(mode, chunks, istream, a2a, graph, direct="0", native="0", packed="0"):
             env = {"HPF_SHARD_MODE": mode, "HPF_AR_CHUNKS": chunks, "HPF_ITEM_STREAM": istream, "HPF_RS_ALLTOALL": a2a,
-                   "HPF_GRAPH": graph, "HPF_RCCL_DIRECT": direct}
+                   "HPF_GRAPH": graph, "HPF_RCCL_DIRECT": direct, "HPF_NATIVE_SHARD": native, "HPF_AG_PACKED": packed}
             os.environ.update(env)
-            key = "%s/%s%s%s%s%s" % (mode, chunks, "/item-stream" if istream == "1" else "",
-                                     "/all-to-all" if a2a == "1" else "", "/direct-rccl" if direct == "1" else "",
-                                     "/hipgraph" if graph == "1" else "")
+            key = "%s/%s%s%s%s%s%s%s" % (mode, chunks, "/item-stream" if istream == "1" else "",
+                                         "/all-to-all" if a2a == "1" else "", "/direct-rccl" if direct == "1" else "",
+                                         "/native" if native == "1" else "", "/packed-ag" if packed == "1" else "",
+                                         "/hipgraph" if graph == "1" else "")
             t_ms, err, m = None, None, None
+
+            def joined_barrier():
+                # the model's own-communicator collectives may still be in flight on the exchange stream: join it
+                # before ANOTHER communicator's barrier (never two communicators with concurrent work on one device)
+                if getattr(m, "shard_mode", None) == "scatter":
+                    m._sync_scatter_streams()
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
             try:
                 m = build_model()
                 m.iterate_many(4, not args.lean)         # (graph candidates: 2 eager + the capture + 1 replayed pair)
-                dist.barrier()
-                torch.cuda.synchronize()
+                joined_barrier()
                 t0 = time.perf_counter()
                 m.iterate_many(tune_iters, not args.lean)
-                dist.barrier()
-                torch.cuda.synchronize()
+                joined_barrier()
                 t_ms = (time.perf_counter() - t0) / tune_iters * 1e3
                 if graph == "1" and not any(g is not None for g in m.__dict__.get("_graphs", {}).values()):
                     err, t_ms = "no hipGraph captured: %s" % getattr(m, "_graph_error", "backend not capturable"), None
                 if direct == "1" and getattr(m, "comm", None) is None:
                     err, t_ms = "no communicator of our own (backend is not RCCL)", None
+                if native == "1" and getattr(m, "_plan", None) is None:
+                    err, t_ms = "no C-issued plan: %s" % (getattr(m, "native_error", None) or "backend has no RCCL"), None
                 m.flush_items()
             except Exception as exc:   # noqa: BLE001
                 err = "%s: %s" % (type(exc).__name__, str(exc)[:200])
@@ -387,22 +404,27 @@ def main():
         envs = {}
         # the plain all-reduce configurations go first: they are the most conservative use of RCCL
         for cand in (("allreduce", "3", "0", "0", "0"), ("allreduce", "2", "0", "0", "0"), ("scatter", "2", "0", "0", "0"),
-                     ("scatter", "1", "0", "0", "0"), ("scatter", "3", "0", "0", "0"), ("scatter", "2", "1", "0", "0"),
-                     ("scatter", "2", "0", "1", "0")):
+                     ("scatter", "1", "0", "0", "0"), ("scatter", "2", "1", "0", "0"), ("scatter", "2", "0", "1", "0")):
             key, env = candidate(*cand)
             envs[key] = env
-        # the collectives on an RCCL communicator of our own (hpfrec_amd/rccl.py): eager, then -- the fastest of the two
-        # -- replayed from captured hipGraphs (nothing of torch's polls that communicator's work, so the capture is safe)
-        for cand in (("scatter", "2", "0", "0", "0", "1"), ("scatter", "1", "0", "0", "0", "1")):
+        # the collectives on an RCCL communicator of our own (hpfrec_amd/rccl.py), still issued call by call from Python
+        key, env = candidate("scatter", "2", "0", "0", "0", "1")
+        envs[key] = env
+        # the library default on RCCL: the whole iteration issued by one C call on that communicator
+        # (hpf_hip_shard_iterate), with the new E rows all-gathered ld-padded or k-packed, in 2 ranges or 1; then the
+        # fastest of them replayed from captured hipGraphs (nothing of torch's polls that communicator's work, so the
+        # capture is safe)
+        for cand in (("scatter", "2", "0", "0", "0", "0", "1", "0"), ("scatter", "2", "0", "0", "0", "0", "1", "1"),
+                     ("scatter", "1", "0", "0", "0", "0", "1", "1"), ("scatter", "1", "0", "0", "0", "0", "1", "0")):
             key, env = candidate(*cand)
             envs[key] = env
-        dr = {k_: v for k_, v in autotune.items() if "direct-rccl" in k_}
-        if dr:
+        dr = {k_: v for k_, v in autotune.items() if "/native" in k_}
+        if dr and os.environ.get("HPF_BENCH_SELFTEST_GLOO") != "1":
             base = envs[min(dr, key=dr.get)]
-            key, env = candidate("scatter", base["HPF_AR_CHUNKS"], "0", "0", "1", "1")
+            key, env = candidate("scatter", base["HPF_AR_CHUNKS"], "0", "0", "1", "0", "1", base["HPF_AG_PACKED"])
             envs[key] = env
         sc = {k_: v for k_, v in autotune.items() if k_.startswith("scatter") and "item-stream" not in k_
-              and "direct-rccl" not in k_}
+              and "direct-rccl" not in k_ and "/native" not in k_}
         # The fastest torch.distributed scatter configuration replayed from captured hipGraphs -- only on request
         # (--try-hipgraph): in ~1 of 50 captures on this image torch's RCCL watchdog thread queried an event recorded
         # into the capture (hipErrorCapturedEvent) and aborted the process (profiles/r02_hipgraph_watchdog_abort.txt); a
@@ -411,6 +433,7 @@ def main():
             base = envs[min(sc, key=sc.get)]
             key, env = candidate(base["HPF_SHARD_MODE"], base["HPF_AR_CHUNKS"], "0", base["HPF_RS_ALLTOALL"], "1")
             envs[key] = env
+        # ^ (legacy Python-issued candidates pin HPF_NATIVE_SHARD=0 / HPF_AG_PACKED=0 through candidate()'s defaults)
         if autotune:
             best = min(autotune, key=autotune.get)
             os.environ.update(envs[best])
@@ -453,11 +476,15 @@ def main():
     ops.recording = False
     ev_steps = args.steps
     if not events_in_timed and not args.no_events:
+        # (per-kernel HIP events bracket launches made through the Python ops: this pass issues the same schedule call
+        # by call even when the timed region above was issued from C)
         ev_steps = min(args.steps, 10)
         ops.recording = "all"
+        model.native = False
         for _ in range(ev_steps):
             model.iterate(store)
         fence()
+        model.native = True
         ops.recording = False
     if dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -504,6 +531,14 @@ def main():
     # sanity: the state must be finite after the run (a NaN run would be a meaningless number)
     model.flush_items()   # sharded runs: gather the item tables (each rank finalizes a slice of the items)
     finite = bool(torch.isfinite(model.Beta).all().item() and torch.isfinite(model.Theta).all().item())
+
+    # N>1: what the exchange costs on its own and how much of it the iteration failed to hide (last: it spoils the state)
+    collective = None
+    if sharded:
+        try:
+            collective = exchange_report(model, dist, world, device, dt / args.steps * 1e3, store, fence)
+        except Exception as exc:   # noqa: BLE001  (the line must survive)
+            collective = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -570,10 +605,18 @@ def main():
                        "exchange_autotune": autotune,
                        "hipgraph_pairs": any(g is not None for g in model.__dict__.get("_graphs", {}).values()),
                        "direct_rccl_communicator": getattr(model, "comm", None) is not None,
+                       "iteration_issued_by": ("one C call (hpf_hip_shard_iterate)" if getattr(model, "_plan", None)
+                                               is not None else "python, call by call") if sharded else None,
+                       "native_plan_error": getattr(model, "native_error", None) if sharded else None,
+                       "e_rows_all_gathered": ("k-packed + unpack launch" if getattr(model, "ag_packed", False)
+                                               else "ld-padded, straight into the table") if sharded and
+                       getattr(model, "shard_mode", None) == "scatter" else None,
                        "seg_cap": cavi.layout.SEG_CAP, "fused_finalize": model.fused and world == 1,
                        "stores_all_state_tables": store, "state_finite": finite},
             "roofline": roof,
         }
+        if sharded:
+            line["collective"] = collective
         if lean_ms is not None:
             line["ms_per_step_without_output_table_stores"] = lean_ms
         if llk_ms is not None:
@@ -600,6 +643,91 @@ def main():
             pass
         sys.stdout.flush()
         emit(line)
+
+
+def exchange_report(model, dist, world, device, ms_per_step, store, fence, reps=10):
+    """N>1: the `collective` block of the line.  (1) The exchange ALONE: the iteration's reduce-scatters, all-gathers
+    (+ unpack) and k-float all-reduces issued back to back with nothing else on the GPU, HIP events around each group,
+    slowest rank reported -- bytes per rank, ms, algorithm and bus GB/s (nccl-tests' convention: bytes * (n-1)/n / t).
+    (2) The compute ALONE: the same iterations with every collective replaced by its one-rank form (the plan's dry run:
+    this rank's slice copied locally), barrier-bracketed -> exposed_ms = iteration - compute_only: what the schedule
+    failed to hide.  Needs the C-issued plan (RCCL, or the self-test's gloo callback); the state is garbage afterwards."""
+    from hpfrec_amd import shard_native as sn
+    plan = getattr(model, "_plan", None)
+    if plan is None and getattr(model, "shard_mode", None) == "scatter":
+        model._scatter_views()
+        plan = model._plan
+    if plan is None:
+        return {"skipped": "no C-issued plan on this configuration (%s)" %
+                (getattr(model, "native_error", None) or "exchange mode %s" % getattr(model, "shard_mode", None))}
+    k, ld, W = model.k, model.ld, world
+    views = model._chunk_views
+    rows = sum(c["hi"] - c["lo"] for c in views)
+    e_ld = int(model.e_own_all.shape[1])
+    comm = None
+    for c in list(cavi._DIRECT_COMMS.values()):
+        comm = c
+    ranks = comm.count() if comm is not None else None
+    cur = lambda: torch.cuda.current_stream(device).cuda_stream   # noqa: E731
+    fence()
+
+    def timed(fn):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        fn()                                   # warm
+        fence()
+        ev[0].record()
+        for _ in range(reps):
+            fn()
+        ev[1].record()
+        torch.cuda.synchronize()
+        t = torch.tensor([ev[0].elapsed_time(ev[1]) / reps], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    rs_ms = timed(lambda: [plan.exchange_only(sn.COLL_REDUCE_SCATTER, j, cur()) for j in range(len(views))])
+    ag_ms = timed(lambda: [plan.exchange_only(sn.COLL_ALL_GATHER, j, cur()) for j in range(len(views))])
+    ar_ms = timed(lambda: [plan.exchange_only(sn.COLL_ALL_REDUCE, -1, cur()) for _ in range(2)])
+    rs_bytes, ag_bytes = rows * k * 4, rows * e_ld * 4           # the whole buffer a collective spans, per rank
+    bus = (W - 1) / W
+
+    # compute only: a dry-run twin of the plan over the same tensors
+    import ctypes
+    d = sn.ShardDesc()
+    ctypes.memmove(ctypes.byref(d), ctypes.byref(plan.desc), ctypes.sizeof(d))
+    d.dry_run, d.comm, d.coll_ctx = 1, None, None
+    d.coll = sn.COLLECTIVE_FN()
+    dry = sn.ShardPlan(d, keep=plan.keep)
+    fence()
+    its = 20
+    stream = cur()
+
+    def run(n):
+        for _ in range(n):
+            dry.iterate(model.eT, model.eT_next, store, stream)
+            model.eT, model.eT_next = model.eT_next, model.eT
+    run(3)
+    dry.join(stream)
+    fence()
+    t0 = time.perf_counter()
+    run(its)
+    dry.join(stream)
+    fence()
+    comp = torch.tensor([(time.perf_counter() - t0) / its * 1e3], dtype=torch.float64, device=device)
+    dist.all_reduce(comp, op=dist.ReduceOp.MAX)
+    comp_ms = float(comp.item())
+    dry.close()
+    return {"ranks": ranks if ranks is not None else W,
+            "ranks_source": "ncclCommCount of the iteration's communicator" if ranks is not None
+            else "torch.distributed world size (no RCCL communicator: gloo callback)",
+            "ranges": len(views),
+            "bytes_per_rank": {"reduce_scatter_buffer": rs_bytes, "all_gather_buffer": ag_bytes,
+                               "sent_and_received_per_rank": (rs_bytes + ag_bytes) * bus, "small_all_reduces": 2 * ld * 4},
+            "rs_ms": rs_ms, "ag_ms": ag_ms, "ag_includes_unpack": bool(e_ld != ld), "small_allreduce_ms_each": ar_ms / 2,
+            "algbw_GBps": {"reduce_scatter": rs_bytes / rs_ms / 1e6, "all_gather": ag_bytes / ag_ms / 1e6},
+            "busbw_GBps": {"reduce_scatter": rs_bytes * bus / rs_ms / 1e6, "all_gather": ag_bytes * bus / ag_ms / 1e6},
+            "exchange_alone_ms": rs_ms + ag_ms + ar_ms, "compute_only_ms": comp_ms, "iteration_ms": ms_per_step,
+            "exposed_ms": ms_per_step - comp_ms,
+            "note": "exchange alone: back-to-back collectives, nothing else running; compute only: every collective "
+                    "replaced by the local copy of this rank's slice (state not meaningful afterwards)"}
 
 
 def kernel_source_sha16():

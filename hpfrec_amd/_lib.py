@@ -18,10 +18,11 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 # HPF_HIP_SO: load a differently-tuned build of the same source (kernel A/B runs); default in-tree build
 SO_PATH = os.environ.get("HPF_HIP_SO") or os.path.join(_PKG, "libhpf_hip.so")
-SRC_PATH = os.path.join(_PKG, "csrc", "hpf_hip.hip")
+SRC_PATH = os.path.join(_PKG, "csrc", "hpf_hip.hip")          # the kernels + their launchers
+SHARD_SRC_PATH = os.path.join(_PKG, "csrc", "hpf_shard.hip")  # host code: one rank's sharded iteration, RCCL binding
 INC_PATH = os.path.join(_ROOT, "include")
 
-HPF_HIP_ABI_VERSION = 11
+HPF_HIP_ABI_VERSION = 12
 
 #: every symbol include/hpf_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = (
@@ -30,6 +31,10 @@ SYMBOLS = (
     "hpf_hip_row_finalize_f32", "hpf_hip_row_finalize_ranges_f32", "hpf_hip_colsum_reduce_f32", "hpf_hip_colsum_f32", "hpf_hip_expect_f32",
     "hpf_hip_segsum_f32", "hpf_hip_pair_llk_f32", "hpf_hip_llk_sweep_f32", "hpf_hip_pair_dot_f32", "hpf_hip_score_rows_f32", "hpf_hip_gather_probe_f32",
     "hpf_hip_svi_shape_rows_f32", "hpf_hip_svi_refresh_f32", "hpf_hip_svi_rate_rows_f32", "hpf_hip_svi_side_f32", "hpf_hip_mt19937_words", "hpf_hip_uniform_rows_f32", "hpf_hip_gather_rows", "hpf_hip_fill_segments", "hpf_hip_fold_in_f32",
+    "hpf_hip_unpack_rows_f32", "hpf_hip_rccl_open", "hpf_hip_rccl_unique_id", "hpf_hip_rccl_comm_init", "hpf_hip_rccl_comm_count",
+    "hpf_hip_rccl_comm_destroy", "hpf_hip_rccl_all_reduce_f32", "hpf_hip_rccl_reduce_scatter_f32",
+    "hpf_hip_rccl_all_gather_f32", "hpf_hip_shard_plan_create", "hpf_hip_shard_plan_destroy", "hpf_hip_shard_iterate",
+    "hpf_hip_shard_join", "hpf_hip_shard_exchange_only", "hpf_hip_shard_desc_layout",
 )
 
 _lib = None
@@ -42,10 +47,11 @@ class HpfHipError(RuntimeError):
 def build(force=False, verbose=False):
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     if (not force) and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= max(
-            os.path.getmtime(SRC_PATH), os.path.getmtime(os.path.join(INC_PATH, "hpf_hip.h"))):
+            os.path.getmtime(SRC_PATH), os.path.getmtime(SHARD_SRC_PATH),
+            os.path.getmtime(os.path.join(INC_PATH, "hpf_hip.h"))):
         return SO_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I" + INC_PATH,
-           "-o", SO_PATH, SRC_PATH]
+           "-o", SO_PATH, SRC_PATH, SHARD_SRC_PATH, "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -76,7 +82,22 @@ def lib():
     L.hpf_hip_row_finalize_f32.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, ci, ci, ci,
                                            ci, vp]
     L.hpf_hip_row_finalize_ranges_f32.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, ci,
-                                                  ci, ci, ci, vp]
+                                                  ci, ci, ci, ci, vp]
+    L.hpf_hip_unpack_rows_f32.argtypes = [vp, vp, i64, ci, ci, vp]
+    L.hpf_hip_rccl_open.argtypes = [ctypes.c_char_p]
+    L.hpf_hip_rccl_unique_id.argtypes = [vp]
+    L.hpf_hip_rccl_comm_init.argtypes = [ctypes.POINTER(vp), ci, ci, vp]
+    L.hpf_hip_rccl_comm_count.argtypes = [vp, ctypes.POINTER(ci)]
+    L.hpf_hip_rccl_comm_destroy.argtypes = [vp]
+    L.hpf_hip_rccl_all_reduce_f32.argtypes = [vp, vp, i64, vp]
+    L.hpf_hip_rccl_reduce_scatter_f32.argtypes = [vp, vp, vp, i64, vp]
+    L.hpf_hip_rccl_all_gather_f32.argtypes = [vp, vp, vp, i64, vp]
+    L.hpf_hip_shard_desc_layout.argtypes = [vp]
+    L.hpf_hip_shard_plan_create.argtypes = [vp, ctypes.POINTER(vp)]
+    L.hpf_hip_shard_plan_destroy.argtypes = [vp]
+    L.hpf_hip_shard_iterate.argtypes = [vp, vp, vp, ci, vp]
+    L.hpf_hip_shard_join.argtypes = [vp, vp]
+    L.hpf_hip_shard_exchange_only.argtypes = [vp, ci, ci, vp]
     L.hpf_hip_colsum_reduce_f32.argtypes = [vp, ci, vp, ci, vp]
     L.hpf_hip_colsum_f32.argtypes = [vp, i64, ci, vp, ci, vp]
     L.hpf_hip_expect_f32.argtypes = [vp, vp, vp, vp, i64, ci, ci, vp]

@@ -56,6 +56,7 @@ def _dist():
 
 
 _DIRECT_COMMS = {}
+NATIVE_PLANS_CREATED = [0]      # how many models of this process run their sharded iteration from C (tests, bench)
 
 
 def _direct_comm(dist, device, rank, world):
@@ -206,6 +207,18 @@ class FullBatchCavi:
         self.comm = _direct_comm(self.dist, self.device, self.rank, self.world) \
             if (self.shard_mode == "scatter" and not self.rs_alltoall) else None
         self.item_stream = os.environ.get("HPF_ITEM_STREAM", "0") == "1"   # scatter mode: item pass on its own stream
+        # scatter mode: the new E rows are all-gathered k-PACKED (the pad columns -- 22 % of an ld = 64 row at k = 50 --
+        # stay off the links) into the exchange buffer and a streaming kernel restores the padded layout the sweeps
+        # gather from.  "auto": whenever the padding is at least an eighth of the row
+        pk = os.environ.get("HPF_AG_PACKED", "auto")
+        self.ag_packed = self.shard_mode == "scatter" and not self.rs_alltoall and (
+            pk == "1" or (pk == "auto" and 8 * (self.ld - self.k) >= self.ld))
+        # scatter mode on RCCL: the whole iteration issued by ONE C call (hpf_hip_shard_iterate) on a communicator of
+        # our own; HPF_NATIVE_SHARD=0 keeps the call-by-call Python form (also the path of gloo / stand-in runs)
+        self._plan = None
+        self.native = True            # (False: issue call by call even when a plan exists -- bench's per-kernel event pass)
+        self._last_native = False
+        self.native_error = None
         self.lazy_items = os.environ.get("HPF_LAZY_ITEMS", "1") == "1"
         self.item_pending = False   # sharded path: acc_i holds reduced statistics not yet applied to the item tables
 
@@ -505,7 +518,8 @@ class FullBatchCavi:
         cuda = self.device.type == "cuda"
         total = sum((hi - lo) // W for lo, hi, _, _ in self.item_chunks)
         self.acc_own_all = torch.zeros((total, k), **f32)
-        self.e_own_all = torch.zeros((total, ld), **f32)
+        e_ld = k if self.ag_packed else ld            # row stride of the all-gather send buffer
+        self.e_own_all = torch.zeros((total, e_ld), **f32)
         views, t0, ranges = [], 0, []
         for lo, hi, view, multi in self.item_chunks:
             m = (hi - lo) // W
@@ -520,6 +534,10 @@ class FullBatchCavi:
                 # views used every iteration (slicing costs host time in a loop that is ~40 % host-bound at 8 ranks)
                 a2a_recv=torch.zeros((W * m, k), **f32) if self.rs_alltoall else None,
                 eB_range=self.eB[lo:hi],
+                # packed all-gather: received into the exchange buffer's rows of the range (free by then: the
+                # reduce-scatter that read them precedes the all-gather on the exchange stream, and the next sweep of
+                # the range -- their next writer -- waits for the all-gather)
+                ag_recv=self.acc_i[lo:hi] if self.ag_packed else None,
                 # dedicated events (re-recorded every iteration, waited for before the next record)
                 sw_done=torch.cuda.Event() if cuda else None, ag_done=torch.cuda.Event() if cuda else None))
             t0 += m
@@ -528,7 +546,86 @@ class FullBatchCavi:
         self._csT_ready = torch.cuda.Event() if cuda else None
         self._sc_fresh = True
         self._chunk_views = views
+        self._plan = self._make_plan(views)
         return views
+
+    def _make_plan(self, views):
+        """The native form of _iterate_scatter (hpf_hip_shard_iterate) over this model's tensors, or None: it needs a
+        GPU, the fused user side, the two-stream schedule, and a way to run the collectives from C -- RCCL (backend
+        "nccl": a communicator of our own, created here), or what a stand-in for torch.distributed brings
+        (`native_collective`: a callback, tests with gloo ranks; `native_dry_run`: this rank alone, probes).  Every rank
+        must end up with a plan, or none does (one collective of torch.distributed decides)."""
+        dist = self.dist
+        if (self.device.type != "cuda" or os.environ.get("HPF_NATIVE_SHARD", "1") != "1" or not self.fused
+                or self.item_stream or self.rs_alltoall or self.users.nseg == 0 or len(views) > 8):
+            return None
+        plan, err = None, None
+        try:
+            from . import rccl, shard_native as sn
+            coll = comm = None
+            dry = 0
+            keep = []
+            if hasattr(dist, "native_collective"):
+                coll = sn.COLLECTIVE_FN(dist.native_collective(self))
+                keep.append(coll)
+            elif getattr(dist, "native_dry_run", False):
+                dry = 1
+                comm = dist.direct_comm(self.device, raw=True) if hasattr(dist, "direct_comm") else None
+            elif dist.get_backend() == "nccl":
+                comm = self.comm
+                if comm is None:
+                    key = (str(self.device), self.world, self.rank)
+                    if key not in _DIRECT_COMMS:
+                        _DIRECT_COMMS[key] = rccl.DirectComm(self.device, dist, self.rank, self.world)
+                    comm = _DIRECT_COMMS[key]
+                if not comm.self_check():
+                    raise RuntimeError("the communicator's self-check failed")
+            else:
+                return None
+            d = sn.ShardDesc()
+            hy, u, it = self.hy, self.users, self.items
+            d.world, d.rank, d.k, d.ld, d.nU, d.nI = self.world, self.rank, self.k, self.ld, self.nU, self.nI
+            d.u_segs, d.u_nseg, d.u_idx, d.u_y = u.segs.data_ptr(), u.nseg, u.idx.data_ptr(), u.y.data_ptr()
+            d.u_row_seg_ptr, d.u_nmulti = u.row_seg_ptr.data_ptr(), u.nmulti
+            d.u_multi_rows = u.multi_rows.data_ptr() if u.nmulti else None
+            d.i_segs, d.i_idx, d.i_y, d.i_row_seg_ptr = (it.segs.data_ptr(), it.idx.data_ptr(), it.y.data_ptr(),
+                                                         it.row_seg_ptr.data_ptr())
+            d.nranges = len(views)
+            for j, c in enumerate(views):
+                r = d.ranges[j]
+                r.lo, r.hi, r.seg_lo, r.nseg = c["lo"], c["hi"], c["view"].seg_lo, c["view"].nseg
+                r.nmulti, r.short_rows = c["nmulti"], int(c["view"].short_rows)
+                r.multi_rows = c["multi"].data_ptr() if c["nmulti"] else None
+            for n in ("eB", "part_u", "part_i", "Gamma_shp", "Theta", "k_rte", "k_rte_prev", "Lambda_shp", "Beta", "t_rte",
+                      "t_rte_prev", "csT", "csB", "csB_used", "csT_part", "acc_i"):
+                setattr(d, n, getattr(self, n).data_ptr())
+            d.csT_part_rows, d.user_sweep_grid = int(self.csT_part.shape[0]), self.gsu
+            d.user_multi_grid = max(1, min(self.gu, (u.nmulti + 3) // 4))
+            d.csB_part, d.csB_part_rows = self.csB_part_sc.data_ptr(), int(self.csB_part_sc.shape[0])
+            d.acc_own, d.e_own = self.acc_own_all.data_ptr(), self.e_own_all.data_ptr()
+            d.e_own_ld, d.item_sweep_grid = int(self.e_own_all.shape[1]), int(self.item_sweep_blocks)
+            d.ag_recv = self.acc_i.data_ptr() if self.ag_packed else None
+            d.a, d.k_shp, d.add_k_rte = float(hy.a), float(hy.k_shp), float(hy.add_k_rte)
+            d.c, d.t_shp, d.add_t_rte = float(hy.c), float(hy.t_shp), float(hy.add_t_rte)
+            d.comm = comm.handle if comm is not None else None
+            if coll is not None:
+                d.coll = coll
+            d.xstream = self._xstream().cuda_stream
+            d.dry_run = dry
+            plan = sn.ShardPlan(d, keep=keep + [comm, views])
+        except Exception as exc:   # noqa: BLE001
+            plan, err = None, "%s: %s" % (type(exc).__name__, str(exc)[:200])
+        # all or none (a rank that issued its collectives through another communicator than its peers would hang them)
+        if self.world > 1 and hasattr(dist, "all_reduce") and not getattr(dist, "native_dry_run", False):
+            ok = torch.tensor([1.0 if plan is not None else 0.0], device=self.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) < 1.0 and plan is not None:
+                plan.close()
+                plan, err = None, "another rank could not create its plan"
+        self.native_error = err
+        if plan is not None:
+            NATIVE_PLANS_CREATED[0] += 1
+        return plan
 
     def _iterate_scatter(self, store):
         """Users sharded over ranks, item FINALIZER sharded too.  Per item range (fewest rows first):
@@ -549,6 +646,20 @@ class FullBatchCavi:
         next sweep crosses streams exactly twice; all other waits are for work that finished long before."""
         ops, hy, k, ld, dist = self.ops, self.hy, self.k, self.ld, self.dist
         views = self._scatter_views()
+        if self._plan is not None and self.native and self.fused:       # the same schedule, issued by one C call
+            if not self._last_native:
+                self._sync_scatter_streams()      # (switching forms: the other one's exchanges first)
+            self._last_native = True
+            self._plan.iterate(self.eT, self.eT_next, store, torch.cuda.current_stream(self.device).cuda_stream)
+            self.rte_factored = True         # (_keep_csB: the C call copies colsum(Beta) on storing iterations)
+            self._sc_fresh = False
+            self._tables_split = True
+            self.eT, self.eT_next = self.eT_next, self.eT
+            self.niter_done += 1
+            return
+        if self._last_native:
+            self._sync_scatter_streams()
+        self._last_native = False
         xs = self._xstream()
         cuda = xs is not None
         cs = torch.cuda.current_stream(self.device) if cuda else None
@@ -601,17 +712,20 @@ class FullBatchCavi:
                 ops.row_finalize_ranges(self.acc_own_all, self._fin_ranges, self.eB, self.e_own_all,
                                         self.Lambda_shp if store else None, None, self.Beta if store else None,
                                         self.t_rte, self.csT, self.csB_part_sc, hy.c, hy.t_shp, hy.add_t_rte, k, ld, k,
-                                        rs_prev=self.t_rte_prev)
+                                        rs_prev=self.t_rte_prev, e_new_ld=int(self.e_own_all.shape[1]))
             for j, c in enumerate(views):
                 if j == len(views) - 1:
                     # colsum(Beta) -- read by the next USER side only -- goes ahead of the last all-gather (which the
                     # user side waits for anyway) and behind the first one (which the next item sweep is waiting for)
                     ops.colsum_reduce(self.csB_part_sc, self.csB, ld)      # this rank's partial colsum(Beta) ...
                     ar(self.csB)                                           # ... summed over ranks
+                ag_out = c["ag_recv"] if self.ag_packed else c["eB_range"]
                 if self.comm is not None:
-                    self.comm.all_gather(c["eB_range"], c["e_own"])
+                    self.comm.all_gather(ag_out, c["e_own"])
                 else:
-                    dist.all_gather_into_tensor(c["eB_range"], c["e_own"])
+                    dist.all_gather_into_tensor(ag_out, c["e_own"])
+                if self.ag_packed:
+                    ops.unpack_rows(ag_out, c["eB_range"], c["hi"] - c["lo"], k, ld)
                 if cuda:
                     c["ag_done"].record(xs)
         self._sc_fresh = False
@@ -669,8 +783,11 @@ class FullBatchCavi:
         """Scatter mode: the current stream waits for the exchanges still in flight on the side streams."""
         views = self._chunk_views or []
         if views and not getattr(self, "_sc_fresh", True):
-            for c in views:
-                self._wait(c["ag_done"])
+            if self._last_native:
+                self._plan.join(torch.cuda.current_stream(self.device).cuda_stream)
+            else:
+                for c in views:
+                    self._wait(c["ag_done"])
             self._sc_fresh = True        # the next iteration re-synchronises its side streams with this one
 
     def _sync_scatter(self):

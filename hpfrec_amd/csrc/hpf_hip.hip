@@ -438,7 +438,8 @@ __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
     int64_t nrows, const float *e_old, float *e_new, float *__restrict__ shp, float *__restrict__ rte,
     float *__restrict__ fac, float *rs, float *__restrict__ rs_prev, const float *__restrict__ cs_other,
     float *__restrict__ cs_partial, float prior_shp, float top_shp, float add_rte, int k, int part_ld,
-    const RowRanges rr) {
+    const RowRanges rr, int e_new_ld) {
+    // e_new_ld: row stride of e_new (LD, or k <= e_new_ld < LD: the packed all-gather send buffer of the sharded path)
     constexpr int CPL = (LD + WAVE - 1) / WAVE;  // factors per lane
     __shared__ float red[WPB][LD];
     const int lane = threadIdx.x & (WAVE - 1);
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
             if (c < LD) {
                 const size_t o = (size_t)r * LD + c;
                 const bool valid = c < k;
-                e_new[(size_t)re * LD + c] = valid ? (float)(ev[q] * inv) : 0.f;
+                if (c < e_new_ld) e_new[(size_t)re * e_new_ld + c] = valid ? (float)(ev[q] * inv) : 0.f;
                 if (shp) shp[o] = valid ? sh[q] : 0.f;
                 if (rte) rte[o] = valid ? rt[q] : 0.f;
                 if (fac) fac[o] = fc[q];
@@ -1456,6 +1457,29 @@ __global__ __launch_bounds__(BLOCK) void uniform_rows_kernel(const uint32_t *__r
     }
 }
 
+// dst[r][0:k] = src[r][0:k] for rows of a packed [n][k] table into a padded [n][ld] one (pad columns are not written):
+// the receive side of the sharded path's k-packed all-gather of new E rows.  vec: one thread per float4 (k % 4 == 0 and
+// 16-byte aligned bases), else one per float.
+__global__ __launch_bounds__(BLOCK) void unpack_rows_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                            long long nrows, int k, int ld, int vec) {
+    if (vec) {
+        const int kq = k >> 2, ldq = ld >> 2;
+        const long long total = nrows * kq;
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        for (long long t = (long long)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * BLOCK) {
+            const long long r = t / kq;
+            d4[r * ldq + (t - r * kq)] = s4[t];
+        }
+    } else {
+        const long long total = nrows * k;
+        for (long long t = (long long)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * BLOCK) {
+            const long long r = t / k;
+            dst[r * ld + (t - r * k)] = src[t];
+        }
+    }
+}
+
 inline int clamp_grid(int64_t want, int grid_blocks) {
     int64_t g = grid_blocks > 0 ? grid_blocks : 2048;
     if (want < g) g = want;
@@ -1600,11 +1624,11 @@ int hpf_hip_row_finalize_f32(const float *part, const int64_t *row_seg_ptr, cons
     if (!row_seg_ptr && !row_list)                                                                                     \
         hipLaunchKernelGGL((row_finalize_kernel<LD, true>), dim3(grid_blocks), dim3(BLOCK), 0, st, part, row_seg_ptr,      \
                            row_list, nrows, e_old, e_new, shp, rte, fac, rs, rs_prev, cs_other, cs_partial, prior_shp,     \
-                           top_shp, add_rte, k, part_ld, rr);                                                              \
+                           top_shp, add_rte, k, part_ld, rr, LD);                                                          \
     else                                                                                                               \
         hipLaunchKernelGGL((row_finalize_kernel<LD, false>), dim3(grid_blocks), dim3(BLOCK), 0, st, part, row_seg_ptr,     \
                            row_list, nrows, e_old, e_new, shp, rte, fac, rs, rs_prev, cs_other, cs_partial, prior_shp,     \
-                           top_shp, add_rte, k, part_ld, rr);
+                           top_shp, add_rte, k, part_ld, rr, LD);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
     return last_error();
@@ -1614,11 +1638,11 @@ int hpf_hip_row_finalize_ranges_f32(const float *acc, int nranges, const int64_t
                                     const int64_t *range_acc_begin, const int64_t *range_row_begin,
                                     const float *e_old, float *e_new, float *shp, float *rte, float *fac, float *rs,
                                     float *rs_prev, const float *cs_other, float *cs_partial, float prior_shp,
-                                    float top_shp, float add_rte, int k, int ld, int acc_ld, int grid_blocks,
-                                    void *stream) {
+                                    float top_shp, float add_rte, int k, int ld, int acc_ld, int e_new_ld,
+                                    int grid_blocks, void *stream) {
     if (!acc || !range_rows || !range_acc_begin || !range_row_begin || !e_old || !e_new || !rs || !cs_other ||
         !cs_partial || nranges <= 0 || nranges > HPF_MAX_ROW_RANGES || k <= 0 || ld != hpf_hip_ld_for_k(k) ||
-        grid_blocks <= 0 || acc_ld < k || acc_ld > ld)
+        grid_blocks <= 0 || acc_ld < k || acc_ld > ld || e_new_ld < k || e_new_ld > ld)
         return HPF_EINVAL;
     RowRanges rr = {};
     rr.n = nranges;
@@ -1634,7 +1658,7 @@ int hpf_hip_row_finalize_ranges_f32(const float *acc, int nranges, const int64_t
 #define CALL(LD)                                                                                                       \
     hipLaunchKernelGGL((row_finalize_kernel<LD, true>), dim3(grid_blocks), dim3(BLOCK), 0, st, acc,                    \
                        (const int64_t *)nullptr, (const int64_t *)nullptr, nrows, e_old, e_new, shp, rte, fac, rs,     \
-                       rs_prev, cs_other, cs_partial, prior_shp, top_shp, add_rte, k, acc_ld, rr);
+                       rs_prev, cs_other, cs_partial, prior_shp, top_shp, add_rte, k, acc_ld, rr, e_new_ld);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
     return last_error();
@@ -1795,6 +1819,18 @@ int hpf_hip_svi_rate_rows_f32(const int64_t *row_list, int64_t nrows, float *rte
                        cs_other, top, add, step, step_prev, mode, k);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
+    return last_error();
+}
+
+int hpf_hip_unpack_rows_f32(const float *src, float *dst, int64_t nrows, int k, int ld, void *stream) {
+    if (nrows == 0) return 0;
+    if (!src || !dst || nrows < 0 || k <= 0 || ld < k || (ld & 3)) return HPF_EINVAL;
+    // float4 path: both row starts must be 16-byte aligned (k % 4 == 0 and an aligned base), else the scalar path
+    const bool vec = ((k & 3) == 0) && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
+    const int64_t work = nrows * (vec ? (k >> 2) : k);
+    const int grid = clamp_grid((work + BLOCK - 1) / BLOCK, 8192);
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, src, dst,
+                       (long long)nrows, k, ld, vec ? 1 : 0);
     return last_error();
 }
 

@@ -1,0 +1,393 @@
+// hpf_shard.hip -- one rank's whole user-sharded CAVI iteration issued from C (include/hpf_hip.h, last section).
+//
+// What this replaces: nothing in the reference (it is single-node OpenMP, cython_loops.pxi:227-259); it is the multi-GPU
+// schedule of SURVEY.md section 8(e) / DESIGN.md section 6 ("scatter" exchange), previously issued call by call from
+// Python (hpfrec_amd/cavi.py, FullBatchCavi._iterate_scatter -- kept as the fallback and as the gloo/CPU test path).
+// Host code only: the kernels are reached through the public C ABI of hpf_hip.hip, the collectives through RCCL's C API
+// resolved at run time from the librccl.so the process has already loaded (never linked: one RCCL instance must serve
+// torch.distributed and this library).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types, enums and prototypes only (decltype below); no RCCL symbol is referenced
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <mutex>
+#include <new>
+
+#include "hpf_hip.h"
+
+namespace {
+
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclReduceScatter) ReduceScatter = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    bool ok = false;
+};
+
+RcclApi g_rccl;
+std::mutex g_rccl_mutex;
+
+inline int rccl_rc(ncclResult_t r) { return r == ncclSuccess ? 0 : HPF_ERCCL_BASE - (int)r; }
+
+#define HPF_TRY(expr)              \
+    do {                           \
+        const int rc__ = (expr);   \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        const hipError_t e__ = (expr);                 \
+        if (e__ != hipSuccess) return (int)e__;        \
+    } while (0)
+
+struct Plan {
+    hpf_shard_desc d;
+    hipStream_t xs;
+    hipEvent_t sw_done[HPF_MAX_ROW_RANGES], ag_done[HPF_MAX_ROW_RANGES], csT_ready, start;
+    int nevents;
+    int64_t m[HPF_MAX_ROW_RANGES];    // rows of this rank's slice of range j (= (hi-lo)/world)
+    int64_t t0[HPF_MAX_ROW_RANGES];   // first row of that slice in acc_own / e_own
+    int nfin;                         // slices with at least one real (non-pad) row
+    int64_t fin_rows[HPF_MAX_ROW_RANGES], fin_acc[HPF_MAX_ROW_RANGES], fin_row0[HPF_MAX_ROW_RANGES];
+    bool fresh;                       // nothing of this plan in flight on the exchange stream
+};
+
+// one collective of the schedule.  `slice`: element offset of this rank's part inside the world-sized buffer
+int collective(Plan *p, int op, const float *send, float *recv, int64_t count, hipStream_t st) {
+    const hpf_shard_desc &d = p->d;
+    if (d.dry_run) {
+        // this rank alone: the one-rank form of the collective on this rank's slice ...
+        const size_t bytes = (size_t)count * sizeof(float);
+        if (op == HPF_COLL_REDUCE_SCATTER)
+            HIP_TRY(hipMemcpyAsync(recv, send + (size_t)d.rank * count, bytes, hipMemcpyDeviceToDevice, st));
+        else if (op == HPF_COLL_ALL_GATHER)
+            HIP_TRY(hipMemcpyAsync(recv + (size_t)d.rank * count, send, bytes, hipMemcpyDeviceToDevice, st));
+        // ... plus a real (one-rank, one-element: identity) RCCL call, so that a launch of RCCL's is paid
+        if (d.comm) {
+            if (!g_rccl.ok) return HPF_ENOLIB;
+            float *tiny = p->d.acc_own;   // (an identity on one element, in order with its readers and writers on `st`)
+            return rccl_rc(g_rccl.AllReduce(tiny, tiny, 1, ncclFloat32, ncclSum, (ncclComm_t)d.comm, st));
+        }
+        return 0;
+    }
+    if (d.coll) return d.coll(d.coll_ctx, op, send, recv, count, (void *)st);
+    if (d.world == 1 && !d.comm) {      // a single rank without a communicator: the identity forms
+        if (op != HPF_COLL_ALL_REDUCE && recv != send)
+            HIP_TRY(hipMemcpyAsync(recv, send, (size_t)count * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return 0;
+    }
+    if (!g_rccl.ok) return HPF_ENOLIB;
+    ncclComm_t comm = (ncclComm_t)d.comm;
+    switch (op) {
+        case HPF_COLL_ALL_REDUCE:
+            return rccl_rc(g_rccl.AllReduce(send, recv, (size_t)count, ncclFloat32, ncclSum, comm, st));
+        case HPF_COLL_REDUCE_SCATTER:
+            return rccl_rc(g_rccl.ReduceScatter(send, recv, (size_t)count, ncclFloat32, ncclSum, comm, st));
+        case HPF_COLL_ALL_GATHER:
+            return rccl_rc(g_rccl.AllGather(send, recv, (size_t)count, ncclFloat32, comm, st));
+    }
+    return HPF_EINVAL;
+}
+
+int all_gather_range(Plan *p, int j, hipStream_t st) {
+    const hpf_shard_desc &d = p->d;
+    const hpf_shard_range &r = d.ranges[j];
+    const int64_t m = p->m[j];
+    if (d.e_own_ld == d.ld)     // padded rows straight into the replicated E table
+        return collective(p, HPF_COLL_ALL_GATHER, d.e_own + (size_t)p->t0[j] * d.ld, d.eB + (size_t)r.lo * d.ld,
+                          m * d.ld, st);
+    // k-packed rows into the receive buffer, then back to the padded layout the sweeps gather from
+    HPF_TRY(collective(p, HPF_COLL_ALL_GATHER, d.e_own + (size_t)p->t0[j] * d.e_own_ld,
+                       d.ag_recv + (size_t)r.lo * d.e_own_ld, m * d.e_own_ld, st));
+    if (d.e_own_ld != d.k) return HPF_EINVAL;
+    return hpf_hip_unpack_rows_f32(d.ag_recv + (size_t)r.lo * d.k, d.eB + (size_t)r.lo * d.ld, r.hi - r.lo, d.k, d.ld,
+                                   (void *)st);
+}
+
+int reduce_scatter_range(Plan *p, int j, hipStream_t st) {
+    const hpf_shard_desc &d = p->d;
+    return collective(p, HPF_COLL_REDUCE_SCATTER, d.acc_i + (size_t)d.ranges[j].lo * d.k,
+                      d.acc_own + (size_t)p->t0[j] * d.k, p->m[j] * d.k, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int hpf_hip_rccl_open(const char *librccl_path) {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.ok) return 0;
+    const char *path = librccl_path ? librccl_path : "librccl.so";
+    // the instance the process has loaded already (torch's), else load it
+    void *h = dlopen(path, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    if (!h) h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return HPF_ENOLIB;
+    RcclApi a;
+    a.handle = h;
+#define HPF_SYM(field, name)                                        \
+    a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, name));  \
+    if (!a.field) return HPF_ENOLIB;
+    HPF_SYM(GetUniqueId, "ncclGetUniqueId")
+    HPF_SYM(CommInitRank, "ncclCommInitRank")
+    HPF_SYM(CommDestroy, "ncclCommDestroy")
+    HPF_SYM(CommCount, "ncclCommCount")
+    HPF_SYM(AllReduce, "ncclAllReduce")
+    HPF_SYM(ReduceScatter, "ncclReduceScatter")
+    HPF_SYM(AllGather, "ncclAllGather")
+#undef HPF_SYM
+    a.ok = true;
+    g_rccl = a;
+    return 0;
+}
+
+int hpf_hip_rccl_unique_id(uint8_t id[128]) {
+    if (!id) return HPF_EINVAL;
+    if (!g_rccl.ok) return HPF_ENOLIB;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId uid;
+    const int rc = rccl_rc(g_rccl.GetUniqueId(&uid));
+    if (rc == 0) memcpy(id, &uid, sizeof(uid));
+    return rc;
+}
+
+int hpf_hip_rccl_comm_init(void **comm, int world, int rank, const uint8_t id[128]) {
+    if (!comm || !id || world <= 0 || rank < 0 || rank >= world) return HPF_EINVAL;
+    if (!g_rccl.ok) return HPF_ENOLIB;
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    ncclComm_t c = nullptr;
+    const int rc = rccl_rc(g_rccl.CommInitRank(&c, world, uid, rank));
+    if (rc == 0) *comm = (void *)c;
+    return rc;
+}
+
+int hpf_hip_rccl_comm_count(void *comm, int *count) {
+    if (!comm || !count) return HPF_EINVAL;
+    if (!g_rccl.ok) return HPF_ENOLIB;
+    return rccl_rc(g_rccl.CommCount((ncclComm_t)comm, count));
+}
+
+int hpf_hip_rccl_comm_destroy(void *comm) {
+    if (!comm) return HPF_EINVAL;
+    if (!g_rccl.ok) return HPF_ENOLIB;
+    return rccl_rc(g_rccl.CommDestroy((ncclComm_t)comm));
+}
+
+int hpf_hip_rccl_all_reduce_f32(void *comm, float *buf, int64_t n, void *stream) {
+    if (!comm || !buf || n < 0) return HPF_EINVAL;
+    if (!g_rccl.ok) return HPF_ENOLIB;
+    if (n == 0) return 0;
+    return rccl_rc(g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, (ncclComm_t)comm, (hipStream_t)stream));
+}
+
+int hpf_hip_rccl_reduce_scatter_f32(void *comm, const float *send, float *recv, int64_t recv_n, void *stream) {
+    if (!comm || !send || !recv || recv_n < 0) return HPF_EINVAL;
+    if (!g_rccl.ok) return HPF_ENOLIB;
+    if (recv_n == 0) return 0;
+    return rccl_rc(g_rccl.ReduceScatter(send, recv, (size_t)recv_n, ncclFloat32, ncclSum, (ncclComm_t)comm,
+                                        (hipStream_t)stream));
+}
+
+int hpf_hip_rccl_all_gather_f32(void *comm, const float *send, float *recv, int64_t send_n, void *stream) {
+    if (!comm || !send || !recv || send_n < 0) return HPF_EINVAL;
+    if (!g_rccl.ok) return HPF_ENOLIB;
+    if (send_n == 0) return 0;
+    return rccl_rc(g_rccl.AllGather(send, recv, (size_t)send_n, ncclFloat32, (ncclComm_t)comm, (hipStream_t)stream));
+}
+
+int hpf_hip_shard_desc_layout(int64_t out[4]) {
+    if (!out) return HPF_EINVAL;
+    out[0] = (int64_t)sizeof(hpf_shard_desc);
+    out[1] = (int64_t)offsetof(hpf_shard_desc, ranges);
+    out[2] = (int64_t)offsetof(hpf_shard_desc, acc_i);
+    out[3] = (int64_t)offsetof(hpf_shard_desc, dry_run);
+    return 0;
+}
+
+int hpf_hip_shard_plan_create(const hpf_shard_desc *desc, void **plan) {
+    if (!desc || !plan) return HPF_EINVAL;
+    const hpf_shard_desc &d = *desc;
+    if (d.world <= 0 || d.rank < 0 || d.rank >= d.world || d.k <= 0 || d.ld != hpf_hip_ld_for_k(d.k) || d.nU <= 0 ||
+        d.nI <= 0 || d.nranges <= 0 || d.nranges > HPF_MAX_ROW_RANGES)
+        return HPF_EINVAL;
+    if (!d.u_segs || d.u_nseg <= 0 || !d.u_idx || !d.u_y || !d.u_row_seg_ptr || (d.u_nmulti > 0 && !d.u_multi_rows) ||
+        !d.i_segs || !d.i_idx || !d.i_y || !d.i_row_seg_ptr)
+        return HPF_EINVAL;
+    if (!d.eB || !d.part_u || !d.part_i || !d.Gamma_shp || !d.Theta || !d.k_rte || !d.k_rte_prev || !d.Lambda_shp ||
+        !d.Beta || !d.t_rte || !d.t_rte_prev || !d.csT || !d.csB || !d.csB_used || !d.csT_part || !d.csB_part ||
+        !d.acc_i || !d.acc_own || !d.e_own || !d.xstream)
+        return HPF_EINVAL;
+    if (d.user_sweep_grid <= 0 || d.user_multi_grid <= 0 || d.user_sweep_grid + d.user_multi_grid > d.csT_part_rows ||
+        d.csB_part_rows <= 0 || d.item_sweep_grid <= 0)
+        return HPF_EINVAL;
+    if (d.e_own_ld != d.ld && (d.e_own_ld != d.k || !d.ag_recv)) return HPF_EINVAL;
+    if (d.dry_run) {
+        if (d.comm) {   // the stand-in call of a dry run must be an identity: a one-rank communicator
+            int n = 0;
+            HPF_TRY(hpf_hip_rccl_comm_count(d.comm, &n));
+            if (n != 1) return HPF_EINVAL;
+        }
+    } else if (d.world > 1 && !d.comm && !d.coll) {
+        return HPF_EINVAL;
+    } else if (d.comm && !d.coll) {
+        int n = 0;
+        HPF_TRY(hpf_hip_rccl_comm_count(d.comm, &n));
+        if (n != d.world) return HPF_EINVAL;
+    }
+    Plan *p = new (std::nothrow) Plan();
+    if (!p) return (int)hipErrorOutOfMemory;
+    p->d = d;
+    p->xs = (hipStream_t)d.xstream;
+    p->nevents = 0;
+    p->nfin = 0;
+    p->fresh = true;
+    int64_t t = 0;
+    for (int j = 0; j < d.nranges; j++) {
+        const hpf_shard_range &r = d.ranges[j];
+        if (r.lo < 0 || r.hi <= r.lo || (r.hi - r.lo) % d.world != 0 || r.nseg < 0 || r.seg_lo < 0 || r.nmulti < 0 ||
+            (r.nmulti > 0 && !r.multi_rows)) {
+            delete p;
+            return HPF_EINVAL;
+        }
+        const int64_t m = (r.hi - r.lo) / d.world;
+        const int64_t o0 = r.lo + (int64_t)d.rank * m;
+        int64_t n_real = d.nI - o0;          // rows of the slice that are real items (the last range ends in pad rows)
+        if (n_real > m) n_real = m;
+        p->m[j] = m;
+        p->t0[j] = t;
+        if (n_real > 0) {
+            p->fin_rows[p->nfin] = n_real;
+            p->fin_acc[p->nfin] = t;
+            p->fin_row0[p->nfin] = o0;
+            p->nfin++;
+        }
+        t += m;
+    }
+    hipEvent_t *evs[2 * HPF_MAX_ROW_RANGES + 2];
+    int ne = 0;
+    for (int j = 0; j < d.nranges; j++) {
+        evs[ne++] = &p->sw_done[j];
+        evs[ne++] = &p->ag_done[j];
+    }
+    evs[ne++] = &p->csT_ready;
+    evs[ne++] = &p->start;
+    for (int i = 0; i < ne; i++) {
+        const hipError_t e = hipEventCreateWithFlags(evs[i], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            for (int q = 0; q < i; q++) (void)hipEventDestroy(*evs[q]);
+            delete p;
+            return (int)e;
+        }
+    }
+    p->nevents = ne;
+    *plan = p;
+    return 0;
+}
+
+int hpf_hip_shard_plan_destroy(void *plan) {
+    if (!plan) return HPF_EINVAL;
+    Plan *p = (Plan *)plan;
+    for (int j = 0; j < p->d.nranges; j++) {
+        (void)hipEventDestroy(p->sw_done[j]);
+        (void)hipEventDestroy(p->ag_done[j]);
+    }
+    (void)hipEventDestroy(p->csT_ready);
+    (void)hipEventDestroy(p->start);
+    delete p;
+    return 0;
+}
+
+int hpf_hip_shard_join(void *plan, void *stream) {
+    if (!plan) return HPF_EINVAL;
+    Plan *p = (Plan *)plan;
+    if (!p->fresh) {
+        // the exchange stream is in order and the last range's all-gather (+ unpack) is the last thing on it
+        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, p->ag_done[p->d.nranges - 1], 0));
+        p->fresh = true;
+    }
+    return 0;
+}
+
+int hpf_hip_shard_iterate(void *plan, const float *eT, float *eT_next, int store, void *compute_stream) {
+    if (!plan || !eT || !eT_next || eT == eT_next) return HPF_EINVAL;
+    Plan *p = (Plan *)plan;
+    const hpf_shard_desc &d = p->d;
+    hipStream_t cs = (hipStream_t)compute_stream, xs = p->xs;
+    const int k = d.k, ld = d.ld;
+    const bool fresh = p->fresh;
+    if (fresh) {   // first iteration after a join: the exchange stream orders itself after whatever the caller queued
+        HIP_TRY(hipEventRecord(p->start, cs));
+        HIP_TRY(hipStreamWaitEvent(xs, p->start, 0));
+    }
+    p->fresh = false;
+    // item pass, range by range: sweep this rank's CSC slice into the packed exchange buffer (split / empty rows via
+    // part[] + segsum), then reduce-scatter the range on the exchange stream
+    for (int j = 0; j < d.nranges; j++) {
+        const hpf_shard_range &r = d.ranges[j];
+        if (!fresh) HIP_TRY(hipStreamWaitEvent(cs, p->ag_done[j], 0));   // the range's E rows of the last iteration
+        if (r.nseg > 0)
+            HPF_TRY(hpf_hip_sweep_f32(d.i_segs + r.seg_lo, r.nseg, d.i_idx, d.i_y, d.eB, eT,
+                                      d.part_i + (size_t)r.seg_lo * ld, d.acc_i, k, k, ld, r.short_rows,
+                                      d.item_sweep_grid, (void *)cs));
+        if (r.nmulti > 0)
+            HPF_TRY(hpf_hip_segsum_f32(d.part_i, d.i_row_seg_ptr, r.multi_rows, r.nmulti, d.acc_i, ld, k, 1, (void *)cs));
+        HIP_TRY(hipEventRecord(p->sw_done[j], cs));
+        HIP_TRY(hipStreamWaitEvent(xs, p->sw_done[j], 0));
+        HPF_TRY(reduce_scatter_range(p, j, xs));
+    }
+    // user side under the exchange: fused sweep + finalizer, the split / empty rows, colsum(Theta) of this rank
+    if (store) HIP_TRY(hipMemcpyAsync(d.csB_used, d.csB, (size_t)ld * sizeof(float), hipMemcpyDeviceToDevice, cs));
+    float *shp = store ? d.Gamma_shp : nullptr, *fac = store ? d.Theta : nullptr;
+    HPF_TRY(hpf_hip_sweep_finalize_f32(d.u_segs, d.u_nseg, d.u_idx, d.u_y, eT, d.eB, d.part_u, eT_next, shp, nullptr, fac,
+                                       d.k_rte, d.k_rte_prev, d.csB, d.csT_part, d.a, d.k_shp, d.add_k_rte, k, ld,
+                                       d.user_sweep_grid, (void *)cs));
+    HPF_TRY(hpf_hip_row_finalize_f32(d.part_u, d.u_row_seg_ptr, d.u_multi_rows, d.u_nmulti, eT, eT_next, shp, nullptr, fac,
+                                     d.k_rte, d.k_rte_prev, d.csB, d.csT_part + (size_t)d.user_sweep_grid * ld, d.a,
+                                     d.k_shp, d.add_k_rte, k, ld, ld, d.user_multi_grid, (void *)cs));
+    HPF_TRY(hpf_hip_colsum_reduce_f32(d.csT_part, d.csT_part_rows, d.csT, ld, (void *)cs));
+    HIP_TRY(hipEventRecord(p->csT_ready, cs));
+    HIP_TRY(hipStreamWaitEvent(xs, p->csT_ready, 0));
+    // one in-order chain on the exchange stream: colsum(Theta) summed over ranks, the finalizer of this rank's slices
+    // of all ranges, the all-gathers of the new E rows, colsum(Beta) summed over ranks ahead of the last all-gather
+    HPF_TRY(collective(p, HPF_COLL_ALL_REDUCE, d.csT, d.csT, ld, xs));
+    if (p->nfin > 0)
+        HPF_TRY(hpf_hip_row_finalize_ranges_f32(d.acc_own, p->nfin, p->fin_rows, p->fin_acc, p->fin_row0, d.eB, d.e_own,
+                                                store ? d.Lambda_shp : nullptr, nullptr, store ? d.Beta : nullptr,
+                                                d.t_rte, d.t_rte_prev, d.csT, d.csB_part, d.c, d.t_shp, d.add_t_rte, k,
+                                                ld, k, d.e_own_ld, d.csB_part_rows, (void *)xs));
+    for (int j = 0; j < d.nranges; j++) {
+        if (j == d.nranges - 1) {
+            HPF_TRY(hpf_hip_colsum_reduce_f32(d.csB_part, d.csB_part_rows, d.csB, ld, (void *)xs));
+            HPF_TRY(collective(p, HPF_COLL_ALL_REDUCE, d.csB, d.csB, ld, xs));
+        }
+        HPF_TRY(all_gather_range(p, j, xs));
+        HIP_TRY(hipEventRecord(p->ag_done[j], xs));
+    }
+    return 0;
+}
+
+int hpf_hip_shard_exchange_only(void *plan, int op, int range, void *stream) {
+    if (!plan) return HPF_EINVAL;
+    Plan *p = (Plan *)plan;
+    const hpf_shard_desc &d = p->d;
+    hipStream_t st = (hipStream_t)stream;
+    if (range < 0) {
+        if (op != HPF_COLL_ALL_REDUCE) return HPF_EINVAL;
+        // scratch between iterations: the reduce-scatter outputs are rewritten before the finalizer reads them
+        return collective(p, HPF_COLL_ALL_REDUCE, d.acc_own, d.acc_own, d.ld, st);
+    }
+    if (range >= d.nranges) return HPF_EINVAL;
+    if (op == HPF_COLL_REDUCE_SCATTER) return reduce_scatter_range(p, range, st);
+    if (op == HPF_COLL_ALL_GATHER) return all_gather_range(p, range, st);   // (idempotent: e_own still holds the rows)
+    return HPF_EINVAL;
+}
+
+}  // extern "C"

@@ -83,8 +83,9 @@ class HipOps:
                    "hpf_hip_row_finalize_f32")
 
     def row_finalize_ranges(self, acc, ranges, e_old, e_new, shp, rte, fac, rs, cs_other, cs_partial, prior_shp,
-                            top_shp, add_rte, k, ld, acc_ld, rs_prev=None):
-        """Dense finalize of several row ranges in one launch; ranges = [(rows, first acc row, first table row)]."""
+                            top_shp, add_rte, k, ld, acc_ld, rs_prev=None, e_new_ld=None):
+        """Dense finalize of several row ranges in one launch; ranges = [(rows, first acc row, first table row)];
+        e_new_ld: row stride of e_new (ld, or k for a packed all-gather send buffer)."""
         import ctypes
         n = len(ranges)
         arr = (ctypes.c_int64 * n)
@@ -92,8 +93,14 @@ class HipOps:
         _lib.check(self.L.hpf_hip_row_finalize_ranges_f32(
             _ptr(acc), n, ctypes.addressof(rows), ctypes.addressof(t0), ctypes.addressof(r0), _ptr(e_old), _ptr(e_new),
             _ptr(shp), _ptr(rte), _ptr(fac), _ptr(rs), _ptr(rs_prev), _ptr(cs_other), _ptr(cs_partial),
-            float(prior_shp), float(top_shp), float(add_rte), k, ld, int(acc_ld), cs_partial.shape[0], self._stream()),
+            float(prior_shp), float(top_shp), float(add_rte), k, ld, int(acc_ld), int(ld if e_new_ld is None else e_new_ld),
+            cs_partial.shape[0], self._stream()),
             "hpf_hip_row_finalize_ranges_f32")
+
+    def unpack_rows(self, src, dst, nrows, k, ld):
+        """dst[r, :k] = src[r, :k]: a packed [nrows, k] table into a padded [nrows, ld] one."""
+        _lib.check(self.L.hpf_hip_unpack_rows_f32(_ptr(src), _ptr(dst), int(nrows), k, ld, self._stream()),
+                   "hpf_hip_unpack_rows_f32")
 
     def colsum_reduce(self, cs_partial, cs_out, ld):
         _lib.check(self.L.hpf_hip_colsum_reduce_f32(_ptr(cs_partial), cs_partial.shape[0], _ptr(cs_out), ld,

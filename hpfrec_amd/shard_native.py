@@ -1,0 +1,87 @@
+"""ctypes binding of the "one rank's whole sharded iteration from C" entries of include/hpf_hip.h
+(hpf_hip_shard_plan_create / _iterate / _join / _exchange_only; hpfrec_amd/csrc/hpf_shard.hip).
+
+cavi.FullBatchCavi builds a ShardPlan over its own device tensors when its exchange mode is "scatter" and the job runs
+on RCCL: an iteration is then ONE host call instead of ~30 (kernel launches through ctypes, torch.distributed
+collectives, stream and event operations).  The Python form of the same schedule (cavi._iterate_scatter) stays as the
+path for gloo / CPU stand-in runs and as the fallback when a plan cannot be created on every rank.
+"""
+import ctypes
+
+from . import _lib
+
+MAX_ROW_RANGES = 8      # HPF_MAX_ROW_RANGES
+COLL_ALL_REDUCE, COLL_REDUCE_SCATTER, COLL_ALL_GATHER = 0, 1, 2
+
+_vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+
+#: hpf_collective_fn: int (*)(void *ctx, int op, const float *send, float *recv, int64_t count, void *stream)
+COLLECTIVE_FN = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _i64, _vp)
+
+
+class ShardRange(ctypes.Structure):
+    """hpf_shard_range"""
+    _fields_ = [("lo", _i64), ("hi", _i64), ("seg_lo", _i64), ("nseg", _i64), ("multi_rows", _vp), ("nmulti", _i64),
+                ("short_rows", _i32), ("reserved", _i32)]
+
+
+class ShardDesc(ctypes.Structure):
+    """hpf_shard_desc (field for field; tests/test_host_logic.py checks the size against the header's)."""
+    _fields_ = [
+        ("world", _i32), ("rank", _i32), ("k", _i32), ("ld", _i32),
+        ("nU", _i64), ("nI", _i64),
+        ("u_segs", _vp), ("u_nseg", _i64), ("u_idx", _vp), ("u_y", _vp),
+        ("u_row_seg_ptr", _vp), ("u_multi_rows", _vp), ("u_nmulti", _i64),
+        ("i_segs", _vp), ("i_idx", _vp), ("i_y", _vp), ("i_row_seg_ptr", _vp),
+        ("nranges", _i32), ("pad0", _i32), ("ranges", ShardRange * MAX_ROW_RANGES),
+        ("eB", _vp), ("part_u", _vp), ("part_i", _vp),
+        ("Gamma_shp", _vp), ("Theta", _vp), ("k_rte", _vp), ("k_rte_prev", _vp),
+        ("Lambda_shp", _vp), ("Beta", _vp), ("t_rte", _vp), ("t_rte_prev", _vp),
+        ("csT", _vp), ("csB", _vp), ("csB_used", _vp),
+        ("csT_part", _vp), ("csT_part_rows", _i32), ("user_sweep_grid", _i32), ("user_multi_grid", _i32), ("pad1", _i32),
+        ("csB_part", _vp), ("csB_part_rows", _i32), ("pad2", _i32),
+        ("acc_i", _vp), ("acc_own", _vp), ("e_own", _vp),
+        ("e_own_ld", _i32), ("item_sweep_grid", _i32),
+        ("ag_recv", _vp),
+        ("a", _f32), ("k_shp", _f32), ("add_k_rte", _f32), ("c", _f32), ("t_shp", _f32), ("add_t_rte", _f32),
+        ("comm", _vp), ("coll", COLLECTIVE_FN), ("coll_ctx", _vp),
+        ("xstream", _vp),
+        ("dry_run", _i32), ("pad3", _i32),
+    ]
+
+
+class ShardPlan:
+    """Owns one hpf_shard plan.  `keep`: whatever must outlive the plan on the Python side (tensors whose pointers the
+    descriptor holds, the callback object of a stand-in collective)."""
+
+    def __init__(self, desc, keep=()):
+        self.L = _lib.lib()
+        self.desc = desc
+        self.keep = list(keep)
+        h = ctypes.c_void_p()
+        rc = self.L.hpf_hip_shard_plan_create(ctypes.byref(desc), ctypes.byref(h))
+        if rc != 0:
+            raise _lib.HpfHipError("hpf_hip_shard_plan_create failed with code %d" % rc)
+        self.handle = h
+
+    def iterate(self, eT, eT_next, store, stream):
+        _lib.check(self.L.hpf_hip_shard_iterate(self.handle, eT.data_ptr(), eT_next.data_ptr(), int(bool(store)), stream),
+                   "hpf_hip_shard_iterate")
+
+    def join(self, stream):
+        _lib.check(self.L.hpf_hip_shard_join(self.handle, stream), "hpf_hip_shard_join")
+
+    def exchange_only(self, op, rng, stream):
+        _lib.check(self.L.hpf_hip_shard_exchange_only(self.handle, int(op), int(rng), stream),
+                   "hpf_hip_shard_exchange_only")
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self.L.hpf_hip_shard_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001
+            pass

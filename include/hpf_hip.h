@@ -10,8 +10,9 @@
  * and binds this ABI through ctypes.
  *
  * Conventions
- *   - every pointer is a DEVICE pointer (e.g. torch.Tensor.data_ptr()); nothing is
- *     allocated, retained or freed by the library; all launches are asynchronous on
+ *   - every pointer is a DEVICE pointer (e.g. torch.Tensor.data_ptr()) unless stated otherwise; no device
+ *     memory is allocated, retained or freed by the library (a shard plan, last section, keeps host-side state:
+ *     a descriptor and a few events); all launches are asynchronous on
  *     `stream` (a hipStream_t passed as void*; NULL = the default stream);
  *   - return value: 0 on success, otherwise the hipError_t of the failed launch or a
  *     negative HPF_E* code for argument errors; no exception crosses the ABI;
@@ -31,10 +32,12 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 11
+#define HPF_HIP_ABI_VERSION 12
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
+#define HPF_ENOLIB (-3)       /* RCCL entry points not bound (hpf_hip_rccl_open failed or was not called) */
+#define HPF_ERCCL_BASE (-1000) /* an RCCL call failed: the return value is HPF_ERCCL_BASE - ncclResult_t */
 
 /* A contiguous run of nonzeros belonging to one sparse row (CSR row of a user, or CSC
  * column of an item).  Rows longer than the segment cap are split into several
@@ -141,15 +144,20 @@ int hpf_hip_row_finalize_f32(const float *part, const int64_t *row_seg_ptr, cons
  * buffer).  The multi-GPU "scatter" exchange leaves each rank with one slice of every item range (the
  * reduce-scatter outputs, concatenated in acc); this finishes all of them at once.  The three range arrays are
  * HOST arrays of nranges <= HPF_MAX_ROW_RANGES entries, read during the call.  cs_partial: grid_blocks rows, all
- * written.
+ * written.  e_new_ld: row stride of e_new -- ld, or k <= e_new_ld < ld when the send buffer is packed (only the first
+ * e_new_ld columns are written; hpf_hip_unpack_rows_f32 restores the padded layout on the receiving side).
  */
 #define HPF_MAX_ROW_RANGES 8
 int hpf_hip_row_finalize_ranges_f32(const float *acc, int nranges, const int64_t *range_rows,
                                     const int64_t *range_acc_begin, const int64_t *range_row_begin,
                                     const float *e_old, float *e_new, float *shp, float *rte, float *fac, float *rs,
                                     float *rs_prev, const float *cs_other, float *cs_partial, float prior_shp,
-                                    float top_shp, float add_rte, int k, int ld, int acc_ld, int grid_blocks,
-                                    void *stream);
+                                    float top_shp, float add_rte, int k, int ld, int acc_ld, int e_new_ld,
+                                    int grid_blocks, void *stream);
+
+/* dst[r][0:k] = src[r][0:k], r < nrows: a packed [nrows][k] table into a padded [nrows][ld] one (pad columns are left
+ * as they are -- zero in an E table).  The receive side of a k-packed all-gather of E rows. */
+int hpf_hip_unpack_rows_f32(const float *src, float *dst, int64_t nrows, int k, int ld, void *stream);
 
 /* cs_out[c] = sum_b cs_partial[b][c], fixed order, double accumulation (Beta.sum(axis=0), PXI:236,255). */
 int hpf_hip_colsum_reduce_f32(const float *cs_partial, int nblk, float *cs_out, int ld, void *stream);
@@ -283,6 +291,98 @@ int hpf_hip_gather_probe_f32(const int32_t *idx, int64_t n, const float *tab, fl
  * HPF.topN, Theta[user].dot(Beta.T) (hpfrec/__init__.py:1337). */
 int hpf_hip_score_rows_f32(const float *vec, const float *tab, int64_t nrows, float *out, int k, int ld,
                            void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Multi-GPU: one rank's whole sharded iteration issued by ONE call (hpfrec_amd/csrc/hpf_shard.hip).
+ *
+ * The reference is single-node OpenMP (PXI:227-259); SURVEY.md section 8(e) shards the users over the GPUs of a node
+ * and exchanges the item statistics once per iteration.  The Python driver (hpfrec_amd/cavi.py, _iterate_scatter)
+ * issues ~12 kernel launches, 6 collectives and ~12 stream/event operations per iteration through ctypes and
+ * torch.distributed: 0.26 ms of host time inside a 0.6 ms iteration at 8 ranks.  The entries below issue the same
+ * schedule from C: the kernels through the entry points above, the collectives through RCCL's C API on a communicator
+ * of the caller's, the dependencies through HIP events on two streams.
+ *
+ * RCCL is NOT linked: hpf_hip_rccl_open() resolves its entry points from the librccl.so the host process has already
+ * loaded (PyTorch ships and loads its own), so that one RCCL instance serves torch.distributed and this library.
+ * A plan retains host-side state only (the descriptor, a few hipEvents); all device memory stays the caller's.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int hpf_hip_rccl_open(const char *librccl_path);   /* NULL: "librccl.so" by the loader's search; idempotent */
+int hpf_hip_rccl_unique_id(uint8_t id[128]);        /* ncclGetUniqueId (rank 0; the id travels by the caller's means) */
+int hpf_hip_rccl_comm_init(void **comm, int world, int rank, const uint8_t id[128]);  /* ncclCommInitRank, current device */
+int hpf_hip_rccl_comm_count(void *comm, int *count);                                  /* ncclCommCount */
+int hpf_hip_rccl_comm_destroy(void *comm);
+/* float32 sum collectives on `stream` (in place all-reduce; recv_n / send_n = elements PER RANK) */
+int hpf_hip_rccl_all_reduce_f32(void *comm, float *buf, int64_t n, void *stream);
+int hpf_hip_rccl_reduce_scatter_f32(void *comm, const float *send, float *recv, int64_t recv_n, void *stream);
+int hpf_hip_rccl_all_gather_f32(void *comm, const float *send, float *recv, int64_t send_n, void *stream);
+
+#define HPF_COLL_ALL_REDUCE 0      /* recv == send, count elements                                  */
+#define HPF_COLL_REDUCE_SCATTER 1  /* count = elements received per rank (send holds world*count)   */
+#define HPF_COLL_ALL_GATHER 2      /* count = elements sent per rank (recv holds world*count)       */
+/* A stand-in for RCCL (tests: gloo ranks sharing one GPU): called instead of RCCL when given; must leave the result
+ * usable by work queued on `stream` afterwards.  Returns 0 on success. */
+typedef int (*hpf_collective_fn)(void *ctx, int op, const float *send, float *recv, int64_t count, void *stream);
+
+/* One item range of the exchange: table rows [lo, hi), (hi - lo) % world == 0 (the last range may run past nI into pad
+ * rows of the item tables); its segments are segs[seg_lo .. seg_lo + nseg) of the item side. */
+typedef struct hpf_shard_range {
+    int64_t lo, hi;
+    int64_t seg_lo, nseg;
+    const int64_t *multi_rows; /* device: rows of the range that are split into several segments or have none */
+    int64_t nmulti;
+    int32_t short_rows;        /* launch hint of hpf_hip_sweep_f32 for this range */
+    int32_t reserved;
+} hpf_shard_range;
+
+/* Everything one rank's iteration touches ("scatter" exchange).  All table pointers are device
+ * memory owned by the caller and must stay valid while the plan lives. */
+typedef struct hpf_shard_desc {
+    int32_t world, rank, k, ld;
+    int64_t nU, nI;                /* this rank's users; all items (the item tables hold ranges[last].hi rows) */
+    /* user side (CSR of this rank's users) */
+    const hpf_segment *u_segs; int64_t u_nseg; const int32_t *u_idx; const float *u_y;
+    const int64_t *u_row_seg_ptr; const int64_t *u_multi_rows; int64_t u_nmulti;
+    /* item side (CSC of this rank's nonzeros) */
+    const hpf_segment *i_segs; const int32_t *i_idx; const float *i_y; const int64_t *i_row_seg_ptr;
+    int32_t nranges, pad0; hpf_shard_range ranges[HPF_MAX_ROW_RANGES];   /* in issue order */
+    /* tables ([rows][ld] unless noted) */
+    float *eB; float *part_u; float *part_i;
+    float *Gamma_shp, *Theta, *k_rte, *k_rte_prev;       /* user outputs ([nU] scalars) */
+    float *Lambda_shp, *Beta, *t_rte, *t_rte_prev;       /* item outputs, current on the owning rank */
+    float *csT, *csB, *csB_used;                          /* [ld] column sums */
+    float *csT_part; int32_t csT_part_rows, user_sweep_grid, user_multi_grid, pad1;
+    float *csB_part; int32_t csB_part_rows, pad2;        /* = finalize grid of this rank's item slices */
+    float *acc_i;                  /* [ranges[last].hi][k] packed exchange buffer (reduce-scatter input) */
+    float *acc_own;                /* [sum of slice lengths][k] reduce-scatter outputs, range after range */
+    float *e_own;                  /* [sum of slice lengths][e_own_ld] new E rows of the slices (all-gather input) */
+    int32_t e_own_ld, item_sweep_grid;   /* e_own_ld = ld: all-gather straight into eB; = k: packed, see ag_recv */
+    float *ag_recv;                /* packed all-gather: [ranges[last].hi][k] receive buffer (may alias acc_i) */
+    float a, k_shp, add_k_rte, c, t_shp, add_t_rte;
+    void *comm;                    /* ncclComm_t (hpf_hip_rccl_comm_init), or NULL */
+    hpf_collective_fn coll; void *coll_ctx;   /* used instead of RCCL when coll != NULL */
+    void *xstream;                 /* the exchange stream (hipStream_t) */
+    int32_t dry_run, pad3;         /* 1: this rank alone -- every collective is its one-rank form (local copy of the
+                                      rank's slice) + a 1-element all-reduce on comm if given: the compute-only
+                                      schedule of a rank, for probes and the bench's exposed-exchange figure */
+} hpf_shard_desc;
+
+/* {sizeof(hpf_shard_desc), offsetof ranges, offsetof acc_i, offsetof dry_run}: lets a foreign-function binding check
+ * its mirror of the struct against the compiled one. */
+int hpf_hip_shard_desc_layout(int64_t out[4]);
+int hpf_hip_shard_plan_create(const hpf_shard_desc *desc, void **plan);
+int hpf_hip_shard_plan_destroy(void *plan);
+/* One iteration on compute_stream (+ the plan's exchange stream): item sweeps per range -> reduce-scatter; the user
+ * side (sweep fused with its finalizer, split rows, colsum) under the exchange; then on the exchange stream the
+ * all-reduce of colsum(Theta), the finalizer of this rank's item slices, all-gathers of the new E rows (each waited
+ * for by the next iteration's sweep of that range only) and the all-reduce of colsum(Beta).  eT: the users' current E
+ * table, eT_next: receives the new one (the caller swaps).  store = 0 skips the six [n][k] output tables. */
+int hpf_hip_shard_iterate(void *plan, const float *eT, float *eT_next, int store, void *compute_stream);
+/* `stream` waits for everything the plan has in flight on its exchange stream (call before reading the item tables,
+ * before work of ANOTHER communicator, and before destroying the plan); the next iterate re-synchronises. */
+int hpf_hip_shard_join(void *plan, void *stream);
+/* 1 (one collective of op HPF_COLL_*) of `count` per-rank elements between scratch regions of the plan's buffers, on
+ * `stream`: the exchange-only timing pass of bench.py.  range < 0: the k-float all-reduce. */
+int hpf_hip_shard_exchange_only(void *plan, int op, int range, void *stream);
 
 #ifdef __cplusplus
 }

@@ -129,9 +129,10 @@ class CpuOps:
         cp[0] = fc.astype(np.float64).sum(axis=0).astype(np.float32)
 
     def row_finalize_ranges(self, acc, ranges, e_old, e_new, shp, rte, fac, rs, cs_other, cs_partial, prior_shp,
-                            top_shp, add_rte, k, ld, acc_ld, rs_prev=None):
+                            top_shp, add_rte, k, ld, acc_ld, rs_prev=None, e_new_ld=None):
         """ranges = [(rows, first acc row, first table row)]: acc / e_new are indexed by accumulator row, the tables
-        by table row (hpf_hip_row_finalize_ranges_f32)."""
+        by table row (hpf_hip_row_finalize_ranges_f32); e_new_ld: row stride of e_new (ld, or k when packed)."""
+        e_ld = ld if e_new_ld is None else int(e_new_ld)
         total = np.zeros(ld, np.float64)
         for n, t0, r0 in ranges:
             if n <= 0:
@@ -143,11 +144,14 @@ class CpuOps:
             cp = torch.zeros_like(cs_partial)
             self.row_finalize(big, None, n, e_old, tmp_e, shp, rte, fac, rs, cs_other, cp, prior_shp, top_shp, add_rte,
                               k, ld, row_list=rows, part_ld=acc_ld, rs_prev=rs_prev)
-            _np(e_new)[t0:t0 + n] = _np(tmp_e)[r0:r0 + n]
+            _np(e_new)[t0:t0 + n, :e_ld] = _np(tmp_e)[r0:r0 + n, :e_ld]
             total += _np(cp).astype(np.float64).sum(axis=0)
         cpo = _np(cs_partial)
         cpo[:] = 0
         cpo[0] = total.astype(np.float32)
+
+    def unpack_rows(self, src, dst, nrows, k, ld):
+        _np(dst)[:nrows, :k] = _np(src).reshape(-1)[: nrows * k].reshape(nrows, k)
 
     def colsum_reduce(self, cs_partial, cs_out, ld):
         _np(cs_out)[:] = _np(cs_partial).astype(np.float64).sum(axis=0).astype(np.float32)

@@ -22,6 +22,45 @@ def run(rank, world, port, out_dir, k, its, case, device="cpu"):
         raise
 
 
+def gloo_collective(dist, model):
+    """hpf_collective_fn for a cavi.FullBatchCavi: the three collectives of the sharded iteration carried by gloo (which
+    stages CUDA tensors through the host), synchronously.  The C side hands over raw device pointers; they are mapped
+    back onto the model's exchange buffers."""
+    import torch
+    bufs = [model.acc_i, model.acc_own_all, model.e_own_all, model.eB, model.csT, model.csB]
+    calls = model.__dict__.setdefault("_native_collective_calls", [0, 0, 0])
+
+    def view(ptr, count):
+        for b in bufs:
+            base = b.data_ptr()
+            if base <= ptr < base + 4 * b.numel():
+                off = (ptr - base) // 4
+                assert off + count <= b.numel()
+                return b.view(-1)[off: off + count]
+        raise KeyError("pointer outside the exchange buffers")
+
+    def coll(ctx, op, send, recv, count, stream):
+        try:
+            W = dist.get_world_size()
+            torch.cuda.synchronize()
+            if op == 0:
+                dist.all_reduce(view(recv, count))
+            elif op == 1:
+                dist.reduce_scatter_tensor(view(recv, count), view(send, count * W))
+            elif op == 2:
+                dist.all_gather_into_tensor(view(recv, count * W), view(send, count))
+            else:
+                return -1
+            torch.cuda.synchronize()
+            calls[op] += 1
+            return 0
+        except BaseException:   # noqa: BLE001  (no exception may cross the C frame)
+            import traceback
+            traceback.print_exc()
+            return -7
+    return coll
+
+
 def _run(rank, world, port, out_dir, k, its, case, device="cpu"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -35,6 +74,9 @@ def _run(rank, world, port, out_dir, k, its, case, device="cpu"):
     else:
         import torch
         torch.cuda.set_device(0)
+        if os.environ.get("HPF_TEST_NATIVE_GLOO") == "1":
+            # the C-issued iteration (hpf_hip_shard_iterate) with gloo standing in for RCCL through its callback hook
+            dist.native_collective = lambda model: gloo_collective(dist, model)
     seed = 123
     if case.endswith("-entropy"):       # random_seed <= 0: OS entropy (PXI:127) -- every rank must end up with rank 0's
         case, seed = case[: -len("-entropy")], 0
@@ -52,6 +94,11 @@ def _run(rank, world, port, out_dir, k, its, case, device="cpu"):
     i, temp, llk = be.fit_hpf(0.3, 0.3, 1.0, 0.3, 0.3, 1.0, Y, iu, ii, Theta, Beta, its, "maxiter", its, 1e-3, 0, 0, None,
                               0, np.zeros(1, np.uint64), "", seed, 1, 1, 0, 0, np.empty(0, np.float32),
                               np.empty(0, np.uint64), np.empty(0, np.uint64), 0, 1, 0)
+    native = 0
+    if os.environ.get("HPF_TEST_NATIVE_GLOO") == "1":
+        from hpfrec_amd import cavi
+        native = int(cavi.NATIVE_PLANS_CREATED[0])
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), Theta=Theta, Beta=Beta, Gamma_shp=temp[0], Gamma_rte=temp[1],
-             Lambda_shp=temp[2], Lambda_rte=temp[3], k_rte=temp[4], t_rte=temp[5], llk=np.float64(llk), niter=i)
+             Lambda_shp=temp[2], Lambda_rte=temp[3], k_rte=temp[4], t_rte=temp[5], llk=np.float64(llk), niter=i,
+             native_plans=native)
     dist.destroy_process_group()

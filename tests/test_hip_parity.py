@@ -444,10 +444,13 @@ def test_fused_and_split_drivers_agree(hip_backend):
 
 
 @pytest.mark.parametrize("mode", ["scatter", "allreduce", "scatter-graph", "scatter-item-stream", "scatter-direct",
-                                  "scatter-direct-graph"])
+                                  "scatter-direct-graph", "scatter-native", "scatter-native-graph",
+                                  "scatter-native-padded"])
 def test_sharded_path_single_rank_nccl(mode):
     """The multi-GPU code path on one GPU with a real RCCL group: "scatter" = asynchronous reduce-scatter / dense
-    finalize of the own slice / all-gather into the E table; "allreduce" = async packed all-reduce + deferred finalize."""
+    finalize of the own slice / all-gather into the E table; "allreduce" = async packed all-reduce + deferred finalize.
+    "native": the library default on RCCL -- the whole iteration issued by one C call on a communicator of our own
+    (hpf_hip_shard_iterate); the other scatter modes pin the call-by-call Python form (HPF_NATIVE_SHARD=0)."""
     import subprocess
     import sys
     if not torch.cuda.is_available():
@@ -455,6 +458,9 @@ def test_sharded_path_single_rank_nccl(mode):
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                HPF_SHARD_MODE=mode.split("-")[0])
+    env["HPF_NATIVE_SHARD"] = "1" if "native" in mode else "0"
+    if mode == "scatter-native-padded":   # all-gather of ld-padded E rows straight into the table (no unpack launch)
+        env["HPF_AG_PACKED"] = "0"
     if mode.endswith("graph"):            # pairs of iterations replayed from a captured hipGraph (RCCL calls included)
         env["HPF_GRAPH"] = "1"
     if "direct" in mode:                  # the collectives on an RCCL communicator of our own (hpfrec_amd/rccl.py)
@@ -468,6 +474,7 @@ def test_sharded_path_single_rank_nccl(mode):
         assert "GRAPH_PAIRS_REPLAYED" in out.stdout, out.stdout[-2000:]
     if "direct" in mode:
         assert "DIRECT_RCCL_USED" in out.stdout, out.stdout[-2000:]
+    assert ("NATIVE_PLAN_USED" in out.stdout) == ("native" in mode), out.stdout[-2000:]
 
 
 @pytest.mark.parametrize("k", [30, 50, 200])
@@ -703,6 +710,8 @@ def test_tiny_shape_priors(hip_backend):
 @pytest.mark.parametrize("world,mode,lazy,k", [(2, "scatter", "1", 20), (3, "scatter", "1", 20),
                                                (2, "scatter", "item-stream", 20), (2, "scatter", "1", 100),
                                                (3, "scatter", "a2a", 20),
+                                               (2, "scatter", "native", 20), (3, "scatter", "native", 50),
+                                               (2, "scatter", "native-padded", 100), (3, "scatter", "packed", 50),
                                                (2, "allreduce", "1", 20), (3, "allreduce", "1", 20),
                                                (2, "allreduce", "0", 20), (2, "allreduce", "1", 100)])
 def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypatch, world, mode, lazy, k):
@@ -716,6 +725,14 @@ def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypat
         lazy = "1"
     if lazy == "a2a":                             # scatter mode, reduce-scatter as all-to-all + local sum
         monkeypatch.setenv("HPF_RS_ALLTOALL", "1")
+        lazy = "1"
+    native = lazy.startswith("native")
+    if native:                                    # the whole iteration issued from C (hpf_hip_shard_iterate), gloo
+        monkeypatch.setenv("HPF_TEST_NATIVE_GLOO", "1")     # standing in for RCCL through the collective callback
+        monkeypatch.setenv("HPF_AG_PACKED", "0" if lazy == "native-padded" else "1")
+        lazy = "1"
+    if lazy == "packed":                          # the Python-issued schedule with the k-packed all-gather
+        monkeypatch.setenv("HPF_AG_PACKED", "1")
         lazy = "1"
     monkeypatch.setenv("HPF_LAZY_ITEMS", lazy)   # all-reduce mode, "0": standalone item finalizer after the exchange
     its = 5
@@ -734,6 +751,8 @@ def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypat
     for r in range(world):
         assert int(outs[r]["niter"]) == i
         assert abs(float(outs[r]["llk"]) / float(llk) - 1) < 1e-6
+        if native:
+            assert int(outs[r]["native_plans"]) >= 1, "the iteration was not issued from C"
         for n in names:
             assert np.max(np.abs(outs[r][n] - single[n]) / np.abs(single[n])) < 1e-5, (r, n)
             assert np.array_equal(outs[r][n], outs[0][n]), (r, n)   # replicas agree bit for bit
@@ -779,7 +798,7 @@ def test_bench_multi_rank_path_selftest(ranks):
                HPF_BENCH_WATCHDOG_S="600")     # (8 gloo ranks SHARING one GPU are slow: not what the watchdog is for)
     for v in ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_FORCE_SHARDED"):
         env.pop(v, None)
-    for v in ("HPF_RS_ALLTOALL", "HPF_GRAPH"):
+    for v in ("HPF_RS_ALLTOALL", "HPF_GRAPH", "HPF_NATIVE_SHARD", "HPF_AG_PACKED", "HPF_RCCL_DIRECT"):
         env.pop(v, None)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
                           "--master-addr", "127.0.0.1", "--master-port", str(29588 + ranks), os.path.join(root, "bench.py"),
@@ -790,13 +809,21 @@ def test_bench_multi_rank_path_selftest(ranks):
     d = json.loads(lines[0])
     assert d["n_gpus"] == ranks and d["steps"] == 2 and d["config"]["state_finite"] is True
     at = d["config"]["exchange_autotune"]
-    assert {"scatter/2", "scatter/1", "scatter/3", "allreduce/3", "scatter/2/item-stream", "scatter/2/all-to-all"} \
+    assert {"scatter/2", "scatter/1", "allreduce/3", "allreduce/2", "scatter/2/item-stream", "scatter/2/all-to-all",
+            "scatter/2/native", "scatter/2/native/packed-ag", "scatter/1/native/packed-ag", "scatter/1/native"} \
         <= set(at["ms_per_iteration"]), at
     assert at["chosen"] in at["ms_per_iteration"]
     # gloo: no communicator of our own, nothing to capture -- reported as failed candidates, not as timings
     assert any(key.endswith("/hipgraph") for key in at["failed"]) and d["config"]["hipgraph_pairs"] is False
     assert any("direct-rccl" in key for key in at["failed"]) and d["config"]["direct_rccl_communicator"] is False
     assert d["roofline"]["events"].startswith("separate pass") and d["cpu_baseline"] is None
+    # the exchange-only / compute-only block every N>1 line carries (here through the gloo callback of the C-issued plan)
+    co = d["collective"]
+    assert "error" not in co, co
+    if "skipped" not in co:      # (skipped only when the chosen configuration has no C-issued plan: all-reduce mode)
+        assert co["ranks"] == ranks and co["rs_ms"] > 0 and co["ag_ms"] > 0 and co["compute_only_ms"] > 0
+        assert co["bytes_per_rank"]["reduce_scatter_buffer"] > 0 and co["busbw_GBps"]["all_gather"] > 0
+        assert abs(co["exposed_ms"] - (co["iteration_ms"] - co["compute_only_ms"])) < 1e-9
 
 
 def test_bench_autotune_on_a_one_rank_rccl_group():
@@ -811,7 +838,7 @@ def test_bench_autotune_on_a_one_rank_rccl_group():
     env = dict(os.environ, HPF_FORCE_SHARDED="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                MASTER_PORT="29577")
     for v in ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_RS_ALLTOALL", "HPF_GRAPH", "HPF_RCCL_DIRECT",
-              "HPF_BENCH_SELFTEST_GLOO"):
+              "HPF_BENCH_SELFTEST_GLOO", "HPF_NATIVE_SHARD", "HPF_AG_PACKED"):
         env.pop(v, None)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
                           "--workload", "small", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
@@ -821,9 +848,14 @@ def test_bench_autotune_on_a_one_rank_rccl_group():
     d = json.loads(lines[0])
     at = d["config"]["exchange_autotune"]
     assert at["failed"] == {}, at
-    assert {"scatter/2/direct-rccl", "scatter/1/direct-rccl"} <= set(at["ms_per_iteration"])
-    assert any(key.endswith("direct-rccl/hipgraph") for key in at["ms_per_iteration"])
+    assert {"scatter/2/direct-rccl", "scatter/2/native", "scatter/2/native/packed-ag", "scatter/1/native/packed-ag",
+            "scatter/1/native"} <= set(at["ms_per_iteration"])
+    assert any("/native" in key and key.endswith("/hipgraph") for key in at["ms_per_iteration"])
     assert d["config"]["state_finite"] is True and d["value"] > 0
+    co = d["collective"]          # exchange alone / compute alone, on the real (one-rank) RCCL communicator
+    assert "error" not in co, co
+    if "skipped" not in co:
+        assert co["ranks"] == 1 and co["ranks_source"].startswith("ncclCommCount") and co["compute_only_ms"] > 0
 
 
 def test_long_horizon_ends_at_the_same_optimum(hip_backend):

@@ -276,15 +276,19 @@ def test_fit_rejects_ids_outside_the_tables(cpu_ops_backend, dtype, bad):
             _fit(cpu_ops_backend, Y, ids[0], ids[1], nU, nI, 8, 2)
 
 
-def test_rccl_unique_id_travels_whole():
-    """The ncclUniqueId rank 0 hands to the others (hpfrec_amd/rccl.py) is 128 BINARY bytes: zeros inside it must
-    survive the trip through a byte tensor (a c_char array field would be cut at the first NUL)."""
+def test_rccl_binding_and_unique_id_bytes():
+    """libhpf_hip.so binds RCCL's entry points at run time from the librccl.so PyTorch ships (dlsym, nothing linked),
+    rejects bad arguments before touching RCCL, and the ncclUniqueId rank 0 hands to the others is carried as 128 BINARY
+    bytes: zeros inside it survive the trip through a byte tensor and into the C array the init call reads."""
     import ctypes
     from hpfrec_amd import rccl
+    L = rccl.open_rccl()
+    assert L.hpf_hip_rccl_open(None) == 0                         # idempotent once bound
+    assert L.hpf_hip_rccl_comm_init(None, 1, 0, None) == -1       # HPF_EINVAL
+    assert L.hpf_hip_rccl_comm_count(None, None) == -1
+    assert L.hpf_hip_rccl_all_reduce_f32(None, None, 4, None) == -1
     raw = bytes([7, 0, 0, 9] + [0] * 60 + list(range(64)))
-    uid = rccl._uid_from(raw)
-    assert ctypes.sizeof(uid) == 128 and rccl._uid_bytes(uid) == raw
-    buf = torch.frombuffer(bytearray(rccl._uid_bytes(uid)), dtype=torch.uint8)
-    assert buf.numel() == 128
-    assert rccl._uid_bytes(rccl._uid_from(buf.numpy().tobytes())) == raw
-    assert rccl._uid_bytes(rccl._UniqueId()) == bytes(128)
+    buf = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    assert buf.numel() == rccl.UID_BYTES and buf.numpy().tobytes() == raw
+    uid = (ctypes.c_uint8 * rccl.UID_BYTES).from_buffer_copy(buf.numpy().tobytes())
+    assert bytes(uid) == raw

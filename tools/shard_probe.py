@@ -71,12 +71,20 @@ class EmulatedRank:
             return _EvWork(e1) if async_op else torch.cuda.current_stream().wait_event(e1) or _Done()
         return dist.all_reduce(t, async_op=async_op) or _Done()
 
-    def direct_comm(self, device):
-        """HPF_RCCL_DIRECT=1: the collectives as calls on a one-rank communicator of our own + the same local copies."""
+    #: HPF_NATIVE_SHARD=1 (the library default): the whole iteration issued by hpf_hip_shard_iterate in its dry-run
+    #: form -- this rank alone, every collective = the local copy of the rank's slice + a one-element call on a one-rank
+    #: RCCL communicator (the same stand-in as the Python paths below use)
+    native_dry_run = True
+
+    def direct_comm(self, device, raw=False):
+        """HPF_RCCL_DIRECT=1: the collectives as calls on a one-rank communicator of our own + the same local copies.
+        raw: the communicator itself (for the native plan's dry run)."""
         emu = self
         if not hasattr(EmulatedRank, "_comm"):
             from hpfrec_amd import rccl
             EmulatedRank._comm = rccl.DirectComm(device)
+        if raw:
+            return EmulatedRank._comm
 
         class Direct:
             def all_reduce(self, t):
@@ -148,8 +156,10 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
             ops.recording = False
             if store:
                 ks = {n: round(v["total_ms"] / steps, 3) for n, v in ops.summary().items()}
-                print("world %d rank %d: %d users, %d nnz: %.3f ms/iteration (all tables stored; host issue time %.3f ms); "
-                      "kernels ms/iter %s%s" % (world, r, u1 - u0, m.nnz, dt, t_issue, ks,
+                print("world %d rank %d [%s%s]: %d users, %d nnz: %.3f ms/iteration (all tables stored; host issue time %.3f ms); "
+                      "kernels ms/iter %s%s" % (world, r, "native C issue" if m._plan is not None else "python issue",
+                                                ", packed all-gather" if getattr(m, "ag_packed", False) else "",
+                                                u1 - u0, m.nnz, dt, t_issue, ks,
                                                 " [hipGraph pairs: %s]" % ("ok" if m.__dict__.get("_graphs", {}).get(True) is not None
                                                                            else getattr(m, "_graph_error", "off")) if many else ""), flush=True)
             else:
