@@ -207,12 +207,13 @@ class FullBatchCavi:
         self.comm = _direct_comm(self.dist, self.device, self.rank, self.world) \
             if (self.shard_mode == "scatter" and not self.rs_alltoall) else None
         self.item_stream = os.environ.get("HPF_ITEM_STREAM", "0") == "1"   # scatter mode: item pass on its own stream
-        # scatter mode: the new E rows are all-gathered k-PACKED (the pad columns -- 22 % of an ld = 64 row at k = 50 --
-        # stay off the links) into the exchange buffer and a streaming kernel restores the padded layout the sweeps
-        # gather from.  "auto": whenever the padding is at least an eighth of the row
-        pk = os.environ.get("HPF_AG_PACKED", "auto")
-        self.ag_packed = self.shard_mode == "scatter" and not self.rs_alltoall and (
-            pk == "1" or (pk == "auto" and 8 * (self.ld - self.k) >= self.ld))
+        # scatter mode, HPF_AG_PACKED=1: the new E rows are all-gathered k-PACKED (the pad columns -- 22 % of an ld = 64
+        # row at k = 50 -- stay off the links) into the exchange buffer and a streaming kernel restores the padded layout
+        # the sweeps gather from.  Off by default: the unpack launch costs 30-40 us per C3 iteration at 8 ranks
+        # (profiles/r03_shard_probe_native_c3_c4.txt) against ~50 us of link time it would save at 300 GB/s -- only a
+        # run on real links can decide, so it is one of bench.py's autotune candidates
+        self.ag_packed = self.shard_mode == "scatter" and not self.rs_alltoall and \
+            os.environ.get("HPF_AG_PACKED", "0") == "1"
         # scatter mode on RCCL: the whole iteration issued by ONE C call (hpf_hip_shard_iterate) on a communicator of
         # our own; HPF_NATIVE_SHARD=0 keeps the call-by-call Python form (also the path of gloo / stand-in runs)
         self._plan = None
