@@ -20,6 +20,7 @@ _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.environ.get("HPF_HIP_SO") or os.path.join(_PKG, "libhpf_hip.so")
 SRC_PATH = os.path.join(_PKG, "csrc", "hpf_hip.hip")          # the kernels + their launchers
 SHARD_SRC_PATH = os.path.join(_PKG, "csrc", "hpf_shard.hip")  # host code: one rank's sharded iteration, RCCL binding
+MT_SRC_PATH = os.path.join(_PKG, "csrc", "hpf_mt19937.hip")   # the MT19937 stream of the initial draws (jump-ahead)
 INC_PATH = os.path.join(_ROOT, "include")
 
 HPF_HIP_ABI_VERSION = 12
@@ -35,6 +36,7 @@ SYMBOLS = (
     "hpf_hip_rccl_comm_destroy", "hpf_hip_rccl_all_reduce_f32", "hpf_hip_rccl_reduce_scatter_f32",
     "hpf_hip_rccl_all_gather_f32", "hpf_hip_shard_plan_create", "hpf_hip_shard_plan_destroy", "hpf_hip_shard_iterate",
     "hpf_hip_shard_join", "hpf_hip_shard_exchange_only", "hpf_hip_shard_desc_layout",
+    "hpf_hip_mt19937_scratch_words", "hpf_hip_mt19937_jump_poly",
 )
 
 _lib = None
@@ -47,11 +49,11 @@ class HpfHipError(RuntimeError):
 def build(force=False, verbose=False):
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     if (not force) and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= max(
-            os.path.getmtime(SRC_PATH), os.path.getmtime(SHARD_SRC_PATH),
+            os.path.getmtime(SRC_PATH), os.path.getmtime(SHARD_SRC_PATH), os.path.getmtime(MT_SRC_PATH),
             os.path.getmtime(os.path.join(INC_PATH, "hpf_hip.h"))):
         return SO_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I" + INC_PATH,
-           "-o", SO_PATH, SRC_PATH, SHARD_SRC_PATH, "-ldl"]
+           "-o", SO_PATH, SRC_PATH, SHARD_SRC_PATH, MT_SRC_PATH, "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -106,7 +108,9 @@ def lib():
     L.hpf_hip_llk_sweep_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     L.hpf_hip_pair_dot_f32.argtypes = [vp, vp, vp, vp, i64, vp, ci, ci, vp]
     L.hpf_hip_score_rows_f32.argtypes = [vp, vp, i64, vp, ci, ci, vp]
-    L.hpf_hip_mt19937_words.argtypes = [vp, vp, i64, vp]
+    L.hpf_hip_mt19937_words.argtypes = [vp, vp, i64, vp, vp]
+    L.hpf_hip_mt19937_scratch_words.argtypes = [i64]
+    L.hpf_hip_mt19937_jump_poly.argtypes = [ci, vp]
     L.hpf_hip_gather_rows.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp]
     L.hpf_hip_fold_in_f32.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, cf, ci, ci, ci, vp]
     L.hpf_hip_fill_segments.argtypes = [vp, vp, vp, vp, i64, ci, vp, vp]
@@ -119,6 +123,7 @@ def lib():
     L.hpf_hip_svi_rate_rows_f32.argtypes = [vp, i64, vp, vp, vp, vp, cf, cf, cf, cf, ci, ci, ci, vp]
     for s in SYMBOLS:
         getattr(L, s).restype = ci
+    L.hpf_hip_mt19937_scratch_words.restype = i64
     if L.hpf_hip_abi_version() != HPF_HIP_ABI_VERSION:
         raise HpfHipError("hpfrec_amd: ABI version mismatch, rebuild libhpf_hip.so")
     _lib = L

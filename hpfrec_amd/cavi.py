@@ -114,8 +114,9 @@ def mt19937_state_words(random_seed):
 
 def draw_init_words(ops, mt_state, nU, nI, k):
     """The 2*(nU + nI)*k stream words initialize_parameters consumes (PXI:127-138), on the current stream; `mt_state`
-    (device int32[625]) is advanced.  One workgroup walks the recurrence (60 ms at C3): callers start it on a side
-    stream before the CSR/CSC build."""
+    (device int32[625]) is advanced.  Long draws are walked by 512-1024 workgroups at once after a polynomial jump-ahead
+    (hpf_mt19937.hip: 2.9 ms for C3's 138M words, 4.2 ms for C5's 552M; one workgroup: 61 / 242 ms); callers still start
+    it on a side stream before the CSR/CSC build."""
     raw = torch.empty(2 * (int(nU) + int(nI)) * int(k), dtype=torch.int32, device=mt_state.device)
     ops.mt19937_words(mt_state, raw)
     return raw

@@ -1376,67 +1376,10 @@ __global__ __launch_bounds__(BLOCK) void gather_probe_kernel(const int32_t *__re
 // ---------------------------------------------------------------------------------------------------------------
 // initialize_parameters (PXI:127-138): the reference fills its four [n,k] tables from ONE MT19937 stream
 // (numpy Generator.random(dtype=float32): one 32-bit output per value, (y >> 8) * 2^-24), as prior + 0.01*U.
-// Two kernels.  (1) The recurrence x[n+624] = x[n+397] ^ A(x[n], x[n+1]) is sequential with 227-word strides, so ONE
-// workgroup walks it: thread t of 227 produces words t, 227+t and 454+t of every 624-word state -- each depends on
-// the OLD state and on the word the SAME thread produced just before (x[i-227]) -- and stores them, untempered, as a
-// linear stream; the state is double-buffered in LDS, one barrier per 624 words.  The stream position carries over
-// between launches (state[624], numpy's `pos`).  (2) Everything else -- tempering, the float conversion, the
-// affine map, the padded table layout, the ratio -- is a chip-wide elementwise pass over the stored words.
+// The stream's state words come from hpf_mt19937.hip (the recurrence, walked by many workgroups at once after a
+// polynomial jump-ahead); everything else -- tempering, the float conversion, the affine map, the padded table layout,
+// the ratio -- is the chip-wide elementwise pass below over the stored words.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t mt_twist(uint32_t hi, uint32_t lo) {
-    const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
-    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-}
-
-__global__ __launch_bounds__(256) void mt19937_words_kernel(uint32_t *__restrict__ state, uint32_t *__restrict__ raw,
-                                                            long long n) {
-    __shared__ uint32_t buf[2][624];
-    const int t = threadIdx.x;
-    for (int i = t; i < 624; i += 256) buf[0][i] = state[i];
-    const int pos = (int)state[624];
-    __syncthreads();
-    for (int i = t; i < 624; i += 256) {             // words left in the current state
-        const long long j = (long long)i - pos;
-        if (j >= 0 && j < n) raw[j] = buf[0][i];
-    }
-    const long long rest = n - (624 - pos);
-    if (rest <= 0) {
-        if (t == 0) state[624] = (uint32_t)(pos + n);
-        return;
-    }
-    const long long nblk = (rest + 623) / 624;
-    uint32_t *dst = raw + (624 - pos) + t;           // this thread's word of the current block, first of three
-    long long left = rest - t;                       // words of the stream from dst on
-    const int tc = t < 170 ? t : 0;                  // (all ten LDS reads of a step are issued together, unconditionally)
-    for (long long b = 0; b < nblk; ++b) {
-        const uint32_t *old = buf[b & 1];
-        uint32_t *nw = buf[(b & 1) ^ 1];
-        if (t < 227) {
-            const uint32_t a0 = old[t], a1 = old[t + 1], am = old[t + 397];
-            const uint32_t b0 = old[227 + t], b1 = old[228 + t];
-            const uint32_t c0 = old[454 + tc], c1 = old[455 + (t < 169 ? t : 0)];
-            const uint32_t w0 = old[0], w1 = old[1], wm = old[397];
-            asm volatile("" ::"v"(w0), "v"(w1), "v"(wm));      // (keeps these reads out of the t == 169 branch: one LDS latency)
-            const uint32_t nA = am ^ mt_twist(a0, a1);
-            const uint32_t nB = nA ^ mt_twist(b0, b1);
-            // word 623 wraps around to the NEW word 0 (recomputed here instead of waiting for thread 0)
-            const uint32_t nC = nB ^ mt_twist(c0, t < 169 ? c1 : (wm ^ mt_twist(w0, w1)));
-            nw[t] = nA;
-            nw[227 + t] = nB;
-            if (t < 170) nw[454 + t] = nC;
-            if (left > 0) dst[0] = nA;
-            if (left > 227) dst[227] = nB;
-            if (t < 170 && left > 454) dst[454] = nC;
-            dst += 624;
-            left -= 624;
-        }
-        __syncthreads();
-    }
-    const uint32_t *fin = buf[nblk & 1];
-    for (int i = t; i < 624; i += 256) state[i] = fin[i];
-    if (t == 0) state[624] = (uint32_t)(rest - 624 * (nblk - 1));
-}
-
 __global__ __launch_bounds__(BLOCK) void uniform_rows_kernel(const uint32_t *__restrict__ raw, float *__restrict__ out,
                                                              const float *__restrict__ den, float *__restrict__ ratio,
                                                              long long nrows, int k, int ld, float base, float scale) {
@@ -1892,13 +1835,6 @@ int hpf_hip_fill_segments(const int64_t *start, const int64_t *count, const int6
     const int grid = clamp_grid((nrows + BLOCK - 1) / BLOCK, 2048);
     hipLaunchKernelGGL(fill_segments_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, start, count,
                        row_seg_ptr, row_ids, nrows, seg_cap, segs);
-    return last_error();
-}
-
-int hpf_hip_mt19937_words(uint32_t *state, uint32_t *raw, int64_t n, void *stream) {
-    if (!state || n < 0 || (n > 0 && !raw)) return HPF_EINVAL;
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(mt19937_words_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, state, raw, (long long)n);
     return last_error();
 }
 

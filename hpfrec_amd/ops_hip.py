@@ -171,8 +171,13 @@ class HipOps:
     def mt19937_words(self, state, raw):
         """raw[:] = the next raw.numel() state words of the MT19937 stream in `state` (int32[625] device tensor:
         numpy's key + pos, advanced in place); the sequential half of initialize_parameters' draws (PXI:127-138)."""
-        _lib.check(self.L.hpf_hip_mt19937_words(_ptr(state), _ptr(raw), int(raw.numel()), self._stream()),
+        n = int(raw.numel())
+        words = int(self.L.hpf_hip_mt19937_scratch_words(n))     # > 0: a long draw, walked by many workgroups at once
+        scratch = torch.empty(words, dtype=torch.int32, device=raw.device) if words > 0 else None
+        _lib.check(self.L.hpf_hip_mt19937_words(_ptr(state), _ptr(raw), n, _ptr(scratch), self._stream()),
                    "hpf_hip_mt19937_words")
+        if scratch is not None:
+            scratch.record_stream(torch.cuda.current_stream(self.device))
 
     def uniform_rows(self, raw, out, nrows, k, ld, base, scale, den=None, ratio=None):
         """out[r, :k] = base + scale*U for the nrows*k stored words `raw` (numpy's float32 uniforms, bit for bit);

@@ -269,7 +269,13 @@ int hpf_hip_fill_segments(const int64_t *start, const int64_t *count, const int6
  * hpf_hip_mt19937_words: the next n words of an MT19937 stream, raw[0..n) -- the recurrence's state words, before the
  *   tempering that turns a word into an output.  `state` is uint32[625] in device memory: numpy's 624 key words + its
  *   `pos` (bit_generator.state); it is left at the stream's new position, so consecutive calls continue one stream like
- *   consecutive numpy draws.  One workgroup: the recurrence is sequential (timing in DESIGN.md).
+ *   consecutive numpy draws.  The recurrence only parallelises over 227 words, so short draws (and any draw without
+ *   scratch) are walked by ONE workgroup (0.27 us per 624 words).  Long draws are cut into 512-1024 chunks, each walked
+ *   by its own workgroup from a state obtained by polynomial jump-ahead (x^n mod the characteristic polynomial of the
+ *   generator, applied as a 19937-term XOR over a window of the stream; hpfrec_amd/csrc/hpf_mt19937.hip): `scratch` must
+ *   then hold hpf_hip_mt19937_scratch_words(n) uint32 words of device memory (0: no scratch needed for this n).
+ * hpf_hip_mt19937_jump_poly: out[0..624) = the coefficients of x^(624 * 2^q) mod phi, bit i of word i/32 (HOST memory;
+ *   lets a test check the jump against a generator's own stepping without a GPU).
  * hpf_hip_uniform_rows_f32: nrows*k stored words -> numpy's Generator.random(dtype=float32) values (tempering, then
  *   (y >> 8) * 2^-24), laid out row-major with leading dimension ld:
  *     out[r*ld + j] = base + scale*U[r*k + j]       (two float32 roundings, like `a_prime + 0.01 * draw`)
@@ -277,7 +283,9 @@ int hpf_hip_fill_segments(const int64_t *start, const int64_t *count, const int6
  *   PXI:140-141; den and ratio are laid out like out).  Pad columns are not written.  A rank of a sharded fit passes
  *   the words of its own rows (raw + row0*k).
  */
-int hpf_hip_mt19937_words(uint32_t *state, uint32_t *raw, int64_t n, void *stream);
+int64_t hpf_hip_mt19937_scratch_words(int64_t n);
+int hpf_hip_mt19937_jump_poly(int q, uint32_t *out);
+int hpf_hip_mt19937_words(uint32_t *state, uint32_t *raw, int64_t n, uint32_t *scratch, void *stream);
 int hpf_hip_uniform_rows_f32(const uint32_t *raw, float *out, const float *den, float *ratio, int64_t nrows, float base,
                              float scale, int k, int ld, void *stream);
 

@@ -949,6 +949,60 @@ def test_mt19937_stream_is_numpys(ops, seed, skip, shapes):
         assert np.array_equal(ratio.cpu().numpy()[:nout, :k], want[row0: row0 + nout] / den.cpu().numpy()[:nout, :k])
 
 
+@pytest.mark.parametrize("seed,skip,n", [(9, 0, (1 << 22) + 17), (31, 407, 624 * 1024 * 8 + 1),
+                                         (123, 0, 2 * (1_000_000 + 380_000) * 50)])
+def test_mt19937_parallel_draw_is_the_serial_stream(ops, seed, skip, n):
+    """Long draws take the jump-ahead path (512-1024 workgroups, hpf_mt19937.hip): the words, the zone past the end and
+    the state left behind equal numpy's -- from a fresh state and from the middle of one; the last case is C3's whole
+    initial draw (138M words)."""
+    dev = ops.device
+    assert int(ops.L.hpf_hip_mt19937_scratch_words(n)) > 0 and int(ops.L.hpf_hip_mt19937_scratch_words(1 << 20)) == 0
+    bg = np.random.MT19937(seed)
+    if skip:
+        bg.random_raw(skip)
+    state = _mt_state_tensor(bg, dev)
+    raw = torch.full((n + 5,), 0x5a5a5a5a, dtype=torch.int32, device=dev)
+    ops.mt19937_words(state, raw[:n])
+    torch.cuda.synchronize()
+    assert torch.all(raw[n:] == 0x5a5a5a5a)
+    ref = cpu_ops.CpuOps()
+    want_state = _mt_state_tensor(bg, "cpu")
+    want = torch.empty(n, dtype=torch.int32)
+    ref.mt19937_words(want_state, want)
+    assert torch.equal(raw[:n].cpu(), want)
+    assert torch.equal(state.cpu(), want_state)
+    # and the stream goes on from there (a short, serial draw on the state the parallel one left)
+    more = torch.empty(1000, dtype=torch.int32, device=dev)
+    ops.mt19937_words(state, more)
+    want_more = torch.empty(1000, dtype=torch.int32)
+    ref.mt19937_words(want_state, want_more)
+    assert torch.equal(more.cpu(), want_more) and torch.equal(state.cpu(), want_state)
+
+
+def test_mt19937_parallel_draw_past_2_to_the_30_words(ops):
+    """A 2^30 + 2^22-word draw (the jump tree then spans polynomials up to x^(624 * 2^20)): its last 4M words and the
+    final state against numpy's generator advanced by 2^30 draws on the host."""
+    dev = ops.device
+    n_skip, n_tail = 1 << 30, 1 << 22
+    n = n_skip + n_tail
+    bg = np.random.MT19937(77)
+    state = _mt_state_tensor(bg, dev)
+    raw = torch.empty(n, dtype=torch.int32, device=dev)
+    ops.mt19937_words(state, raw)
+    tail = raw[n_skip:].cpu()
+    del raw
+    left = n_skip
+    while left > 0:                           # numpy has no arbitrary advance for MT19937: draw and discard
+        step = min(left, 1 << 24)
+        bg.random_raw(step)
+        left -= step
+    want_state = _mt_state_tensor(bg, "cpu")
+    want = torch.empty(n_tail, dtype=torch.int32)
+    cpu_ops.CpuOps().mt19937_words(want_state, want)
+    assert torch.equal(tail, want)
+    assert torch.equal(state.cpu(), want_state)
+
+
 def test_device_initialisation_is_the_reference_draw(ops):
     """cavi.init_state == the host initialize_parameters (the reference's draw order, PXI:127-141), bit for bit, for a
     whole model and for a rank's user shard."""

@@ -292,3 +292,52 @@ def test_rccl_binding_and_unique_id_bytes():
     assert buf.numel() == rccl.UID_BYTES and buf.numpy().tobytes() == raw
     uid = (ctypes.c_uint8 * rccl.UID_BYTES).from_buffer_copy(buf.numpy().tobytes())
     assert bytes(uid) == raw
+
+
+def _mt_key_after(bg, nwords):
+    """numpy's MT19937 key after `nwords` more draws (nwords a multiple of 624, generator at a block boundary)."""
+    left = nwords
+    while left > 0:
+        step = min(left, 624 * 4096)
+        bg.random_raw(step)
+        left -= step
+    st = bg.state["state"]
+    assert int(st["pos"]) == 624
+    return st["key"].astype(np.uint32)
+
+
+@pytest.mark.parametrize("q", [0, 3, 5, 9, 12])
+def test_mt19937_jump_polynomials_against_numpy_stepping(q):
+    """The jump-ahead of the parallel initial draw (hpfrec_amd/csrc/hpf_mt19937.hip): the state 624 * 2^q words ahead is
+    the XOR, over the set coefficients i of x^(624 * 2^q) mod phi, of the stream window z[i .. i+624) -- checked against
+    numpy's own generator stepped that far (which also pins the table of phi's 135 exponents: phi has degree 19937 and
+    q >= 5 needs the reduction).  Host only: the polynomial comes from the library, the XOR is numpy."""
+    import ctypes
+    from hpfrec_amd import _lib
+    L = _lib.lib()
+    poly = np.zeros(624, dtype=np.uint32)
+    assert L.hpf_hip_mt19937_jump_poly(q, poly.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert L.hpf_hip_mt19937_jump_poly(99, poly.ctypes.data_as(ctypes.c_void_p)) == -1
+    bits = np.unpackbits(poly.view(np.uint8), bitorder="little")
+    idx = np.nonzero(bits)[0]
+    assert idx.max() < 19937
+    if q <= 4:
+        assert idx.tolist() == [624 << q]          # still a monomial below the degree
+    else:
+        assert idx.shape[0] >= 134                 # reduced at least once (q = 5: x^31 times phi's low terms)
+    bg = np.random.MT19937(2024)
+    bg.random_raw(624 - int(bg.state["state"]["pos"]))   # (a fresh numpy state has one word left: pos = 623)
+    bg.random_raw(624)                             # one regeneration: every key word is a full stream word now
+    base = bg.state["state"]["key"].astype(np.uint32)
+    # the stream window z[0 .. 19937 + 624) from that state: the key itself, then the following keys
+    walker = np.random.MT19937()
+    walker.state = bg.state
+    win = [base]
+    while sum(w.shape[0] for w in win) < 19937 + 624:
+        win.append(_mt_key_after(walker, 624))
+    z = np.concatenate(win)
+    jumped = np.zeros(624, dtype=np.uint32)
+    for i in idx:
+        jumped ^= z[i: i + 624]
+    want = _mt_key_after(bg, 624 << q)
+    assert np.array_equal(jumped, want)
