@@ -127,9 +127,18 @@ def _whole_table(name):
     return method
 
 
+# every dict method that reads or edits the table as a whole, or whose result depends on whether a key is present in the
+# dict part (setdefault would shadow a mapped id with its default; clear would leave the mapping answering lookups)
 for _n in ("__len__", "__iter__", "__eq__", "__ne__", "__repr__", "keys", "values", "items", "copy", "pop", "popitem",
-           "__delitem__", "__reversed__", "__or__", "__ror__"):
+           "__delitem__", "__reversed__", "__or__", "__ror__", "__ior__", "setdefault", "clear", "update", "__sizeof__",
+           "__reduce_ex__", "__reduce__"):
     setattr(IdTable, _n, _whole_table(_n))
+
+
+def _default_step_size(x):
+    """The reference's default SVI schedule (INIT:207: `lambda x: 1/np.sqrt(x+2)`), as a named function so that a model
+    with default settings can be pickled."""
+    return 1 / np.sqrt(x + 2)
 
 
 class HPF:
@@ -170,7 +179,7 @@ class HPF:
 
     def __init__(self, k=30, a=0.3, a_prime=0.3, b_prime=1.0, c=0.3, c_prime=0.3, d_prime=1.0, ncores=-1,
                  stop_crit='maxiter', check_every=10, stop_thr=1e-3, users_per_batch=None, items_per_batch=None,
-                 step_size=lambda x: 1 / np.sqrt(x + 2), maxiter=100, use_float=True, reindex=True, verbose=True,
+                 step_size=_default_step_size, maxiter=100, use_float=True, reindex=True, verbose=True,
                  random_seed=None, allow_inconsistent_math=False, full_llk=False, alloc_full_phi=False,
                  keep_data=True, save_folder=None, produce_dicts=True, keep_all_objs=True, sum_exp_trick=False):
         assert isinstance(k, int) and k > 0
@@ -889,21 +898,27 @@ class HPF:
             out[~unknown] = self._predict_pairs(user[~unknown], item[~unknown])
         return out
 
+    def __getstate__(self):
+        """Pickles carry host data only (loadable on a machine without this GPU): the device-backed `seen` list is
+        brought down, the device-side id lookups and triplets are dropped (they are caches / fit-time scratch), the
+        state tables pickle through ResidentState's own host-array form."""
+        d = dict(self.__dict__)
+        if d.get("_devbacked_seen") is not None:
+            d["_devbacked_seen"] = [type(self).seen.__get__(self), None]
+        for n in ("_id_lookup", "_dev_triplets", "_tick_t"):
+            d.pop(n, None)
+        return d
+
     def _pair_tables(self, n_pairs):
         """(Theta, Beta) operands for n_pairs listed pairs: the resident device tables when they are current or the
         pairs are many, else the host arrays (the backend then ships only the rows the pairs touch)."""
         st = self._state
         be = self._backend()
-        if (st.on_device("Theta") and st.on_device("Beta")) or 2 * n_pairs >= self.Theta_rows() + self.Beta_rows():
+        rows = int(st.host["Theta"].shape[0]) + int(st.host["Beta"].shape[0])
+        if (st.on_device("Theta") and st.on_device("Beta")) or 2 * n_pairs >= rows:
             ops = be._make_ops()
             return st.table(ops, "Theta"), st.table(ops, "Beta"), True
         return st.peek_host("Theta"), st.peek_host("Beta"), False
-
-    def Theta_rows(self):
-        return int(self._state.host["Theta"].shape[0])
-
-    def Beta_rows(self):
-        return int(self._state.host["Beta"].shape[0])
 
     def _predict_pairs(self, user, item):
         be = self._backend()

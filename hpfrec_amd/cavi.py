@@ -428,6 +428,15 @@ class FullBatchCavi:
             torch.cuda.synchronize(self.device)
             self._sc_fresh = True
         self.niter_done = done0         # capture records the launches, it does not run them
+        # all ranks replay, or none does: a rank that fell back would issue its collectives call by call while its peers
+        # replay theirs -- same count, but nothing guarantees the same order against the control plane's
+        if self.world > 1 and hasattr(self.dist, "ReduceOp"):
+            ok = torch.tensor([1.0 if g is not None else 0.0], device=self.device)
+            self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
+            if float(ok.item()) < 1.0 and g is not None:
+                g = None
+                self._graph_failed = True
+                self._graph_error = "capture failed on another rank"
         graphs[store] = g
         return g
 

@@ -221,6 +221,9 @@ class DeviceBackedArray:
             raise AttributeError(self.name)
         if cell[0] is None:
             cell[0] = cell[1].cpu().numpy()
+        # handed out: the caller may edit the host array in place at any time, so the device copy is no longer trusted
+        # (the same rule ResidentState applies to the state tables); device_of() answers None from now on
+        cell[1] = None
         return cell[0]
 
     def __set__(self, obj, value):

@@ -91,7 +91,7 @@ def test_mid_vs_golden(hip_backend):
 # ---------------------------------------------------------------------------------------------
 # vs the oracle on seeded inputs, other k (every kernel instantiation)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("k", [5, 32, 33, 64, 100, 130, 200, 300])
+@pytest.mark.parametrize("k", [5, 32, 33, 64, 100, 130, 200, 300, 600, 1024])
 def test_other_k_vs_oracle(hip_backend, k):
     iu, ii, Y = datagen.synthetic_hpf_shaped(400, 300, 12000, seed=k)
     nU, nI = 400, 300
@@ -138,7 +138,7 @@ def _rand_tables(rs, n, k, ld):
     return torch.from_numpy(t)
 
 
-@pytest.mark.parametrize("k", [30, 50, 100, 200, 300])
+@pytest.mark.parametrize("k", [30, 50, 100, 200, 300, 600, 1024])
 def test_sweep_op(ops, k):
     rs = np.random.RandomState(k)
     ld = _lib.ld_for_k(k)
@@ -243,7 +243,7 @@ def test_row_finalize_ranges_op(ops, k):
     assert bool((fac.cpu()[~touched] == -1).all()) and bool((fac.cpu()[touched][:, :k] > 0).all())
 
 
-@pytest.mark.parametrize("k", [30, 50, 100, 300])
+@pytest.mark.parametrize("k", [30, 50, 100, 300, 600, 1024])
 def test_row_finalize_expect_colsum_ops(ops, k):
     rs = np.random.RandomState(k + 1)
     ld = _lib.ld_for_k(k)
@@ -319,7 +319,7 @@ def test_device_expectation_against_scipy_grid(ops):
     assert np.all(got.max(axis=1) >= 1.0) and np.all(got.max(axis=1) < 2.0)
 
 
-@pytest.mark.parametrize("k", [30, 50, 200])
+@pytest.mark.parametrize("k", [30, 50, 200, 600, 1024])
 def test_pair_ops(ops, k):
     rs = np.random.RandomState(k)
     ld = _lib.ld_for_k(k)
@@ -367,7 +367,7 @@ def test_invariants_at_2m_nnz(hip_backend):
     assert np.isfinite(arrs["Beta"]).all() and (arrs["Beta"] > 0).all()
 
 
-@pytest.mark.parametrize("k", [30, 50, 100, 300])
+@pytest.mark.parametrize("k", [30, 50, 100, 300, 600, 1024])
 def test_fused_sweep_finalize_op(ops, k):
     """sweep_kernel<FUSE=true> + row_finalize(row_list) == separate sweep + row_finalize over all rows."""
     rs = np.random.RandomState(k + 7)
@@ -477,7 +477,7 @@ def test_sharded_path_single_rank_nccl(mode):
     assert ("NATIVE_PLAN_USED" in out.stdout) == ("native" in mode), out.stdout[-2000:]
 
 
-@pytest.mark.parametrize("k", [30, 50, 200])
+@pytest.mark.parametrize("k", [30, 50, 200, 1024])
 def test_llk_sweep_op(ops, k):
     rs = np.random.RandomState(k + 3)
     ld = _lib.ld_for_k(k)
@@ -607,7 +607,7 @@ def test_svi_row_ops(ops, k):
     assert float(((g2 - w2).abs() / w2.abs().clamp_min(1e-30))[:k].max()) < 2e-6
 
 
-@pytest.mark.parametrize("k", [30, 50, 130, 200, 300])
+@pytest.mark.parametrize("k", [30, 50, 130, 200, 300, 600, 1024])
 @pytest.mark.parametrize("rate_mode,rs_mode,w", [(0, 1, (1.0, 0.0)), (1, 1, (0.35, 0.55)), (0, 2, (1.0, 0.0)),
                                                   (1, 2, (0.6, 0.4)), (1, 0, (0.6, 0.4))])
 def test_svi_side_op(ops, k, rate_mode, rs_mode, w):

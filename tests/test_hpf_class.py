@@ -296,3 +296,40 @@ def test_partial_fit_continues_from_the_tables_a_fit_left_on_the_device(any_back
         assert _maxrel(getattr(a, n), getattr(b, n)) < 2e-6, n
     new = nxt[["ItemId", "Count"]].iloc[:9]
     assert np.allclose(a.predict_factors(new.copy()), b.predict_factors(new.copy()), rtol=1e-5)
+
+
+def test_pickle_carries_host_data_only_and_seen_edits_are_honoured(any_backend):
+    """ADVICE r02: a fitted model pickles without device tensors (seen list, id lookups), the copy predicts the same;
+    once `model.seen` has been handed out, topN(exclude_seen) follows in-place edits of it; the lazily filled id tables
+    behave like the plain dicts of the reference for setdefault / clear / update."""
+    import pickle
+    df, nU, nI = datagen.readme_counts()
+    m = HPF(k=8, maxiter=5, verbose=False, random_seed=1, check_every=None, stop_crit="maxiter")
+    m.fit(df.copy())
+    blob = pickle.dumps(m)
+    import torch
+    assert b"torch" not in blob[:200] and not any(torch.is_tensor(v) for v in m.__getstate__().values())
+    m2 = pickle.loads(blob)
+    u = int(df.UserId.iloc[0])
+    assert np.array_equal(m.topN(u, n=5), m2.topN(u, n=5))
+    assert np.allclose(m.predict(user=[u], item=[int(df.ItemId.iloc[0])]), m2.predict(user=[u], item=[int(df.ItemId.iloc[0])]))
+    # seen handed out -> edits count
+    best = m.topN(u, n=3, exclude_seen=True)
+    seen = m.seen
+    ui = m.user_dict_[u]
+    st, n = int(m._st_ix_user[ui]), int(m._n_seen_by_user[ui])
+    assert n > 0
+    first_seen_item = int(seen[st])
+    seen[st] = m.item_dict_[int(best[0])] if hasattr(m, "item_dict_") else int(best[0])   # pretend she saw the best one
+    again = m.topN(u, n=3, exclude_seen=True)
+    assert int(best[0]) not in [int(x) for x in again]
+    seen[st] = first_seen_item
+    # id tables: whole-table methods see the mapped ids
+    d = m.user_dict_
+    some = int(m.user_mapping_[3])
+    assert d.setdefault(some, -5) == 3 and d[some] == 3
+    d2 = type(d)(m.user_mapping_, getattr(d, "_sorted", None), getattr(d, "_codes", None))
+    d2.update({some: 99})
+    assert d2[some] == 99 and len(d2) == len(m.user_mapping_)
+    d2.clear()
+    assert len(d2) == 0 and some not in d2

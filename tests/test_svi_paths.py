@@ -201,7 +201,8 @@ def test_batch_structures_fast_path_equals_the_tensor_library_path(any_backend, 
 
 
 @pytest.mark.parametrize("k,n,stop_thr,maxiter", [(30, 40, 1e-3, 10), (50, 7, 0.0, 6), (50, 2500, 1e-2, 12),
-                                                 (130, 300, 1e-3, 10), (200, 64, 0.5, 10), (5, 1, 1e-3, 3)])
+                                                 (130, 300, 1e-3, 10), (200, 64, 0.5, 10), (5, 1, 1e-3, 3),
+                                                 (600, 90, 1e-3, 6), (1024, 33, 1e-3, 5)])
 def test_fold_in_one_launch_equals_the_round_trip_path(any_backend, k, n, stop_thr, maxiter):
     """hpf_hip_fold_in_f32 (the whole local coordinate ascent of PXI:505-517 looping on the device) gives what an
     {expect, sweep, segsum} round trip with a host-side check per round gives (tests/fold_in_rounds.py): same Theta,
