@@ -341,3 +341,106 @@ def test_mt19937_jump_polynomials_against_numpy_stepping(q):
         jumped ^= z[i: i + 624]
     want = _mt_key_after(bg, 624 << q)
     assert np.array_equal(jumped, want)
+
+
+def _synth_call(fn_name, params, sig, rs):
+    """Arguments for one recorded call of the reference class into the backend module (tests/golden/swap_calls.json):
+    arrays of the recorded dtype / shape / layout with valid contents chosen by the parameter's name."""
+    by_name = dict(zip(params, sig))
+    tab = by_name.get("Theta") or by_name.get("M1")
+    tabB = by_name.get("Beta") or by_name.get("M2")
+    nU = tab["shape"][0] if tab["ndim"] == 2 else None
+    nI = tabB["shape"][0]
+    k = tabB["shape"][1]
+    ints = {"maxiter": 2, "check_every": 2, "users_per_batch": 0, "items_per_batch": 0, "sum_exp_trick": 0,
+            "random_seed": 5, "verbose": 0, "nthreads": 1, "par_sh": 0, "has_valset": 0, "full_llk": 0, "keep_all_objs": 1,
+            "alloc_full_phi": 0, "k": k, "return_all": 1}
+    floats = {"a": 0.3, "a_prime": 0.3, "b_prime": 1.0, "c": 0.3, "c_prime": 0.3, "d_prime": 1.0, "stop_thr": 1e-3,
+              "add_k_rte": 0.3, "add_t_rte": 0.3, "k_shp": 0.3 + k * 0.3, "t_shp": 0.3 + k * 0.3, "step_size_batch": 0.5,
+              "multiplier_batch": 4.0}
+    batch_users = None
+    if fn_name == "partial_fit":
+        batch_users = np.sort(rs.choice(nU, size=by_name["users_this_batch"]["shape"][0], replace=False))
+        batch_items = np.sort(rs.choice(nI, size=by_name["items_this_batch"]["shape"][0], replace=False))
+    args = []
+    for name, d in zip(params, sig):
+        kind = d["kind"]
+        if kind == "ndarray":
+            shape, dt = tuple(d["shape"]), np.dtype(d["dtype"])
+            n = int(np.prod(shape))
+            if name in ("users_this_batch",):
+                v = batch_users.astype(dt)
+            elif name in ("items_this_batch",):
+                v = batch_items.astype(dt)
+            elif name.startswith("ix_u"):
+                v = (rs.choice(batch_users, size=n) if batch_users is not None else rs.randint(0, nU, size=n)).astype(dt)
+            elif name.startswith("ix_i"):
+                pool = batch_items if batch_users is not None else np.arange(nI)
+                v = (rs.choice(pool, size=n, replace=(fn_name != "calc_user_factors"))).astype(dt)
+            elif name == "st_ix_u":
+                v = np.zeros(shape, dtype=dt)
+            elif name.startswith("Y"):
+                v = (1 + rs.poisson(1.0, size=n)).astype(dt)
+            else:                                   # a table or a scalar-rate column: positive
+                v = (0.3 + rs.random_sample(size=shape)).astype(dt)
+            v = np.ascontiguousarray(v.reshape(shape))
+            assert d["c_contiguous"], (fn_name, name)          # the reference always passes C-contiguous arrays
+            args.append(v)
+        elif kind == "callable":
+            args.append(lambda it: 1.0 / np.sqrt(it + 2))
+        elif kind == "str":
+            args.append(d["value"])
+        elif kind == "bool":
+            args.append(True)
+        elif kind == "int":
+            args.append(int(by_name and ints.get(name, 1)) if name != "nY" else by_name["Y"]["shape"][0])
+        elif kind == "float":
+            args.append(float(floats[name]))
+        else:
+            raise AssertionError((fn_name, name, d))
+    return args
+
+
+def test_backend_accepts_what_the_reference_class_passes(cpu_ops_backend):
+    """tests/golden/swap_calls.json holds the argument kinds / dtypes / shapes the REAL hpfrec.HPF class passed to every
+    function of this backend module when it was swapped in for the compiled extension (tests/golden/swap_check.py, build
+    container; the two runs agreed to 3e-6).  Here, without the reference: every recorded call shape is replayed with
+    synthetic contents -- same arity and order (INIT:650-669, 882, 914-927, 1038, 1145, 1284, 1433), same dtypes
+    (float32 / uint64 / Python scalars), same layouts -- and must be accepted and honour the in-place contracts."""
+    import inspect
+    import json
+    be = cpu_ops_backend
+    rec = json.load(open(os.path.join(GOLDEN, "swap_calls.json")))
+    assert max(rec["agreement_max_rel"].values()) < 1e-4
+    calls = rec["calls"]
+    assert {"fit_hpf", "partial_fit", "calc_user_factors", "calc_llk", "predict_arr", "initialize_parameters", "cast_real_t",
+            "cast_int", "cast_ind_type"} <= set(calls)
+    rs = np.random.RandomState(11)
+    assert be.cast_real_t(0.25) == np.float32(0.25) and isinstance(be.cast_int(3), (int, np.integer))
+    for fn_name in ("fit_hpf", "partial_fit", "calc_user_factors", "calc_llk", "predict_arr", "initialize_parameters"):
+        fn = getattr(be, fn_name)
+        params = [p for p in inspect.signature(fn).parameters if p not in ("device_triplets", "resident")]
+        for sig in calls[fn_name]:
+            assert not any("keyword" in d for d in sig), "the reference passes everything positionally"
+            assert len(sig) == len(params), (fn_name, len(sig), len(params))
+            args = _synth_call(fn_name, params, sig, rs)
+            before = [a.copy() if isinstance(a, np.ndarray) else None for a in args]
+            out = fn(*args)
+            named = dict(zip(params, args))
+            if fn_name == "fit_hpf":
+                i, temp, llk = out
+                assert i == named["maxiter"] - 1 and len(temp) == 6
+                assert np.isfinite(named["Theta"]).all() and np.isfinite(named["Beta"]).all()
+                assert temp[0].shape == named["Theta"].shape and temp[4].shape == (named["Theta"].shape[0], 1)
+            elif fn_name == "partial_fit":
+                assert out is None
+                changed = [n for n, a, b in zip(params, args, before) if isinstance(a, np.ndarray) and not np.array_equal(a, b)]
+                assert {"Theta", "Beta", "Gamma_shp", "Lambda_shp", "k_rte", "t_rte"} <= set(changed), changed
+            elif fn_name == "calc_user_factors":
+                assert len(out) == 3 and out[2].shape == (named["nY"], named["k"]) and np.isfinite(named["Theta"]).all()
+            elif fn_name == "calc_llk":
+                assert np.isfinite(float(out))
+            elif fn_name == "predict_arr":
+                assert out.shape == named["ix_u"].shape and out.dtype == np.float32
+            else:
+                assert len(out) == 6 and out[0].shape == named["Theta"].shape
