@@ -580,10 +580,24 @@ def main():
                     "events": ("timed region (dominant kernel; the per-kernel breakdown is a separate pass of 4 "
                                "iterations)") if events_in_timed
                     else "separate pass of %d iterations after the timed region" % ev_steps}
+            if world == 1 and dom == "sweep_finalize" and len(ops.events.get("sweep_finalize", [])) >= 2:
+                # the two launches of an iteration apart: even = user side (CSR rows, gathers from the item table),
+                # odd = item side (CSC rows, gathers from the user table)
+                ev = ops.events["sweep_finalize"]
+                side = lambda o: float(np.mean([a.elapsed_time(b) for a, b in ev[o::2]]))   # noqa: E731
+                bu = n_loc * (4 + 4 * k) + model.nU * (12 + 20 * k)
+                bi = n_loc * (4 + 4 * k) + model.nI * (4 + 24 * k)
+                roof["per_side"] = {"user_launch_ms": side(0), "item_launch_ms": side(1),
+                                    "user_frac_of_hbm_peak": bu / (side(0) * 1e-3) / HBM_PEAK,
+                                    "item_frac_of_hbm_peak": bi / (side(1) * 1e-3) / HBM_PEAK}
             if traffic:
-                # the PMC bytes over the live launch duration: what the memory side actually moved per second
-                roof["traffic_rate"] = {"GB/s": traffic / t_k / 1e9, "frac_of_peak": traffic / t_k / HBM_PEAK,
-                                        "over_algorithmic": traffic / b_launch}
+                # the PMC bytes over the live launch duration.  FETCH_SIZE / WRITE_SIZE count at the L2 <-> fabric
+                # boundary, so Infinity-Cache hits (the 97 MB item table is MALL-resident) are included: this is a
+                # FABRIC-side rate, an upper bound on what HBM itself moved -- not to be read as an HBM utilisation
+                roof["traffic_rate"] = {"fabric_side_GB/s": traffic / t_k / 1e9,
+                                        "fabric_side_over_hbm_peak": traffic / t_k / HBM_PEAK,
+                                        "over_algorithmic": traffic / b_launch,
+                                        "counts": "L2<->fabric requests (includes Infinity-Cache hits); not HBM-only"}
             if roof["frac"] > 1.0:
                 roof["note"] = ("algorithmic bytes exceed what HBM delivers: at this size the gathered tables stay in "
                                 "L2 / Infinity Cache (each gather is still counted at face value, SURVEY.md section 8d)")

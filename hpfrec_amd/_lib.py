@@ -21,9 +21,11 @@ SO_PATH = os.environ.get("HPF_HIP_SO") or os.path.join(_PKG, "libhpf_hip.so")
 SRC_PATH = os.path.join(_PKG, "csrc", "hpf_hip.hip")          # the kernels + their launchers
 SHARD_SRC_PATH = os.path.join(_PKG, "csrc", "hpf_shard.hip")  # host code: one rank's sharded iteration, RCCL binding
 MT_SRC_PATH = os.path.join(_PKG, "csrc", "hpf_mt19937.hip")   # the MT19937 stream of the initial draws (jump-ahead)
+SVI_SRC_PATH = os.path.join(_PKG, "csrc", "hpf_svi_prep.hip") # index structures of a stochastic batch, on the device
+SOURCES = (SRC_PATH, SHARD_SRC_PATH, MT_SRC_PATH, SVI_SRC_PATH)
 INC_PATH = os.path.join(_ROOT, "include")
 
-HPF_HIP_ABI_VERSION = 12
+HPF_HIP_ABI_VERSION = 13
 
 #: every symbol include/hpf_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = (
@@ -31,7 +33,7 @@ SYMBOLS = (
     "hpf_hip_sweep_finalize_f32", "hpf_hip_sweep_prefinalize_f32",
     "hpf_hip_row_finalize_f32", "hpf_hip_row_finalize_ranges_f32", "hpf_hip_colsum_reduce_f32", "hpf_hip_colsum_f32", "hpf_hip_expect_f32",
     "hpf_hip_segsum_f32", "hpf_hip_pair_llk_f32", "hpf_hip_llk_sweep_f32", "hpf_hip_pair_dot_f32", "hpf_hip_score_rows_f32", "hpf_hip_gather_probe_f32",
-    "hpf_hip_svi_shape_rows_f32", "hpf_hip_svi_refresh_f32", "hpf_hip_svi_rate_rows_f32", "hpf_hip_svi_side_f32", "hpf_hip_mt19937_words", "hpf_hip_uniform_rows_f32", "hpf_hip_gather_rows", "hpf_hip_fill_segments", "hpf_hip_fold_in_f32",
+    "hpf_hip_svi_shape_rows_f32", "hpf_hip_svi_refresh_f32", "hpf_hip_svi_rate_rows_f32", "hpf_hip_svi_side_f32", "hpf_hip_mt19937_words", "hpf_hip_uniform_rows_f32", "hpf_hip_svi_batch_prepare", "hpf_hip_svi_prep_scratch_words", "hpf_hip_svi_batch_sizeof", "hpf_hip_segsum_desc_f32", "hpf_hip_fold_in_f32",
     "hpf_hip_unpack_rows_f32", "hpf_hip_rccl_open", "hpf_hip_rccl_unique_id", "hpf_hip_rccl_comm_init", "hpf_hip_rccl_comm_count",
     "hpf_hip_rccl_comm_destroy", "hpf_hip_rccl_all_reduce_f32", "hpf_hip_rccl_reduce_scatter_f32",
     "hpf_hip_rccl_all_gather_f32", "hpf_hip_shard_plan_create", "hpf_hip_shard_plan_destroy", "hpf_hip_shard_iterate",
@@ -49,11 +51,10 @@ class HpfHipError(RuntimeError):
 def build(force=False, verbose=False):
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     if (not force) and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= max(
-            os.path.getmtime(SRC_PATH), os.path.getmtime(SHARD_SRC_PATH), os.path.getmtime(MT_SRC_PATH),
-            os.path.getmtime(os.path.join(INC_PATH, "hpf_hip.h"))):
+            max(os.path.getmtime(p) for p in SOURCES), os.path.getmtime(os.path.join(INC_PATH, "hpf_hip.h"))):
         return SO_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I" + INC_PATH,
-           "-o", SO_PATH, SRC_PATH, SHARD_SRC_PATH, MT_SRC_PATH, "-ldl"]
+           "-o", SO_PATH] + list(SOURCES) + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -76,7 +77,7 @@ def lib():
     L.hpf_hip_abi_version.argtypes = []
     L.hpf_hip_ld_for_k.argtypes = [ci]
     L.hpf_hip_device_info.argtypes = [ctypes.POINTER(ci), ctypes.c_char_p, ci]
-    L.hpf_hip_sweep_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+    L.hpf_hip_sweep_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp]
     L.hpf_hip_sweep_finalize_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, ci,
                                              ci, ci, vp]
     L.hpf_hip_sweep_prefinalize_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, cf,
@@ -102,7 +103,7 @@ def lib():
     L.hpf_hip_shard_exchange_only.argtypes = [vp, ci, ci, vp]
     L.hpf_hip_colsum_reduce_f32.argtypes = [vp, ci, vp, ci, vp]
     L.hpf_hip_colsum_f32.argtypes = [vp, i64, ci, vp, ci, vp]
-    L.hpf_hip_expect_f32.argtypes = [vp, vp, vp, vp, i64, ci, ci, vp]
+    L.hpf_hip_expect_f32.argtypes = [vp, vp, vp, vp, vp, i64, ci, ci, vp]
     L.hpf_hip_segsum_f32.argtypes = [vp, vp, vp, i64, vp, ci, ci, ci, vp]
     L.hpf_hip_pair_llk_f32.argtypes = [vp, vp, vp, vp, vp, i64, vp, ci, ci, ci, ci, vp]
     L.hpf_hip_llk_sweep_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
@@ -111,9 +112,11 @@ def lib():
     L.hpf_hip_mt19937_words.argtypes = [vp, vp, i64, vp, vp]
     L.hpf_hip_mt19937_scratch_words.argtypes = [i64]
     L.hpf_hip_mt19937_jump_poly.argtypes = [ci, vp]
-    L.hpf_hip_gather_rows.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp]
+    L.hpf_hip_svi_batch_prepare.argtypes = [vp, vp]
+    L.hpf_hip_svi_prep_scratch_words.argtypes = []
+    L.hpf_hip_svi_batch_sizeof.argtypes = []
+    L.hpf_hip_segsum_desc_f32.argtypes = [vp, vp, vp, i64, vp, ci, vp]
     L.hpf_hip_fold_in_f32.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, cf, ci, ci, ci, vp]
-    L.hpf_hip_fill_segments.argtypes = [vp, vp, vp, vp, i64, ci, vp, vp]
     L.hpf_hip_uniform_rows_f32.argtypes = [vp, vp, vp, vp, i64, cf, cf, ci, ci, vp]
     L.hpf_hip_gather_probe_f32.argtypes = [vp, i64, vp, vp, ci, vp]
     L.hpf_hip_svi_shape_rows_f32.argtypes = [vp, i64, vp, vp, vp, cf, cf, cf, ci, ci, ci, vp]
@@ -124,6 +127,8 @@ def lib():
     for s in SYMBOLS:
         getattr(L, s).restype = ci
     L.hpf_hip_mt19937_scratch_words.restype = i64
+    L.hpf_hip_svi_prep_scratch_words.restype = i64
+    L.hpf_hip_svi_batch_sizeof.restype = i64
     if L.hpf_hip_abi_version() != HPF_HIP_ABI_VERSION:
         raise HpfHipError("hpfrec_amd: ABI version mismatch, rebuild libhpf_hip.so")
     _lib = L

@@ -190,6 +190,7 @@ struct FinalizeArgs {  // the row-finalize operands when it is fused into the sw
     float *acc_rows;  // MODE 0/2: packed [rows][acc_ld] accumulator rows of whole-row segments (or null);
                       // MODE 2 also reads last iteration's reduced statistics from it
     int acc_ld;
+    const int64_t *nseg_dev;  // optional: the live segment count on the device (<= nseg; stochastic batches)
 };
 
 // MODE: 0 = plain sweep; 1 = row finalize fused as EPILOGUE of whole-row segments (single GPU);
@@ -214,6 +215,7 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
     const int j = lane % LPR;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * WPB;
+    if (fa.nseg_dev) nseg = min(nseg, fa.nseg_dev[0]);   // (a batch whose size only the device knows)
 
     // FUSE: after the cross-group fold every group holds the whole accumulator row, so the
     // finalize work is dealt out over ALL 64 lanes: lane (g,j) owns the NC factors q = g + t*NG of
@@ -653,29 +655,49 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float *__rest
 }
 
 template <int LD>
+__device__ __forceinline__ void expect_row(const float *__restrict__ shp, const float *__restrict__ rte,
+                                           float *__restrict__ e, int64_t r, int k, int lane) {
+    constexpr int CPL = (LD + WAVE - 1) / WAVE;
+    double ev[CPL];
+    int ehi = 0;
+#pragma unroll
+    for (int q = 0; q < CPL; q++) {
+        const int c = lane + WAVE * q;
+        ev[q] = (c < k) ? expect_ratio(shp[(size_t)r * LD + c], rte[(size_t)r * LD + c]) : 0.0;
+        ehi = max(ehi, __double2hiint(ev[q]));
+    }
+    const double inv = row_pow2_scale(ehi);
+#pragma unroll
+    for (int q = 0; q < CPL; q++) {
+        const int c = lane + WAVE * q;
+        if (c < LD) e[(size_t)r * LD + c] = (c < k) ? (float)(ev[q] * inv) : 0.f;
+    }
+}
+
+template <int LD>
 __global__ __launch_bounds__(BLOCK) void expect_kernel(const float *__restrict__ shp, const float *__restrict__ rte,
                                                        float *__restrict__ e, const int64_t *__restrict__ row_list,
-                                                       int64_t nrows, int k) {
-    constexpr int CPL = (LD + WAVE - 1) / WAVE;
+                                                       const uint8_t *__restrict__ flag, int64_t nrows, int k) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * WPB;
+    if (flag && !row_list) {
+        // the flagged rows of a stochastic step, a few per cent of the table: a wave reads 64 flags at once and visits the
+        // set ones (a flag test per row would walk the whole table at one dependent load per row)
+        for (int64_t g = ((int64_t)blockIdx.x * WPB + wid) * WAVE; g < nrows; g += nwaves * WAVE) {
+            unsigned long long m = __ballot(g + lane < nrows && flag[g + lane] != 0);
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                expect_row<LD>(shp, rte, e, g + b, k, lane);
+            }
+        }
+        return;
+    }
     for (int64_t t = (int64_t)blockIdx.x * WPB + wid; t < nrows; t += nwaves) {
         const int64_t r = row_list ? row_list[t] : t;
-        double ev[CPL];
-        int ehi = 0;
-#pragma unroll
-        for (int q = 0; q < CPL; q++) {
-            const int c = lane + WAVE * q;
-            ev[q] = (c < k) ? expect_ratio(shp[(size_t)r * LD + c], rte[(size_t)r * LD + c]) : 0.0;
-            ehi = max(ehi, __double2hiint(ev[q]));
-        }
-        const double inv = row_pow2_scale(ehi);
-#pragma unroll
-        for (int q = 0; q < CPL; q++) {
-            const int c = lane + WAVE * q;
-            if (c < LD) e[(size_t)r * LD + c] = (c < k) ? (float)(ev[q] * inv) : 0.f;
-        }
+        if (flag && !flag[r]) continue;
+        expect_row<LD>(shp, rte, e, r, k, lane);
     }
 }
 
@@ -822,56 +844,6 @@ __global__ __launch_bounds__(BLOCK) void fold_in_kernel(const int32_t *__restric
             }
         }
         if (lane == 0) rounds[0] = it;
-    }
-}
-
-// ----------------------------------------------------------------------------------------
-// index plumbing of a stochastic batch (svi.py: the batch's rows gathered out of the CSR / CSC, the other side's
-// segments): two launches in place of the ~150 tensor-library launches a batch took -- the batches were bound by
-// the host's launch rate, not by their kernels (profiles/r02_svi_c5_timeline.txt)
-// ----------------------------------------------------------------------------------------
-// row t of the list: its nonzeros src_idx/src_y[src_begin[t] ...) copied to out[dst_begin[t] .. dst_begin[t+1]),
-// out_row = the row's id (one wavefront per row)
-__global__ __launch_bounds__(BLOCK) void gather_rows_kernel(const int64_t *__restrict__ src_begin,
-                                                            const int64_t *__restrict__ dst_begin,
-                                                            const int64_t *__restrict__ row_ids, int64_t nrows,
-                                                            const int32_t *__restrict__ src_idx,
-                                                            const float *__restrict__ src_y,
-                                                            int32_t *__restrict__ out_idx, float *__restrict__ out_y,
-                                                            int32_t *__restrict__ out_row) {
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int64_t nwaves = (int64_t)gridDim.x * WPB;
-    for (int64_t t = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); t < nrows; t += nwaves) {
-        const int64_t s = src_begin[t], d = dst_begin[t];
-        const int64_t n = dst_begin[t + 1] - d;
-        const int32_t r = (int32_t)row_ids[t];
-        for (int64_t i = lane; i < n; i += WAVE) {
-            out_idx[d + i] = src_idx[s + i];
-            out_y[d + i] = src_y[s + i];
-            out_row[d + i] = r;
-        }
-    }
-}
-
-// row t (count[t] > 0 nonzeros from start[t] on, id row_ids[t]) cut into ceil(count/cap) segments, written at
-// segs[row_seg_ptr[t] ...): the layout of layout.build_segments, with the GLOBAL row id in the descriptor
-__global__ __launch_bounds__(BLOCK) void fill_segments_kernel(const int64_t *__restrict__ start,
-                                                              const int64_t *__restrict__ count,
-                                                              const int64_t *__restrict__ row_seg_ptr,
-                                                              const int64_t *__restrict__ row_ids, int64_t nrows,
-                                                              int cap, hpf_segment *__restrict__ segs) {
-    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < nrows; t += (int64_t)gridDim.x * BLOCK) {
-        const int64_t s0 = row_seg_ptr[t], ns = row_seg_ptr[t + 1] - s0;
-        const int64_t b = start[t], c = count[t];
-        const int32_t r = (int32_t)row_ids[t];
-        for (int64_t q = 0; q < ns; ++q) {
-            const int64_t left = c - q * cap;
-            hpf_segment sg;
-            sg.begin = b + q * cap;
-            sg.len = (int32_t)(left < cap ? left : cap) | (ns == 1 ? HPF_SEG_WHOLE_ROW : 0);
-            sg.row = r;
-            segs[s0 + q] = sg;
-        }
     }
 }
 
@@ -1488,7 +1460,7 @@ int hpf_hip_device_info(int *cu_count, char *arch, int arch_len) {
 
 int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
                       const float *tab_self, const float *tab_other, float *part, float *acc_rows, int acc_ld, int k,
-                      int ld, int short_rows, int grid_blocks, void *stream) {
+                      int ld, int short_rows, int grid_blocks, const int64_t *nseg_dev, void *stream) {
     if (nseg == 0) return 0;
     if (!segs || !idx || !y || !tab_self || !tab_other || !part || nseg < 0 || k <= 0 || ld != hpf_hip_ld_for_k(k))
         return HPF_EINVAL;
@@ -1498,6 +1470,7 @@ int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx,
     FinalizeArgs fa = {};
     fa.acc_rows = acc_rows;
     fa.acc_ld = acc_ld;
+    fa.nseg_dev = nseg_dev;
     // short rows (a batch or a shard of a many-rank run: ~16 nonzeros per row): half the gathers in flight per wave
     // fill just as well and the smaller register file buys occupancy (-15 % at N=8)
     constexpr int US = (HPF_U >= 8) ? HPF_U / 2 : HPF_U;
@@ -1524,7 +1497,7 @@ int hpf_hip_sweep_finalize_f32(const hpf_segment *segs, int64_t nseg, const int3
     hipStream_t st = (hipStream_t)stream;
     // grid NOT clamped: every block writes its cs_partial row
     const FinalizeArgs fa = {cs_other, cs_partial, e_new, shp, rte, fac, rs, prior_shp, top_shp, add_rte, k, rs_prev,
-                             nullptr, 0};
+                             nullptr, 0, nullptr};
 #define CALL(LPR, VPL)                                                                                            \
     hipLaunchKernelGGL((sweep_kernel<LPR, VPL, 1>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg, idx, y,    \
                        tab_self, tab_other, part, fa);
@@ -1544,7 +1517,7 @@ int hpf_hip_sweep_prefinalize_f32(const hpf_segment *segs, int64_t nseg, const i
     hipStream_t st = (hipStream_t)stream;
     // grid NOT clamped: every block writes its cs_partial row
     const FinalizeArgs fa = {cs_other, cs_partial, tab_self, shp, rte, fac, rs, prior_shp, top_shp, add_rte, k,
-                             rs_prev, acc_rows, acc_ld};
+                             rs_prev, acc_rows, acc_ld, nullptr};
 #define CALL(LPR, VPL)                                                                                          \
     hipLaunchKernelGGL((sweep_kernel<LPR, VPL, 2>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg, idx, y,    \
                        (const float *)tab_self, tab_other, part, fa);
@@ -1624,14 +1597,15 @@ int hpf_hip_colsum_f32(const float *tab, int64_t nrows, int ld, float *cs_partia
     return last_error();
 }
 
-int hpf_hip_expect_f32(const float *shp, const float *rte, float *e, const int64_t *row_list, int64_t nrows, int k,
-                       int ld, void *stream) {
+int hpf_hip_expect_f32(const float *shp, const float *rte, float *e, const int64_t *row_list, const uint8_t *flag,
+                       int64_t nrows, int k, int ld, void *stream) {
     if (nrows == 0) return 0;
     if (!shp || !rte || !e || nrows < 0 || k <= 0 || ld != hpf_hip_ld_for_k(k)) return HPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const int grid = clamp_grid((nrows + WPB - 1) / WPB, 2048);
+    const int grid = (flag && !row_list) ? clamp_grid((nrows + WPB * WAVE - 1) / (WPB * WAVE), 2048)
+                                         : clamp_grid((nrows + WPB - 1) / WPB, 2048);
 #define CALL(LD) \
-    hipLaunchKernelGGL((expect_kernel<LD>), dim3(grid), dim3(BLOCK), 0, st, shp, rte, e, row_list, nrows, k);
+    hipLaunchKernelGGL((expect_kernel<LD>), dim3(grid), dim3(BLOCK), 0, st, shp, rte, e, row_list, flag, nrows, k);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
     return last_error();
@@ -1811,30 +1785,6 @@ int hpf_hip_fold_in_f32(const int32_t *idx, const float *y, int64_t n, const flo
                        e_last, rounds, prior, top, add, rs, stop_thr, maxiter, k);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
-    return last_error();
-}
-
-int hpf_hip_gather_rows(const int64_t *src_begin, const int64_t *dst_begin, const int64_t *row_ids, int64_t nrows,
-                        const int32_t *src_idx, const float *src_y, int32_t *out_idx, float *out_y, int32_t *out_row,
-                        void *stream) {
-    if (nrows == 0) return 0;
-    if (!src_begin || !dst_begin || !row_ids || !src_idx || !src_y || !out_idx || !out_y || !out_row || nrows < 0)
-        return HPF_EINVAL;
-    const int grid = clamp_grid((nrows + WPB - 1) / WPB, 4096);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, src_begin, dst_begin,
-                       row_ids, nrows, src_idx, src_y, out_idx, out_y, out_row);
-    return last_error();
-}
-
-int hpf_hip_fill_segments(const int64_t *start, const int64_t *count, const int64_t *row_seg_ptr,
-                          const int64_t *row_ids, int64_t nrows, int seg_cap, hpf_segment *segs, void *stream) {
-    if (nrows == 0) return 0;
-    if (!start || !count || !row_seg_ptr || !row_ids || !segs || nrows < 0 || seg_cap <= 0 ||
-        seg_cap > HPF_SEG_LEN_MASK)
-        return HPF_EINVAL;
-    const int grid = clamp_grid((nrows + BLOCK - 1) / BLOCK, 2048);
-    hipLaunchKernelGGL(fill_segments_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, start, count,
-                       row_seg_ptr, row_ids, nrows, seg_cap, segs);
     return last_error();
 }
 

@@ -336,7 +336,7 @@ int hpf_hip_shard_iterate(void *plan, const float *eT, float *eT_next, int store
         if (r.nseg > 0)
             HPF_TRY(hpf_hip_sweep_f32(d.i_segs + r.seg_lo, r.nseg, d.i_idx, d.i_y, d.eB, eT,
                                       d.part_i + (size_t)r.seg_lo * ld, d.acc_i, k, k, ld, r.short_rows,
-                                      d.item_sweep_grid, (void *)cs));
+                                      d.item_sweep_grid, nullptr, (void *)cs));
         if (r.nmulti > 0)
             HPF_TRY(hpf_hip_segsum_f32(d.part_i, d.i_row_seg_ptr, r.multi_rows, r.nmulti, d.acc_i, ld, k, 1, (void *)cs));
         HIP_TRY(hipEventRecord(p->sw_done[j], cs));

@@ -1,0 +1,548 @@
+// hpf_svi_prep.hip -- the index structures of one stochastic batch, built on the device by ONE host call.
+//
+// What this replaces (reference: /root/reference/hpfrec/cython_loops.pxi = "PXI"): an SVI epoch slices its data per batch
+// with numpy fancy indexing on the host -- the batch's rows of the CSR (PXI:280-290) or of scipy's CSC (PXI:332-342),
+// and the set of other-side rows they touch (get_unique_items_batch, PXI:27-42).  Rounds 1-2 of this build did the
+// equivalent with host numpy over a host copy of the row pointers, a pinned upload, a device sort, a histogram and a few
+// size read-backs per batch: 0.35 s of host work in a 0.56 s epoch loop at BASELINE config C5
+// (profiles/r02_final_svi_c5.txt).  Here a batch costs the host one call and no read-back:
+//
+//   own side   (the batch's rows of the side it is drawn from): nothing is copied -- the batch's segment list is the
+//              stable compaction of the side's GLOBAL segment list by a per-row flag, its descriptors keep pointing into the
+//              global idx / y arrays;
+//   other side (the same nonzeros grouped by the other side's rows): the other side's global layout already holds every
+//              row's nonzeros in ascending order of the own side's ids, so the batch's view of it is that layout FILTERED by
+//              the flag -- a count pass, a scan over rows, a write pass: stable, deterministic, no sort.
+//
+// Every data-dependent size stays on the device (`sizes`); the consumers (hpf_hip_sweep_f32, hpf_hip_expect_f32,
+// hpf_hip_segsum_desc_f32) read their trip counts from there, and the buffers are sized once per fit from a bound.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hpf_hip.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256;
+constexpr int WPB = BLOCK / WAVE;
+constexpr int TILES = 1024;           // scan tiles (= blocks of the two-launch scans)
+
+// exclusive prefix of NC int64 components over the threads of a block, plus the block totals
+template <int NC>
+__device__ __forceinline__ void block_exclusive_scan(const long long (&v)[NC], long long (&excl)[NC], long long (&total)[NC]) {
+    __shared__ long long wsum[WPB][NC];
+    const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x >> 6;
+    long long inc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        long long x = v[c];
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const long long y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        inc[c] = x;
+    }
+    __syncthreads();                  // (wsum may still be read by the previous call)
+    if (lane == WAVE - 1) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) wsum[wid][c] = inc[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        long long before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < WPB; w++) {
+            const long long s = wsum[w][c];
+            if (w < wid) before += s;
+            all += s;
+        }
+        excl[c] = before + inc[c] - v[c];
+        total[c] = all;
+    }
+}
+
+// sum over tiles before `tile` of the per-tile totals (NC components each) -- every block does its own: TILES is small
+template <int NC>
+__device__ __forceinline__ void tiles_before(const long long *__restrict__ tiles, int tile, long long (&before)[NC],
+                                             long long (&all)[NC]) {
+    long long mine[NC], tot[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) mine[c] = tot[c] = 0;
+    for (int t = threadIdx.x; t < TILES; t += BLOCK) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const long long x = tiles[(size_t)t * NC + c];
+            tot[c] += x;
+            if (t < tile) mine[c] += x;
+        }
+    }
+    long long e1[NC], e2[NC];
+    block_exclusive_scan<NC>(mine, e1, before);
+    block_exclusive_scan<NC>(tot, e2, all);
+}
+
+// (1) flags of the batch's rows: the previous batch that used this workspace is unmarked, the new one marked; a batch row
+// without any nonzero gets its accumulator row zeroed (the dense step reads acc[row] of every flagged row)
+__global__ __launch_bounds__(BLOCK) void svi_mark_kernel(const int64_t *__restrict__ prev_ids, int64_t nprev,
+                                                         const int64_t *__restrict__ ids, int64_t nids,
+                                                         uint8_t *__restrict__ flag, const int64_t *__restrict__ indptr,
+                                                         float *__restrict__ acc, int ld, int phase) {
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    if (phase == 0) {
+        for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < nprev; t += stride) flag[prev_ids[t]] = 0;
+        return;
+    }
+    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < nids; t += stride) {
+        const int64_t r = ids[t];
+        flag[r] = 1;
+        if (indptr[r + 1] == indptr[r]) {           // (ld is a multiple of 32 and rows are 128-byte aligned)
+            float4 *row = reinterpret_cast<float4 *>(acc + (size_t)r * ld);
+            for (int c = 0; c < ld / 4; c++) row[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+// (2a) own side: per tile of the side's global segment list, how many segments belong to flagged rows and how many of
+// those open a split row
+__global__ __launch_bounds__(BLOCK) void svi_own_count_kernel(const hpf_segment *__restrict__ segs, int64_t nseg,
+                                                              const uint8_t *__restrict__ flag,
+                                                              long long *__restrict__ tiles) {
+    const int64_t per = (nseg + TILES - 1) / TILES;
+    const int64_t s0 = (int64_t)blockIdx.x * per, s1 = min(nseg, s0 + per);
+    long long v[2] = {0, 0};
+    for (int64_t s = s0 + threadIdx.x; s < s1; s += BLOCK) {
+        const hpf_segment g = segs[s];
+        if (flag[g.row]) {
+            v[0]++;
+            // the first segment of a split row: not flagged whole-row, and the previous segment is another row's
+            if (!(g.len & HPF_SEG_WHOLE_ROW) && (s == 0 || segs[s - 1].row != g.row)) v[1]++;
+        }
+    }
+    long long e[2], tot[2];
+    block_exclusive_scan<2>(v, e, tot);
+    if (threadIdx.x == 0) {
+        tiles[(size_t)blockIdx.x * 2 + 0] = tot[0];
+        tiles[(size_t)blockIdx.x * 2 + 1] = tot[1];
+    }
+}
+
+// (2b) own side: the stable compaction itself.  b_segs = the flagged rows' descriptors (unchanged: they index the global
+// idx / y); b_multi[m] = {first compacted segment, segments, row} of every split row of the batch
+__global__ __launch_bounds__(BLOCK) void svi_own_write_kernel(const hpf_segment *__restrict__ segs, int64_t nseg,
+                                                              const int64_t *__restrict__ row_seg_ptr,
+                                                              const uint8_t *__restrict__ flag,
+                                                              const long long *__restrict__ tiles,
+                                                              hpf_segment *__restrict__ b_segs, int64_t b_cap,
+                                                              int64_t *__restrict__ b_multi, int64_t m_cap,
+                                                              int64_t *__restrict__ sizes) {
+    long long base[2], all[2];
+    tiles_before<2>(tiles, blockIdx.x, base, all);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sizes[0] = min((long long)b_cap, all[0]);
+        sizes[1] = min((long long)m_cap, all[1]);
+        if (all[0] > b_cap || all[1] > m_cap) sizes[7] = 1;      // overflow (cannot happen with the caller's bound)
+    }
+    const int64_t per = (nseg + TILES - 1) / TILES;
+    const int64_t s0 = (int64_t)blockIdx.x * per, s1 = min(nseg, s0 + per);
+    for (int64_t c0 = s0; c0 < s1; c0 += BLOCK) {                 // chunks of BLOCK segments, in order
+        const int64_t s = c0 + threadIdx.x;
+        long long v[2] = {0, 0};
+        hpf_segment g;
+        g.begin = 0;
+        g.len = 0;
+        g.row = 0;
+        bool keep = false, opens = false;
+        if (s < s1) {
+            g = segs[s];
+            keep = flag[g.row] != 0;
+            opens = keep && !(g.len & HPF_SEG_WHOLE_ROW) && (s == 0 || segs[s - 1].row != g.row);
+            v[0] = keep;
+            v[1] = opens;
+        }
+        long long e[2], tot[2];
+        block_exclusive_scan<2>(v, e, tot);
+        const long long pos = base[0] + e[0], mpos = base[1] + e[1];
+        if (keep && pos < b_cap) b_segs[pos] = g;
+        if (opens && mpos < m_cap) {
+            b_multi[mpos * 3 + 0] = pos;
+            b_multi[mpos * 3 + 1] = row_seg_ptr[g.row + 1] - row_seg_ptr[g.row];
+            b_multi[mpos * 3 + 2] = g.row;
+        }
+        base[0] += tot[0];
+        base[1] += tot[1];
+    }
+}
+
+// ---- other side: the side's flat nonzero array (grouped by its rows, own-side ids ascending inside a row) FILTERED by the
+// own side's flag.  Flat order is row order, so the compaction keeps exactly the order a stable sort by row would give.
+// Entry e is kept iff flag[idx[e]]; its output position is P(e) = kept entries before e, read off a bitmask + a prefix per
+// tile of 1024 entries: no pass over the nonzeros ever depends on a row's length.
+constexpr int CHUNKS_PER_TILE = 16;       // 64-entry chunks per tile
+
+// (3a') the own side's flags as a bitset (a 1M-row side: 128 KB -- it fits the LDS of a CU, the byte table does not)
+__global__ __launch_bounds__(BLOCK) void svi_flag_bits_kernel(const uint8_t *__restrict__ flag, int64_t nrows,
+                                                              uint32_t *__restrict__ bits) {
+    const int64_t nwords = (nrows + 31) / 32;
+    for (int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < nwords; w += (int64_t)gridDim.x * BLOCK) {
+        uint32_t v = 0;
+        for (int b = 0; b < 32; b++) {
+            const int64_t r = w * 32 + b;
+            if (r < nrows && flag[r]) v |= 1u << b;
+        }
+        bits[w] = v;
+    }
+}
+
+// (3a) one wavefront per tile of 1024 entries: mask[c] = keep bits of entries [64c, 64c+64) for its 16 chunks, chunk_pre[c] =
+// kept entries of the tile before chunk c, tile_cnt[t] = kept entries of the tile.  Four chunks' loads are in flight at once.
+// The 48M flag look-ups are the cost: as byte gathers from memory they bound the kernel at ~4x the time the id stream
+// takes; LDS_BITS: every workgroup (1024 threads, one per CU) first copies the bitset into LDS and looks the ids up there.
+template <bool LDS_BITS>
+__global__ __launch_bounds__(1024) void svi_oth_mask_kernel(const int32_t *__restrict__ idx, int64_t nnz,
+                                                            const uint32_t *__restrict__ bits, int64_t nwords,
+                                                            unsigned long long *__restrict__ mask,
+                                                            uint16_t *__restrict__ chunk_pre,
+                                                            int32_t *__restrict__ tile_cnt) {
+    extern __shared__ uint32_t lbits[];
+    const uint32_t *tab = bits;
+    if constexpr (LDS_BITS) {
+        for (int64_t w = threadIdx.x; w < nwords; w += blockDim.x) lbits[w] = bits[w];
+        __syncthreads();
+        tab = lbits;
+    }
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wpb = blockDim.x / WAVE;
+    const int64_t ntiles = (nnz + 1023) / 1024;
+    const int64_t nwaves = (int64_t)gridDim.x * wpb;
+    for (int64_t t = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); t < ntiles; t += nwaves) {
+        unsigned long long mine = 0;               // lane j < 16 ends up holding the mask of chunk j
+#pragma unroll
+        for (int j0 = 0; j0 < CHUNKS_PER_TILE; j0 += 4) {
+            int32_t id[4];
+            bool in[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int64_t e = (t * CHUNKS_PER_TILE + j0 + u) * WAVE + lane;
+                in[u] = e < nnz;
+                id[u] = in[u] ? idx[e] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const unsigned long long m = __ballot(in[u] && ((tab[id[u] >> 5] >> (id[u] & 31)) & 1u));
+                if (lane == j0 + u) mine = m;
+            }
+        }
+        int pc = (lane < CHUNKS_PER_TILE) ? __popcll(mine) : 0, inc = pc;
+#pragma unroll
+        for (int d = 1; d < CHUNKS_PER_TILE; d <<= 1) {
+            const int y = __shfl_up(inc, d);
+            if (lane >= d) inc += y;
+        }
+        if (lane < CHUNKS_PER_TILE) {
+            mask[t * CHUNKS_PER_TILE + lane] = mine;
+            chunk_pre[t * CHUNKS_PER_TILE + lane] = (uint16_t)(inc - pc);
+        }
+        if (lane == CHUNKS_PER_TILE - 1) tile_cnt[t] = inc;
+    }
+}
+
+// (3b) exclusive scan of the tile counts, two launches like the other scans: group sums, then the offsets
+__global__ __launch_bounds__(BLOCK) void svi_tile_sums_kernel(const int32_t *__restrict__ tile_cnt, int64_t ntiles,
+                                                              long long *__restrict__ groups) {
+    const int64_t per = (ntiles + TILES - 1) / TILES;
+    const int64_t t0 = (int64_t)blockIdx.x * per, t1 = min(ntiles, t0 + per);
+    long long v[1] = {0};
+    for (int64_t t = t0 + threadIdx.x; t < t1; t += BLOCK) v[0] += tile_cnt[t];
+    long long e[1], tot[1];
+    block_exclusive_scan<1>(v, e, tot);
+    if (threadIdx.x == 0) groups[blockIdx.x] = tot[0];
+}
+
+__global__ __launch_bounds__(BLOCK) void svi_tile_offsets_kernel(const int32_t *__restrict__ tile_cnt, int64_t ntiles,
+                                                                 const long long *__restrict__ groups,
+                                                                 int64_t *__restrict__ tile_off) {
+    long long base[1], all[1];
+    tiles_before<1>(groups, blockIdx.x, base, all);
+    const int64_t per = (ntiles + TILES - 1) / TILES;
+    const int64_t t0 = (int64_t)blockIdx.x * per, t1 = min(ntiles, t0 + per);
+    for (int64_t c0 = t0; c0 < t1; c0 += BLOCK) {
+        const int64_t t = c0 + threadIdx.x;
+        long long v[1] = {0};
+        if (t < t1) v[0] = tile_cnt[t];
+        long long e[1], tot[1];
+        block_exclusive_scan<1>(v, e, tot);
+        if (t < t1) tile_off[t] = base[0] + e[0];
+        base[0] += tot[0];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) tile_off[ntiles] = all[0];
+}
+
+// kept entries before entry e
+__device__ __forceinline__ long long kept_before(const unsigned long long *__restrict__ mask,
+                                                 const uint16_t *__restrict__ chunk_pre,
+                                                 const int64_t *__restrict__ tile_off, int64_t e) {
+    const int64_t chunk = e >> 6;
+    long long p = tile_off[chunk / CHUNKS_PER_TILE] + chunk_pre[chunk];
+    const int b = (int)(e & 63);
+    if (b) p += __popcll(mask[chunk] & ((1ull << b) - 1));
+    return p;
+}
+
+// (3c) other side: per row, where its kept nonzeros start and how many there are; per tile of rows, the totals of
+// {rows present, batch segments, split rows}
+__global__ __launch_bounds__(BLOCK) void svi_oth_rows_kernel(const int64_t *__restrict__ indptr, int64_t nrows, int64_t nnz,
+                                                             const unsigned long long *__restrict__ mask,
+                                                             const uint16_t *__restrict__ chunk_pre,
+                                                             const int64_t *__restrict__ tile_off, int cap,
+                                                             int64_t *__restrict__ row_start, int32_t *__restrict__ row_cnt,
+                                                             long long *__restrict__ tiles) {
+    const int64_t per = (nrows + TILES - 1) / TILES;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(nrows, r0 + per);
+    long long v[3] = {0, 0, 0};
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += BLOCK) {
+        const int64_t e0 = indptr[r], e1 = indptr[r + 1];
+        long long p0 = 0, p1 = 0;
+        if (e1 > e0) {
+            p0 = kept_before(mask, chunk_pre, tile_off, e0);
+            p1 = (e1 < nnz) ? kept_before(mask, chunk_pre, tile_off, e1) : tile_off[(nnz + 1023) / 1024];
+        }
+        const int c = (int)(p1 - p0);
+        row_start[r] = p0;
+        row_cnt[r] = c;
+        if (c > 0) {
+            const int ns = (c + cap - 1) / cap;
+            v[0]++;
+            v[1] += ns;
+            v[2] += ns > 1;
+        }
+    }
+    long long e[3], tot[3];
+    block_exclusive_scan<3>(v, e, tot);
+    if (threadIdx.x == 0)
+        for (int c = 0; c < 3; c++) tiles[(size_t)blockIdx.x * 3 + c] = tot[c];
+}
+
+// (3d) other side: the scan over rows applied.  Every row gets its flag (present or not); a present row gets its batch
+// segments {begin in o_idx / o_y, length, row} cut at `cap`, split rows their {first segment, segments, row} descriptor
+__global__ __launch_bounds__(BLOCK) void svi_oth_layout_kernel(int64_t nrows, const int64_t *__restrict__ row_start,
+                                                               const int32_t *__restrict__ row_cnt, int cap,
+                                                               const long long *__restrict__ tiles,
+                                                               const int64_t *__restrict__ tile_off, int64_t ntiles_e,
+                                                               uint8_t *__restrict__ flag_oth,
+                                                               hpf_segment *__restrict__ o_segs, int64_t o_segs_cap,
+                                                               int64_t *__restrict__ o_multi, int64_t m_cap, int64_t o_cap,
+                                                               int64_t *__restrict__ sizes) {
+    long long base[3], all[3];
+    tiles_before<3>(tiles, blockIdx.x, base, all);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long entries = tile_off[ntiles_e];
+        sizes[5] = all[0];
+        sizes[4] = min((long long)o_cap, entries);
+        sizes[2] = min((long long)o_segs_cap, all[1]);
+        sizes[3] = min((long long)m_cap, all[2]);
+        if (entries > o_cap || all[1] > o_segs_cap || all[2] > m_cap) sizes[7] = 1;
+    }
+    const int64_t per = (nrows + TILES - 1) / TILES;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(nrows, r0 + per);
+    for (int64_t c0 = r0; c0 < r1; c0 += BLOCK) {
+        const int64_t r = c0 + threadIdx.x;
+        long long v[3] = {0, 0, 0};
+        int c = 0, ns = 0;
+        if (r < r1) {
+            c = row_cnt[r];
+            ns = (c + cap - 1) / cap;
+            flag_oth[r] = c > 0;
+            v[0] = c > 0;
+            v[1] = ns;
+            v[2] = ns > 1;
+        }
+        long long e[3], tot[3];
+        block_exclusive_scan<3>(v, e, tot);
+        if (c > 0) {
+            const long long start = row_start[r], sg0 = base[1] + e[1], m0 = base[2] + e[2];
+            for (int q = 0; q < ns; q++) {
+                if (sg0 + q >= o_segs_cap) break;
+                hpf_segment g;
+                g.begin = start + (long long)q * cap;
+                const int left = c - q * cap;
+                g.len = (left < cap ? left : cap) | (ns == 1 ? HPF_SEG_WHOLE_ROW : 0);
+                g.row = (int32_t)r;
+                o_segs[sg0 + q] = g;
+            }
+            if (ns > 1 && m0 < m_cap) {
+                o_multi[m0 * 3 + 0] = sg0;
+                o_multi[m0 * 3 + 1] = ns;
+                o_multi[m0 * 3 + 2] = r;
+            }
+        }
+        for (int q = 0; q < 3; q++) base[q] += tot[q];
+    }
+}
+
+// (3e) other side: the kept nonzeros written in order -- o_idx = the own side's row id, o_y = the count.  One wavefront
+// per tile: the tile's 16 masks and prefixes arrive in one load each, four chunks' gathers are in flight at once
+__global__ __launch_bounds__(BLOCK) void svi_oth_write_kernel(const int32_t *__restrict__ idx, const float *__restrict__ y,
+                                                              int64_t nnz, const unsigned long long *__restrict__ mask,
+                                                              const uint16_t *__restrict__ chunk_pre,
+                                                              const int64_t *__restrict__ tile_off,
+                                                              int32_t *__restrict__ o_idx, float *__restrict__ o_y,
+                                                              int64_t o_cap) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t ntiles = (nnz + 1023) / 1024;
+    const int64_t nwaves = (int64_t)gridDim.x * WPB;
+    for (int64_t t = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); t < ntiles; t += nwaves) {
+        const long long base = tile_off[t];
+        if (tile_off[t + 1] == base) continue;     // nothing kept in this tile
+        unsigned long long mine = 0;
+        int pre = 0;
+        if (lane < CHUNKS_PER_TILE) {
+            mine = mask[t * CHUNKS_PER_TILE + lane];
+            pre = chunk_pre[t * CHUNKS_PER_TILE + lane];
+        }
+#pragma unroll
+        for (int j0 = 0; j0 < CHUNKS_PER_TILE; j0 += 4) {
+            int32_t id[4];
+            float yy[4];
+            long long pos[4];
+            bool keep[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const unsigned long long m = __shfl(mine, j0 + u);
+                const int p = __shfl(pre, j0 + u);
+                keep[u] = (m >> lane) & 1ull;
+                pos[u] = base + p + __popcll(m & ((1ull << lane) - 1));
+                const int64_t e = (t * CHUNKS_PER_TILE + j0 + u) * WAVE + lane;
+                id[u] = keep[u] ? idx[e] : 0;
+                yy[u] = keep[u] ? y[e] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (keep[u] && pos[u] < o_cap) {
+                    o_idx[pos[u]] = id[u];
+                    o_y[pos[u]] = yy[u];
+                }
+            }
+        }
+    }
+}
+
+// acc[row] = sum of the part[] rows of a split row, for the descriptors {first segment, segments, row} a batch
+// preparation produced; *ndesc_dev descriptors (device-side count)
+__global__ __launch_bounds__(BLOCK) void segsum_desc_kernel(const float *__restrict__ part,
+                                                            const int64_t *__restrict__ desc,
+                                                            const int64_t *__restrict__ ndesc_dev, int64_t ndesc_max,
+                                                            float *__restrict__ acc, int ld) {
+    const int64_t nd = min(ndesc_max, ndesc_dev[0]);
+    const int64_t total = nd * ld;
+    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLOCK) {
+        const int64_t d = t / ld;
+        const int c = (int)(t - d * ld);
+        int64_t sg = desc[d * 3 + 0];
+        const int64_t s1 = sg + desc[d * 3 + 1];
+        const int64_t row = desc[d * 3 + 2];
+        float a = 0.f;
+        for (; sg + 8 <= s1; sg += 8) {  // same fold order as row_finalize_kernel / segsum_kernel
+            float p[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) p[u] = part[(size_t)(sg + u) * ld + c];
+            a += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        }
+        for (; sg < s1; sg++) a += part[(size_t)sg * ld + c];
+        acc[(size_t)row * ld + c] = a;
+    }
+}
+
+inline int last_error() { return (int)hipGetLastError(); }
+
+}  // namespace
+
+extern "C" {
+
+int64_t hpf_hip_svi_prep_scratch_words(void) { return (int64_t)TILES * 8; }   // int64 words of `tiles`
+int64_t hpf_hip_svi_batch_sizeof(void) { return (int64_t)sizeof(hpf_svi_batch); }
+
+int hpf_hip_svi_batch_prepare(const hpf_svi_batch *b, void *stream) {
+    if (!b || !b->own_segs || !b->own_row_seg_ptr || !b->own_indptr || !b->oth_idx || !b->oth_y || !b->ids || !b->flag_own || !b->flag_oth || !b->acc_own || !b->b_segs || !b->b_multi ||
+        !b->o_idx || !b->o_y || !b->o_segs || !b->o_multi || !b->sizes || !b->mask || !b->chunk_pre || !b->flag_bits || !b->tile_cnt || !b->tile_off ||
+        !b->row_cnt || !b->row_start || !b->tiles || !b->oth_indptr || b->oth_nnz < 0 || b->own_nseg < 0 || b->nids < 0 || b->nprev < 0 || (b->nprev > 0 && !b->prev_ids) ||
+        b->seg_cap <= 0 || b->seg_cap > HPF_SEG_LEN_MASK || b->ld <= 0 || b->own_nrows <= 0 || b->oth_nrows <= 0)
+        return HPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    auto grid_for = [](int64_t n, int per) { int64_t g = (n + per - 1) / per; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); };
+    hipError_t e = hipMemsetAsync(b->sizes, 0, 8 * sizeof(int64_t), st);
+    if (e != hipSuccess) return (int)e;
+    if (b->nprev > 0)
+        hipLaunchKernelGGL(svi_mark_kernel, dim3(grid_for(b->nprev, BLOCK)), dim3(BLOCK), 0, st, b->prev_ids, b->nprev,
+                           b->ids, b->nids, b->flag_own, b->own_indptr, b->acc_own, b->ld, 0);
+    if (b->nids > 0)
+        hipLaunchKernelGGL(svi_mark_kernel, dim3(grid_for(b->nids, BLOCK)), dim3(BLOCK), 0, st, b->prev_ids, b->nprev,
+                           b->ids, b->nids, b->flag_own, b->own_indptr, b->acc_own, b->ld, 1);
+    long long *tiles_own = (long long *)b->tiles, *tiles_oth = (long long *)b->tiles + TILES * 4;   // [2 | 3 | 1 per tile]
+    hipLaunchKernelGGL(svi_own_count_kernel, dim3(TILES), dim3(BLOCK), 0, st, b->own_segs, b->own_nseg, b->flag_own,
+                       tiles_own);
+    hipLaunchKernelGGL(svi_own_write_kernel, dim3(TILES), dim3(BLOCK), 0, st, b->own_segs, b->own_nseg,
+                       b->own_row_seg_ptr, b->flag_own, (const long long *)tiles_own, b->b_segs, b->b_segs_cap, b->b_multi,
+                       b->multi_cap, b->sizes);
+    const int64_t nnz = b->oth_nnz;
+    const int64_t ntiles_e = (nnz + 1023) / 1024;
+    unsigned long long *mask = (unsigned long long *)b->mask;
+    long long *groups = (long long *)b->tiles + TILES * 4 + TILES * 3;
+    uint16_t *chunk_pre = (uint16_t *)b->chunk_pre;
+    const int tgrid = grid_for(ntiles_e, WPB);
+    if (nnz > 0) {
+        const int64_t nwords = (b->own_nrows + 31) / 32;
+        hipLaunchKernelGGL(svi_flag_bits_kernel, dim3(grid_for(nwords, BLOCK)), dim3(BLOCK), 0, st,
+                           (const uint8_t *)b->flag_own, b->own_nrows, b->flag_bits);
+        const size_t lds = (size_t)nwords * sizeof(uint32_t);
+        static int cus = 0;
+        static bool big_lds = false;
+        if (cus == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            else
+                cus = 256;
+            big_lds = hipFuncSetAttribute(reinterpret_cast<const void *>(svi_oth_mask_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) == hipSuccess;
+        }
+        if (lds <= 64 * 1024 - 512 || (big_lds && lds <= 160 * 1024 - 512))
+            hipLaunchKernelGGL((svi_oth_mask_kernel<true>), dim3(cus), dim3(1024), lds, st, b->oth_idx, nnz,
+                               (const uint32_t *)b->flag_bits, nwords, mask, chunk_pre, b->tile_cnt);
+        else    // a side too large for the LDS: the bitset is still 8x smaller than the byte table in the caches
+            hipLaunchKernelGGL((svi_oth_mask_kernel<false>), dim3(grid_for(ntiles_e, 16)), dim3(1024), 0, st, b->oth_idx,
+                               nnz, (const uint32_t *)b->flag_bits, nwords, mask, chunk_pre, b->tile_cnt);
+    }
+    hipLaunchKernelGGL(svi_tile_sums_kernel, dim3(TILES), dim3(BLOCK), 0, st, (const int32_t *)b->tile_cnt, ntiles_e,
+                       groups);
+    hipLaunchKernelGGL(svi_tile_offsets_kernel, dim3(TILES), dim3(BLOCK), 0, st, (const int32_t *)b->tile_cnt, ntiles_e,
+                       (const long long *)groups, b->tile_off);
+    hipLaunchKernelGGL(svi_oth_rows_kernel, dim3(TILES), dim3(BLOCK), 0, st, b->oth_indptr, b->oth_nrows, nnz,
+                       (const unsigned long long *)mask, (const uint16_t *)chunk_pre, (const int64_t *)b->tile_off,
+                       b->seg_cap, b->row_start, b->row_cnt, tiles_oth);
+    hipLaunchKernelGGL(svi_oth_layout_kernel, dim3(TILES), dim3(BLOCK), 0, st, b->oth_nrows,
+                       (const int64_t *)b->row_start, (const int32_t *)b->row_cnt, b->seg_cap,
+                       (const long long *)tiles_oth, (const int64_t *)b->tile_off, ntiles_e, b->flag_oth, b->o_segs,
+                       b->o_segs_cap, b->o_multi, b->multi_cap, b->o_cap, b->sizes);
+    if (nnz > 0)
+        hipLaunchKernelGGL(svi_oth_write_kernel, dim3(tgrid), dim3(BLOCK), 0, st, b->oth_idx, b->oth_y, nnz,
+                           (const unsigned long long *)mask, (const uint16_t *)chunk_pre, (const int64_t *)b->tile_off,
+                           b->o_idx, b->o_y, b->o_cap);
+    return last_error();
+}
+
+int hpf_hip_segsum_desc_f32(const float *part, const int64_t *desc, const int64_t *ndesc_dev, int64_t ndesc_max,
+                            float *acc, int ld, void *stream) {
+    if (ndesc_max == 0) return 0;
+    if (!part || !desc || !ndesc_dev || !acc || ndesc_max < 0 || ld < 32) return HPF_EINVAL;
+    int64_t g = (ndesc_max * ld + BLOCK - 1) / BLOCK;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(segsum_desc_kernel, dim3((unsigned)g), dim3(BLOCK), 0, (hipStream_t)stream, part, desc, ndesc_dev,
+                       ndesc_max, acc, ld);
+    return last_error();
+}
+
+}  // extern "C"

@@ -16,6 +16,26 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _svi_batch_struct():
+    import ctypes
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+
+    class SviBatchDesc(ctypes.Structure):
+        """hpf_svi_batch (include/hpf_hip.h), field for field."""
+        _fields_ = [("own_segs", vp), ("own_nseg", i64), ("own_row_seg_ptr", vp), ("own_indptr", vp), ("own_nrows", i64),
+                    ("oth_idx", vp), ("oth_y", vp), ("oth_indptr", vp), ("oth_nrows", i64), ("oth_nnz", i64),
+                    ("ids", vp), ("nids", i64), ("prev_ids", vp), ("nprev", i64),
+                    ("flag_own", vp), ("flag_oth", vp), ("acc_own", vp), ("ld", i32), ("seg_cap", i32),
+                    ("b_segs", vp), ("b_segs_cap", i64), ("b_multi", vp), ("multi_cap", i64),
+                    ("o_idx", vp), ("o_y", vp), ("o_cap", i64), ("o_segs", vp), ("o_segs_cap", i64), ("o_multi", vp),
+                    ("sizes", vp), ("mask", vp), ("chunk_pre", vp), ("tile_cnt", vp), ("tile_off", vp), ("row_start", vp), ("row_cnt", vp),
+                    ("tiles", vp), ("flag_bits", vp)]
+    return SviBatchDesc
+
+
+SviBatchDesc = _svi_batch_struct()
+
+
 class HipOps:
     name = "hip"
 
@@ -38,10 +58,13 @@ class HipOps:
 
     # -- every method mirrors one C entry point ------------------------------------------
     def sweep(self, side, tab_self, tab_other, part, k, ld, acc_rows=None, acc_ld=0, grid_blocks=None):
+        """`side.nseg_dev` (optional, device int64[1]): the live segment count of a batch built on the device; side.nseg
+        is then the capacity of its segment list."""
         _lib.check(self.L.hpf_hip_sweep_f32(_ptr(side.segs), side.nseg, _ptr(side.idx), _ptr(side.y),
                                             _ptr(tab_self), _ptr(tab_other), _ptr(part), _ptr(acc_rows), int(acc_ld),
                                             k, ld, int(getattr(side, "short_rows", 0)),
-                                            grid_blocks or self.sweep_blocks, self._stream()),
+                                            grid_blocks or self.sweep_blocks, _ptr(getattr(side, "nseg_dev", None)),
+                                            self._stream()),
                    "hpf_hip_sweep_f32")
 
     def sweep_grid(self, nseg, blocks=None):
@@ -110,8 +133,9 @@ class HipOps:
         _lib.check(self.L.hpf_hip_colsum_f32(_ptr(tab), nrows, ld, _ptr(cs_partial), cs_partial.shape[0],
                                              self._stream()), "hpf_hip_colsum_f32")
 
-    def expect(self, shp, rte, e, nrows, k, ld, row_list=None):
-        _lib.check(self.L.hpf_hip_expect_f32(_ptr(shp), _ptr(rte), _ptr(e), _ptr(row_list), nrows, k, ld,
+    def expect(self, shp, rte, e, nrows, k, ld, row_list=None, flag=None):
+        """flag (uint8 per table row): only rows with a non-zero flag."""
+        _lib.check(self.L.hpf_hip_expect_f32(_ptr(shp), _ptr(rte), _ptr(e), _ptr(row_list), _ptr(flag), nrows, k, ld,
                                              self._stream()), "hpf_hip_expect_f32")
 
     def segsum(self, part, row_seg_ptr, nrows, acc, ld, row_list=None, acc_ld=None, acc_by_row=False):
@@ -155,18 +179,41 @@ class HipOps:
                                               float(top), float(add), float(rs), float(stop_thr), int(maxiter), k, ld,
                                               self._stream()), "hpf_hip_fold_in_f32")
 
-    # -- index plumbing of a stochastic batch ---------------------------------------------------
-    def gather_rows(self, src_begin, dst_begin, row_ids, src_idx, src_y, out_idx, out_y, out_row):
-        """Nonzeros of the listed rows (row t: src[src_begin[t] ...) -> out[dst_begin[t] .. dst_begin[t+1]))."""
-        _lib.check(self.L.hpf_hip_gather_rows(_ptr(src_begin), _ptr(dst_begin), _ptr(row_ids), int(row_ids.shape[0]),
-                                              _ptr(src_idx), _ptr(src_y), _ptr(out_idx), _ptr(out_y), _ptr(out_row),
-                                              self._stream()), "hpf_hip_gather_rows")
+    # -- index structures of a stochastic batch ------------------------------------------------
+    def svi_batch_prepare(self, ws):
+        """Everything a stochastic batch needs besides the dense algebra, built on the device by ONE call
+        (hpf_hip_svi_batch_prepare) into the workspace `ws` (svi.BatchWorkspace): flags of the batch's rows (ws.ids; the
+        workspace's previous batch, ws.prev_ids, is unmarked), the own side's compacted segment list, the other side's
+        filtered copy, all sizes in ws.sizes -- nothing is read back."""
+        import ctypes
+        d = ws.__dict__.get("_hip_desc")
+        if d is None:
+            d = ws._hip_desc = SviBatchDesc()
+            own, oth = ws.own, ws.oth
+            d.own_segs, d.own_nseg, d.own_row_seg_ptr = _ptr(own.segs), own.nseg, _ptr(own.row_seg_ptr)
+            d.own_indptr, d.own_nrows = _ptr(own.indptr), own.nrows
+            d.oth_idx, d.oth_y, d.oth_indptr = _ptr(oth.idx), _ptr(oth.y), _ptr(oth.indptr)
+            d.oth_nrows, d.oth_nnz = oth.nrows, oth.nnz
+            assert ctypes.sizeof(d) == int(self.L.hpf_hip_svi_batch_sizeof())
+            d.flag_own, d.flag_oth, d.acc_own = _ptr(ws.flag_own), _ptr(ws.flag_oth), _ptr(ws.acc_own)
+            d.ld, d.seg_cap = int(ws.ld), int(ws.seg_cap)
+            d.b_segs, d.b_segs_cap, d.b_multi, d.multi_cap = _ptr(ws.b_segs), ws.b_cap, _ptr(ws.b_multi), ws.multi_cap
+            d.o_idx, d.o_y, d.o_cap = _ptr(ws.o_idx), _ptr(ws.o_y), ws.o_cap
+            d.o_segs, d.o_segs_cap, d.o_multi = _ptr(ws.o_segs), ws.o_segs_cap, _ptr(ws.o_multi)
+            d.sizes, d.mask, d.tile_cnt, d.tile_off = _ptr(ws.sizes), _ptr(ws.mask), _ptr(ws.tile_cnt), _ptr(ws.tile_off)
+            d.chunk_pre, d.flag_bits = _ptr(ws.chunk_pre), _ptr(ws.flag_bits)
+            d.row_start, d.row_cnt, d.tiles = _ptr(ws.row_start), _ptr(ws.row_cnt), _ptr(ws.tiles)
+        d.ids, d.nids = _ptr(ws.ids), int(ws.ids.shape[0])
+        d.prev_ids, d.nprev = (_ptr(ws.prev_ids), int(ws.prev_ids.shape[0])) if ws.prev_ids is not None else (None, 0)
+        _lib.check(self.L.hpf_hip_svi_batch_prepare(ctypes.byref(d), self._stream()), "hpf_hip_svi_batch_prepare")
 
-    def fill_segments(self, start, count, row_seg_ptr, row_ids, seg_cap, segs):
-        """hpf_segment descriptors (int64 [nseg,2] image) of rows (start, count, id) cut at seg_cap nonzeros."""
-        _lib.check(self.L.hpf_hip_fill_segments(_ptr(start), _ptr(count), _ptr(row_seg_ptr), _ptr(row_ids),
-                                                int(row_ids.shape[0]), int(seg_cap), _ptr(segs), self._stream()),
-                   "hpf_hip_fill_segments")
+    def svi_prep_scratch_words(self):
+        return int(self.L.hpf_hip_svi_prep_scratch_words())
+
+    def segsum_desc(self, part, desc, ndesc_dev, ndesc_max, acc, ld):
+        """acc[row] = sum of a split row's part[] rows for the {first, n, row} descriptors of a device-built batch."""
+        _lib.check(self.L.hpf_hip_segsum_desc_f32(_ptr(part), _ptr(desc), _ptr(ndesc_dev), int(ndesc_max), _ptr(acc), ld,
+                                                  self._stream()), "hpf_hip_segsum_desc_f32")
 
     def mt19937_words(self, state, raw):
         """raw[:] = the next raw.numel() state words of the MT19937 stream in `state` (int32[625] device tensor:

@@ -29,7 +29,7 @@ class BatchSide:
 
     def __init__(self, rows, cols, y, seg_cap=layout.SEG_CAP, grouped=False):
         """rows/cols: int64 device tensors of a COO batch.  grouped=True: the triplets already come grouped by
-        ascending `rows` (what gather_rows returns for a sorted row list) -- no sort needed; otherwise they are
+        ascending `rows` (a sorted row list's nonzeros gathered out of a CSR) -- no sort needed; otherwise they are
         grouped here with a stable sort."""
         if grouped:
             r_s, c_s, y_s = rows, cols, y
@@ -69,151 +69,70 @@ class BatchSide:
         return [self.rows, self.idx, self.y, self.row_seg_ptr, self.segs, self.multi_local]
 
 
-class PinnedStaging:
-    """Page-locked host memory for the small int64 arrays a batch sends to the device (row lists, offsets, segment
-    descriptors), allocated ONCE: a copy from pageable memory makes the host wait for everything queued on the stream
-    before it, and pinning per copy costs milliseconds on this platform.  All arrays of a batch go up in ONE
-    asynchronous copy.  A few slots are used round-robin; a slot is re-used only after its copy has completed."""
+class DevSide:
+    """One grouping of a batch BUILT ON THE DEVICE (BatchWorkspace), as the sweep launcher sees a side: `nseg` is the
+    capacity of the segment list, the live count stays on the device (`nseg_dev`); split rows come as {first segment,
+    segments, row} descriptors (`multi`, `nmulti_dev` of them)."""
 
-    def __init__(self, device, words=1 << 20, slots=4):
-        self.device = device
-        self.bufs = [torch.empty(words, dtype=torch.int64, pin_memory=True) for _ in range(slots)]
-        self.events = [None] * slots
-        self.turn = -1
-
-    def upload(self, arrays):
-        """int64 numpy arrays -> device tensors of the same shapes (one transfer)."""
-        arrays = [np.ascontiguousarray(a, dtype=np.int64) for a in arrays]
-        total = sum(int(a.size) for a in arrays)
-        self.turn = (self.turn + 1) % len(self.bufs)
-        slot, buf = self.turn, self.bufs[self.turn]
-        if total > buf.shape[0]:                                  # (does not fit: plain synchronous copies)
-            return [torch.from_numpy(a).to(self.device) for a in arrays]
-        if self.events[slot] is not None:
-            self.events[slot].synchronize()
-        host, at = buf.numpy(), 0
-        for a in arrays:
-            host[at: at + a.size] = a.reshape(-1)
-            at += a.size
-        dev_all = buf[:total].to(self.device, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self.events[slot] = ev
-        out, at = [], 0
-        for a in arrays:
-            out.append(dev_all[at: at + a.size].reshape(a.shape))
-            at += a.size
-        return out
+    def __init__(self, segs, nseg_cap, idx, y, nseg_dev, multi, nmulti_dev, multi_cap, short_rows):
+        self.segs, self.nseg, self.idx, self.y, self.nseg_dev = segs, int(nseg_cap), idx, y, nseg_dev
+        self.multi, self.nmulti_dev, self.multi_cap, self.short_rows = multi, nmulti_dev, int(multi_cap), int(short_rows)
 
 
-class _BatchInFlight:
-    """A batch whose device work has been launched (batch_sides_start) but whose data-dependent sizes -- how many rows
-    of the other side it touches, into how many segments they are cut -- have not been read yet."""
-    pass
+class BatchWorkspace:
+    """Device buffers for the index structures of ONE stochastic batch drawn from the rows of `own` (users' CSR for a
+    user batch, items' CSC for an item batch), filled by ops.svi_batch_prepare (hpf_hip_svi_batch_prepare: one host
+    call, nothing read back).  Sized once per fit from a bound -- the nonzeros of the `batch_rows` largest rows of the
+    side -- so that no batch can overflow it.  The reference slices the same things on the host per batch
+    (PXI:280-290, 332-342, 27-42)."""
 
+    def __init__(self, ops, own, oth, acc_own, ld, batch_rows, seg_cap=layout.SEG_CAP):
+        dev = own.idx.device
+        i64 = dict(dtype=torch.int64, device=dev)
+        self.own, self.oth, self.acc_own, self.ld, self.seg_cap = own, oth, acc_own, int(ld), int(seg_cap)
+        B = int(min(batch_rows, own.nrows))
+        deg = own.indptr[1:] - own.indptr[:-1]
+        bound = int(torch.topk(deg, B).values.sum().item()) if B > 0 else 0       # (once per fit)
+        self.nnz_bound = bound
+        self.b_cap = B + bound // seg_cap + 1
+        self.multi_cap = bound // seg_cap + 2
+        self.o_cap = max(bound, 1)
+        self.o_segs_cap = min(oth.nrows, bound) + bound // seg_cap + 1
+        self.flag_own = torch.zeros(own.nrows, dtype=torch.uint8, device=dev)
+        self.flag_oth = torch.zeros(oth.nrows, dtype=torch.uint8, device=dev)
+        self.b_segs = torch.zeros((self.b_cap, 2), **i64)
+        self.b_multi = torch.zeros((self.multi_cap, 3), **i64)
+        self.o_multi = torch.zeros((self.multi_cap, 3), **i64)
+        self.o_idx = torch.zeros(self.o_cap, dtype=torch.int32, device=dev)
+        self.o_y = torch.zeros(self.o_cap, dtype=torch.float32, device=dev)
+        self.o_segs = torch.zeros((self.o_segs_cap, 2), **i64)
+        self.sizes = torch.zeros(8, **i64)
+        # scratch of the other side's filter: a keep bit per nonzero of the side, a count and an offset per 1024 of them
+        ntiles = (oth.nnz + 1023) // 1024
+        self.mask = torch.zeros(max(1, 16 * ntiles), **i64)
+        self.chunk_pre = torch.zeros(max(1, 16 * ntiles), dtype=torch.int16, device=dev)
+        self.flag_bits = torch.zeros((own.nrows + 31) // 32, dtype=torch.int32, device=dev)
+        self.tile_cnt = torch.zeros(ntiles + 1, dtype=torch.int32, device=dev)
+        self.tile_off = torch.zeros(ntiles + 1, **i64)
+        self.row_start = torch.zeros(oth.nrows, **i64)
+        self.row_cnt = torch.zeros(oth.nrows, dtype=torch.int32, device=dev)
+        self.tiles = torch.zeros(ops.svi_prep_scratch_words(), **i64)
+        self.ids = self.prev_ids = None
+        self.ready = self.free = None         # events: structures built (preparation stream) / consumed (compute stream)
+        # own side: descriptors index the side's GLOBAL idx / y; rows of a batch average tens of nonzeros -> no hint.
+        # other side: the batch's nonzeros spread over many rows, a handful each -> the short-row launch
+        self.side_own = DevSide(self.b_segs, self.b_cap, own.idx, own.y, self.sizes[0:1], self.b_multi, self.sizes[1:2],
+                                self.multi_cap, 0)
+        self.side_oth = DevSide(self.o_segs, self.o_segs_cap, self.o_idx, self.o_y, self.sizes[2:3], self.o_multi,
+                                self.sizes[3:4], self.multi_cap, 1)
 
-def batch_sides_start(ops, side, indptr_host, ids, n_other, seg_cap=layout.SEG_CAP, staging=None):
-    """First half of `batch_sides`: everything that needs no data-dependent size on the host.  The batch's own side is
-    complete after it (numpy on the host copy of the row pointers -- whose sizes the host therefore knows -- and ONE
-    gather launch); the other side is sorted (int32 keys) and its three sizes (rows, segments, split rows) are on
-    their way to pinned host memory.  No host synchronisation."""
-    dev = ops.device
-    b = _BatchInFlight()
-    b.ops, b.cap = ops, int(seg_cap)
-    rows_h = np.sort(np.ascontiguousarray(ids).astype(np.int64, copy=False))
-    st = indptr_host[rows_h]
-    deg = indptr_host[rows_h + 1] - st
-    keep = deg > 0
-    rk, stk, dk = (rows_h, st, deg) if keep.all() else (rows_h[keep], st[keep], deg[keep])
-    nr = int(rk.shape[0])
-    dst = np.zeros(nr + 1, dtype=np.int64)
-    np.cumsum(dk, out=dst[1:])
-    total = b.total = int(dst[-1])
-    nsr = (dk + (seg_cap - 1)) // seg_cap
-    rsp = np.zeros(nr + 1, dtype=np.int64)
-    np.cumsum(nsr, out=rsp[1:])
-    nseg = int(rsp[-1])
-    if nseg == nr:                       # no row of the batch is longer than a segment
-        begin, length = dst[:-1], dk | layout.SEG_WHOLE_ROW
-        row_of = rk
-    else:
-        local = np.repeat(np.arange(nr, dtype=np.int64), nsr)
-        within = np.arange(nseg, dtype=np.int64) - rsp[local]
-        begin = dst[local] + within * seg_cap
-        length = np.minimum(dk[local] - within * seg_cap, seg_cap) | np.where(nsr[local] == 1, layout.SEG_WHOLE_ROW, 0)
-        row_of = rk[local]
-    segs_h = np.stack([begin, length | (row_of << 32)], axis=1)
-    multi_h = np.nonzero(nsr > 1)[0]
+    def prepare(self, ops, ids):
+        """Builds the structures of the batch made of rows `ids` (device int64) on the current stream."""
+        self.prev_ids, self.ids = self.ids, ids
+        ops.svi_batch_prepare(self)
 
-    host_arrays = [rows_h, rk, stk, dst, rsp, segs_h, multi_h]
-    if staging is not None:
-        d_rows, d_rk, d_stk, d_dst, d_rsp, d_segs, d_multi = staging.upload(host_arrays)
-    else:
-        d_rows, d_rk, d_stk, d_dst, d_rsp, d_segs, d_multi = (torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-                                                              for a in host_arrays)
-    b.rows_all = d_rows
-    rows_own = d_rows if nr == rows_h.shape[0] else d_rk
-    out_idx = torch.empty(total, dtype=torch.int32, device=dev)
-    out_y = torch.empty(total, dtype=torch.float32, device=dev)
-    out_row = torch.empty(total, dtype=torch.int32, device=dev)
-    if total:
-        ops.gather_rows(d_stk, d_dst, rows_own, side.idx, side.y, out_idx, out_y, out_row)
-    b.own = BatchSide.from_parts(rows_own, out_idx, out_y, d_rsp, d_segs.reshape(-1, 2), d_multi, nseg,
-                                 multi_h.shape[0])
-    # the other side: a stable sort of the gathered ids groups the batch by them (ties keep the order of the own side)
-    order = torch.sort(out_idx, stable=True).indices
-    b.o_idx, b.o_y = out_row[order], out_y[order]
-    b.sizes_host = b.sizes_ready = None
-    if total:
-        # nonzeros per row of the other side (a histogram over ALL its rows: integer atomics, exact) and, from it, the
-        # three sizes the second half needs: rows present, segments, rows cut into several segments
-        b.per_row = torch.zeros(int(n_other), dtype=torch.int32, device=dev)
-        b.per_row.index_add_(0, out_idx, torch.ones(total, dtype=torch.int32, device=dev))
-        sizes = torch.stack([(b.per_row > 0).sum(), ((b.per_row + (seg_cap - 1)) // seg_cap).sum(),
-                             (b.per_row > seg_cap).sum()])
-        if dev.type == "cuda":
-            b.sizes_host = torch.empty(3, dtype=torch.int64, pin_memory=True)
-            b.sizes_host.copy_(sizes, non_blocking=True)
-            b.sizes_ready = torch.cuda.Event()
-            b.sizes_ready.record()
-        else:
-            b.sizes_host = sizes
-    return b
-
-
-def batch_sides_finish(b):
-    """Second half: reads the three sizes (long since on the host when the first half ran a batch earlier) and lays out
-    the other side's row list and segment descriptors.  -> (rows of the list, ascending, on the device; own BatchSide;
-    other BatchSide)."""
-    ops, cap, dev = b.ops, b.cap, b.ops.device
-    if not b.total:
-        e = torch.empty(0, dtype=torch.int64, device=dev)
-        other = BatchSide.from_parts(e, b.o_idx, b.o_y, torch.zeros(1, dtype=torch.int64, device=dev),
-                                     torch.empty((0, 2), dtype=torch.int64, device=dev), e, 0, 0)
-        return b.rows_all, b.own, other
-    if b.sizes_ready is not None:
-        b.sizes_ready.synchronize()
-    R, nseg, nmulti = (int(v) for v in b.sizes_host.tolist())
-    o_rows = torch.nonzero_static(b.per_row > 0, size=R).reshape(-1)            # ascending = the sorted keys' runs
-    counts = b.per_row[o_rows].to(torch.int64)
-    starts = torch.cumsum(counts, 0) - counts
-    o_nsr = (counts + (cap - 1)) // cap
-    o_rsp = torch.zeros(R + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(o_nsr, 0, out=o_rsp[1:])
-    o_segs = torch.empty((nseg, 2), dtype=torch.int64, device=dev)
-    ops.fill_segments(starts, counts, o_rsp, o_rows, cap, o_segs)
-    o_multi = torch.nonzero_static(o_nsr > 1, size=nmulti).reshape(-1)
-    other = BatchSide.from_parts(o_rows, b.o_idx, b.o_y, o_rsp, o_segs, o_multi, nseg, nmulti)
-    return b.rows_all, b.own, other
-
-
-def batch_sides(ops, side, indptr_host, ids, n_other, seg_cap=layout.SEG_CAP):
-    """The two BatchSides of the batch made of the listed rows of `side` (the users' CSR for a user batch, the items'
-    CSC for an item batch) -> (rows of the list, ascending, on the device; the batch grouped by those rows; the batch
-    grouped by the other side's rows).  Same structures as BatchSide(gather_rows(...)) builds with ~150 tensor-library
-    launches and four host synchronisations per batch -- a batch was bound by the host, not by its kernels.  In two
-    halves, so that a driver can run the first one a batch ahead and never waits for a size."""
-    return batch_sides_finish(batch_sides_start(ops, side, indptr_host, ids, n_other, seg_cap))
+    def overflowed(self):
+        return bool(int(self.sizes[7].item()) != 0)
 
 
 class DeviceModel:
@@ -243,7 +162,8 @@ class DeviceModel:
         self.acc_u = torch.zeros((self.nU, self.ld), **f32)
         self.acc_i = torch.zeros((self.nI, self.ld), **f32)
         self.flag_u = torch.zeros(self.nU, dtype=torch.uint8, device=dev)   # rows of the current step, per side
-        self.flag_i = torch.zeros(self.nI, dtype=torch.uint8, device=dev)
+        self.flag_i = torch.zeros(self.nI, dtype=torch.uint8, device=dev)     # (partial_fit; epochs use the workspace's)
+        self._part = None                    # scratch for the split rows' partial sums of a device-built batch
         self.csT = torch.zeros(self.ld, **f32)      # Theta.sum(axis=0) / Beta.sum(axis=0): set by put(), kept
         self.csB = torch.zeros(self.ld, **f32)      # current by every step
         if "Theta" in tables:
@@ -318,18 +238,30 @@ class DeviceModel:
         return out
 
     # ------------------------------------------------------------------------------------------
-    def batch_phi_sums(self, su, si):
+    def _part_scratch(self, rows):
+        if self._part is None or self._part.shape[0] < rows:
+            self._part = torch.empty((rows, self.ld), dtype=torch.float32, device=self.ops.device)
+        return self._part
+
+    def batch_phi_sums(self, su, si, flag_u, flag_i):
         """Per touched row, sum_n w_n * (other side's E row) over the batch's nonzeros (update_phi[_csr] +
         update_G_n_L_sh[_csr] restricted to the batch; sum phi = E_row (*) this), from the CURRENT shapes/rates,
-        left in acc_u[user] / acc_i[item] for the rows present in the batch (su / si: its two BatchSides)."""
+        left in acc_u[user] / acc_i[item] for the rows present in the batch.  su / si: the batch grouped by user / by
+        item -- BatchSides (partial_fit: sizes known on the host) or DevSides (epochs: sizes on the device); flag_u /
+        flag_i: one byte per row, the rows of the step."""
         ops, k, ld = self.ops, self.k, self.ld
-        ops.expect(self.Gamma_shp, self.Gamma_rte, self.eT, su.nrows, k, ld, row_list=su.rows)
-        ops.expect(self.Lambda_shp, self.Lambda_rte, self.eB, si.nrows, k, ld, row_list=si.rows)
+        ops.expect(self.Gamma_shp, self.Gamma_rte, self.eT, self.nU, k, ld, flag=flag_u)
+        ops.expect(self.Lambda_shp, self.Lambda_rte, self.eB, self.nI, k, ld, flag=flag_i)
         for side, e_self, e_other, acc in ((su, self.eT, self.eB, self.acc_u), (si, self.eB, self.eT, self.acc_i)):
             if side.nseg == 0:
                 continue
-            part = torch.empty((side.nseg, ld), dtype=torch.float32, device=ops.device)
             # a row that is one segment long writes its sums straight to acc[row]; split rows go through part[]
+            if isinstance(side, DevSide):
+                part = self._part_scratch(side.nseg)
+                ops.sweep(side, e_self, e_other, part, k, ld, acc_rows=acc, acc_ld=ld)
+                ops.segsum_desc(part, side.multi, side.nmulti_dev, side.multi_cap, acc, ld)
+                continue
+            part = torch.empty((side.nseg, ld), dtype=torch.float32, device=ops.device)
             ops.sweep(side, e_self, e_other, part, k, ld, acc_rows=acc, acc_ld=ld)
             if side.nmulti > 0:
                 tmp = torch.zeros((side.nmulti, ld), dtype=torch.float32, device=ops.device)
@@ -337,25 +269,20 @@ class DeviceModel:
                 acc.index_copy_(0, side.rows[side.multi_local], tmp)
 
 
-def _svi_step(m, hy, su, si, users_tb, items_tb, step, mult, user_batch, all_scalar_rows):
+def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_rows):
     """One stochastic update in the reference's statement order (user batch: PXI:292-325 / 438-473;
-    item batch: PXI:344-377).  su / si: the batch grouped by user / by item; users_tb / items_tb: the row lists
-    the updates run over (supersets of the rows present in the batch: listed rows without a nonzero get a zero
-    phi-sum).  `hy` carries a, c, k_shp, t_shp, add_k_rte, add_t_rte as python floats."""
+    item batch: PXI:344-377).  su / si: the batch grouped by user / by item; flag_u / flag_i (uint8 per row): the rows
+    the updates run over -- supersets of the rows present in the batch; a listed row without a nonzero must hold a zero
+    phi-sum in acc_u / acc_i (the callers see to that).  `hy` carries a, c, k_shp, t_shp, add_k_rte, add_t_rte as
+    python floats."""
     ops, k, ld = m.ops, m.k, m.ld
     step_prev = float(np.float32(1) - np.float32(step))
     step = float(np.float32(step))
     w_other = float(np.float32(step * float(np.float32(mult))))   # step*multiplier as one float32 scalar (PXI:316)
-    for tb, side, acc in ((users_tb, su, m.acc_u), (items_tb, si, m.acc_i)):
-        if tb.shape[0] != side.nrows:        # listed rows without any nonzero in the batch
-            acc.index_fill_(0, tb, 0.0)
-    m.batch_phi_sums(su, si)                                      # phi from the OLD parameters
-    for flag, tb in ((m.flag_u, users_tb), (m.flag_i, items_tb)):
-        flag.zero_()
-        flag.index_fill_(0, tb, 1)
-    U = dict(n=m.nU, flag=m.flag_u, shp=m.Gamma_shp, rte=m.Gamma_rte, fac=m.Theta, rs=m.k_rte, e=m.eT, acc=m.acc_u,
+    m.batch_phi_sums(su, si, flag_u, flag_i)                      # phi from the OLD parameters
+    U = dict(n=m.nU, flag=flag_u, shp=m.Gamma_shp, rte=m.Gamma_rte, fac=m.Theta, rs=m.k_rte, e=m.eT, acc=m.acc_u,
              prior=hy["a"], top=hy["k_shp"], add=hy["add_k_rte"], cs="csT")
-    I = dict(n=m.nI, flag=m.flag_i, shp=m.Lambda_shp, rte=m.Lambda_rte, fac=m.Beta, rs=m.t_rte, e=m.eB, acc=m.acc_i,
+    I = dict(n=m.nI, flag=flag_i, shp=m.Lambda_shp, rte=m.Lambda_rte, fac=m.Beta, rs=m.t_rte, e=m.eB, acc=m.acc_i,
              prior=hy["c"], top=hy["t_shp"], add=hy["add_t_rte"], cs="csB")
     B, O = (U, I) if user_batch else (I, U)     # batch side, other side
     # SVI epochs blend the scalar rates of the step's rows only (PXI:324-325, 376-377), partial_fit of all (PXI:472-473)
@@ -374,16 +301,6 @@ def _svi_step(m, hy, su, si, users_tb, items_tb, step, mult, user_batch, all_sca
     cs_o = torch.zeros(ld, dtype=torch.float32, device=ops.device)
     ops.colsum_reduce(m._cs_part, cs_o, ld)
     setattr(m, O["cs"], cs_o)
-
-
-def gather_rows(side, rows):
-    """COO triplets (row, col, y) of the listed rows of a SparseSide (ascending `rows`: the triplets come grouped)."""
-    st = side.indptr[rows]
-    deg = side.indptr[rows + 1] - st
-    total = int(deg.sum().item())
-    offs = torch.cumsum(deg, 0) - deg
-    pos = torch.repeat_interleave(st - offs, deg, output_size=total) + torch.arange(total, device=rows.device)
-    return (torch.repeat_interleave(rows, deg, output_size=total), side.idx[pos].to(torch.int64), side.y[pos])
 
 
 def _dev_ids(a, dev):
@@ -408,7 +325,12 @@ def partial_fit_device(m, Y_batch, ix_u_batch, ix_i_batch, add_k_rte, add_t_rte,
     users_tb, items_tb = _dev_ids(users_this_batch, dev), _dev_ids(items_this_batch, dev)
     if not (bool(torch.isin(su.rows, users_tb).all()) and bool(torch.isin(si.rows, items_tb).all())):
         raise ValueError("the batch contains users/items that are not in users_in_batch/items_in_batch")
-    _svi_step(m, hy, su, si, users_tb, items_tb, step_size_batch, multiplier_batch, user_batch, all_scalar_rows=True)
+    for tb, side, acc, flag in ((users_tb, su, m.acc_u, m.flag_u), (items_tb, si, m.acc_i, m.flag_i)):
+        if tb.shape[0] != side.nrows:        # listed rows without any nonzero in the batch: a zero phi-sum
+            acc.index_fill_(0, tb, 0.0)
+        flag.zero_()
+        flag.index_fill_(0, tb, 1)
+    _svi_step(m, hy, su, si, m.flag_u, m.flag_i, step_size_batch, multiplier_batch, user_batch, all_scalar_rows=True)
 
 
 def partial_fit_step(ops, Y_batch, ix_u_batch, ix_i_batch, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp,
@@ -469,52 +391,53 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
     nbatches_i = int(np.ceil(float(nI) / float(items_per_batch))) if items_per_batch > 0 else 0
     rng = np.random.default_rng(seed=random_seed if random_seed > 0 else None)   # PXI:207
 
-    # HPF_SVI_PREP=torch: the batch structures built with tensor-library calls only (the round-1 path; A/B and tests)
-    fast_prep = os.environ.get("HPF_SVI_PREP", "fast") != "torch"
-    indptr_host = (users.indptr.cpu().numpy(), items.indptr.cpu().numpy()) if fast_prep else None
-    # (HPF_SVI_PREP_STREAM=0: the preparation on the compute stream, between the batches -- measured slower, 4.7 vs 4.2 ms
-    # per C5 batch)
-    own_stream = os.environ.get("HPF_SVI_PREP_STREAM", "1") == "1"
-    prep_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and own_stream) else None
-    # (a batch sends ~7 words per listed row; a batch that needs more falls back to plain copies)
-    staging = PinnedStaging(dev, words=8 * max(int(users_per_batch), int(items_per_batch), 1) + 4096, slots=3) \
-        if (fast_prep and dev.type == "cuda") else None
+    # A batch's index structures (its rows' segment list, the same nonzeros grouped by the other side, the flags of the
+    # rows both touch) are built ON THE DEVICE by one call per batch (BatchWorkspace / hpf_hip_svi_batch_prepare) on a
+    # second stream, one batch ahead of the batch whose kernels run: two workspaces per epoch type, alternating.  The
+    # host's share of a batch is that call, the shuffle (numpy's, as in the reference) once per epoch and one 8-byte-per-
+    # row upload of the epoch's order -- nothing data-dependent comes back.
+    prep_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
     if prep_stream is not None:
         prep_stream.wait_stream(torch.cuda.current_stream(dev))      # the CSR / CSC built above
+    workspaces = {}
 
-    import contextlib
+    def workspace(user_epoch, slot):
+        key = (bool(user_epoch), slot)
+        if key not in workspaces:
+            own, oth = (users, items) if user_epoch else (items, users)
+            workspaces[key] = BatchWorkspace(ops, own, oth, m.acc_u if user_epoch else m.acc_i, m.ld,
+                                             users_per_batch if user_epoch else items_per_batch)
+        return workspaces[key]
 
-    def on_prep_stream():
-        return torch.cuda.stream(prep_stream) if prep_stream is not None else contextlib.nullcontext()
+    order_host = {}      # page-locked staging for an epoch's order, per epoch type (re-used once its copy has completed)
 
-    def prepare_start(ids, user_epoch):
-        """Launches the index work of a batch (the listed rows gathered from the CSR / CSC, the other side sorted) on the
-        preparation stream; nothing here waits for the device (fast path)."""
-        with on_prep_stream():
-            if fast_prep:
-                return batch_sides_start(ops, users if user_epoch else items, indptr_host[0 if user_epoch else 1], ids,
-                                         nI if user_epoch else nU, staging=staging)
-            rows = torch.sort(_dev_ids(ids, dev)).values             # ascending: the gathered triplets come grouped
-            if user_epoch:
-                bu, bi, by = gather_rows(users, rows)
-                return BatchSide(bu, bi, by, grouped=True), BatchSide(bi, bu, by), rows
-            bi, bu, by = gather_rows(items, rows)
-            return BatchSide(bu, bi, by), BatchSide(bi, bu, by, grouped=True), rows
+    def upload_order(numeration, user_epoch):
+        """The epoch's shuffled row order -> device int64 (one asynchronous copy from page-locked memory)."""
+        n = numeration.shape[0]
+        if dev.type != "cuda":
+            return torch.from_numpy(numeration.astype(np.int64))
+        slot = order_host.get(user_epoch)
+        if slot is None:
+            slot = order_host[user_epoch] = [torch.empty(n, dtype=torch.int64, pin_memory=True), None]
+        if slot[1] is not None:
+            slot[1].synchronize()
+        slot[0].numpy()[:] = numeration.view(np.int64)
+        out = slot[0].to(dev, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        return out
 
-    def prepare_finish(started, user_epoch):
-        """-> ((su, si, users_tb, items_tb), ready event): the batch grouped by user and by item."""
-        with on_prep_stream():
-            if fast_prep:
-                rows, own, other = batch_sides_finish(started)
-                su, si = (own, other) if user_epoch else (other, own)
-            else:
-                su, si, rows = started
-            out = (su, si, rows, si.rows) if user_epoch else (su, si, su.rows, rows)
-            ready = None
-            if prep_stream is not None:
-                ready = torch.cuda.Event()
-                ready.record(prep_stream)
-        return out, ready
+    def prepare(ws, ids):
+        """Queue the preparation of a batch on the preparation stream (after the step that last used `ws`)."""
+        if prep_stream is None:
+            ws.prepare(ops, ids)
+            return
+        if ws.free is not None:
+            prep_stream.wait_event(ws.free)
+        with torch.cuda.stream(prep_stream):
+            ws.prepare(ops, ids)
+            ws.ready = torch.cuda.Event()
+            ws.ready.record(prep_stream)
 
     errs = np.zeros(2, dtype=np.longdouble)
     last_crit = -np.inf
@@ -531,7 +454,8 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
             errs[0] = np.longdouble(t[0]) - np.longdouble(sub)
             errs[1] = np.sqrt(np.longdouble(t[1]) / val[0].shape[0])
         else:
-            t = ops.pair_llk(m.Theta, m.Beta, u_sorted, users.idx, users.y, k, m.ld, full_llk).cpu().numpy()
+            # the training nonzeros in the row-grouped layout: user rows read once per segment, item rows gathered
+            t = ops.llk_sweep(users, m.Theta, m.Beta, k, m.ld, full_llk).cpu().numpy()
             sub = np.dot(m.csT[:k].cpu().numpy(), m.csB[:k].cpu().numpy())
             errs[0] = np.longdouble(t[0]) - np.longdouble(sub)
             errs[1] = np.sqrt(np.longdouble(t[1]) / users.nnz)
@@ -553,38 +477,43 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
             user_epoch = users_per_batch > 0
         if user_epoch:
             rng.shuffle(users_numeration)
-            chunks = [users_numeration[bt * users_per_batch: min(nU, (bt + 1) * users_per_batch)].copy()
-                      for bt in range(nbatches_u)]
+            numeration, per, n_side = users_numeration, int(users_per_batch), nU
         else:
             rng.shuffle(items_numeration)
-            chunks = [items_numeration[bt * items_per_batch: min(nI, (bt + 1) * items_per_batch)].copy()
-                      for bt in range(nbatches_i)]
-        n_side = nU if user_epoch else nI
-        # a batch's index structures (its rows gathered from the CSR / CSC, grouped by both sides, cut into segments)
-        # are data-only and are prepared on a second stream in two halves (batch_sides_start / _finish): before batch j
-        # is issued, batch j+1 -- started one batch ago, so the sizes it needs from the device are on the host by now
-        # -- is finished and batch j+2 is started, so a batch's structures are ready long before its turn.  What is
-        # left of the preparation in a C5 batch is ~0.7 ms of 4.0 (3.3 ms with every batch re-using the first one's
-        # structures): its ~50 small launches run between / beside the batch's long whole-GPU kernels
-        # (profiles/r02_svi_c5_timeline.txt)
-        pending = prepare_finish(prepare_start(chunks[0], user_epoch), user_epoch)
-        started = prepare_start(chunks[1], user_epoch) if len(chunks) > 1 else None
-        for j in range(len(chunks)):
+            numeration, per, n_side = items_numeration, int(items_per_batch), nI
+        t_h = time.perf_counter()
+        order = upload_order(numeration, user_epoch)
+        if prep_stream is not None:
+            prep_stream.wait_stream(torch.cuda.current_stream(dev))      # (the order's copy is queued on this stream)
+            order.record_stream(prep_stream)
+        nb = nbatches_u if user_epoch else nbatches_i
+        chunks = [order[bt * per: min(n_side, (bt + 1) * per)] for bt in range(nb)]
+        prepare(workspace(user_epoch, 0), chunks[0])
+        host_s[0] += time.perf_counter() - t_h
+        for j in range(nb):
             t_h = time.perf_counter()
-            # batch j+1 was started one batch ago: its sizes are on the host by now; batch j+2 is started
-            nxt = prepare_finish(started, user_epoch) if started is not None else None
-            started = prepare_start(chunks[j + 2], user_epoch) if j + 2 < len(chunks) else None
-            host_s[0] += time.perf_counter() - t_h
-            t_h = time.perf_counter()
-            (su, si, utb, itb), ready = pending
-            if ready is not None:
-                torch.cuda.current_stream(dev).wait_event(ready)
-                for t in su.tensors() + si.tensors() + [utb, itb]:
-                    t.record_stream(torch.cuda.current_stream(dev))
-            _svi_step(m, hyd, su, si, utb, itb, step, float(n_side) / float(chunks[j].shape[0]), user_epoch,
+            ws = workspace(user_epoch, j % 2)
+            if ws.ready is not None:
+                torch.cuda.current_stream(dev).wait_event(ws.ready)
+            su, si = (ws.side_own, ws.side_oth) if user_epoch else (ws.side_oth, ws.side_own)
+            flag_u, flag_i = (ws.flag_own, ws.flag_oth) if user_epoch else (ws.flag_oth, ws.flag_own)
+            _svi_step(m, hyd, su, si, flag_u, flag_i, step, float(n_side) / float(chunks[j].shape[0]), user_epoch,
                       all_scalar_rows=False)
-            pending = nxt
+            if prep_stream is not None:
+                ws.free = torch.cuda.Event()
+                ws.free.record(torch.cuda.current_stream(dev))
             host_s[1] += time.perf_counter() - t_h
+            if j + 1 < nb:
+                # the next batch's structures are built while this batch's kernels run.  Its workspace was last used by
+                # batch j-1: the host waits for that step here (not a bubble -- batch j is queued already), which also
+                # keeps it at most a batch ahead of the device, so the two clocks below time host WORK, not a full
+                # launch queue
+                nxt = workspace(user_epoch, (j + 1) % 2)
+                if nxt.free is not None:
+                    nxt.free.synchronize()
+                t_h = time.perf_counter()
+                prepare(nxt, chunks[j + 1])
+                host_s[0] += time.perf_counter() - t_h
 
         if check_every > 0 and ((i + 1) % check_every) == 0:
             if stop_crit == "diff-norm":
@@ -607,6 +536,8 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
                             break
                         last_crit = errs[0]
 
+    if any(ws.overflowed() for ws in workspaces.values()):        # (cannot happen: capacities come from the largest rows)
+        raise _lib.HpfHipError("hpfrec_amd: a stochastic batch outgrew its workspace")
     tick("epochs and checks")
     if timing:
         if dev.type == "cuda":

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 12
+#define HPF_HIP_ABI_VERSION 13
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -77,10 +77,12 @@ int hpf_hip_device_info(int *cu_count, char *arch, int arch_len);
  * acc_rows[row][0:acc_ld] (k <= acc_ld <= ld, packed) instead of part[g] -- the multi-GPU exchange buffer.
  * short_rows: tuning hint (0/1) for rows that average a few dozen nonzeros at most: the same kernel with half the
  * gathers in flight per wavefront (smaller register file, more wavefronts resident).  Results are identical.
+ * nseg_dev (optional, device): the live number of segments, <= nseg -- a stochastic batch whose size only the device
+ * knows (hpf_hip_svi_batch_prepare); nseg is then the capacity of segs[] / part[].
  */
 int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
                       const float *tab_self, const float *tab_other, float *part, float *acc_rows, int acc_ld, int k,
-                      int ld, int short_rows, int grid_blocks, void *stream);
+                      int ld, int short_rows, int grid_blocks, const int64_t *nseg_dev, void *stream);
 
 /*
  * hpf_hip_sweep_f32 with the row finalizer (next entry) fused in: a segment flagged
@@ -167,9 +169,10 @@ int hpf_hip_colsum_f32(const float *tab, int64_t nrows, int ld, float *cs_partia
 
 /* e[r] = exp(psi(shp[r]) - log(rte[r])) / rowmax, pads zeroed: the hoisted transcendental part of
  * update_phi (PXI:570,588,685) for rows whose shape/rate did not come out of hpf_hip_row_finalize_f32
- * (initialisation PXI:134-138; the rows of an SVI batch).  r = row_list ? row_list[t] : t, t < nrows. */
-int hpf_hip_expect_f32(const float *shp, const float *rte, float *e, const int64_t *row_list, int64_t nrows, int k,
-                       int ld, void *stream);
+ * (initialisation PXI:134-138; the rows of an SVI batch).  r = row_list ? row_list[t] : t, t < nrows; with `flag`
+ * (optional, one byte per table row) only rows with flag[r] != 0 are touched. */
+int hpf_hip_expect_f32(const float *shp, const float *rte, float *e, const int64_t *row_list, const uint8_t *flag,
+                       int64_t nrows, int k, int ld, void *stream);
 
 /* acc[t][0:acc_ld] (or acc[r][0:acc_ld] when acc_by_row) = sum of the part[] segments of row
  * r = row_list ? row_list[t] : t, t < nrows (multi-GPU item side before the all-reduce -- acc_ld = k packs the
@@ -249,20 +252,47 @@ int hpf_hip_fold_in_f32(const int32_t *idx, const float *y, int64_t n, const flo
                         float add, float rs, float stop_thr, int maxiter, int k, int ld, void *stream);
 
 /*
- * Index plumbing of a stochastic batch (the reference slices its CSR / CSC per batch with numpy fancy indexing,
- * PXI:280-290, 332-342, and scipy; here the batch's structures are built on the device).
- * hpf_hip_gather_rows: the nonzeros of the listed rows of a CSR (or CSC): row t's entries
- *   src_idx / src_y [src_begin[t] ...) are copied to out_idx / out_y [dst_begin[t], dst_begin[t+1]) and out_row there is
- *   row_ids[t] (dst_begin has nrows+1 entries).
- * hpf_hip_fill_segments: hpf_segment descriptors of rows given by (start, count > 0, id): row t is cut into
- *   row_seg_ptr[t+1]-row_seg_ptr[t] = ceil(count[t]/seg_cap) segments written from segs[row_seg_ptr[t]] on; a row
- *   with one segment carries HPF_SEG_WHOLE_ROW; `row` of the descriptor is row_ids[t].
+ * Index structures of a stochastic batch, built on the device by one call (hpfrec_amd/csrc/hpf_svi_prep.hip).  The
+ * reference slices its CSR / CSC per batch with numpy fancy indexing on the host (PXI:280-290, 332-342) and collects the
+ * other side's rows with get_unique_items_batch (PXI:27-42).  Here, for the batch made of rows `ids` of the "own" side
+ * (users for a user batch, items for an item batch; both sides in the layout of hpf_hip_sweep_f32):
+ *   own side:   b_segs = the stable compaction of the side's global segment list by the batch's rows -- descriptors
+ *               unchanged, they index the side's global idx / y; b_multi[m] = {first compacted segment, segments, row}
+ *               of each split row; flag_own[row] = 1 for the batch's rows (the previous batch of this workspace,
+ *               prev_ids, is unmarked first); acc_own[row] is zeroed for batch rows without nonzeros;
+ *   other side: the batch's nonzeros grouped by the other side's rows, in the order the other side's global layout holds
+ *               them (ascending own-side ids: stable, no sort): o_idx = own-side row id, o_y = count, o_segs / o_multi as
+ *               above with `begin` indexing o_idx / o_y; flag_oth[row] = 1 for rows present, 0 for all others.
+ * sizes[0..8) (device int64): segments own, split rows own, segments other, split rows other, nonzeros, rows other, -,
+ * overflow (a capacity was too small; never with capacities from the side's largest rows).  Nothing is read back: the
+ * consumers take their counts from `sizes` (hpf_hip_sweep_f32 nseg_dev, hpf_hip_segsum_desc_f32, hpf_hip_expect_f32 flag).
+ * How: the own side is a stable compaction of its segment list; the other side is the other side's flat nonzero array
+ * (already grouped by its rows, own-side ids ascending inside a row) filtered by flag_own -- a keep-bitmask pass, prefix
+ * sums per 1024-entry tile, a scan over the rows, a write pass; bandwidth-bound, no sort, no atomics on floats.
+ * All pointers are device memory.
  */
-int hpf_hip_gather_rows(const int64_t *src_begin, const int64_t *dst_begin, const int64_t *row_ids, int64_t nrows,
-                        const int32_t *src_idx, const float *src_y, int32_t *out_idx, float *out_y, int32_t *out_row,
-                        void *stream);
-int hpf_hip_fill_segments(const int64_t *start, const int64_t *count, const int64_t *row_seg_ptr,
-                          const int64_t *row_ids, int64_t nrows, int seg_cap, hpf_segment *segs, void *stream);
+typedef struct hpf_svi_batch {
+    const hpf_segment *own_segs; int64_t own_nseg; const int64_t *own_row_seg_ptr; const int64_t *own_indptr;
+    int64_t own_nrows;
+    const int32_t *oth_idx; const float *oth_y; const int64_t *oth_indptr; int64_t oth_nrows; int64_t oth_nnz;
+    const int64_t *ids; int64_t nids; const int64_t *prev_ids; int64_t nprev;
+    uint8_t *flag_own; uint8_t *flag_oth; float *acc_own; int32_t ld, seg_cap;
+    hpf_segment *b_segs; int64_t b_segs_cap; int64_t *b_multi; int64_t multi_cap;
+    int32_t *o_idx; float *o_y; int64_t o_cap; hpf_segment *o_segs; int64_t o_segs_cap; int64_t *o_multi;
+    int64_t *sizes;
+    /* scratch: mask [16 * ceil(oth_nnz/1024)] 8-byte words (a keep bit per nonzero); chunk_pre [same count] uint16;
+     * tile_cnt [ceil(oth_nnz/1024)+1] int32; tile_off [ceil(oth_nnz/1024)+1] int64; row_start [oth_nrows] int64;
+     * row_cnt [oth_nrows] int32; tiles [hpf_hip_svi_prep_scratch_words()] int64 */
+    uint64_t *mask; uint16_t *chunk_pre; int32_t *tile_cnt; int64_t *tile_off; int64_t *row_start; int32_t *row_cnt;
+    int64_t *tiles; uint32_t *flag_bits;   /* flag_bits [ceil(own_nrows/32)]: flag_own as a bitset (it fits a CU's LDS) */
+} hpf_svi_batch;
+int64_t hpf_hip_svi_batch_sizeof(void);   /* sizeof(hpf_svi_batch), for a binding's layout check */
+int64_t hpf_hip_svi_prep_scratch_words(void);
+int hpf_hip_svi_batch_prepare(const hpf_svi_batch *batch, void *stream);
+/* acc[row][0:ld] = sum of part[first .. first+n) for the descriptors {first, n, row} (b_multi / o_multi above), the
+ * first min(ndesc_max, *ndesc_dev) of them: the split rows of a batch sweep (hpf_hip_segsum_f32 with device-side lists). */
+int hpf_hip_segsum_desc_f32(const float *part, const int64_t *desc, const int64_t *ndesc_dev, int64_t ndesc_max,
+                            float *acc, int ld, void *stream);
 
 /*
  * initialize_parameters (PXI:127-141) without the host, in two steps.

@@ -21,8 +21,14 @@ def _np(t):
     return t.numpy()
 
 
+def _live_nseg(side):
+    """Segments of a side that count: all of them, or -- a batch built on the device -- the count kept there."""
+    nd = getattr(side, "nseg_dev", None)
+    return int(side.nseg) if nd is None else min(int(side.nseg), int(_np(nd)[0]))
+
+
 def _decode_segs(side):
-    s = _np(side.segs)
+    s = _np(side.segs)[: _live_nseg(side)]
     begin = s[:, 0].copy()
     meta = s[:, 1]
     length = (meta & 0x00FFFFFF).astype(np.int64)
@@ -65,10 +71,11 @@ class CpuOps:
         self.sweep(side, tab_self, tab_other, part, k, ld, acc_rows=acc_rows, acc_ld=acc_ld)
 
     def sweep(self, side, tab_self, tab_other, part, k, ld, acc_rows=None, acc_ld=0, grid_blocks=None):
-        if side.nseg == 0:
+        nseg = _live_nseg(side)
+        if nseg == 0:
             return
         begin, length, row = _decode_segs(side)
-        seg_of_nnz = np.repeat(np.arange(side.nseg), length)
+        seg_of_nnz = np.repeat(np.arange(nseg), length)
         offs = np.concatenate([[0], np.cumsum(length)[:-1]])
         # positions of every segment's nonzeros (segments may be any subset of the rows)
         pos = np.repeat(begin, length) + (np.arange(length.sum()) - np.repeat(offs, length))
@@ -81,11 +88,11 @@ class CpuOps:
         contrib = w[:, None] * O
         out = np.add.reduceat(contrib, offs, axis=0)
         if acc_rows is not None:
-            whole = (_np(side.segs)[:, 1] & 0x40000000) != 0
+            whole = (_np(side.segs)[:nseg, 1] & 0x40000000) != 0
             _np(acc_rows)[row[whole], :acc_ld] = out[whole][:, :acc_ld].astype(np.float32)
-            _np(part)[: side.nseg][~whole] = out[~whole].astype(np.float32)
+            _np(part)[:nseg][~whole] = out[~whole].astype(np.float32)
         else:
-            _np(part)[: side.nseg] = out.astype(np.float32)
+            _np(part)[:nseg] = out.astype(np.float32)
 
     def row_finalize(self, part, row_seg_ptr, nrows, e_old, e_new, shp, rte, fac, rs, cs_other, cs_partial,
                      prior_shp, top_shp, add_rte, k, ld, row_list=None, part_ld=None, rs_prev=None):
@@ -161,8 +168,10 @@ class CpuOps:
         cp[:] = 0
         cp[0] = _np(tab)[:nrows].astype(np.float64).sum(axis=0).astype(np.float32)
 
-    def expect(self, shp, rte, e, nrows, k, ld, row_list=None):
+    def expect(self, shp, rte, e, nrows, k, ld, row_list=None, flag=None):
         rows = np.arange(nrows) if row_list is None else _np(row_list)[:nrows].astype(np.int64)
+        if flag is not None:
+            rows = rows[_np(flag)[rows] != 0]
         if rows.shape[0] == 0:
             return
         valid = np.arange(ld) < k
@@ -237,22 +246,75 @@ class CpuOps:
         _np(e_last)[:] = _np(e_row)[0]
         _np(rounds)[0] = it
 
-    def gather_rows(self, src_begin, dst_begin, row_ids, src_idx, src_y, out_idx, out_y, out_row):
-        sb, db, ids = _np(src_begin), _np(dst_begin), _np(row_ids)
-        for t in range(ids.shape[0]):
-            n = int(db[t + 1] - db[t])
-            _np(out_idx)[db[t]: db[t] + n] = _np(src_idx)[sb[t]: sb[t] + n]
-            _np(out_y)[db[t]: db[t] + n] = _np(src_y)[sb[t]: sb[t] + n]
-            _np(out_row)[db[t]: db[t] + n] = ids[t]
+    def svi_prep_scratch_words(self):
+        return 8
 
-    def fill_segments(self, start, count, row_seg_ptr, row_ids, seg_cap, segs):
-        st, cn, rsp, ids, out = _np(start), _np(count), _np(row_seg_ptr), _np(row_ids), _np(segs)
-        for t in range(ids.shape[0]):
-            ns = int(rsp[t + 1] - rsp[t])
-            for q in range(ns):
-                ln = min(int(cn[t]) - q * seg_cap, seg_cap)
-                out[rsp[t] + q, 0] = st[t] + q * seg_cap
-                out[rsp[t] + q, 1] = ln | (0x40000000 if ns == 1 else 0) | (int(ids[t]) << 32)
+    def svi_batch_prepare(self, ws):
+        """hpf_hip_svi_batch_prepare in numpy: same outputs in the same layout (tests compare them with the kernels')."""
+        own, oth, cap = ws.own, ws.oth, int(ws.seg_cap)
+        flag = _np(ws.flag_own)
+        if ws.prev_ids is not None:
+            flag[_np(ws.prev_ids)] = 0
+        ids = _np(ws.ids)
+        flag[ids] = 1
+        ptr = _np(own.indptr)
+        empty = ids[ptr[ids + 1] == ptr[ids]]
+        _np(ws.acc_own)[empty] = 0
+        sizes = _np(ws.sizes)
+        sizes[:] = 0
+        # own side: stable compaction of the global segment list
+        segs = _np(own.segs)
+        row = (segs[:, 1] >> 32).astype(np.int64)
+        keep = flag[row] != 0
+        kept = segs[keep]
+        nb = kept.shape[0]
+        assert nb <= ws.b_cap
+        _np(ws.b_segs)[:nb] = kept
+        krow = row[keep]
+        rsp = _np(own.row_seg_ptr)
+        opens = np.nonzero(((kept[:, 1] & 0x40000000) == 0) & (np.concatenate([[True], krow[1:] != krow[:-1]])))[0]
+        bm = _np(ws.b_multi)
+        bm[: opens.shape[0], 0] = opens
+        bm[: opens.shape[0], 1] = rsp[krow[opens] + 1] - rsp[krow[opens]]
+        bm[: opens.shape[0], 2] = krow[opens]
+        sizes[0], sizes[1] = nb, opens.shape[0]
+        # other side: its global layout filtered by the flag
+        optr = _np(oth.indptr)
+        mask = flag[_np(oth.idx).astype(np.int64)] != 0
+        row_of = np.repeat(np.arange(oth.nrows), optr[1:] - optr[:-1])
+        n = int(mask.sum())
+        assert n <= ws.o_cap
+        _np(ws.o_idx)[:n] = _np(oth.idx)[mask]
+        _np(ws.o_y)[:n] = _np(oth.y)[mask]
+        cnt = np.bincount(row_of[mask], minlength=oth.nrows).astype(np.int64)
+        _np(ws.flag_oth)[:] = cnt > 0
+        rows = np.nonzero(cnt > 0)[0]
+        c = cnt[rows]
+        start = np.cumsum(c) - c
+        ns = (c + cap - 1) // cap
+        sg0 = np.cumsum(ns) - ns
+        nseg = int(ns.sum())
+        assert nseg <= ws.o_segs_cap
+        local = np.repeat(np.arange(rows.shape[0]), ns)
+        within = np.arange(nseg) - sg0[local]
+        begin = start[local] + within * cap
+        length = np.minimum(c[local] - within * cap, cap) | np.where(ns[local] == 1, 0x40000000, 0)
+        osegs = _np(ws.o_segs)
+        osegs[:nseg, 0] = begin
+        osegs[:nseg, 1] = length | (rows[local] << 32)
+        multi = np.nonzero(ns > 1)[0]
+        om = _np(ws.o_multi)
+        om[: multi.shape[0], 0] = sg0[multi]
+        om[: multi.shape[0], 1] = ns[multi]
+        om[: multi.shape[0], 2] = rows[multi]
+        sizes[2], sizes[3], sizes[4], sizes[5] = nseg, multi.shape[0], n, rows.shape[0]
+
+    def segsum_desc(self, part, desc, ndesc_dev, ndesc_max, acc, ld):
+        nd = min(int(ndesc_max), int(_np(ndesc_dev)[0]))
+        P, D = _np(part).astype(np.float64), _np(desc)
+        for d in range(nd):
+            first, n, r = int(D[d, 0]), int(D[d, 1]), int(D[d, 2])
+            _np(acc)[r] = P[first: first + n].sum(axis=0).astype(np.float32)
 
     def mt19937_words(self, state, raw):
         """numpy's own generator positioned at `state`; its outputs, un-tempered, are the stream's state words."""

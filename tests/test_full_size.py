@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 import torch
 
+import batch_reference
 import datagen
 from hpfrec_amd import HPF, cavi, svi
 from oracle import hpf_oracle as O
@@ -168,20 +169,29 @@ def test_c5_batches_full_size_identities(ops):
     step = float(np.float32(1 / np.sqrt(2.0)))
     for user_batch, side, n_side, prior_b, prior_o in ((True, users, nU, hyd["a"], hyd["c"]),
                                                        (False, items, nI, hyd["c"], hyd["a"])):
-        rows = torch.sort(torch.randperm(n_side, generator=g, device=dev)[:B]).values
-        br, bc, by = svi.gather_rows(side, rows)
+        ids = torch.randperm(n_side, generator=g, device=dev)[:B]          # (an epoch's batch: unsorted)
+        rows = torch.sort(ids).values
+        other = items if user_batch else users
+        # the product's path: the batch's structures built on the device (svi.BatchWorkspace, one call)
+        ws = svi.BatchWorkspace(ops, side, other, m.acc_u if user_batch else m.acc_i, m.ld, B)
+        ws.prepare(ops, ids)
+        assert not ws.overflowed()
+        br, bc, by = batch_reference.gather_rows(side, rows)             # (reference triplets, for the identities)
         mult = float(n_side) / B
+        other_rows = torch.nonzero(ws.flag_oth).reshape(-1)
+        assert int(ws.sizes[4].item()) == int(by.shape[0]) and torch.equal(other_rows, torch.unique(bc))
         if user_batch:
-            su, si = svi.BatchSide(br, bc, by, grouped=True), svi.BatchSide(bc, br, by)
-            utb, itb, other_rows, other_shp, batch_shp = rows, si.rows, si.rows, m.Lambda_shp, m.Gamma_shp
+            su, si, flag_u, flag_i = ws.side_own, ws.side_oth, ws.flag_own, ws.flag_oth
+            other_shp, batch_shp = m.Lambda_shp, m.Gamma_shp
         else:
-            su, si = svi.BatchSide(bc, br, by), svi.BatchSide(br, bc, by, grouped=True)
-            utb, itb, other_rows, other_shp, batch_shp = su.rows, rows, su.rows, m.Gamma_shp, m.Lambda_shp
+            su, si, flag_u, flag_i = ws.side_oth, ws.side_own, ws.flag_oth, ws.flag_own
+            other_shp, batch_shp = m.Gamma_shp, m.Lambda_shp
         ysum_b = torch.zeros(n_side, dtype=torch.float64, device=dev).index_add_(0, br, by.double())[rows]
         n_other = other_shp.shape[0]
         ysum_o = torch.zeros(n_other, dtype=torch.float64, device=dev).index_add_(0, bc, by.double())[other_rows]
         before_o = other_shp[other_rows][:, :k].double().sum(dim=1)
-        svi._svi_step(m, hyd, su, si, utb, itb, step, mult, user_batch, all_scalar_rows=False)
+        svi._svi_step(m, hyd, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_rows=False)
+        del ws
         mass_b = batch_shp[rows][:, :k].double().sum(dim=1) - k * prior_b
         assert float(((mass_b - ysum_b).abs() / ysum_b.clamp_min(1)).max()) < 3e-5
         w = float(np.float32(step * float(np.float32(mult))))

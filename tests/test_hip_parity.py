@@ -343,7 +343,9 @@ def test_pair_ops(ops, k):
     from hpfrec_amd import cython_loops_float as be
     iu64, ii64 = iu.numpy().astype(np.uint64), ii.numpy().astype(np.uint64)
     Tk, Bk = T[:, :k].contiguous().numpy(), B[:, :k].contiguous().numpy()
-    assert np.max(np.abs(be.predict_arr(Tk, Bk, iu64, ii64, 1) / O.predict_arr(Tk, Bk, iu64, ii64) - 1)) < 1e-6
+    # (the oracle's dot is BLAS sdot; a k-term float32 sum in another order differs by ~sqrt(k) ulps)
+    assert np.max(np.abs(be.predict_arr(Tk, Bk, iu64, ii64, 1) / O.predict_arr(Tk, Bk, iu64, ii64) - 1)) < \
+        (1e-6 if k <= 200 else 4e-6)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1024,20 +1026,3 @@ def test_device_initialisation_is_the_reference_draw(ops):
         for name in NAMES:
             w = want[name][u0:u1] if name in ("Theta", "Gamma_shp", "Gamma_rte", "k_rte") else want[name]
             assert np.array_equal(m.fetch(name), w), (name, u0)
-
-
-def test_pinned_staging_uploads(ops):
-    """svi.PinnedStaging: one asynchronous transfer per batch out of page-locked memory, slots re-used round-robin
-    after their copy completed, plain copies when a batch does not fit."""
-    from hpfrec_amd import svi
-    dev = ops.device
-    rs = np.random.RandomState(0)
-    st = svi.PinnedStaging(dev, words=1000, slots=2)
-    for rep in range(7):                                        # wraps around the slots several times
-        arrays = [rs.randint(0, 2 ** 40, size=s).astype(np.int64) for s in ((5,), (0,), (17, 2), (300,))]
-        got = st.upload(arrays)
-        for a, g in zip(arrays, got):
-            assert tuple(g.shape) == a.shape and g.dtype == torch.int64 and np.array_equal(g.cpu().numpy(), a)
-    big = [rs.randint(0, 9, size=600).astype(np.int64), rs.randint(0, 9, size=(300, 2)).astype(np.int64)]   # 1200 > 1000 words
-    for a, g in zip(big, st.upload(big)):
-        assert np.array_equal(g.cpu().numpy(), a)

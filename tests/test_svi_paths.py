@@ -161,43 +161,77 @@ def test_partial_fit_growing_model_on_gpu(hip_backend):
 
 
 @pytest.mark.parametrize("case", ["ragged", "hubs", "empty-rows", "no-nonzeros"])
-def test_batch_structures_fast_path_equals_the_tensor_library_path(any_backend, case):
-    """svi.batch_sides (numpy on the host row pointers + hpf_hip_gather_rows + one sort + hpf_hip_fill_segments) builds
-    exactly the structures BatchSide(gather_rows(...)) builds with tensor-library calls: same row lists, same nonzero
-    order, same segment descriptors, for both sides of user and item batches -- incl. rows longer than a segment, listed
-    rows without nonzeros and a batch without any nonzero."""
+def test_batch_workspace_equals_the_tensor_library_structures(any_backend, case):
+    """svi.BatchWorkspace (hpf_hip_svi_batch_prepare: everything on the device, one call, nothing read back) builds
+    the structures BatchSide(gather_rows(...)) builds with tensor-library sorts: same rows, same nonzeros in the same
+    order, same segment descriptors and split-row lists, same flags, for both sides of user and item batches -- incl.
+    rows longer than a segment, listed rows without nonzeros (their accumulator rows zeroed), a batch without any
+    nonzero, and a workspace re-used for a second batch (the first one's marks removed)."""
     import torch
+    import batch_reference
     from hpfrec_amd import layout, svi
     ops = any_backend._make_ops()
     dev = ops.device
     rs = np.random.RandomState({"ragged": 1, "hubs": 2, "empty-rows": 3, "no-nonzeros": 4}[case])
-    nU, nI, cap = 700, 300, 16
+    nU, nI, cap, ld = 700, 300, 16, 32
     nnz = 9000 if case != "empty-rows" else 900
     iu = (nU * rs.random_sample(nnz) ** (3 if case == "hubs" else 1.3)).astype(np.int64)
     ii = (nI * rs.random_sample(nnz) ** (4 if case == "hubs" else 1.5)).astype(np.int64)
     y = (1 + rs.poisson(1.0, size=nnz)).astype(np.float32)
     users, items, _ = layout.build_sides(torch.from_numpy(iu).to(dev), torch.from_numpy(ii).to(dev),
                                          torch.from_numpy(y).to(dev), nU, nI, seg_cap=cap)
-    for side, n_rows in ((users, nU), (items, nI)):
-        ids = rs.permutation(n_rows)[: n_rows // 3].astype(np.uint64)
-        if case == "no-nonzeros":
-            deg = (side.indptr[1:] - side.indptr[:-1]).cpu().numpy()
-            ids = np.nonzero(deg == 0)[0].astype(np.uint64)
+    for side, other, n_rows in ((users, items, nU), (items, users, nI)):
+        acc = torch.ones((n_rows, ld), dtype=torch.float32, device=dev)
+        ws = svi.BatchWorkspace(ops, side, other, acc, ld, max(1, n_rows // 3), seg_cap=cap)
+        deg = (side.indptr[1:] - side.indptr[:-1]).cpu().numpy()
+        for rep in range(2):                                      # the second batch re-uses the workspace
+            ids = rs.permutation(n_rows)[: n_rows // 3].astype(np.int64)
+            if case == "no-nonzeros":
+                ids = np.nonzero(deg == 0)[0].astype(np.int64)[: max(1, n_rows // 3)]
             if ids.size == 0:
-                ids = np.array([], dtype=np.uint64)
-        rows_t = torch.sort(svi._dev_ids(ids, dev)).values
-        br, bc, by = svi.gather_rows(side, rows_t)
-        want_own = svi.BatchSide(br, bc, by, seg_cap=cap, grouped=True)
-        want_other = svi.BatchSide(bc, br, by, seg_cap=cap)
-        rows, own, other = svi.batch_sides(ops, side, side.indptr.cpu().numpy(), ids, nI if side is users else nU,
-                                           seg_cap=cap)
-        assert torch.equal(rows, rows_t)
-        for got, want in ((own, want_own), (other, want_other)):
-            assert (got.nseg, got.nmulti, got.nrows, got.short_rows) == (want.nseg, want.nmulti, want.nrows, want.short_rows)
-            for a, b, name in zip(got.tensors(), want.tensors(), ("rows", "idx", "y", "row_seg_ptr", "segs", "multi_local")):
-                assert a.dtype == b.dtype and torch.equal(a.reshape(-1), b.reshape(-1)), (case, name)
-        if case == "hubs":
-            assert own.nmulti > 0 and other.nmulti > 0
+                continue
+            acc.fill_(1.0)
+            ws.prepare(ops, torch.from_numpy(ids).to(dev))
+            rows_t = torch.sort(torch.from_numpy(ids).to(dev)).values
+            br, bc, by = batch_reference.gather_rows(side, rows_t)
+            want_own = svi.BatchSide(br, bc, by, seg_cap=cap, grouped=True)
+            want_oth = svi.BatchSide(bc, br, by, seg_cap=cap)
+            sz = ws.sizes.cpu().numpy()
+            assert sz[7] == 0
+            assert (sz[0], sz[2], sz[4], sz[5]) == (want_own.nseg, want_oth.nseg, int(by.shape[0]), want_oth.nrows), (case, sz)
+            assert (sz[1], sz[3]) == (want_own.nmulti, want_oth.nmulti)
+            # flags
+            f = np.zeros(n_rows, np.uint8)
+            f[ids] = 1
+            assert np.array_equal(ws.flag_own.cpu().numpy(), f)
+            fo = np.zeros(other.nrows, np.uint8)
+            fo[want_oth.rows.cpu().numpy()] = 1
+            assert np.array_equal(ws.flag_oth.cpu().numpy(), fo)
+            # accumulator rows of batch rows without nonzeros are zeroed, nothing else is touched
+            a = acc.cpu().numpy()
+            empty = ids[deg[ids] == 0]
+            assert np.all(a[empty] == 0) and np.all(np.delete(a, empty, axis=0) == 1)
+            # own side: the same rows, lengths and flags; the descriptors index the side's GLOBAL arrays
+            got = ws.b_segs[: sz[0]].cpu().numpy()
+            want = want_own.segs.cpu().numpy()
+            assert np.array_equal(got[:, 1], want[:, 1])
+            gi, gy = side.idx.cpu().numpy(), side.y.cpu().numpy()
+            wi, wy = want_own.idx.cpu().numpy(), want_own.y.cpu().numpy()
+            for (gb, meta), (wb, _) in zip(got, want):
+                n = int(meta & 0x00FFFFFF)
+                assert np.array_equal(gi[gb: gb + n], wi[wb: wb + n]) and np.array_equal(gy[gb: gb + n], wy[wb: wb + n])
+            # other side: identical arrays
+            assert torch.equal(ws.o_idx[: sz[4]], want_oth.idx) and torch.equal(ws.o_y[: sz[4]], want_oth.y)
+            assert torch.equal(ws.o_segs[: sz[2]], want_oth.segs)
+            # split rows: {first segment, segments, row}
+            for desc, n, wside in ((ws.b_multi, sz[1], want_own), (ws.o_multi, sz[3], want_oth)):
+                d = desc[:n].cpu().numpy()
+                ml = wside.multi_local.cpu().numpy()
+                rsp = wside.row_seg_ptr.cpu().numpy()
+                assert np.array_equal(d[:, 0], rsp[ml]) and np.array_equal(d[:, 1], rsp[ml + 1] - rsp[ml])
+                assert np.array_equal(d[:, 2], wside.rows.cpu().numpy()[ml])
+            if case == "hubs":
+                assert sz[1] > 0 and sz[3] > 0
 
 
 @pytest.mark.parametrize("k,n,stop_thr,maxiter", [(30, 40, 1e-3, 10), (50, 7, 0.0, 6), (50, 2500, 1e-2, 12),

@@ -52,3 +52,17 @@ print("epoch loop of the last fit alone (device-synchronised; includes the one l
       % (loop["epochs"], loop["seconds"], per_epoch, per_epoch / ((-(-nU // 65536) + -(-nI // 65536)) / 2.0),
          loop["host_prepare_s"], loop["host_issue_s"]))
 print("phases of the last fit [s]: %s" % {p: round(v, 3) for p, v in be.FIT_TIMINGS.items()})
+# roofline-style line: algorithmic bytes of an epoch over its time.  Per batch of B rows with n nonzeros touching R rows of
+# the other side (fp32, int32 ids; every gather counted once): the two sweeps n*(8 + 8k) (ids, counts, one gathered row and
+# one accumulated row per nonzero and side); the reference's per-batch whole-table statements (PXI:300,318,322 / 352,370,374):
+# the batch side's rates, means and shapes of ALL its rows -- (nU or nI)*12k -- and the other side's means -- *8k; E rows and
+# accumulators of the touched rows (B + R)*16k.  Summed over an epoch's batches: sum n = nnz, sum B = rows of the side.
+nb_u, nb_i = -(-nU // 65536), -(-nI // 65536)
+nnz = Y.shape[0]
+R_u, R_i = min(nI, nnz // nb_u), min(nU, nnz // nb_i)       # (upper bounds on the other side's rows per batch)
+b_user_epoch = nnz * (8 + 8 * k) + nb_u * (nU * 12 * k + nI * 8 * k + R_u * 16 * k) + nU * 16 * k
+b_item_epoch = nnz * (8 + 8 * k) + nb_i * (nI * 12 * k + nU * 8 * k + R_i * 16 * k) + nI * 16 * k
+b_epoch = (b_user_epoch + b_item_epoch) / 2.0
+print("roofline (algorithmic bytes per epoch, mean of a user and an item epoch: %.1f GB) / %.1f ms per epoch = %.2f TB/s = "
+      "%.0f %% of the 8 TB/s HBM peak" % (b_epoch / 1e9, per_epoch, b_epoch / (per_epoch * 1e-3) / 1e12,
+                                            100 * b_epoch / (per_epoch * 1e-3) / 8e12))
