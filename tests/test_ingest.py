@@ -66,8 +66,9 @@ def _fit_pair(backend_name):
     users5 = [a.user_mapping_[j] for j in (0, 3, 7, 11, 19)]
     on_device = [list(a.topN(user=u, n=6)) for u in users5]
     assert a._state.stats["d2h_bytes"] == 0                     # (neither Theta nor Beta came down for those queries)
-    assert a.seen.shape[0] == b.seen.shape[0] and HPF.seen.device_of(a) is not None
-    a.seen = a.seen.copy()                                      # an assigned list is the host's: device copy dropped
+    # once the list has been handed out the caller may edit it in place: the device copy is not trusted any more
+    assert a.seen.shape[0] == b.seen.shape[0] and HPF.seen.device_of(a) is None
+    a.seen = a.seen.copy()                                      # an assigned list is the host's too
     assert HPF.seen.device_of(a) is None
     assert [list(a.topN(user=u, n=6)) for u in users5] == on_device
     assert a.nusers == b.nusers and a.nitems == b.nitems
