@@ -332,7 +332,7 @@ def main():
     # first and the fastest one -- by the slowest rank's clock -- is the configuration that is then benchmarked.
     autotune = None
     TUNED = ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_RS_ALLTOALL", "HPF_GRAPH", "HPF_RCCL_DIRECT",
-             "HPF_NATIVE_SHARD", "HPF_AG_PACKED")
+             "HPF_NATIVE_SHARD", "HPF_AG_PACKED", "HPF_GATHER_EARLY")
     if os.environ.get("HPF_BENCH_SELFTEST_GLOO") == "1" and dist is not None:
         # the one-GPU self-test has no RCCL between its ranks: gloo stands in for it behind the C-issued iteration's
         # collective callback (tests/dist_worker.py), so that the native path and the `collective` block are exercised
@@ -353,14 +353,15 @@ def main():
         tune_iters = 6 if os.environ.get("HPF_BENCH_SELFTEST_GLOO") == "1" else 20
         watchdog_state["meta"]["tune_iters"] = tune_iters
 
-        def candidate(mode, chunks, istream, a2a, graph, direct="0", native="0", packed="0"):
+        def candidate(mode, chunks, istream, a2a, graph, direct="0", native="0", packed="0", early="0"):
             env = {"HPF_SHARD_MODE": mode, "HPF_AR_CHUNKS": chunks, "HPF_ITEM_STREAM": istream, "HPF_RS_ALLTOALL": a2a,
-                   "HPF_GRAPH": graph, "HPF_RCCL_DIRECT": direct, "HPF_NATIVE_SHARD": native, "HPF_AG_PACKED": packed}
+                   "HPF_GRAPH": graph, "HPF_RCCL_DIRECT": direct, "HPF_NATIVE_SHARD": native, "HPF_AG_PACKED": packed,
+                   "HPF_GATHER_EARLY": early}
             os.environ.update(env)
-            key = "%s/%s%s%s%s%s%s%s" % (mode, chunks, "/item-stream" if istream == "1" else "",
-                                         "/all-to-all" if a2a == "1" else "", "/direct-rccl" if direct == "1" else "",
-                                         "/native" if native == "1" else "", "/packed-ag" if packed == "1" else "",
-                                         "/hipgraph" if graph == "1" else "")
+            key = "%s/%s%s%s%s%s%s%s%s" % (mode, chunks, "/item-stream" if istream == "1" else "",
+                                           "/all-to-all" if a2a == "1" else "", "/direct-rccl" if direct == "1" else "",
+                                           "/native" if native == "1" else "", "/packed-ag" if packed == "1" else "",
+                                           "/gather-early" if early == "1" else "", "/hipgraph" if graph == "1" else "")
             t_ms, err, m = None, None, None
 
             def joined_barrier():
@@ -415,13 +416,16 @@ def main():
         # fastest of them replayed from captured hipGraphs (nothing of torch's polls that communicator's work, so the
         # capture is safe)
         for cand in (("scatter", "2", "0", "0", "0", "0", "1", "0"), ("scatter", "2", "0", "0", "0", "0", "1", "1"),
-                     ("scatter", "1", "0", "0", "0", "0", "1", "1"), ("scatter", "1", "0", "0", "0", "0", "1", "0")):
+                     ("scatter", "1", "0", "0", "0", "0", "1", "1"), ("scatter", "1", "0", "0", "0", "0", "1", "0"),
+                     # the gather-early schedule (split item finalizer: the all-gather runs under the user sweep)
+                     ("scatter", "2", "0", "0", "0", "0", "1", "0", "1"), ("scatter", "1", "0", "0", "0", "0", "1", "0", "1")):
             key, env = candidate(*cand)
             envs[key] = env
         dr = {k_: v for k_, v in autotune.items() if "/native" in k_}
         if dr and os.environ.get("HPF_BENCH_SELFTEST_GLOO") != "1":
             base = envs[min(dr, key=dr.get)]
-            key, env = candidate("scatter", base["HPF_AR_CHUNKS"], "0", "0", "1", "0", "1", base["HPF_AG_PACKED"])
+            key, env = candidate("scatter", base["HPF_AR_CHUNKS"], "0", "0", "1", "0", "1", base["HPF_AG_PACKED"],
+                                 base["HPF_GATHER_EARLY"])
             envs[key] = env
         sc = {k_: v for k_, v in autotune.items() if k_.startswith("scatter") and "item-stream" not in k_
               and "direct-rccl" not in k_ and "/native" not in k_}
@@ -622,7 +626,9 @@ def main():
                        "iteration_issued_by": ("one C call (hpf_hip_shard_iterate)" if getattr(model, "_plan", None)
                                                is not None else "python, call by call") if sharded else None,
                        "native_plan_error": getattr(model, "native_error", None) if sharded else None,
-                       "e_rows_all_gathered": ("k-packed + unpack launch" if getattr(model, "ag_packed", False)
+                       "e_rows_all_gathered": ("[k numerators | base rate] rows in one collective, under the user sweep"
+                                               if getattr(model, "gather_early", False) else
+                                               "k-packed + unpack launch" if getattr(model, "ag_packed", False)
                                                else "ld-padded, straight into the table") if sharded and
                        getattr(model, "shard_mode", None) == "scatter" else None,
                        "seg_cap": cavi.layout.SEG_CAP, "fused_finalize": model.fused and world == 1,
@@ -735,7 +741,10 @@ def exchange_report(model, dist, world, device, ms_per_step, store, fence, reps=
             "ranges": len(views),
             "bytes_per_rank": {"reduce_scatter_buffer": rs_bytes, "all_gather_buffer": ag_bytes,
                                "sent_and_received_per_rank": (rs_bytes + ag_bytes) * bus, "small_all_reduces": 2 * ld * 4},
-            "rs_ms": rs_ms, "ag_ms": ag_ms, "ag_includes_unpack": bool(e_ld != ld), "small_allreduce_ms_each": ar_ms / 2,
+            "schedule": "gather-early (all-gather under the user sweep)" if getattr(model, "gather_early", False)
+            else "finalize-then-gather",
+            "rs_ms": rs_ms, "ag_ms": ag_ms, "ag_includes_unpack": bool(getattr(model, "ag_packed", False)),
+            "small_allreduce_ms_each": ar_ms / 2,
             "algbw_GBps": {"reduce_scatter": rs_bytes / rs_ms / 1e6, "all_gather": ag_bytes / ag_ms / 1e6},
             "busbw_GBps": {"reduce_scatter": rs_bytes * bus / rs_ms / 1e6, "all_gather": ag_bytes * bus / ag_ms / 1e6},
             "exchange_alone_ms": rs_ms + ag_ms + ar_ms, "compute_only_ms": comp_ms, "iteration_ms": ms_per_step,

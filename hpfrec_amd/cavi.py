@@ -215,6 +215,15 @@ class FullBatchCavi:
         # run on real links can decide, so it is one of bench.py's autotune candidates
         self.ag_packed = self.shard_mode == "scatter" and not self.rs_alltoall and \
             os.environ.get("HPF_AG_PACKED", "0") == "1"
+        # scatter mode, HPF_GATHER_EARLY=1: the "gather-early" schedule -- the item finalizer split in two
+        # (hpf_hip_item_shape_rows_f32 right after the reduce-scatters, hpf_hip_item_apply_rows_f32 on every rank once
+        # colsum(Theta) is known), so that the all-gather of the new item expectations runs UNDER THE USER SWEEP instead
+        # of after it (include/hpf_hip.h, HPF_SCHEDULE_GATHER_EARLY).  One more float32 rounding in
+        # the E rows than the one-part finalizer; everything else is the same arithmetic
+        self.gather_early = self.shard_mode == "scatter" and not self.rs_alltoall and not self.item_stream and \
+            os.environ.get("HPF_GATHER_EARLY", "0") == "1"
+        if self.gather_early:
+            self.ag_packed = False
         # scatter mode on RCCL: the whole iteration issued by ONE C call (hpf_hip_shard_iterate) on a communicator of
         # our own; HPF_NATIVE_SHARD=0 keeps the call-by-call Python form (also the path of gloo / stand-in runs)
         self._plan = None
@@ -530,6 +539,10 @@ class FullBatchCavi:
         total = sum((hi - lo) // W for lo, hi, _, _ in self.item_chunks)
         self.acc_own_all = torch.zeros((total, k), **f32)
         e_ld = k if self.ag_packed else ld            # row stride of the all-gather send buffer
+        if self.gather_early:                         # [k numerators | base rate] rows, gathered in one collective
+            e_ld = ops.gather_payload_ld(k)
+            self.ag_recv_all = torch.ones((W * total, e_ld), **f32)
+            self.shp_own_all = torch.zeros((total, ld), **f32)      # the shapes, between the finalizer's two halves
         self.e_own_all = torch.zeros((total, e_ld), **f32)
         views, t0, ranges = [], 0, []
         for lo, hi, view, multi in self.item_chunks:
@@ -553,7 +566,13 @@ class FullBatchCavi:
                 sw_done=torch.cuda.Event() if cuda else None, ag_done=torch.cuda.Event() if cuda else None))
             t0 += m
         self._fin_ranges = ranges
-        self.csB_part_sc = torch.zeros((ops.finalize_grid(max(1, sum(n for n, _, _ in ranges))), ld), **f32)
+        self._range_rows = [(c["lo"], c["hi"]) for c in views]       # in issue order (= slice order inside a rank's block)
+        fin_rows = max(1, sum(n for n, _, _ in ranges))
+        # (gather-early: the apply kernel streams ALL item rows -- twice the finalize grid keeps 32 waves per CU in flight)
+        grid = ops.finalize_grid(fin_rows)
+        if self.gather_early:      # (gx blocks for each rank's block of the gathered buffer: a multiple of the world size)
+            grid = W * max(1, -(-2 * ops.finalize_grid(self.nI) // W))
+        self.csB_part_sc = torch.zeros((grid, ld), **f32)
         self._csT_ready = torch.cuda.Event() if cuda else None
         self._sc_fresh = True
         self._chunk_views = views
@@ -616,6 +635,8 @@ class FullBatchCavi:
             d.acc_own, d.e_own = self.acc_own_all.data_ptr(), self.e_own_all.data_ptr()
             d.e_own_ld, d.item_sweep_grid = int(self.e_own_all.shape[1]), int(self.item_sweep_blocks)
             d.ag_recv = self.acc_i.data_ptr() if self.ag_packed else None
+            if self.gather_early:
+                d.schedule, d.ag_recv, d.shp_own = 1, self.ag_recv_all.data_ptr(), self.shp_own_all.data_ptr()
             d.a, d.k_shp, d.add_k_rte = float(hy.a), float(hy.k_shp), float(hy.add_k_rte)
             d.c, d.t_shp, d.add_t_rte = float(hy.c), float(hy.t_shp), float(hy.add_t_rte)
             d.comm = comm.handle if comm is not None else None
@@ -671,6 +692,8 @@ class FullBatchCavi:
         if self._last_native:
             self._sync_scatter_streams()
         self._last_native = False
+        if self.gather_early:
+            return self._iterate_gather_early(store)
         xs = self._xstream()
         cuda = xs is not None
         cs = torch.cuda.current_stream(self.device) if cuda else None
@@ -740,6 +763,43 @@ class FullBatchCavi:
                 if cuda:
                     c["ag_done"].record(xs)
         self._sc_fresh = False
+        self._tables_split = True
+        self.eT, self.eT_next = self.eT_next, self.eT
+        self.niter_done += 1
+
+    def _iterate_gather_early(self, store):
+        """The gather-early schedule issued call by call, IN ORDER on the current stream (gloo / stand-in runs and the
+        fallback; the overlapped form is hpf_hip_shard_iterate with HPF_SCHEDULE_GATHER_EARLY): item sweeps +
+        reduce-scatter per range; the shape half of the finalizer for this rank's slices; one all-gather of the
+        [numerators | base rate] rows; the user side; colsum(Theta) summed over ranks; the rates applied to all items
+        locally; colsum(Beta) summed over ranks."""
+        ops, hy, k, ld, dist = self.ops, self.hy, self.k, self.ld, self.dist
+        views = self._chunk_views
+        self._sync_scatter_streams()
+        for c in views:
+            if c["view"].nseg > 0:
+                ops.sweep(c["view"], self.eB, self.eT, c["part"], k, ld, acc_rows=self.acc_i, acc_ld=k,
+                          grid_blocks=self.item_sweep_blocks)
+            if c["nmulti"] > 0:
+                ops.segsum(self.part_i, self.items.row_seg_ptr, c["nmulti"], self.acc_i, ld, row_list=c["multi"],
+                           acc_ld=k, acc_by_row=True)
+            dist.reduce_scatter_tensor(c["acc_own"], c["acc"])
+        if self._fin_ranges:
+            ops.item_shape_rows(self.acc_own_all, self._fin_ranges, self.eB, self.shp_own_all, self.e_own_all, self.t_rte,
+                                hy.c, hy.t_shp, k, ld, rs_prev=self.t_rte_prev)
+        dist.all_gather_into_tensor(self.ag_recv_all.view(-1), self.e_own_all.view(-1))
+        self._keep_csB(store)
+        self._side_update(self.users, self.nU, self.eT, self.eB, self.eT_next, self.part_u, self.Gamma_shp,
+                          self.k_rte_prev, self.Theta, self.k_rte, self.csB, self.csT_part, self.gsu, self.gu,
+                          hy.a, hy.k_shp, hy.add_k_rte, store)
+        ops.colsum_reduce(self.csT_part, self.csT, ld)
+        dist.all_reduce(self.csT)
+        ops.item_apply_rows(self.ag_recv_all, self.shp_own_all, self.eB, self.Lambda_shp if store else None,
+                            self.Beta if store else None, self.t_rte, self.csT, self.csB_part_sc, hy.add_t_rte, k, ld,
+                            self.rank, self.world, self.nI, self._range_rows)
+        ops.colsum_reduce(self.csB_part_sc, self.csB, ld)
+        dist.all_reduce(self.csB)
+        self._sc_fresh = True          # (in order on one stream: nothing stays in flight)
         self._tables_split = True
         self.eT, self.eT_next = self.eT_next, self.eT
         self.niter_done += 1

@@ -585,6 +585,230 @@ __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// The item finalizer of the sharded path in TWO parts ("gather-early" exchange).  The finalizer's
+// expensive half -- shp = c + e (*) acc and exp(psi(shp)) -- needs only the reduce-scattered statistics; only the rate
+// rte = t_shp/tau + colsum(Theta) needs the user side of the same iteration.  So the owner of a slice computes
+//   part 1 (item_shape_kernel):  shp (kept in place of acc), num = exp(psi(shp)) row-scaled, base = t_shp/tau_old
+// right after the reduce-scatter, and [num | base] rows are ALL-GATHERED WHILE THE USER SWEEP RUNS; after colsum(Theta)
+// has been summed over the ranks every rank runs
+//   part 2 (item_apply_kernel):  E = num / (base + colsum(Theta)), row-scaled, for ALL items into its replicated table
+//                                (identical arithmetic on identical inputs: replicas stay bit-identical); the owner of a
+//                                row also finishes Beta = shp/rte, tau = add + sum_k Beta and its colsum(Beta) partials.
+// Against the one-part finalizer E carries one more float32 rounding (num is rounded before the division).
+// ----------------------------------------------------------------------------------------------------------------
+template <int LD>
+__global__ __launch_bounds__(BLOCK) void item_shape_kernel(const float *__restrict__ acc, const float *__restrict__ e_old,
+                                                           float *__restrict__ shp_out, float *__restrict__ send,
+                                                           int sld, const float *__restrict__ rs,
+                                                           float *__restrict__ rs_prev, float prior_shp, float top_shp,
+                                                           int k, const RowRanges rr, int64_t nrows) {
+    // send rows: k numerators, the row's base rate at column k, zero up to the stride sld (a multiple of 4 floats, so
+    // that part 2 reads them as float4); shp_out rows: the padded table layout [.][LD]
+    constexpr int CPL = (LD + WAVE - 1) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WPB;
+    for (int64_t v = (int64_t)blockIdx.x * WPB + wid; v < nrows; v += nwaves) {
+        int64_t t = rr.t_begin[0] + v, r = rr.row_begin[0] + v;
+#pragma unroll
+        for (int i = 1; i < HPF_MAX_ROW_RANGES; i++)
+            if (i < rr.n && v >= rr.v_begin[i]) {
+                t = rr.t_begin[i] + (v - rr.v_begin[i]);
+                r = rr.row_begin[i] + (v - rr.v_begin[i]);
+            }
+        double ev[CPL];
+        float sh[CPL];
+        int ehi = 0;
+#pragma unroll
+        for (int q = 0; q < CPL; q++) {
+            const int c = lane + WAVE * q;
+            const bool valid = c < k;
+            const float a = valid ? acc[(size_t)t * k + c] : 0.f;
+            const float eo = valid ? e_old[(size_t)r * LD + c] : 0.f;
+            sh[q] = fmaf(eo, a, prior_shp);
+            ev[q] = valid ? expect_ratio(sh[q], 1.0f) : 0.0;       // exp(psi(shp))
+            ehi = max(ehi, __double2hiint(ev[q]));
+        }
+        const double inv = row_pow2_scale(ehi);
+        const float rs_old = rs[r];
+#pragma unroll
+        for (int q = 0; q < CPL; q++) {
+            const int c = lane + WAVE * q;
+            if (c < LD) shp_out[(size_t)t * LD + c] = (c < k) ? sh[q] : 0.f;      // the shape row, for part 2
+            if (c < k) send[(size_t)t * sld + c] = (float)(ev[q] * inv);
+        }
+        // the base rate and the zero tail of the payload row (sld - k <= 4 columns; with k == LD they lie past the table row)
+        if (lane < sld - k) send[(size_t)t * sld + k + lane] = (lane == 0) ? top_shp / rs_old : 0.f;
+        if (lane == 0 && rs_prev) rs_prev[r] = rs_old;
+    }
+}
+
+struct ApplyRanges {   // the item ranges of the exchange in issue order = the order of the slices inside a rank's block
+    int n;
+    int64_t lo[HPF_MAX_ROW_RANGES], m[HPF_MAX_ROW_RANGES], t0[HPF_MAX_ROW_RANGES];   // first row, slice rows, slice offset
+    int64_t total;     // rows per rank in the gathered buffer (= sum of m)
+};
+
+template <int W>
+__device__ __forceinline__ float group_max(float v) {          // all lanes of an aligned W-lane group get the maximum
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    if constexpr (W >= 8) v = fmaxf(v, dpp_f<0x141>(v));
+    if constexpr (W >= 16) v = fmaxf(v, dpp_f<0x140>(v));
+    if constexpr (W >= 32) v = fmaxf(v, __shfl_xor(v, 16));
+    if constexpr (W >= 64) v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+
+// grid (gx, world): blockIdx.y = the rank whose block of the gathered buffer is read, so a row's owner costs nothing.
+// A row is held by LPR lanes as one float4 each (VPL of them when ld > 256), 64/LPR rows per wave step, R steps in
+// flight -- the layout of the sweep; with one row per wavefront this kernel spent 340 instructions per row and was
+// bound by instruction issue at a third of its memory rate.  All loads, then all arithmetic, then all stores.
+template <int LPR, int VPL>
+__global__ __launch_bounds__(BLOCK) void item_apply_kernel(const float *__restrict__ recv, int sld,
+                                                           const float *__restrict__ shp_own, float *__restrict__ e_tab,
+                                                           float *__restrict__ shp, float *__restrict__ fac,
+                                                           float *__restrict__ rs, const float *__restrict__ cs_other,
+                                                           float *__restrict__ cs_partial, float add_rte, int k,
+                                                           int rank, int64_t nrows, const ApplyRanges ar) {
+    constexpr int LD = 4 * LPR * VPL;
+    constexpr int NG = WAVE / LPR;
+    constexpr int R = (VPL == 1) ? 4 : (VPL == 2 ? 2 : 1);
+    __shared__ float red[WPB][LD];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int g = lane / LPR, j = lane % LPR;
+    const int wid = threadIdx.x >> 6;
+    const int owner = blockIdx.y;
+    const bool mine = owner == rank;
+    const float *block = recv + (size_t)owner * ar.total * sld;
+    const int sq = min(sld >> 2, LPR * VPL);                   // float4s of a gathered row that hold numerators
+    float4 csl[VPL], csacc[VPL];
+    bool valid[VPL][4];
+#pragma unroll
+    for (int v = 0; v < VPL; v++) {
+        const int c = (v * LPR + j) * 4;
+        csl[v] = make_float4(c + 0 < k ? cs_other[c + 0] : 0.f, c + 1 < k ? cs_other[c + 1] : 0.f,
+                             c + 2 < k ? cs_other[c + 2] : 0.f, c + 3 < k ? cs_other[c + 3] : 0.f);
+        csacc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int e = 0; e < 4; e++) valid[v][e] = c + e < k;
+    }
+    const int64_t ngroups = (int64_t)gridDim.x * WPB * NG;
+    const int64_t gid = ((int64_t)blockIdx.x * WPB + wid) * NG + g;
+    const int64_t iters = (ar.total + ngroups * R - 1) / (ngroups * R);        // wave-uniform trip count
+    for (int64_t it = 0; it < iters; it++) {
+        float4 nv[R][VPL], sv[R][VPL];
+        float base[R];
+        int64_t row[R];
+        bool live[R];
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int64_t pos = (it * R + i) * ngroups + gid;
+            int64_t lo = ar.lo[0], m = ar.m[0], t0 = ar.t0[0];
+#pragma unroll
+            for (int q = 1; q < HPF_MAX_ROW_RANGES; q++)
+                if (q < ar.n && pos >= ar.t0[q]) {
+                    lo = ar.lo[q];
+                    m = ar.m[q];
+                    t0 = ar.t0[q];
+                }
+            row[i] = lo + (int64_t)owner * m + (pos - t0);
+            live[i] = pos < ar.total && row[i] < nrows;            // (slices end in pad rows past the last item)
+            const float4 *src = reinterpret_cast<const float4 *>(block + (size_t)(live[i] ? pos : 0) * sld);
+            const float4 *sp = reinterpret_cast<const float4 *>(shp_own + (size_t)(live[i] ? pos : 0) * LD);
+            base[i] = live[i] ? block[(size_t)pos * sld + k] : 1.f;     // (one address per lane group: a broadcast)
+#pragma unroll
+            for (int v = 0; v < VPL; v++) {
+                const int q4 = v * LPR + j;
+                nv[i][v] = (live[i] && q4 < sq) ? src[q4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                sv[i][v] = (mine && live[i]) ? sp[q4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        float4 en[R][VPL], fc[R][VPL];
+        float fs[R];
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            float emax = 0.f, fsum = 0.f;
+#pragma unroll
+            for (int v = 0; v < VPL; v++) {
+                const float n4[4] = {nv[i][v].x, nv[i][v].y, nv[i][v].z, nv[i][v].w};
+                const float s4[4] = {sv[i][v].x, sv[i][v].y, sv[i][v].z, sv[i][v].w};
+                const float c4[4] = {csl[v].x, csl[v].y, csl[v].z, csl[v].w};
+                float e4[4], f4[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float rt = base[i] + c4[e];
+                    // E only has to be the same on every rank and accurate to a few ulps: reciprocal + multiply (the
+                    // means keep the correctly rounded division of the one-part finalizer)
+                    e4[e] = valid[v][e] ? n4[e] * __builtin_amdgcn_rcpf(rt) : 0.f;
+                    f4[e] = (mine && valid[v][e] && live[i]) ? s4[e] / rt : 0.f;
+                    emax = fmaxf(emax, e4[e]);
+                    fsum += f4[e];
+                }
+                en[i][v] = make_float4(e4[0], e4[1], e4[2], e4[3]);
+                fc[i][v] = make_float4(f4[0], f4[1], f4[2], f4[3]);
+                csacc[v].x += f4[0];
+                csacc[v].y += f4[1];
+                csacc[v].z += f4[2];
+                csacc[v].w += f4[3];
+            }
+            // row scale: the power of two that puts the largest entry into [1, 2) (exact)
+            emax = group_max<LPR>(emax);
+            const float scale = __int_as_float((254 - (__float_as_int(emax) >> 23)) << 23);
+#pragma unroll
+            for (int v = 0; v < VPL; v++) {
+                en[i][v].x *= scale;
+                en[i][v].y *= scale;
+                en[i][v].z *= scale;
+                en[i][v].w *= scale;
+            }
+            fs[i] = group_sum<LPR>(fsum);
+        }
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            if (live[i]) {
+                const size_t o4 = (size_t)row[i] * (LD / 4);
+#pragma unroll
+                for (int v = 0; v < VPL; v++) {
+                    reinterpret_cast<float4 *>(e_tab)[o4 + v * LPR + j] = en[i][v];
+                    if (mine) {
+                        if (fac) reinterpret_cast<float4 *>(fac)[o4 + v * LPR + j] = fc[i][v];
+                        if (shp) reinterpret_cast<float4 *>(shp)[o4 + v * LPR + j] = sv[i][v];
+                    }
+                }
+                if (mine && j == 0) rs[row[i]] = add_rte + fs[i];
+            }
+        }
+    }
+    // per-block column sums of the means: fold the wave's groups, then the block's waves
+#pragma unroll
+    for (int v = 0; v < VPL; v++) {
+#pragma unroll
+        for (int m = LPR; m < WAVE; m <<= 1) {
+            csacc[v].x += __shfl_xor(csacc[v].x, m);
+            csacc[v].y += __shfl_xor(csacc[v].y, m);
+            csacc[v].z += __shfl_xor(csacc[v].z, m);
+            csacc[v].w += __shfl_xor(csacc[v].w, m);
+        }
+        if (g == 0) {
+            const int c = (v * LPR + j) * 4;
+            red[wid][c + 0] = csacc[v].x;
+            red[wid][c + 1] = csacc[v].y;
+            red[wid][c + 2] = csacc[v].z;
+            red[wid][c + 3] = csacc[v].w;
+        }
+    }
+    __syncthreads();
+    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    for (int c = threadIdx.x; c < LD; c += BLOCK) {
+        float t = red[0][c];
+#pragma unroll
+        for (int w2 = 1; w2 < WPB; w2++) t += red[w2][c];
+        cs_partial[blk * LD + c] = t;
+    }
+}
+
 template <int LD>
 __global__ __launch_bounds__(BLOCK) void colsum_kernel(const float *__restrict__ tab, int64_t nrows,
                                                        float *__restrict__ cs_partial) {
@@ -1576,6 +1800,67 @@ int hpf_hip_row_finalize_ranges_f32(const float *acc, int nranges, const int64_t
                        (const int64_t *)nullptr, (const int64_t *)nullptr, nrows, e_old, e_new, shp, rte, fac, rs,     \
                        rs_prev, cs_other, cs_partial, prior_shp, top_shp, add_rte, k, acc_ld, rr, e_new_ld);
     HPF_DISPATCH_LD1(ld, CALL)
+#undef CALL
+    return last_error();
+}
+
+int hpf_hip_gather_payload_ld(int k) { return k > 0 ? ((k + 1 + 3) / 4) * 4 : HPF_EINVAL; }
+
+int hpf_hip_item_shape_rows_f32(const float *acc, int nranges, const int64_t *range_rows, const int64_t *range_acc_begin,
+                                const int64_t *range_row_begin, const float *e_old, float *shp_out, float *send,
+                                const float *rs, float *rs_prev, float prior_shp, float top_shp, int k, int ld,
+                                int grid_blocks, void *stream) {
+    if (!acc || !range_rows || !range_acc_begin || !range_row_begin || !e_old || !shp_out || !send || !rs || nranges <= 0 ||
+        nranges > HPF_MAX_ROW_RANGES || k <= 0 || ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0)
+        return HPF_EINVAL;
+    const int sld = hpf_hip_gather_payload_ld(k);
+    RowRanges rr = {};
+    rr.n = nranges;
+    int64_t nrows = 0;
+    for (int i = 0; i < nranges; i++) {
+        if (range_rows[i] < 0 || range_acc_begin[i] < 0 || range_row_begin[i] < 0) return HPF_EINVAL;
+        rr.v_begin[i] = nrows;
+        rr.t_begin[i] = range_acc_begin[i];
+        rr.row_begin[i] = range_row_begin[i];
+        nrows += range_rows[i];
+    }
+    if (nrows == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(LD)                                                                                                      \
+    hipLaunchKernelGGL((item_shape_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, acc, e_old, shp_out, send, sld, \
+                       rs, rs_prev, prior_shp, top_shp, k, rr, nrows);
+    HPF_DISPATCH_LD1(ld, CALL)
+#undef CALL
+    return last_error();
+}
+
+int hpf_hip_item_apply_rows_f32(const float *recv, const float *shp_own, float *e_tab, float *shp, float *fac, float *rs,
+                                const float *cs_other, float *cs_partial, float add_rte, int k, int ld, int rank,
+                                int world, int64_t nrows, int nranges, const int64_t *range_lo, const int64_t *range_hi,
+                                int grid_blocks, void *stream) {
+    if (!recv || !shp_own || !e_tab || !rs || !cs_other || !cs_partial || k <= 0 || ld != hpf_hip_ld_for_k(k) ||
+        rank < 0 || world <= 0 || rank >= world || nrows <= 0 || nranges <= 0 || nranges > HPF_MAX_ROW_RANGES ||
+        !range_lo || !range_hi || grid_blocks <= 0)
+        return HPF_EINVAL;
+    if (grid_blocks % world != 0) return HPF_EINVAL;     // (gx blocks per rank's block of the gathered buffer)
+    ApplyRanges ar = {};
+    ar.n = nranges;
+    int64_t t = 0;
+    for (int i = 0; i < nranges; i++) {
+        if (range_hi[i] <= range_lo[i] || (range_hi[i] - range_lo[i]) % world != 0) return HPF_EINVAL;
+        ar.lo[i] = range_lo[i];
+        ar.m[i] = (range_hi[i] - range_lo[i]) / world;
+        ar.t0[i] = t;
+        t += ar.m[i];
+    }
+    ar.total = t;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)(grid_blocks / world), (unsigned)world);
+    const int sld = hpf_hip_gather_payload_ld(k);
+#define CALL(LPR, VPL)                                                                                                \
+    hipLaunchKernelGGL((item_apply_kernel<LPR, VPL>), grid, dim3(BLOCK), 0, st, recv, sld, shp_own, e_tab, shp, fac,   \
+                       rs, cs_other, cs_partial, add_rte, k, rank, nrows, ar);
+    HPF_DISPATCH_LD(ld, CALL)
 #undef CALL
     return last_error();
 }

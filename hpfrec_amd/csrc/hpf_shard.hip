@@ -52,7 +52,10 @@ struct Plan {
     hpf_shard_desc d;
     hipStream_t xs;
     hipEvent_t sw_done[HPF_MAX_ROW_RANGES], ag_done[HPF_MAX_ROW_RANGES], csT_ready, start;
+    hipEvent_t p2_done, csB_done;     // gather-early: the apply kernel has run (compute) / colsum(Beta) is summed (exchange)
     int nevents;
+    int64_t lo[HPF_MAX_ROW_RANGES], hi[HPF_MAX_ROW_RANGES];   // the ranges' rows, in issue order
+    int64_t total;                    // rows of this rank's slices, all ranges
     int64_t m[HPF_MAX_ROW_RANGES];    // rows of this rank's slice of range j (= (hi-lo)/world)
     int64_t t0[HPF_MAX_ROW_RANGES];   // first row of that slice in acc_own / e_own
     int nfin;                         // slices with at least one real (non-pad) row
@@ -228,7 +231,13 @@ int hpf_hip_shard_plan_create(const hpf_shard_desc *desc, void **plan) {
     if (d.user_sweep_grid <= 0 || d.user_multi_grid <= 0 || d.user_sweep_grid + d.user_multi_grid > d.csT_part_rows ||
         d.csB_part_rows <= 0 || d.item_sweep_grid <= 0)
         return HPF_EINVAL;
-    if (d.e_own_ld != d.ld && (d.e_own_ld != d.k || !d.ag_recv)) return HPF_EINVAL;
+    if (d.schedule == HPF_SCHEDULE_GATHER_EARLY) {
+        if (d.e_own_ld != hpf_hip_gather_payload_ld(d.k) || !d.ag_recv || !d.shp_own) return HPF_EINVAL;
+    } else if (d.schedule != HPF_SCHEDULE_FINALIZE_THEN_GATHER) {
+        return HPF_EINVAL;
+    } else if (d.e_own_ld != d.ld && (d.e_own_ld != d.k || !d.ag_recv)) {
+        return HPF_EINVAL;
+    }
     if (d.dry_run) {
         if (d.comm) {   // the stand-in call of a dry run must be an identity: a one-rank communicator
             int n = 0;
@@ -263,6 +272,8 @@ int hpf_hip_shard_plan_create(const hpf_shard_desc *desc, void **plan) {
         if (n_real > m) n_real = m;
         p->m[j] = m;
         p->t0[j] = t;
+        p->lo[j] = r.lo;
+        p->hi[j] = r.hi;
         if (n_real > 0) {
             p->fin_rows[p->nfin] = n_real;
             p->fin_acc[p->nfin] = t;
@@ -271,7 +282,8 @@ int hpf_hip_shard_plan_create(const hpf_shard_desc *desc, void **plan) {
         }
         t += m;
     }
-    hipEvent_t *evs[2 * HPF_MAX_ROW_RANGES + 2];
+    p->total = t;
+    hipEvent_t *evs[2 * HPF_MAX_ROW_RANGES + 4];
     int ne = 0;
     for (int j = 0; j < d.nranges; j++) {
         evs[ne++] = &p->sw_done[j];
@@ -279,6 +291,8 @@ int hpf_hip_shard_plan_create(const hpf_shard_desc *desc, void **plan) {
     }
     evs[ne++] = &p->csT_ready;
     evs[ne++] = &p->start;
+    evs[ne++] = &p->p2_done;
+    evs[ne++] = &p->csB_done;
     for (int i = 0; i < ne; i++) {
         const hipError_t e = hipEventCreateWithFlags(evs[i], hipEventDisableTiming);
         if (e != hipSuccess) {
@@ -301,6 +315,8 @@ int hpf_hip_shard_plan_destroy(void *plan) {
     }
     (void)hipEventDestroy(p->csT_ready);
     (void)hipEventDestroy(p->start);
+    (void)hipEventDestroy(p->p2_done);
+    (void)hipEventDestroy(p->csB_done);
     delete p;
     return 0;
 }
@@ -309,16 +325,78 @@ int hpf_hip_shard_join(void *plan, void *stream) {
     if (!plan) return HPF_EINVAL;
     Plan *p = (Plan *)plan;
     if (!p->fresh) {
-        // the exchange stream is in order and the last range's all-gather (+ unpack) is the last thing on it
-        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, p->ag_done[p->d.nranges - 1], 0));
+        // the exchange stream is in order: the last thing on it is the last range's all-gather (+ unpack), or -- gather-
+        // early -- the all-reduce of colsum(Beta)
+        hipEvent_t last = (p->d.schedule == HPF_SCHEDULE_GATHER_EARLY) ? p->csB_done : p->ag_done[p->d.nranges - 1];
+        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, last, 0));
         p->fresh = true;
     }
+    return 0;
+}
+
+static int iterate_gather_early(Plan *p, const float *eT, float *eT_next, int store, hipStream_t cs) {
+    const hpf_shard_desc &d = p->d;
+    hipStream_t xs = p->xs;
+    const int k = d.k, ld = d.ld;
+    const bool fresh = p->fresh;
+    if (fresh) {
+        HIP_TRY(hipEventRecord(p->start, cs));
+        HIP_TRY(hipStreamWaitEvent(xs, p->start, 0));
+    }
+    p->fresh = false;
+    // item pass (the E rows it reads were written by the apply kernel of the last iteration, on this very stream), the
+    // reduce-scatter of each range on the exchange stream
+    for (int j = 0; j < d.nranges; j++) {
+        const hpf_shard_range &r = d.ranges[j];
+        if (r.nseg > 0)
+            HPF_TRY(hpf_hip_sweep_f32(d.i_segs + r.seg_lo, r.nseg, d.i_idx, d.i_y, d.eB, eT,
+                                      d.part_i + (size_t)r.seg_lo * ld, d.acc_i, k, k, ld, r.short_rows,
+                                      d.item_sweep_grid, nullptr, (void *)cs));
+        if (r.nmulti > 0)
+            HPF_TRY(hpf_hip_segsum_f32(d.part_i, d.i_row_seg_ptr, r.multi_rows, r.nmulti, d.acc_i, ld, k, 1, (void *)cs));
+        HIP_TRY(hipEventRecord(p->sw_done[j], cs));
+        HIP_TRY(hipStreamWaitEvent(xs, p->sw_done[j], 0));
+        HPF_TRY(reduce_scatter_range(p, j, xs));
+    }
+    // exchange stream, under the user side: the shape / psi half of the finalizer for this rank's slices, then ONE
+    // all-gather of the [numerators | base rate] rows of all ranges
+    if (p->nfin > 0)
+        HPF_TRY(hpf_hip_item_shape_rows_f32(d.acc_own, p->nfin, p->fin_rows, p->fin_acc, p->fin_row0, d.eB, d.shp_own,
+                                            d.e_own, d.t_rte, d.t_rte_prev, d.c, d.t_shp, k, ld, d.csB_part_rows,
+                                            (void *)xs));
+    HPF_TRY(collective(p, HPF_COLL_ALL_GATHER, d.e_own, d.ag_recv, p->total * d.e_own_ld, xs));
+    HIP_TRY(hipEventRecord(p->ag_done[0], xs));
+    // user side on the compute stream; colsum(Beta) of the last iteration was summed on the exchange stream
+    if (!fresh) HIP_TRY(hipStreamWaitEvent(cs, p->csB_done, 0));
+    if (store) HIP_TRY(hipMemcpyAsync(d.csB_used, d.csB, (size_t)ld * sizeof(float), hipMemcpyDeviceToDevice, cs));
+    float *shp = store ? d.Gamma_shp : nullptr, *fac = store ? d.Theta : nullptr;
+    HPF_TRY(hpf_hip_sweep_finalize_f32(d.u_segs, d.u_nseg, d.u_idx, d.u_y, eT, d.eB, d.part_u, eT_next, shp, nullptr, fac,
+                                       d.k_rte, d.k_rte_prev, d.csB, d.csT_part, d.a, d.k_shp, d.add_k_rte, k, ld,
+                                       d.user_sweep_grid, (void *)cs));
+    HPF_TRY(hpf_hip_row_finalize_f32(d.part_u, d.u_row_seg_ptr, d.u_multi_rows, d.u_nmulti, eT, eT_next, shp, nullptr, fac,
+                                     d.k_rte, d.k_rte_prev, d.csB, d.csT_part + (size_t)d.user_sweep_grid * ld, d.a,
+                                     d.k_shp, d.add_k_rte, k, ld, ld, d.user_multi_grid, (void *)cs));
+    HPF_TRY(hpf_hip_colsum_reduce_f32(d.csT_part, d.csT_part_rows, d.csT, ld, (void *)cs));
+    HPF_TRY(collective(p, HPF_COLL_ALL_REDUCE, d.csT, d.csT, ld, cs));      // (on the compute stream: no hand-over)
+    // the rates applied to ALL items locally, from the gathered rows
+    HIP_TRY(hipStreamWaitEvent(cs, p->ag_done[0], 0));
+    HPF_TRY(hpf_hip_item_apply_rows_f32(d.ag_recv, d.shp_own, d.eB, store ? d.Lambda_shp : nullptr,
+                                        store ? d.Beta : nullptr, d.t_rte, d.csT, d.csB_part, d.add_t_rte, k, ld, d.rank,
+                                        d.world, d.nI, d.nranges, p->lo, p->hi, d.csB_part_rows, (void *)cs));
+    HIP_TRY(hipEventRecord(p->p2_done, cs));
+    // colsum(Beta): this rank's partial, summed over ranks on the exchange stream (its reader is the next user side)
+    HIP_TRY(hipStreamWaitEvent(xs, p->p2_done, 0));
+    HPF_TRY(hpf_hip_colsum_reduce_f32(d.csB_part, d.csB_part_rows, d.csB, ld, (void *)xs));
+    HPF_TRY(collective(p, HPF_COLL_ALL_REDUCE, d.csB, d.csB, ld, xs));
+    HIP_TRY(hipEventRecord(p->csB_done, xs));
     return 0;
 }
 
 int hpf_hip_shard_iterate(void *plan, const float *eT, float *eT_next, int store, void *compute_stream) {
     if (!plan || !eT || !eT_next || eT == eT_next) return HPF_EINVAL;
     Plan *p = (Plan *)plan;
+    if (p->d.schedule == HPF_SCHEDULE_GATHER_EARLY)
+        return iterate_gather_early(p, eT, eT_next, store, (hipStream_t)compute_stream);
     const hpf_shard_desc &d = p->d;
     hipStream_t cs = (hipStream_t)compute_stream, xs = p->xs;
     const int k = d.k, ld = d.ld;
@@ -386,7 +464,11 @@ int hpf_hip_shard_exchange_only(void *plan, int op, int range, void *stream) {
     }
     if (range >= d.nranges) return HPF_EINVAL;
     if (op == HPF_COLL_REDUCE_SCATTER) return reduce_scatter_range(p, range, st);
-    if (op == HPF_COLL_ALL_GATHER) return all_gather_range(p, range, st);   // (idempotent: e_own still holds the rows)
+    if (op == HPF_COLL_ALL_GATHER) {
+        if (d.schedule == HPF_SCHEDULE_GATHER_EARLY)     // one collective for all ranges: counted with range 0
+            return range == 0 ? collective(p, HPF_COLL_ALL_GATHER, d.e_own, d.ag_recv, p->total * d.e_own_ld, st) : 0;
+        return all_gather_range(p, range, st);   // (idempotent: e_own still holds the rows)
+    }
     return HPF_EINVAL;
 }
 

@@ -120,6 +120,39 @@ class HipOps:
             cs_partial.shape[0], self._stream()),
             "hpf_hip_row_finalize_ranges_f32")
 
+    @staticmethod
+    def gather_payload_ld(k):
+        """Row stride of the gather-early all-gather payload: k numerators + the base rate, rounded up to 4 floats."""
+        return ((int(k) + 1 + 3) // 4) * 4
+
+    def item_shape_rows(self, acc, ranges, e_old, shp_out, send, rs, prior_shp, top_shp, k, ld, rs_prev=None):
+        """Part 1 of the split item finalizer (gather-early exchange): shapes (from the packed [.][k] `acc`) into the
+        padded `shp_out` [.][ld], the [exp(psi(shp)) row-scaled | top_shp / rs | 0..] rows into `send`
+        ([.][gather_payload_ld(k)]); ranges as in row_finalize_ranges."""
+        import ctypes
+        n = len(ranges)
+        arr = (ctypes.c_int64 * n)
+        rows, t0, r0 = (arr(*[int(r[i]) for r in ranges]) for i in range(3))
+        grid = self.finalize_grid(sum(int(r[0]) for r in ranges))
+        _lib.check(self.L.hpf_hip_item_shape_rows_f32(
+            _ptr(acc), n, ctypes.addressof(rows), ctypes.addressof(t0), ctypes.addressof(r0), _ptr(e_old), _ptr(shp_out),
+            _ptr(send), _ptr(rs), _ptr(rs_prev), float(prior_shp), float(top_shp), k, ld, grid, self._stream()),
+            "hpf_hip_item_shape_rows_f32")
+
+    def item_apply_rows(self, recv, shp_own, e_tab, shp, fac, rs, cs_other, cs_partial, add_rte, k, ld, rank, world, nrows,
+                        range_rows):
+        """Part 2: E rows of ALL items from the gathered [numerators | base] rows and colsum(Theta) (cs_other); the rows
+        this rank owns also get their means, scalar rates, optional shape / mean stores and colsum partials.
+        range_rows = [(lo, hi)] in issue order."""
+        import ctypes
+        n = len(range_rows)
+        arr = (ctypes.c_int64 * n)
+        lo, hi = arr(*[int(r[0]) for r in range_rows]), arr(*[int(r[1]) for r in range_rows])
+        _lib.check(self.L.hpf_hip_item_apply_rows_f32(
+            _ptr(recv), _ptr(shp_own), _ptr(e_tab), _ptr(shp), _ptr(fac), _ptr(rs), _ptr(cs_other), _ptr(cs_partial),
+            float(add_rte), k, ld, int(rank), int(world), int(nrows), n, ctypes.addressof(lo), ctypes.addressof(hi),
+            cs_partial.shape[0], self._stream()), "hpf_hip_item_apply_rows_f32")
+
     def unpack_rows(self, src, dst, nrows, k, ld):
         """dst[r, :k] = src[r, :k]: a packed [nrows, k] table into a padded [nrows, ld] one."""
         _lib.check(self.L.hpf_hip_unpack_rows_f32(_ptr(src), _ptr(dst), int(nrows), k, ld, self._stream()),

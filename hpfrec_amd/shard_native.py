@@ -46,7 +46,8 @@ class ShardDesc(ctypes.Structure):
         ("a", _f32), ("k_shp", _f32), ("add_k_rte", _f32), ("c", _f32), ("t_shp", _f32), ("add_t_rte", _f32),
         ("comm", _vp), ("coll", COLLECTIVE_FN), ("coll_ctx", _vp),
         ("xstream", _vp),
-        ("dry_run", _i32), ("pad3", _i32),
+        ("dry_run", _i32), ("schedule", _i32),
+        ("shp_own", _vp),
     ]
 
 

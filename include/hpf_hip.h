@@ -157,6 +157,34 @@ int hpf_hip_row_finalize_ranges_f32(const float *acc, int nranges, const int64_t
                                     float top_shp, float add_rte, int k, int ld, int acc_ld, int e_new_ld,
                                     int grid_blocks, void *stream);
 
+/*
+ * The item finalizer of the sharded path in two parts (the "gather-early" exchange: the all-gather of the new item
+ * expectations runs UNDER the user sweep; hpf_hip.hip item_shape_kernel / item_apply_kernel).  Same statements as
+ * hpf_hip_row_finalize_ranges_f32 (PXI:239-259 for the items) in a different order of evaluation:
+ * part 1, hpf_hip_item_shape_rows_f32 (owner of a slice, needs only the reduce-scattered statistics): for the rows of the
+ *   ranges (as in hpf_hip_row_finalize_ranges_f32; acc is packed [.][k]): shp = prior + e_old (*) acc -> shp_out[t] (padded
+ *   [.][ld], pads zero); send[t][0:k] = exp(psi(shp)) row-scaled, send[t][k] = top_shp / rs[r], zero up to the row stride
+ *   hpf_hip_gather_payload_ld(k) = k+1 rounded up to a multiple of 4 (the all-gather payload, read as float4 by part 2);
+ *   rs_prev[r] = rs[r].
+ * part 2, hpf_hip_item_apply_rows_f32 (every rank, all items, after colsum(Theta) is known): recv = the all-gathered
+ *   payload, [world][rows per rank][payload ld] with a rank's slices in range (issue) order; for every table row r < nrows:
+ *   e_tab[r] = recv.num / (recv.base + cs_other), row-scaled to [1,2); rows this rank owns also get fac = shp/rte
+ *   (shp_own: the padded shapes of part 1), rs[r] = add_rte + sum_k fac, optional shp / fac stores, and the
+ *   per-block column sums of fac in cs_partial (grid_blocks rows, all written; grid_blocks must be a multiple of
+ *   world: the grid is (grid_blocks / world) x world, one column of blocks per rank's block of the gathered buffer).
+ *   The E rows use reciprocal-and-multiply (a few ulps; identical on every rank), the means the correctly rounded
+ *   division of the one-part finalizer.  range_lo / range_hi: HOST arrays.
+ */
+int hpf_hip_gather_payload_ld(int k);
+int hpf_hip_item_shape_rows_f32(const float *acc, int nranges, const int64_t *range_rows, const int64_t *range_acc_begin,
+                                const int64_t *range_row_begin, const float *e_old, float *shp_out, float *send,
+                                const float *rs, float *rs_prev, float prior_shp, float top_shp, int k, int ld,
+                                int grid_blocks, void *stream);
+int hpf_hip_item_apply_rows_f32(const float *recv, const float *shp_own, float *e_tab, float *shp, float *fac, float *rs,
+                                const float *cs_other, float *cs_partial, float add_rte, int k, int ld, int rank,
+                                int world, int64_t nrows, int nranges, const int64_t *range_lo, const int64_t *range_hi,
+                                int grid_blocks, void *stream);
+
 /* dst[r][0:k] = src[r][0:k], r < nrows: a packed [nrows][k] table into a padded [nrows][ld] one (pad columns are left
  * as they are -- zero in an E table).  The receive side of a k-packed all-gather of E rows. */
 int hpf_hip_unpack_rows_f32(const float *src, float *dst, int64_t nrows, int k, int ld, void *stream);
@@ -399,10 +427,26 @@ typedef struct hpf_shard_desc {
     void *comm;                    /* ncclComm_t (hpf_hip_rccl_comm_init), or NULL */
     hpf_collective_fn coll; void *coll_ctx;   /* used instead of RCCL when coll != NULL */
     void *xstream;                 /* the exchange stream (hipStream_t) */
-    int32_t dry_run, pad3;         /* 1: this rank alone -- every collective is its one-rank form (local copy of the
+    int32_t dry_run;               /* 1: this rank alone -- every collective is its one-rank form (local copy of the
                                       rank's slice) + a 1-element all-reduce on comm if given: the compute-only
                                       schedule of a rank, for probes and the bench's exposed-exchange figure */
+    int32_t schedule;              /* HPF_SCHEDULE_FINALIZE_THEN_GATHER (0) or HPF_SCHEDULE_GATHER_EARLY (1), below */
+    float *shp_own;                /* gather-early: [sum of slice lengths][ld] shapes between the finalizer's halves */
 } hpf_shard_desc;
+
+/* Two schedules of the same exchange.
+ * 0, finalize-then-gather: after the user side, all-reduce colsum(Theta), finish this rank's item slices
+ *    (hpf_hip_row_finalize_ranges_f32), all-gather the new E rows range by range; the next iteration's sweep of a range waits
+ *    for that range's all-gather -- the all-gather hides only under the item sweeps of the other ranges.
+ * 1, gather-early: the finalizer is split (hpf_hip_item_shape_rows_f32 / hpf_hip_item_apply_rows_f32): the shape / psi
+ *    half runs right after the reduce-scatters and its [k numerators | base rate] rows (e_own, e_own_ld =
+ *    hpf_hip_gather_payload_ld(k)) are all-gathered in ONE collective into ag_recv ([world][sum of slice lengths][that
+ *    ld]) WHILE THE USER SWEEP RUNS, the shapes wait in shp_own ([sum of slice lengths][ld]); after the
+ *    all-reduce of colsum(Theta) (on the compute stream: no stream hand-over) every rank applies the rates to all items
+ *    locally.  csB_part then has the grid of the apply kernel (csB_part_rows blocks over nI rows).  The exchange leaves
+ *    the critical path except for two k-float all-reduces. */
+#define HPF_SCHEDULE_FINALIZE_THEN_GATHER 0
+#define HPF_SCHEDULE_GATHER_EARLY 1
 
 /* {sizeof(hpf_shard_desc), offsetof ranges, offsetof acc_i, offsetof dry_run}: lets a foreign-function binding check
  * its mirror of the struct against the compiled one. */

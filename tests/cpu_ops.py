@@ -157,6 +157,61 @@ class CpuOps:
         cpo[:] = 0
         cpo[0] = total.astype(np.float32)
 
+    @staticmethod
+    def gather_payload_ld(k):
+        return ((int(k) + 1 + 3) // 4) * 4
+
+    def item_shape_rows(self, acc, ranges, e_old, shp_out, send, rs, prior_shp, top_shp, k, ld, rs_prev=None):
+        f = np.float32
+        A, S, E, R, SH = _np(acc), _np(send), _np(e_old), _np(rs), _np(shp_out)
+        for n, t0, r0 in ranges:
+            if n <= 0:
+                continue
+            sh = (f(prior_shp) + E[r0:r0 + n, :k].astype(np.float64) * A[t0:t0 + n, :k]).astype(np.float32)
+            P = sp.psi(sh.astype(np.float64))
+            P = P - _LN2 * np.floor(P.max(axis=1, keepdims=True) / _LN2)       # power-of-two row scale: max in [1,2)
+            S[t0:t0 + n] = 0
+            S[t0:t0 + n, :k] = np.exp(P).astype(np.float32)
+            S[t0:t0 + n, k] = f(top_shp) / R[r0:r0 + n]
+            SH[t0:t0 + n] = 0
+            SH[t0:t0 + n, :k] = sh
+            if rs_prev is not None:
+                _np(rs_prev)[r0:r0 + n] = R[r0:r0 + n]
+
+    def item_apply_rows(self, recv, shp_own, e_tab, shp, fac, rs, cs_other, cs_partial, add_rte, k, ld, rank, world, nrows,
+                        range_rows):
+        f = np.float32
+        Rv, So, Et, cs = _np(recv), _np(shp_own), _np(e_tab), _np(cs_other)[:k]
+        total = sum((hi - lo) // world for lo, hi in range_rows)
+        cp = _np(cs_partial)
+        cp[:] = 0
+        csum = np.zeros(ld, np.float64)
+        t0 = 0
+        for lo, hi in range_rows:
+            m = (hi - lo) // world
+            for q in range(world):
+                r0, r1 = lo + q * m, min(lo + (q + 1) * m, nrows)
+                if r1 <= r0:
+                    continue
+                n = r1 - r0
+                src = Rv[q * total + t0: q * total + t0 + n]
+                rt = (src[:, k:k + 1] + cs[None, :]).astype(np.float32)
+                en = (src[:, :k] / rt).astype(np.float32)
+                ex = np.floor(np.log2(en.max(axis=1, keepdims=True).astype(np.float64)))
+                Et[r0:r1, :k] = (en * np.exp2(-ex).astype(np.float32)).astype(np.float32)
+                Et[r0:r1, k:] = 0
+                if q == rank:
+                    sh = So[t0:t0 + n, :k]
+                    fc = (sh / rt).astype(np.float32)
+                    _np(rs)[r0:r1] = (f(add_rte) + fc.astype(np.float64).sum(axis=1)).astype(np.float32)
+                    if shp is not None:
+                        _np(shp)[r0:r1, :k] = sh
+                    if fac is not None:
+                        _np(fac)[r0:r1, :k] = fc
+                    csum[:k] += fc.astype(np.float64).sum(axis=0)
+            t0 += m
+        cp[0] = csum.astype(np.float32)
+
     def unpack_rows(self, src, dst, nrows, k, ld):
         _np(dst)[:nrows, :k] = _np(src).reshape(-1)[: nrows * k].reshape(nrows, k)
 

@@ -27,7 +27,8 @@ def gloo_collective(dist, model):
     stages CUDA tensors through the host), synchronously.  The C side hands over raw device pointers; they are mapped
     back onto the model's exchange buffers."""
     import torch
-    bufs = [model.acc_i, model.acc_own_all, model.e_own_all, model.eB, model.csT, model.csB]
+    bufs = [b for b in (model.acc_i, model.acc_own_all, model.e_own_all, model.eB, model.csT, model.csB,
+                        getattr(model, "ag_recv_all", None)) if b is not None]
     calls = model.__dict__.setdefault("_native_collective_calls", [0, 0, 0])
 
     def view(ptr, count):

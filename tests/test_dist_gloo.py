@@ -25,6 +25,7 @@ def _free_port():
                                              (8, "c1", "scatter"), (4, "mid", "scatter"), (8, "mid", "allreduce"),
                                              (3, "c1", "scatter-a2a"), (3, "c1", "scatter-one-range"),
                                              (3, "c1", "scatter-packed"),
+                                             (3, "c1", "scatter-early"), (2, "mid", "scatter-early"), (8, "c1", "scatter-early"),
                                              (2, "c1", "allreduce"), (3, "mid", "allreduce")])
 def test_sharded_equals_single(tmp_path, cpu_ops_backend, monkeypatch, world, case, mode):
     """mode: "scatter" = reduce-scatter / sharded item finalizer / all-gather (default); "allreduce" = all-reduce +
@@ -36,6 +37,9 @@ def test_sharded_equals_single(tmp_path, cpu_ops_backend, monkeypatch, world, ca
     if mode == "scatter-packed":                  # new E rows all-gathered k-packed + unpacked (pad rows included)
         mode = "scatter"
         monkeypatch.setenv("HPF_AG_PACKED", "1")
+    if mode == "scatter-early":                   # split item finalizer: the all-gather before the user side
+        mode = "scatter"
+        monkeypatch.setenv("HPF_GATHER_EARLY", "1")
     if mode == "scatter-one-range":               # no exchange pipelining
         mode = "scatter"
         monkeypatch.setenv("HPF_AR_CHUNKS", "1")

@@ -243,6 +243,93 @@ def test_row_finalize_ranges_op(ops, k):
     assert bool((fac.cpu()[~touched] == -1).all()) and bool((fac.cpu()[touched][:, :k] > 0).all())
 
 
+@pytest.mark.parametrize("k,world,rank", [(30, 2, 0), (50, 8, 5), (64, 3, 2), (200, 4, 1)])
+def test_item_split_finalize_ops(ops, k, world, rank):
+    """The split item finalizer of the gather-early exchange (hpf_hip_item_shape_rows_f32 on every "rank's" slices, an
+    emulated all-gather, hpf_hip_item_apply_rows_f32) against the numpy stand-in, and against the one-part finalizer
+    (hpf_hip_row_finalize_ranges_f32) it is an evaluation order of: same shapes, means, scalar rates and column sums,
+    E rows equal up to the one extra float32 rounding; pad rows past nI untouched."""
+    rs = np.random.RandomState(7 * k + world)
+    ld = _lib.ld_for_k(k)
+    nI = 1000 + rank
+    cuts = [0, ((nI // 3 + world - 1) // world) * world]
+    cuts.append(cuts[1] + ((nI - cuts[1] + world - 1) // world) * world)
+    ranges = [(cuts[1], cuts[2]), (cuts[0], cuts[1])]            # issue order: NOT ascending
+    nIa = cuts[2]
+    total = sum((hi - lo) // world for lo, hi in ranges)
+    eB = _rand_tables(rs, nIa, k, ld)
+    acc_full = torch.from_numpy(rs.gamma(2.0, 1.0, size=(nIa, k)).astype(np.float32))   # reduced statistics of every row
+    t_rte = torch.from_numpy((0.5 + rs.random_sample(nIa)).astype(np.float32))
+    csT = torch.zeros(ld)
+    csT[:k] = torch.from_numpy((20 + 5 * rs.random_sample(k)).astype(np.float32))
+    prior, top, add = 0.3, 0.3 + k * 0.3, 0.3
+
+    def slices(q):
+        out, t0 = [], 0
+        for lo, hi in ranges:
+            m = (hi - lo) // world
+            o0 = lo + q * m
+            n_real = max(0, min(m, nI - o0))
+            out.append((n_real, t0, o0, m))
+            t0 += m
+        return out
+    ref = cpu_ops.CpuOps()
+    results = {}
+    for name, o, dev in (("ref", ref, "cpu"), ("hip", ops, "cuda")):
+        sld = o.gather_payload_ld(k)
+        assert sld % 4 == 0 and k + 1 <= sld < k + 5
+        recv = torch.zeros((world * total, sld), device=dev)
+        own_acc = None
+        rsv, rsp = t_rte.clone().to(dev), torch.zeros(nIa, device=dev)
+        for q in range(world):                       # every rank's part 1; its block of the gathered buffer
+            acc_own = torch.zeros((total, k), device=dev)
+            for n_real, t0, o0, m in slices(q):
+                acc_own[t0:t0 + m] = acc_full[o0:o0 + m].to(dev)
+            send = torch.full((total, sld), 9.0, device=dev)
+            shp_pad = torch.full((total, ld), 9.0, device=dev)
+            fin = [(n, t0, o0) for n, t0, o0, m in slices(q) if n > 0]
+            o.item_shape_rows(acc_own, fin, eB.to(dev), shp_pad, send, rsv, prior, top, k, ld, rs_prev=rsp)
+            for n, t0, o0 in fin:                    # pads of the payload and of the shape rows are written as zeros
+                assert torch.all(send[t0:t0 + n, k + 1:] == 0) and torch.all(shp_pad[t0:t0 + n, k:] == 0)
+            recv[q * total:(q + 1) * total] = send
+            if q == rank:
+                own_acc = shp_pad
+        e_tab = torch.full((nIa, ld), -3.0, device=dev)
+        shp = torch.zeros((nIa, ld), device=dev)
+        fac = torch.zeros((nIa, ld), device=dev)
+        csp = torch.zeros((world * max(1, o.finalize_grid(nI) // world), ld), device=dev)     # a multiple of `world`
+        o.item_apply_rows(recv, own_acc, e_tab, shp, fac, rsv, csT.to(dev), csp, add, k, ld, rank, world, nI, ranges)
+        cs = torch.zeros(ld, device=dev)
+        o.colsum_reduce(csp, cs, ld)
+        results[name] = [t.cpu() for t in (e_tab, shp, fac, rsv, rsp, cs, recv)]
+    for a, b, nm in zip(results["hip"], results["ref"], ("E", "shp", "fac", "rs", "rs_prev", "colsum", "gathered")):
+        assert float(((a - b).abs() / b.abs().clamp_min(1e-30)).max()) < 3e-6, nm
+    e_tab = results["hip"][0]
+    assert torch.all(e_tab[nI:] == -3.0) and torch.all(e_tab[:nI, k:] == 0)
+    assert torch.all((e_tab[:nI, :k].max(dim=1).values >= 1) & (e_tab[:nI, :k].max(dim=1).values < 2))
+    # the one-part finalizer on the same inputs (this rank's slices)
+    fin = [(n, t0, o0) for n, t0, o0, m in slices(rank) if n > 0]
+    acc_own = torch.zeros((total, k))
+    for n_real, t0, o0, m in slices(rank):
+        acc_own[t0:t0 + m] = acc_full[o0:o0 + m]
+    e_new = torch.zeros((total, ld), device="cuda")
+    shp1, fac1 = torch.zeros((nIa, ld), device="cuda"), torch.zeros((nIa, ld), device="cuda")
+    rs1 = t_rte.clone().cuda()
+    csp = torch.zeros((ops.finalize_grid(sum(n for n, _, _ in fin)), ld), device="cuda")
+    ops.row_finalize_ranges(acc_own.cuda(), fin, eB.cuda(), e_new, shp1, None, fac1, rs1, csT.cuda(), csp, prior, top, add,
+                            k, ld, k)
+    cs1 = torch.zeros(ld, device="cuda")
+    ops.colsum_reduce(csp, cs1, ld)
+    _, shp, fac, rsv, _, cs, _ = results["hip"]
+    for n, t0, o0 in fin:
+        rows = slice(o0, o0 + n)
+        assert float(((e_tab[rows] - e_new[t0:t0 + n].cpu()).abs() / e_new[t0:t0 + n].cpu().abs().clamp_min(1e-30)).max()) < 1e-6
+        assert torch.equal(shp[rows], shp1[rows].cpu()) and torch.equal(fac[rows], fac1[rows].cpu())
+        # (the row sum of the means is taken in another order: float4 per lane, then across the lane group)
+        assert float(((rsv[rows] - rs1[rows].cpu()).abs() / rs1[rows].cpu()).max()) < 5e-7
+    assert float(((cs - cs1.cpu()).abs() / cs1.cpu().abs().clamp_min(1e-30)).max()) < 2e-6
+
+
 @pytest.mark.parametrize("k", [30, 50, 100, 300, 600, 1024])
 def test_row_finalize_expect_colsum_ops(ops, k):
     rs = np.random.RandomState(k + 1)
@@ -447,7 +534,8 @@ def test_fused_and_split_drivers_agree(hip_backend):
 
 @pytest.mark.parametrize("mode", ["scatter", "allreduce", "scatter-graph", "scatter-item-stream", "scatter-direct",
                                   "scatter-direct-graph", "scatter-native", "scatter-native-graph",
-                                  "scatter-native-padded"])
+                                  "scatter-native-padded", "scatter-native-early", "scatter-native-early-graph",
+                                  "scatter-early"])
 def test_sharded_path_single_rank_nccl(mode):
     """The multi-GPU code path on one GPU with a real RCCL group: "scatter" = asynchronous reduce-scatter / dense
     finalize of the own slice / all-gather into the E table; "allreduce" = async packed all-reduce + deferred finalize.
@@ -463,6 +551,8 @@ def test_sharded_path_single_rank_nccl(mode):
     env["HPF_NATIVE_SHARD"] = "1" if "native" in mode else "0"
     if mode == "scatter-native-padded":   # all-gather of ld-padded E rows straight into the table (no unpack launch)
         env["HPF_AG_PACKED"] = "0"
+    if "early" in mode:                   # split item finalizer: the all-gather runs under the user sweep
+        env["HPF_GATHER_EARLY"] = "1"
     if mode.endswith("graph"):            # pairs of iterations replayed from a captured hipGraph (RCCL calls included)
         env["HPF_GRAPH"] = "1"
     if "direct" in mode:                  # the collectives on an RCCL communicator of our own (hpfrec_amd/rccl.py)
@@ -714,6 +804,8 @@ def test_tiny_shape_priors(hip_backend):
                                                (3, "scatter", "a2a", 20),
                                                (2, "scatter", "native", 20), (3, "scatter", "native", 50),
                                                (2, "scatter", "native-padded", 100), (3, "scatter", "packed", 50),
+                                               (2, "scatter", "native-early", 20), (3, "scatter", "native-early", 100),
+                                               (3, "scatter", "early", 50),
                                                (2, "allreduce", "1", 20), (3, "allreduce", "1", 20),
                                                (2, "allreduce", "0", 20), (2, "allreduce", "1", 100)])
 def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypatch, world, mode, lazy, k):
@@ -729,9 +821,13 @@ def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypat
         monkeypatch.setenv("HPF_RS_ALLTOALL", "1")
         lazy = "1"
     native = lazy.startswith("native")
+    if lazy.endswith("early"):                    # split item finalizer, the all-gather under the user sweep
+        monkeypatch.setenv("HPF_GATHER_EARLY", "1")
     if native:                                    # the whole iteration issued from C (hpf_hip_shard_iterate), gloo
         monkeypatch.setenv("HPF_TEST_NATIVE_GLOO", "1")     # standing in for RCCL through the collective callback
         monkeypatch.setenv("HPF_AG_PACKED", "0" if lazy == "native-padded" else "1")
+        lazy = "1"
+    if lazy == "early":
         lazy = "1"
     if lazy == "packed":                          # the Python-issued schedule with the k-packed all-gather
         monkeypatch.setenv("HPF_AG_PACKED", "1")

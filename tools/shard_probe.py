@@ -158,7 +158,8 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
                 ks = {n: round(v["total_ms"] / steps, 3) for n, v in ops.summary().items()}
                 print("world %d rank %d [%s%s]: %d users, %d nnz: %.3f ms/iteration (all tables stored; host issue time %.3f ms); "
                       "kernels ms/iter %s%s" % (world, r, "native C issue" if m._plan is not None else "python issue",
-                                                ", packed all-gather" if getattr(m, "ag_packed", False) else "",
+                                                ", packed all-gather" if getattr(m, "ag_packed", False) else
+                                                ", gather-early" if getattr(m, "gather_early", False) else "",
                                                 u1 - u0, m.nnz, dt, t_issue, ks,
                                                 " [hipGraph pairs: %s]" % ("ok" if m.__dict__.get("_graphs", {}).get(True) is not None
                                                                            else getattr(m, "_graph_error", "off")) if many else ""), flush=True)
