@@ -154,11 +154,10 @@ class FullBatchCavi:
         # all-gather of the new E rows; "allreduce" = all-reduce + replicated (deferred) finalizer
         self.world = self.dist.get_world_size() if self.dist else 1
         self.rank = self.dist.get_rank() if self.dist else 0
-        # default by world size: the sharded finalizer pays for its two extra collectives from 4 ranks on
-        # (per-rank cost at C3, tools/shard_probe.py: N=2 1.97 vs 1.94 ms, N=4 1.09 vs 1.14, N=8 0.68 vs 0.84; with real
-        # links the all-gather of scatter mode is also harder to hide at 2 ranks: one xGMI link per pair)
-        self.shard_mode = os.environ.get("HPF_SHARD_MODE", "scatter" if self.world >= 4 else "allreduce") \
-            if self.dist else None
+        # default: "scatter" at every rank count -- it is the mode the C-issued iteration exists for, and per rank it costs
+        # what the all-reduce form costs at 2 ranks and less from 4 on (C3, tools/shard_probe.py, round 3: N=2 1.91-1.93
+        # vs 1.91-1.93 ms, N=4 1.01 vs 1.11-1.15, N=8 0.54-0.55 vs 0.80; profiles/r03_shard_probe_n2_n4.txt)
+        self.shard_mode = os.environ.get("HPF_SHARD_MODE", "scatter") if self.dist else None
         assert self.shard_mode in (None, "scatter", "allreduce"), self.shard_mode
         # item ranges per iteration.  scatter mode: the all-gather of range j+1 hides under the sweep of range j and
         # the first range's is exposed, so more ranges expose less -- but each extra range costs 0.06 ms of launches
@@ -219,9 +218,13 @@ class FullBatchCavi:
         # (hpf_hip_item_shape_rows_f32 right after the reduce-scatters, hpf_hip_item_apply_rows_f32 on every rank once
         # colsum(Theta) is known), so that the all-gather of the new item expectations runs UNDER THE USER SWEEP instead
         # of after it (include/hpf_hip.h, HPF_SCHEDULE_GATHER_EARLY).  One more float32 rounding in
-        # the E rows than the one-part finalizer; everything else is the same arithmetic
+        # the E rows than the one-part finalizer; everything else is the same arithmetic.  ON by default: on one GPU
+        # (collectives emulated by local copies) it costs 0-40 us more compute per iteration than finalize-then-gather
+        # (profiles/r03_shard_probe_gather_early.txt), but it is the only schedule in which the all-gather -- 85 MB per
+        # rank at C3, 0.15-0.4 ms on xGMI depending on the rank count -- has something to hide under; bench.py's autotune
+        # measures both on whatever links it runs on
         self.gather_early = self.shard_mode == "scatter" and not self.rs_alltoall and not self.item_stream and \
-            os.environ.get("HPF_GATHER_EARLY", "0") == "1"
+            os.environ.get("HPF_GATHER_EARLY", "1") == "1"
         if self.gather_early:
             self.ag_packed = False
         # scatter mode on RCCL: the whole iteration issued by ONE C call (hpf_hip_shard_iterate) on a communicator of

@@ -37,9 +37,9 @@ def test_sharded_equals_single(tmp_path, cpu_ops_backend, monkeypatch, world, ca
     if mode == "scatter-packed":                  # new E rows all-gathered k-packed + unpacked (pad rows included)
         mode = "scatter"
         monkeypatch.setenv("HPF_AG_PACKED", "1")
-    if mode == "scatter-early":                   # split item finalizer: the all-gather before the user side
+    monkeypatch.setenv("HPF_GATHER_EARLY", "1" if mode == "scatter-early" else "0")
+    if mode == "scatter-early":                   # split item finalizer: the all-gather before the user side (the default)
         mode = "scatter"
-        monkeypatch.setenv("HPF_GATHER_EARLY", "1")
     if mode == "scatter-one-range":               # no exchange pipelining
         mode = "scatter"
         monkeypatch.setenv("HPF_AR_CHUNKS", "1")

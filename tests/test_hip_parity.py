@@ -551,8 +551,8 @@ def test_sharded_path_single_rank_nccl(mode):
     env["HPF_NATIVE_SHARD"] = "1" if "native" in mode else "0"
     if mode == "scatter-native-padded":   # all-gather of ld-padded E rows straight into the table (no unpack launch)
         env["HPF_AG_PACKED"] = "0"
-    if "early" in mode:                   # split item finalizer: the all-gather runs under the user sweep
-        env["HPF_GATHER_EARLY"] = "1"
+    # split item finalizer: the all-gather runs under the user sweep (the library default), or the one-part finalizer
+    env["HPF_GATHER_EARLY"] = "1" if "early" in mode else "0"
     if mode.endswith("graph"):            # pairs of iterations replayed from a captured hipGraph (RCCL calls included)
         env["HPF_GRAPH"] = "1"
     if "direct" in mode:                  # the collectives on an RCCL communicator of our own (hpfrec_amd/rccl.py)
@@ -821,8 +821,8 @@ def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypat
         monkeypatch.setenv("HPF_RS_ALLTOALL", "1")
         lazy = "1"
     native = lazy.startswith("native")
-    if lazy.endswith("early"):                    # split item finalizer, the all-gather under the user sweep
-        monkeypatch.setenv("HPF_GATHER_EARLY", "1")
+    # split item finalizer, the all-gather under the user sweep (the library default) -- or the one-part finalizer
+    monkeypatch.setenv("HPF_GATHER_EARLY", "1" if lazy.endswith("early") else "0")
     if native:                                    # the whole iteration issued from C (hpf_hip_shard_iterate), gloo
         monkeypatch.setenv("HPF_TEST_NATIVE_GLOO", "1")     # standing in for RCCL through the collective callback
         monkeypatch.setenv("HPF_AG_PACKED", "0" if lazy == "native-padded" else "1")
