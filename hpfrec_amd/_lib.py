@@ -25,7 +25,7 @@ SVI_SRC_PATH = os.path.join(_PKG, "csrc", "hpf_svi_prep.hip") # index structures
 SOURCES = (SRC_PATH, SHARD_SRC_PATH, MT_SRC_PATH, SVI_SRC_PATH)
 INC_PATH = os.path.join(_ROOT, "include")
 
-HPF_HIP_ABI_VERSION = 13
+HPF_HIP_ABI_VERSION = 14
 
 #: every symbol include/hpf_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = (
@@ -106,7 +106,7 @@ def lib():
     L.hpf_hip_shard_exchange_only.argtypes = [vp, ci, ci, vp]
     L.hpf_hip_colsum_reduce_f32.argtypes = [vp, ci, vp, ci, vp]
     L.hpf_hip_colsum_f32.argtypes = [vp, i64, ci, vp, ci, vp]
-    L.hpf_hip_expect_f32.argtypes = [vp, vp, vp, vp, vp, i64, ci, ci, vp]
+    L.hpf_hip_expect_f32.argtypes = [vp, vp, vp, vp, vp, i64, ci, ci, vp, vp, cf, vp]
     L.hpf_hip_segsum_f32.argtypes = [vp, vp, vp, i64, vp, ci, ci, ci, vp]
     L.hpf_hip_pair_llk_f32.argtypes = [vp, vp, vp, vp, vp, i64, vp, ci, ci, ci, ci, vp]
     L.hpf_hip_llk_sweep_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
@@ -125,7 +125,7 @@ def lib():
     L.hpf_hip_svi_shape_rows_f32.argtypes = [vp, i64, vp, vp, vp, cf, cf, cf, ci, ci, ci, vp]
     L.hpf_hip_svi_refresh_f32.argtypes = [i64, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, ci, ci, ci, ci, ci, vp]
     L.hpf_hip_svi_side_f32.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, cf, cf, cf, ci, ci, ci, ci,
-                                       ci, vp]
+                                       ci, vp, vp, vp]
     L.hpf_hip_svi_rate_rows_f32.argtypes = [vp, i64, vp, vp, vp, vp, cf, cf, cf, cf, ci, ci, ci, vp]
     for s in SYMBOLS:
         getattr(L, s).restype = ci

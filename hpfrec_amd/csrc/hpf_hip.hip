@@ -878,16 +878,25 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float *__rest
     }
 }
 
+struct FactoredRate {     // rte[r][c] = top / rs[r] + cs[c] (rank-1), when the [rows][ld] table is not kept; rs == null: table
+    const float *rs, *cs;
+    float top;
+};
+
 template <int LD>
 __device__ __forceinline__ void expect_row(const float *__restrict__ shp, const float *__restrict__ rte,
-                                           float *__restrict__ e, int64_t r, int k, int lane) {
+                                           float *__restrict__ e, int64_t r, int k, int lane, const FactoredRate fr) {
     constexpr int CPL = (LD + WAVE - 1) / WAVE;
     double ev[CPL];
     int ehi = 0;
+    const float base = fr.rs ? fr.top / fr.rs[r] : 0.f;
 #pragma unroll
     for (int q = 0; q < CPL; q++) {
         const int c = lane + WAVE * q;
-        ev[q] = (c < k) ? expect_ratio(shp[(size_t)r * LD + c], rte[(size_t)r * LD + c]) : 0.0;
+        if (fr.rs)
+            ev[q] = (c < k) ? expect_ratio(shp[(size_t)r * LD + c], base + fr.cs[c]) : 0.0;
+        else
+            ev[q] = (c < k) ? expect_ratio(shp[(size_t)r * LD + c], rte[(size_t)r * LD + c]) : 0.0;
         ehi = max(ehi, __double2hiint(ev[q]));
     }
     const double inv = row_pow2_scale(ehi);
@@ -901,7 +910,8 @@ __device__ __forceinline__ void expect_row(const float *__restrict__ shp, const 
 template <int LD>
 __global__ __launch_bounds__(BLOCK) void expect_kernel(const float *__restrict__ shp, const float *__restrict__ rte,
                                                        float *__restrict__ e, const int64_t *__restrict__ row_list,
-                                                       const uint8_t *__restrict__ flag, int64_t nrows, int k) {
+                                                       const uint8_t *__restrict__ flag, int64_t nrows, int k,
+                                                       const FactoredRate fr) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * WPB;
@@ -913,7 +923,7 @@ __global__ __launch_bounds__(BLOCK) void expect_kernel(const float *__restrict__
             while (m) {
                 const int b = __builtin_ctzll(m);
                 m &= m - 1;
-                expect_row<LD>(shp, rte, e, g + b, k, lane);
+                expect_row<LD>(shp, rte, e, g + b, k, lane, fr);
             }
         }
         return;
@@ -921,7 +931,7 @@ __global__ __launch_bounds__(BLOCK) void expect_kernel(const float *__restrict__
     for (int64_t t = (int64_t)blockIdx.x * WPB + wid; t < nrows; t += nwaves) {
         const int64_t r = row_list ? row_list[t] : t;
         if (flag && !flag[r]) continue;
-        expect_row<LD>(shp, rte, e, r, k, lane);
+        expect_row<LD>(shp, rte, e, r, k, lane, fr);
     }
 }
 
@@ -1205,7 +1215,13 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                                                          const float *__restrict__ cs_other,
                                                          float *__restrict__ cs_partial, float prior, float w_new,
                                                          float w_old, float top, float add, float step,
-                                                         float step_prev, int rate_mode, int rs_mode, int k) {
+                                                         float step_prev, int rate_mode, int rs_mode, int k,
+                                                         const float *__restrict__ rs_rate,
+                                                         float *__restrict__ rs_prev_out) {
+    // rte / fac may be null: the table is not stored (rate_mode 0 only for rte).  A batch side's rate is rank-1,
+    // rte = top/rs + cs_other, and its means are read through their column sums only, so an epoch keeps the row scalar
+    // (rs_prev_out[r] = the rs the rate was formed with) + cs_other instead of two [rows][ld] tables; rs_rate: form the
+    // rate from THAT scalar instead of rs (expanding a factored rate later, bit-identically).
     constexpr int CPL = (LD + WAVE - 1) / WAVE;
     __shared__ float red[WPB][LD];
     const int lane = threadIdx.x & (WAVE - 1);
@@ -1220,7 +1236,7 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
     }
     constexpr int R = (CPL <= 4) ? 2 : 1;   // rows in flight per wavefront
     for (int64_t r0 = (int64_t)blockIdx.x * WPB + wid; r0 < nrows; r0 += R * nwaves) {
-        float sv[R][CPL], rv[R][CPL], av[R][CPL], ev[R][CPL], rs_old[R];
+        float sv[R][CPL], rv[R][CPL], av[R][CPL], ev[R][CPL], rs_old[R], rs_rt[R];
         bool fl[R];
 #pragma unroll
         for (int i = 0; i < R; i++) {
@@ -1228,6 +1244,7 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
             const bool live = r < nrows;
             fl[i] = live && flag && flag[r] != 0;
             rs_old[i] = live ? rs[r] : 1.f;
+            rs_rt[i] = (live && rs_rate) ? rs_rate[r] : rs_old[i];
 #pragma unroll
             for (int q = 0; q < CPL; q++) {
                 const int c = lane + WAVE * q;
@@ -1243,7 +1260,7 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
         for (int i = 0; i < R; i++) {
             const int64_t r = r0 + i * nwaves;
             if (r >= nrows) break;
-            const float base = top / rs_old[i];
+            const float base = top / rs_rt[i];
             float fsum = 0.f;
 #pragma unroll
             for (int q = 0; q < CPL; q++) {
@@ -1261,18 +1278,19 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                         float rt = rv[i][q];
                         if (rate_mode == 0) {
                             rt = base + csl[q];
-                            rte[o] = rt;
+                            if (rte) rte[o] = rt;
                         } else if (fl[i]) {
                             rt = step * (base + csl[q]) + step_prev * rt;
                             rte[o] = rt;
                         }
                         f = s / rt;
                     }
-                    fac[o] = f;
+                    if (fac) fac[o] = f;
                     fsum += f;
                     csacc[q] += f;
                 }
             }
+            if (rs_prev_out && lane == 0) rs_prev_out[r] = rs_rt[i];
             if (rs_mode == 2 || (rs_mode == 1 && fl[i])) {
                 fsum = wave_sum(fsum);
                 if (lane == 0) rs[r] = step * (add + fsum) + step_prev * rs_old[i];
@@ -1883,14 +1901,17 @@ int hpf_hip_colsum_f32(const float *tab, int64_t nrows, int ld, float *cs_partia
 }
 
 int hpf_hip_expect_f32(const float *shp, const float *rte, float *e, const int64_t *row_list, const uint8_t *flag,
-                       int64_t nrows, int k, int ld, void *stream) {
+                       int64_t nrows, int k, int ld, const float *rate_rs, const float *rate_cs, float rate_top,
+                       void *stream) {
     if (nrows == 0) return 0;
-    if (!shp || !rte || !e || nrows < 0 || k <= 0 || ld != hpf_hip_ld_for_k(k)) return HPF_EINVAL;
+    if (!shp || (!rte && !rate_rs) || (rate_rs && !rate_cs) || !e || nrows < 0 || k <= 0 || ld != hpf_hip_ld_for_k(k))
+        return HPF_EINVAL;
+    const FactoredRate fr = {rate_rs, rate_cs, rate_top};
     hipStream_t st = (hipStream_t)stream;
     const int grid = (flag && !row_list) ? clamp_grid((nrows + WPB * WAVE - 1) / (WPB * WAVE), 2048)
                                          : clamp_grid((nrows + WPB - 1) / WPB, 2048);
 #define CALL(LD) \
-    hipLaunchKernelGGL((expect_kernel<LD>), dim3(grid), dim3(BLOCK), 0, st, shp, rte, e, row_list, flag, nrows, k);
+    hipLaunchKernelGGL((expect_kernel<LD>), dim3(grid), dim3(BLOCK), 0, st, shp, rte, e, row_list, flag, nrows, k, fr);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
     return last_error();
@@ -1991,17 +2012,17 @@ int hpf_hip_svi_refresh_f32(int64_t nrows, const float *shp, float *rte, float *
 int hpf_hip_svi_side_f32(int64_t nrows, const uint8_t *flag, const float *acc, const float *e, float *shp, float *rte,
                          float *fac, float *rs, const float *cs_other, float *cs_partial, float prior, float w_new,
                          float w_old, float top, float add, float step, float step_prev, int rate_mode, int rs_mode,
-                         int k, int ld, int grid_blocks, void *stream) {
-    if (!shp || !rte || !fac || !rs || !cs_other || !cs_partial || (flag && (!acc || !e)) || nrows <= 0 || k <= 0 ||
+                         int k, int ld, int grid_blocks, const float *rs_rate, float *rs_prev_out, void *stream) {
+    if (!shp || !rs || !cs_other || !cs_partial || (flag && (!acc || !e)) || nrows <= 0 || k <= 0 ||
         ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0 || (rate_mode != 0 && rate_mode != 1) || rs_mode < 0 ||
-        rs_mode > 2)
+        rs_mode > 2 || (rate_mode == 1 && !rte))
         return HPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     // grid not clamped: every block writes its cs_partial row
 #define CALL(LD)                                                                                                    \
     hipLaunchKernelGGL((svi_side_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, nrows, flag, acc, e, shp, rte, \
                        fac, rs, cs_other, cs_partial, prior, w_new, w_old, top, add, step, step_prev, rate_mode,    \
-                       rs_mode, k);
+                       rs_mode, k, rs_rate, rs_prev_out);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
     return last_error();

@@ -166,10 +166,12 @@ class HipOps:
         _lib.check(self.L.hpf_hip_colsum_f32(_ptr(tab), nrows, ld, _ptr(cs_partial), cs_partial.shape[0],
                                              self._stream()), "hpf_hip_colsum_f32")
 
-    def expect(self, shp, rte, e, nrows, k, ld, row_list=None, flag=None):
-        """flag (uint8 per table row): only rows with a non-zero flag."""
+    def expect(self, shp, rte, e, nrows, k, ld, row_list=None, flag=None, factored=None):
+        """flag (uint8 per table row): only rows with a non-zero flag.  factored = (rs, cs, top): the rate is
+        top / rs[r] + cs[c] instead of a table (rte may be None)."""
+        rs, cs, top = factored if factored is not None else (None, None, 0.0)
         _lib.check(self.L.hpf_hip_expect_f32(_ptr(shp), _ptr(rte), _ptr(e), _ptr(row_list), _ptr(flag), nrows, k, ld,
-                                             self._stream()), "hpf_hip_expect_f32")
+                                             _ptr(rs), _ptr(cs), float(top), self._stream()), "hpf_hip_expect_f32")
 
     def segsum(self, part, row_seg_ptr, nrows, acc, ld, row_list=None, acc_ld=None, acc_by_row=False):
         _lib.check(self.L.hpf_hip_segsum_f32(_ptr(part), _ptr(row_seg_ptr), _ptr(row_list), nrows, _ptr(acc), ld,
@@ -284,11 +286,14 @@ class HipOps:
                                                   ld, cs_partial.shape[0], self._stream()), "hpf_hip_svi_refresh_f32")
 
     def svi_side(self, nrows, flag, acc, e, shp, rte, fac, rs, cs_other, cs_partial, prior, w_new, w_old, top, add, step,
-                 step_prev, rate_mode, rs_mode, k, ld):
+                 step_prev, rate_mode, rs_mode, k, ld, rs_rate=None, rs_prev_out=None):
+        """rte / fac None: not stored (rte: rate_mode 0 only); rs_prev_out: the scalar each row's rate was formed with;
+        rs_rate: form the rate from these scalars instead of rs (expanding a factored rate)."""
         _lib.check(self.L.hpf_hip_svi_side_f32(nrows, _ptr(flag), _ptr(acc), _ptr(e), _ptr(shp), _ptr(rte), _ptr(fac),
                                                _ptr(rs), _ptr(cs_other), _ptr(cs_partial), float(prior), float(w_new),
                                                float(w_old), float(top), float(add), float(step), float(step_prev),
-                                               int(rate_mode), int(rs_mode), k, ld, cs_partial.shape[0], self._stream()),
+                                               int(rate_mode), int(rs_mode), k, ld, cs_partial.shape[0], _ptr(rs_rate),
+                                               _ptr(rs_prev_out), self._stream()),
                    "hpf_hip_svi_side_f32")
 
     def svi_rate_rows(self, row_list, rte, fac, rs, cs_other, top, add, step, step_prev, mode, k, ld):

@@ -164,6 +164,14 @@ class DeviceModel:
         self.flag_u = torch.zeros(self.nU, dtype=torch.uint8, device=dev)   # rows of the current step, per side
         self.flag_i = torch.zeros(self.nI, dtype=torch.uint8, device=dev)     # (partial_fit; epochs use the workspace's)
         self._part = None                    # scratch for the split rows' partial sums of a device-built batch
+        # Lazy epochs (fit_hpf_svi): the rate of a BATCH side is rank-1 -- Gamma_rte = k_shp/k_rte + colsum(Beta) for every
+        # row, recomputed every batch (PXI:300 / 352) -- and the means are read only through their column sums until a
+        # check or the end of the fit.  A side in "factored" form keeps rs_prev (the scalar each row's rate was formed
+        # with) + the column sums used, not the [rows, ld] rate table; `stale` means tables are recomputed on demand
+        # (materialize).  Same float32 operations as the stored form: bit-identical results.
+        self.factored = {"u": None, "i": None}       # None: rate table current; else (rs_prev, cs_used, top)
+        self.means_stale = {"u": False, "i": False}
+        self._rs_prev = {"u": torch.zeros(self.nU, **f32), "i": torch.zeros(self.nI, **f32)}
         self.csT = torch.zeros(self.ld, **f32)      # Theta.sum(axis=0) / Beta.sum(axis=0): set by put(), kept
         self.csB = torch.zeros(self.ld, **f32)      # current by every step
         if "Theta" in tables:
@@ -189,6 +197,7 @@ class DeviceModel:
 
     def get(self, name, out=None):
         """Download one state array; into `out` (in place) when given."""
+        self.materialize()
         t = getattr(self, name).reshape(-1, 1) if name in ("k_rte", "t_rte") else self.v(name)
         if out is not None and isinstance(out, np.ndarray) and out.flags.c_contiguous and out.flags.writeable \
                 and out.dtype == np.float32 and tuple(out.shape) == tuple(t.shape):
@@ -238,6 +247,29 @@ class DeviceModel:
         return out
 
     # ------------------------------------------------------------------------------------------
+    def _side(self, which):
+        if which == "u":
+            return dict(n=self.nU, shp=self.Gamma_shp, rte=self.Gamma_rte, fac=self.Theta, rs=self.k_rte)
+        return dict(n=self.nI, shp=self.Lambda_shp, rte=self.Lambda_rte, fac=self.Beta, rs=self.t_rte)
+
+    def materialize(self, which=("u", "i"), means=True):
+        """Bring the rate table (a factored side) and, with `means`, the mean table of the listed sides up to date: one
+        whole-side pass each, the very statements the stored form executes every batch (rte = top/rs + cs; fac = shp/rte)."""
+        ops, k, ld = self.ops, self.k, self.ld
+        for w in which:
+            S, fr = self._side(w), self.factored[w]
+            if fr is not None:
+                rs_prev, cs_used, top = fr
+                ops.svi_side(S["n"], None, None, None, S["shp"], S["rte"], S["fac"] if means else None, S["rs"], cs_used,
+                             self._cs_part, 0.0, 1.0, 0.0, top, 0.0, 1.0, 0.0, 0, 0, k, ld, rs_rate=rs_prev)
+                self.factored[w] = None
+                if means:
+                    self.means_stale[w] = False
+            elif means and self.means_stale[w]:
+                ops.svi_side(S["n"], None, None, None, S["shp"], S["rte"], S["fac"], S["rs"], self.csT, self._cs_part,
+                             0.0, 1.0, 0.0, 1.0, 0.0, 1.0, 0.0, 1, 0, k, ld)
+                self.means_stale[w] = False
+
     def _part_scratch(self, rows):
         if self._part is None or self._part.shape[0] < rows:
             self._part = torch.empty((rows, self.ld), dtype=torch.float32, device=self.ops.device)
@@ -250,8 +282,8 @@ class DeviceModel:
         item -- BatchSides (partial_fit: sizes known on the host) or DevSides (epochs: sizes on the device); flag_u /
         flag_i: one byte per row, the rows of the step."""
         ops, k, ld = self.ops, self.k, self.ld
-        ops.expect(self.Gamma_shp, self.Gamma_rte, self.eT, self.nU, k, ld, flag=flag_u)
-        ops.expect(self.Lambda_shp, self.Lambda_rte, self.eB, self.nI, k, ld, flag=flag_i)
+        ops.expect(self.Gamma_shp, self.Gamma_rte, self.eT, self.nU, k, ld, flag=flag_u, factored=self.factored["u"])
+        ops.expect(self.Lambda_shp, self.Lambda_rte, self.eB, self.nI, k, ld, flag=flag_i, factored=self.factored["i"])
         for side, e_self, e_other, acc in ((su, self.eT, self.eB, self.acc_u), (si, self.eB, self.eT, self.acc_i)):
             if side.nseg == 0:
                 continue
@@ -269,16 +301,22 @@ class DeviceModel:
                 acc.index_copy_(0, side.rows[side.multi_local], tmp)
 
 
-def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_rows):
+def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_rows, lazy=False):
     """One stochastic update in the reference's statement order (user batch: PXI:292-325 / 438-473;
     item batch: PXI:344-377).  su / si: the batch grouped by user / by item; flag_u / flag_i (uint8 per row): the rows
     the updates run over -- supersets of the rows present in the batch; a listed row without a nonzero must hold a zero
     phi-sum in acc_u / acc_i (the callers see to that).  `hy` carries a, c, k_shp, t_shp, add_k_rte, add_t_rte as
-    python floats."""
+    python floats.  lazy (the epochs of fit_hpf_svi): the batch side's rate stays factored and no mean table is
+    stored -- DeviceModel.materialize() brings the tables up to date when somebody reads them."""
     ops, k, ld = m.ops, m.k, m.ld
     step_prev = float(np.float32(1) - np.float32(step))
     step = float(np.float32(step))
     w_other = float(np.float32(step * float(np.float32(mult))))   # step*multiplier as one float32 scalar (PXI:316)
+    bw, ow = ("u", "i") if user_batch else ("i", "u")
+    if not lazy:
+        m.materialize(means=False)            # (stored form: both rate tables are read and written in place)
+    elif m.factored[ow] is not None:
+        m.materialize((ow,), means=False)     # the other side's rate is BLENDED row by row (PXI:320 / 372): it needs the table
     m.batch_phi_sums(su, si, flag_u, flag_i)                      # phi from the OLD parameters
     U = dict(n=m.nU, flag=flag_u, shp=m.Gamma_shp, rte=m.Gamma_rte, fac=m.Theta, rs=m.k_rte, e=m.eT, acc=m.acc_u,
              prior=hy["a"], top=hy["k_shp"], add=hy["add_k_rte"], cs="csT")
@@ -289,15 +327,23 @@ def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_
     rs_mode = 2 if all_scalar_rows else 1
     # One pass per side (hpf_hip_svi_side_f32).  Batch side: shapes of its rows reset to prior + phi, the rate of
     # EVERY row from the other side's current column sums, means, scalar rates, column sums ...
-    ops.svi_side(B["n"], B["flag"], B["acc"], B["e"], B["shp"], B["rte"], B["fac"], B["rs"], getattr(m, O["cs"]),
-                 m._cs_part, B["prior"], 1.0, 0.0, B["top"], B["add"], step, step_prev, 0, rs_mode, k, ld)
+    cs_for_batch = getattr(m, O["cs"])
+    if lazy:
+        ops.svi_side(B["n"], B["flag"], B["acc"], B["e"], B["shp"], None, None, B["rs"], cs_for_batch,
+                     m._cs_part, B["prior"], 1.0, 0.0, B["top"], B["add"], step, step_prev, 0, rs_mode, k, ld,
+                     rs_prev_out=m._rs_prev[bw])
+        m.factored[bw] = (m._rs_prev[bw], cs_for_batch, B["top"])
+        m.means_stale[bw] = m.means_stale[ow] = True
+    else:
+        ops.svi_side(B["n"], B["flag"], B["acc"], B["e"], B["shp"], B["rte"], B["fac"], B["rs"], cs_for_batch,
+                     m._cs_part, B["prior"], 1.0, 0.0, B["top"], B["add"], step, step_prev, 0, rs_mode, k, ld)
     cs_batch = torch.zeros(ld, dtype=torch.float32, device=ops.device)
     ops.colsum_reduce(m._cs_part, cs_batch, ld)
     setattr(m, B["cs"], cs_batch)
     # ... other side: shapes and rates of the touched rows blended towards the step's estimate (the rates with the
     # batch side's NEW column sums), means of every row, scalar rates, column sums
-    ops.svi_side(O["n"], O["flag"], O["acc"], O["e"], O["shp"], O["rte"], O["fac"], O["rs"], cs_batch, m._cs_part,
-                 O["prior"], w_other, step_prev, O["top"], O["add"], step, step_prev, 1, rs_mode, k, ld)
+    ops.svi_side(O["n"], O["flag"], O["acc"], O["e"], O["shp"], O["rte"], None if lazy else O["fac"], O["rs"], cs_batch,
+                 m._cs_part, O["prior"], w_other, step_prev, O["top"], O["add"], step, step_prev, 1, rs_mode, k, ld)
     cs_o = torch.zeros(ld, dtype=torch.float32, device=ops.device)
     ops.colsum_reduce(m._cs_part, cs_o, ld)
     setattr(m, O["cs"], cs_o)
@@ -396,6 +442,9 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
     # second stream, one batch ahead of the batch whose kernels run: two workspaces per epoch type, alternating.  The
     # host's share of a batch is that call, the shuffle (numpy's, as in the reference) once per epoch and one 8-byte-per-
     # row upload of the epoch's order -- nothing data-dependent comes back.
+    # (HPF_SVI_LAZY=0: every batch stores the rate and mean tables the reference rewrites -- 2-3 GB per C5 batch that nothing
+    # reads before the next check; kept as a switch so that a test can hold the lazy form against it bit for bit)
+    lazy = os.environ.get("HPF_SVI_LAZY", "1") == "1"
     prep_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
     if prep_stream is not None:
         prep_stream.wait_stream(torch.cuda.current_stream(dev))      # the CSR / CSC built above
@@ -444,6 +493,7 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
     Theta_prev = m.Theta.clone() if stop_crit == "diff-norm" else None
 
     def evaluate(final=False):
+        m.materialize()                      # (lazy epochs: the mean tables are brought up to date for the check)
         if val is not None:
             t = ops.pair_llk(m.Theta, m.Beta, val[0], val[1], val[2], k, m.ld, full_llk).cpu().numpy()
             if final:
@@ -498,7 +548,7 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
             su, si = (ws.side_own, ws.side_oth) if user_epoch else (ws.side_oth, ws.side_own)
             flag_u, flag_i = (ws.flag_own, ws.flag_oth) if user_epoch else (ws.flag_oth, ws.flag_own)
             _svi_step(m, hyd, su, si, flag_u, flag_i, step, float(n_side) / float(chunks[j].shape[0]), user_epoch,
-                      all_scalar_rows=False)
+                      all_scalar_rows=False, lazy=lazy)
             if prep_stream is not None:
                 ws.free = torch.cuda.Event()
                 ws.free.record(torch.cuda.current_stream(dev))
@@ -517,6 +567,7 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
 
         if check_every > 0 and ((i + 1) % check_every) == 0:
             if stop_crit == "diff-norm":
+                m.materialize(("u",))
                 d = (m.Theta - Theta_prev).double()
                 last_crit = float(torch.sqrt((d * d).sum()).item())
                 if verbose:
@@ -553,6 +604,7 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
         be._print_final_msg(i + 1, errs[0], float(errs[1]), (time.time() - st_time) / 60.0)
 
     if resident is not None and keep_all_objs and save_folder == "":
+        m.materialize()
         resident.adopt(m)              # the state stays on the device; host copies are made when somebody reads them
         return i, None, last_llk
     m.store(Gamma_shp, Gamma_rte, Lambda_shp, Lambda_rte, k_rte, t_rte, Theta, Beta)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 13
+#define HPF_HIP_ABI_VERSION 14
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -198,9 +198,12 @@ int hpf_hip_colsum_f32(const float *tab, int64_t nrows, int ld, float *cs_partia
 /* e[r] = exp(psi(shp[r]) - log(rte[r])) / rowmax, pads zeroed: the hoisted transcendental part of
  * update_phi (PXI:570,588,685) for rows whose shape/rate did not come out of hpf_hip_row_finalize_f32
  * (initialisation PXI:134-138; the rows of an SVI batch).  r = row_list ? row_list[t] : t, t < nrows; with `flag`
- * (optional, one byte per table row) only rows with flag[r] != 0 are touched. */
+ * (optional, one byte per table row) only rows with flag[r] != 0 are touched.  rate_rs (optional): the rate is not read
+ * from a table but formed as rate_top / rate_rs[r] + rate_cs[c] -- the factored (rank-1) form a stochastic epoch keeps for
+ * its batch side (hpf_hip_svi_side_f32: rs_prev_out); rte may then be NULL. */
 int hpf_hip_expect_f32(const float *shp, const float *rte, float *e, const int64_t *row_list, const uint8_t *flag,
-                       int64_t nrows, int k, int ld, void *stream);
+                       int64_t nrows, int k, int ld, const float *rate_rs, const float *rate_cs, float rate_top,
+                       void *stream);
 
 /* acc[t][0:acc_ld] (or acc[r][0:acc_ld] when acc_by_row) = sum of the part[] segments of row
  * r = row_list ? row_list[t] : t, t < nrows (multi-GPU item side before the all-reduce -- acc_ld = k packs the
@@ -256,11 +259,15 @@ int hpf_hip_svi_refresh_f32(int64_t nrows, const float *shp, float *rte, float *
  *   every row:      fac[r] = shp[r]/rte[r];  cs_partial = per-block column sums of fac
  *   rs_mode 0/1/2:  rs[r] = step*(add + sum_k fac[r]) + step_prev*rs[r] for no / flagged / all rows
  * Row-local, the same float32 operations in the same order as the separate kernels.
+ * fac may be NULL (means not stored: only their column sums and the scalar rates are needed between checks); with
+ * rate_mode 0 rte may be NULL too and rs_prev_out[r] (optional, every row) receives the scalar the rate was formed with,
+ * so that rte = top/rs_prev_out + cs_other can be expanded later: rs_rate (optional) forms the rate from THAT scalar
+ * instead of rs[r] -- the expansion is this same call with flag = NULL, rs_mode 0, rs_rate = the kept scalars.
  */
 int hpf_hip_svi_side_f32(int64_t nrows, const uint8_t *flag, const float *acc, const float *e, float *shp, float *rte,
                          float *fac, float *rs, const float *cs_other, float *cs_partial, float prior, float w_new,
                          float w_old, float top, float add, float step, float step_prev, int rate_mode, int rs_mode,
-                         int k, int ld, int grid_blocks, void *stream);
+                         int k, int ld, int grid_blocks, const float *rs_rate, float *rs_prev_out, void *stream);
 int hpf_hip_svi_rate_rows_f32(const int64_t *row_list, int64_t nrows, float *rte, const float *fac, float *rs,
                               const float *cs_other, float top, float add, float step, float step_prev, int mode,
                               int k, int ld, void *stream);

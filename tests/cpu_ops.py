@@ -223,15 +223,21 @@ class CpuOps:
         cp[:] = 0
         cp[0] = _np(tab)[:nrows].astype(np.float64).sum(axis=0).astype(np.float32)
 
-    def expect(self, shp, rte, e, nrows, k, ld, row_list=None, flag=None):
+    def expect(self, shp, rte, e, nrows, k, ld, row_list=None, flag=None, factored=None):
         rows = np.arange(nrows) if row_list is None else _np(row_list)[:nrows].astype(np.int64)
         if flag is not None:
             rows = rows[_np(flag)[rows] != 0]
         if rows.shape[0] == 0:
             return
         valid = np.arange(ld) < k
+        if factored is not None:        # rte = top / rs[r] + cs[c] in float32, as the kernels form it
+            rs, cs, top = factored
+            R = (np.float32(top) / _np(rs)[rows][:, None] + _np(cs)[None, :]).astype(np.float32)
+            R[:, k:] = 1.0
+        else:
+            R = _np(rte)[rows]
         with np.errstate(divide="ignore", invalid="ignore"):
-            E = sp.psi(_np(shp).astype(np.float64)[rows]) - np.log(_np(rte).astype(np.float64)[rows])
+            E = sp.psi(_np(shp).astype(np.float64)[rows]) - np.log(R.astype(np.float64))
         E = np.where(valid[None, :], E, -np.inf)
         E = E - _LN2 * np.floor(E.max(axis=1, keepdims=True) / _LN2)   # power-of-two row scale: max in [1,2)
         _np(e)[rows] = np.exp(E).astype(np.float32)
@@ -438,18 +444,25 @@ class CpuOps:
         cp[0] = F.astype(np.float64).sum(axis=0).astype(np.float32)
 
     def svi_side(self, nrows, flag, acc, e, shp, rte, fac, rs, cs_other, cs_partial, prior, w_new, w_old, top, add, step,
-                 step_prev, rate_mode, rs_mode, k, ld):
-        """hpf_hip_svi_side_f32 = the separate stand-in statements in the reference's order."""
+                 step_prev, rate_mode, rs_mode, k, ld, rs_rate=None, rs_prev_out=None):
+        """hpf_hip_svi_side_f32 = the separate stand-in statements in the reference's order.  rte / fac None: computed
+        into scratch tables and dropped; rs_rate / rs_prev_out: the factored-rate plumbing of the lazy epochs."""
         rows = torch.nonzero(flag[:nrows] != 0).reshape(-1) if flag is not None else torch.empty(0, dtype=torch.int64)
         self.svi_shape_rows(rows, acc, e, shp, prior, w_new, w_old, k, ld, acc_by_row=True)
+        rte_t = rte if rte is not None else torch.zeros_like(shp)
+        fac_t = fac if fac is not None else torch.zeros_like(shp)
         if rate_mode == 1:
-            self.svi_rate_rows(rows, rte, None, rs, cs_other, top, 0.0, step, step_prev, 0, k, ld)
+            self.svi_rate_rows(rows, rte_t, None, rs, cs_other, top, 0.0, step, step_prev, 0, k, ld)
         rs_before = rs.clone()
-        self.svi_refresh(nrows, shp, rte, fac, rs, cs_other if rate_mode == 0 else None, cs_partial, top, add, step,
-                         step_prev, rate_mode == 0, rs_mode == 2, k, ld)
+        if rs_prev_out is not None:
+            _np(rs_prev_out)[:nrows] = _np(rs_rate if rs_rate is not None else rs)[:nrows]
+        rs_used = rs if rs_rate is None else rs_rate.clone()
+        self.svi_refresh(nrows, shp, rte_t, fac_t, rs_used, cs_other if rate_mode == 0 else None, cs_partial, top, add,
+                         step, step_prev, rate_mode == 0, rs_mode == 2 and rs_rate is None, k, ld)
+        assert not (rs_mode == 2 and rs_rate is not None)
         if rs_mode == 1:
             assert torch.equal(rs, rs_before)
-            self.svi_rate_rows(rows, None, fac, rs, None, 0.0, add, step, step_prev, 1, k, ld)
+            self.svi_rate_rows(rows, None, fac_t, rs, None, 0.0, add, step, step_prev, 1, k, ld)
 
     def svi_rate_rows(self, row_list, rte, fac, rs, cs_other, top, add, step, step_prev, mode, k, ld):
         rows = _np(row_list).astype(np.int64)

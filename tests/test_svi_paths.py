@@ -258,3 +258,25 @@ def test_fold_in_one_launch_equals_the_round_trip_path(any_backend, k, n, stop_t
     for a, b, name in zip(fused, rounds, ("Theta", "Gamma_shp", "Gamma_rte", "phi/Y")):
         assert a.shape == b.shape and np.isfinite(a).all()
         assert _maxrel(a, b) < 2e-5, (name, _maxrel(a, b))
+
+
+@pytest.mark.parametrize("kw", [dict(users_per_batch=20, items_per_batch=25), dict(users_per_batch=30),
+                                dict(items_per_batch=40)])
+def test_lazy_epochs_equal_the_stored_form_bit_for_bit(any_backend, monkeypatch, kw):
+    """The epochs keep a batch side's rate factored (row scalar + column sums) and store no mean table between checks
+    (svi._svi_step lazy=True, DeviceModel.materialize); HPF_SVI_LAZY=0 stores every table every batch as the reference
+    does.  Same float32 statements: all eight arrays and the llk of a verbose fit with a mid-fit check must be EQUAL --
+    with alternating epoch types (rates go factored -> table -> factored), user-only and item-only epochs."""
+    df, nU, nI = datagen.readme_counts()
+    out = {}
+    for lazy in ("1", "0"):
+        monkeypatch.setenv("HPF_SVI_LAZY", lazy)
+        m = HPF(k=12, maxiter=5, random_seed=7, ncores=1, reindex=False, verbose=True, check_every=2,
+                stop_crit="maxiter", **kw)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m.fit(df.copy())
+        out[lazy] = {n: np.array(getattr(m, n)) for n in NAMES}
+        out[lazy]["llk"] = np.float64(m.train_llk)
+    for n in out["1"]:
+        assert np.array_equal(out["1"][n], out["0"][n]), n
