@@ -162,6 +162,9 @@ class FullBatchCavi:
         # item ranges per iteration.  scatter mode: the all-gather of range j+1 hides under the sweep of range j and
         # the first range's is exposed, so more ranges expose less -- but each extra range costs 0.06 ms of launches
         # and stream dependencies per iteration at 8 ranks (tools/shard_probe.py): two ranges (18 % / 82 % of the rows)
+        # (what the order of the item ranges depends on; the full comment is where the switches are read again below)
+        self._early_order = self.shard_mode == "scatter" and os.environ.get("HPF_GATHER_EARLY", "1") == "1" and \
+            os.environ.get("HPF_RS_ALLTOALL", "0") != "1" and os.environ.get("HPF_ITEM_STREAM", "0") != "1"
         default_chunks = "2" if self.shard_mode == "scatter" else "3"
         nchunks = int(os.environ.get("HPF_AR_CHUNKS", default_chunks))
         self.item_bounds = self._item_bounds(nchunks) if self.dist else None
@@ -324,9 +327,15 @@ class FullBatchCavi:
             top = min(hi, self.nI)
             multi = it.multi_rows[(it.multi_rows >= lo) & (it.multi_rows < top)].contiguous()
             out.append((lo, hi, _SideView(it, int(rsp[lo]), int(rsp[top]), nnz=int(ptr[top] - ptr[lo])), multi))
-        if self.shard_mode == "scatter":
-            # fewest rows first: the all-gather of the big range (the tail items) then overlaps the sweep of the
-            # small one in the next iteration, and its reduce-scatter overlaps the user side in this one
+        if self.shard_mode == "scatter" and self._early_order:
+            # gather-early: MOST rows first.  The ranges hold equal nonzeros (equal sweep time) but very different row
+            # counts (= exchange bytes: 82 % / 18 % at C3 with two ranges); the whole exchange -- reduce-scatters, then the
+            # all-gather -- runs under what is left of the iteration, so the big reduce-scatter must start after the FIRST
+            # sweep, not the last (profiles/r03_timeline_links_*.txt: -0.1 ms of exposed exchange at 300 GB/s emulated)
+            out.sort(key=lambda c: c[0] - c[1])
+        elif self.shard_mode == "scatter":
+            # finalize-then-gather: fewest rows first -- the all-gather of the big range (the tail items) then overlaps
+            # the sweep of the small one in the next iteration, and its reduce-scatter overlaps the user side in this one
             out.sort(key=lambda c: c[1] - c[0])
         else:
             # issue order: most rows (= largest all-reduce payload) first.  With nnz-balanced ranges every range
@@ -647,6 +656,9 @@ class FullBatchCavi:
                 d.coll = coll
             d.xstream = self._xstream().cuda_stream
             d.dry_run = dry
+            if dry:      # (probes: hold the streams for the time real links would take, at an assumed bus bandwidth)
+                d.dry_run_busbw_GBps = float(getattr(dist, "native_dry_run_busbw", 0.0))
+                d.dry_run_latency_us = float(getattr(dist, "native_dry_run_latency_us", 0.0))
             plan = sn.ShardPlan(d, keep=keep + [comm, views])
         except Exception as exc:   # noqa: BLE001
             plan, err = None, "%s: %s" % (type(exc).__name__, str(exc)[:200])
@@ -812,7 +824,12 @@ class FullBatchCavi:
         if self.device.type != "cuda":
             return None
         if getattr(self, "_xs", None) is None:
-            self._xs = torch.cuda.Stream(device=self.device)
+            # HIGH priority: the exchange chain is latency-critical, and a priority stream is served by another hardware
+            # queue than the normal-priority compute stream.  ROCm multiplexes streams of one priority over 4 hardware
+            # queues in creation order; when the exchange stream landed on the compute stream's queue, a collective
+            # that waits for the links held back the sweeps queued behind it (seen with tools/shard_probe.py
+            # PROBE_BUSBW=...: the second model of a process ran 0.3 ms slower per iteration than the first)
+            self._xs = torch.cuda.Stream(device=self.device, priority=-1)
         return self._xs
 
     def _istream(self):

@@ -63,6 +63,13 @@ struct Plan {
     bool fresh;                       // nothing of this plan in flight on the exchange stream
 };
 
+// dry runs with an assumed bus bandwidth: the stream is held for the time the links would take by ONE wavefront that
+// sleeps on the wall clock (100 MHz on gfx950) -- it takes a SIMD slot and no memory bandwidth
+__global__ void link_time_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 // one collective of the schedule.  `slice`: element offset of this rank's part inside the world-sized buffer
 int collective(Plan *p, int op, const float *send, float *recv, int64_t count, hipStream_t st) {
     const hpf_shard_desc &d = p->d;
@@ -73,6 +80,12 @@ int collective(Plan *p, int op, const float *send, float *recv, int64_t count, h
             HIP_TRY(hipMemcpyAsync(recv, send + (size_t)d.rank * count, bytes, hipMemcpyDeviceToDevice, st));
         else if (op == HPF_COLL_ALL_GATHER)
             HIP_TRY(hipMemcpyAsync(recv + (size_t)d.rank * count, send, bytes, hipMemcpyDeviceToDevice, st));
+        if (d.dry_run_busbw_GBps > 0.f) {
+            // bytes a rank moves: (world-1)/world of the whole buffer (all-reduce: twice that)
+            const double whole = (double)count * sizeof(float) * (op == HPF_COLL_ALL_REDUCE ? 2.0 : (double)d.world);
+            const double us = d.dry_run_latency_us + whole * (d.world - 1) / d.world / (d.dry_run_busbw_GBps * 1e3);
+            hipLaunchKernelGGL(link_time_kernel, dim3(1), dim3(64), 0, st, (long long)(us * 100.0));
+        }
         // ... plus a real (one-rank, one-element: identity) RCCL call, so that a launch of RCCL's is paid
         if (d.comm) {
             if (!g_rccl.ok) return HPF_ENOLIB;

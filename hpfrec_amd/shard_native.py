@@ -48,6 +48,7 @@ class ShardDesc(ctypes.Structure):
         ("xstream", _vp),
         ("dry_run", _i32), ("schedule", _i32),
         ("shp_own", _vp),
+        ("dry_run_busbw_GBps", _f32), ("dry_run_latency_us", _f32),
     ]
 
 

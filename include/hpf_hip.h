@@ -439,6 +439,10 @@ typedef struct hpf_shard_desc {
                                       schedule of a rank, for probes and the bench's exposed-exchange figure */
     int32_t schedule;              /* HPF_SCHEDULE_FINALIZE_THEN_GATHER (0) or HPF_SCHEDULE_GATHER_EARLY (1), below */
     float *shp_own;                /* gather-early: [sum of slice lengths][ld] shapes between the finalizer's halves */
+    float dry_run_busbw_GBps;      /* dry run only, > 0: every collective additionally occupies its stream for
+                                      latency + bytes * (world-1)/world / busbw -- one idle-spinning wavefront (the links
+                                      do the work on a real node), so that a one-GPU probe shows what each schedule hides */
+    float dry_run_latency_us;
 } hpf_shard_desc;
 
 /* Two schedules of the same exchange.

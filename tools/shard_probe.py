@@ -75,6 +75,10 @@ class EmulatedRank:
     #: form -- this rank alone, every collective = the local copy of the rank's slice + a one-element call on a one-rank
     #: RCCL communicator (the same stand-in as the Python paths below use)
     native_dry_run = True
+    #: PROBE_BUSBW (GB/s) > 0: every emulated collective also holds its stream for latency + bytes*(N-1)/N / busbw (one
+    #: sleeping wavefront): what the iteration would take if the links delivered that, with the schedule's real dependencies
+    native_dry_run_busbw = float(os.environ.get("PROBE_BUSBW", "0"))
+    native_dry_run_latency_us = float(os.environ.get("PROBE_LAT_US", "20"))
 
     def direct_comm(self, device, raw=False):
         """HPF_RCCL_DIRECT=1: the collectives as calls on a one-rank communicator of our own + the same local copies.
@@ -156,6 +160,9 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
             ops.recording = False
             if store:
                 ks = {n: round(v["total_ms"] / steps, 3) for n, v in ops.summary().items()}
+                if EmulatedRank.native_dry_run_busbw > 0 and m._plan is not None:
+                    print("(collectives hold their stream as %.0f GB/s of bus bandwidth + %.0f us would)"
+                          % (EmulatedRank.native_dry_run_busbw, EmulatedRank.native_dry_run_latency_us))
                 print("world %d rank %d [%s%s]: %d users, %d nnz: %.3f ms/iteration (all tables stored; host issue time %.3f ms); "
                       "kernels ms/iter %s%s" % (world, r, "native C issue" if m._plan is not None else "python issue",
                                                 ", packed all-gather" if getattr(m, "ag_packed", False) else
