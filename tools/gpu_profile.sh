@@ -20,6 +20,6 @@ for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC
   python tools/prof_summary.py /tmp/prof_$T sweep_kernel row_finalize >> $S 2>&1
 done
 # HBM-side bytes per launch of the dominant kernel, tied to the kernel source (read by bench.py: roofline.traffic)
-WL=c3; for a in "$@"; do [ "$prev" = "--workload" ] && WL=$a; prev=$a; done
+WL=c3; prev=""; for a in "$@"; do [ "$prev" = "--workload" ] && WL=$a; prev=$a; done
 python tools/pmc_json.py /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE $WL $OUT/pmc_${WL}_n1.json >> $S 2>&1
 cat $S
