@@ -213,8 +213,8 @@ def emit(line):
 
 
 def _arm_watchdog(seconds):
-    """N>1 only: if the run has not produced its line `seconds` after the exchange autotune started, print a line from
-    the best COMPLETED autotune candidate (rank 0) and leave."""
+    """N>1 only: if the run makes no progress for `seconds` (no autotune candidate or phase completes), print a line
+    from the best COMPLETED autotune candidate (rank 0) and leave."""
     import threading
 
     def fire():
@@ -238,9 +238,24 @@ def _arm_watchdog(seconds):
                 "roofline": None, "cpu_baseline": None})
         os._exit(0 if (at or meta["rank"] != 0) else 3)
 
-    t = threading.Timer(seconds, fire)
-    t.daemon = True
+    # "no progress": the deadline moves on whenever a candidate or a phase completes (watchdog_progress)
+    watchdog_state["deadline"] = time.monotonic() + seconds
+    watchdog_state["seconds"] = seconds
+
+    def watch():
+        while not watchdog_state["done"]:
+            if time.monotonic() > watchdog_state["deadline"]:
+                fire()
+                return
+            time.sleep(2.0)
+
+    t = threading.Thread(target=watch, daemon=True)
     t.start()
+
+
+def watchdog_progress():
+    if "seconds" in watchdog_state:
+        watchdog_state["deadline"] = time.monotonic() + watchdog_state["seconds"]
 
 
 def main():
@@ -332,7 +347,7 @@ def main():
     # first and the fastest one -- by the slowest rank's clock -- is the configuration that is then benchmarked.
     autotune = None
     TUNED = ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_RS_ALLTOALL", "HPF_GRAPH", "HPF_RCCL_DIRECT",
-             "HPF_NATIVE_SHARD", "HPF_AG_PACKED", "HPF_GATHER_EARLY")
+             "HPF_NATIVE_SHARD", "HPF_AG_PACKED", "HPF_GATHER_EARLY", "HPF_SHARD_SWEEP_BPC", "HPF_ITEM_SWEEP_BPC")
     if os.environ.get("HPF_BENCH_SELFTEST_GLOO") == "1" and dist is not None:
         # the one-GPU self-test has no RCCL between its ranks: gloo stands in for it behind the C-issued iteration's
         # collective callback (tests/dist_worker.py), so that the native path and the `collective` block are exercised
@@ -353,15 +368,20 @@ def main():
         tune_iters = 6 if os.environ.get("HPF_BENCH_SELFTEST_GLOO") == "1" else 20
         watchdog_state["meta"]["tune_iters"] = tune_iters
 
-        def candidate(mode, chunks, istream, a2a, graph, direct="0", native="0", packed="0", early="0"):
+        def candidate(mode, chunks, istream, a2a, graph, direct="0", native="0", packed="0", early="0", room="4,32"):
+            # room: workgroups per CU of the user sweep / the item sweeps (the library defaults 4 / 32 fill every wave
+            # slot; 3 / 6 leave one wave slot per SIMD and a quarter of the registers to the exchange stream's kernels)
             env = {"HPF_SHARD_MODE": mode, "HPF_AR_CHUNKS": chunks, "HPF_ITEM_STREAM": istream, "HPF_RS_ALLTOALL": a2a,
                    "HPF_GRAPH": graph, "HPF_RCCL_DIRECT": direct, "HPF_NATIVE_SHARD": native, "HPF_AG_PACKED": packed,
-                   "HPF_GATHER_EARLY": early}
+                   "HPF_GATHER_EARLY": early, "HPF_SHARD_SWEEP_BPC": room.split(",")[0],
+                   "HPF_ITEM_SWEEP_BPC": room.split(",")[1]}
             os.environ.update(env)
-            key = "%s/%s%s%s%s%s%s%s%s" % (mode, chunks, "/item-stream" if istream == "1" else "",
+            key = "%s/%s%s%s%s%s%s%s%s%s" % (mode, chunks, "/room-%s" % room.replace(",", "-") if room != "4,32" else "",
+                                           "/item-stream" if istream == "1" else "",
                                            "/all-to-all" if a2a == "1" else "", "/direct-rccl" if direct == "1" else "",
                                            "/native" if native == "1" else "", "/packed-ag" if packed == "1" else "",
-                                           "/gather-early" if early == "1" else "", "/hipgraph" if graph == "1" else "")
+                                           "/gather-early" if early == "1" else "/gather-carried" if early == "2" else "",
+                                           "/hipgraph" if graph == "1" else "")
             t_ms, err, m = None, None, None
 
             def joined_barrier():
@@ -400,6 +420,7 @@ def main():
                 autotune[key] = float(flag[1].item())
             else:
                 failed[key] = err or "failed on another rank"
+            watchdog_progress()
             return key, env
 
         envs = {}
@@ -421,11 +442,24 @@ def main():
                      ("scatter", "2", "0", "0", "0", "0", "1", "0", "1"), ("scatter", "1", "0", "0", "0", "0", "1", "0", "1")):
             key, env = candidate(*cand)
             envs[key] = env
+        # LAST of the eager candidates (a second RCCL communicator is active beside the first -- never run with more
+        # than one rank before the driver's run; everything above has completed by now and the watchdog reports it
+        # should this hang): the gather-carried schedule, the exchange of an iteration running on into the next one
+        if os.environ.get("HPF_BENCH_TRY_CARRIED", "1") == "1":
+            for cand in (("scatter", "2", "0", "0", "0", "0", "1", "0", "2"), ("scatter", "3", "0", "0", "0", "0", "1", "0", "2"),
+                         # ... and with room left on every CU for the exchange stream's kernels: beside sweeps that fill
+                         # every wave slot the shape half ran 4x slower (a one-GPU probe with emulated link time,
+                         # profiles/r03_shard_probe_gather_carried.txt); RCCL's kernels need slots in the same way
+                         ("scatter", "2", "0", "0", "0", "0", "1", "0", "2", "3,32"),
+                         ("scatter", "2", "0", "0", "0", "0", "1", "0", "2", "3,6"),
+                         ("scatter", "2", "0", "0", "0", "0", "1", "0", "1", "3,6")):
+                key, env = candidate(*cand)
+                envs[key] = env
         dr = {k_: v for k_, v in autotune.items() if "/native" in k_}
         if dr and os.environ.get("HPF_BENCH_SELFTEST_GLOO") != "1":
             base = envs[min(dr, key=dr.get)]
             key, env = candidate("scatter", base["HPF_AR_CHUNKS"], "0", "0", "1", "0", "1", base["HPF_AG_PACKED"],
-                                 base["HPF_GATHER_EARLY"])
+                                 base["HPF_GATHER_EARLY"], base["HPF_SHARD_SWEEP_BPC"] + "," + base["HPF_ITEM_SWEEP_BPC"])
             envs[key] = env
         sc = {k_: v for k_, v in autotune.items() if k_.startswith("scatter") and "item-stream" not in k_
               and "direct-rccl" not in k_ and "/native" not in k_}
@@ -455,6 +489,7 @@ def main():
     store = not args.lean
 
     def fence():
+        watchdog_progress()
         if dist:
             if getattr(model, "shard_mode", None) == "scatter":
                 model._sync_scatter_streams()     # (exchange stream joined before another communicator's barrier)
@@ -626,7 +661,9 @@ def main():
                        "iteration_issued_by": ("one C call (hpf_hip_shard_iterate)" if getattr(model, "_plan", None)
                                                is not None else "python, call by call") if sharded else None,
                        "native_plan_error": getattr(model, "native_error", None) if sharded else None,
-                       "e_rows_all_gathered": ("[k numerators | base rate] rows in one collective, under the user sweep"
+                       "e_rows_all_gathered": ("[k numerators | base rate] rows range by range, applied at the start of "
+                                               "the next iteration" if getattr(model, "gather_carried", False) else
+                                               "[k numerators | base rate] rows in one collective, under the user sweep"
                                                if getattr(model, "gather_early", False) else
                                                "k-packed + unpack launch" if getattr(model, "ag_packed", False)
                                                else "ld-padded, straight into the table") if sharded and
@@ -713,7 +750,7 @@ def exchange_report(model, dist, world, device, ms_per_step, store, fence, reps=
     import ctypes
     d = sn.ShardDesc()
     ctypes.memmove(ctypes.byref(d), ctypes.byref(plan.desc), ctypes.sizeof(d))
-    d.dry_run, d.comm, d.coll_ctx = 1, None, None
+    d.dry_run, d.comm, d.comm_small, d.coll_ctx = 1, None, None, None
     d.coll = sn.COLLECTIVE_FN()
     dry = sn.ShardPlan(d, keep=plan.keep)
     fence()
@@ -741,7 +778,9 @@ def exchange_report(model, dist, world, device, ms_per_step, store, fence, reps=
             "ranges": len(views),
             "bytes_per_rank": {"reduce_scatter_buffer": rs_bytes, "all_gather_buffer": ag_bytes,
                                "sent_and_received_per_rank": (rs_bytes + ag_bytes) * bus, "small_all_reduces": 2 * ld * 4},
-            "schedule": "gather-early (all-gather under the user sweep)" if getattr(model, "gather_early", False)
+            "schedule": "gather-carried (range by range; the apply half carried into the next iteration)"
+            if getattr(model, "gather_carried", False) else
+            "gather-early (all-gather under the user sweep)" if getattr(model, "gather_early", False)
             else "finalize-then-gather",
             "rs_ms": rs_ms, "ag_ms": ag_ms, "ag_includes_unpack": bool(getattr(model, "ag_packed", False)),
             "small_allreduce_ms_each": ar_ms / 2,

@@ -163,7 +163,7 @@ class FullBatchCavi:
         # the first range's is exposed, so more ranges expose less -- but each extra range costs 0.06 ms of launches
         # and stream dependencies per iteration at 8 ranks (tools/shard_probe.py): two ranges (18 % / 82 % of the rows)
         # (what the order of the item ranges depends on; the full comment is where the switches are read again below)
-        self._early_order = self.shard_mode == "scatter" and os.environ.get("HPF_GATHER_EARLY", "1") == "1" and \
+        self._early_order = self.shard_mode == "scatter" and os.environ.get("HPF_GATHER_EARLY", "1") in ("1", "2") and \
             os.environ.get("HPF_RS_ALLTOALL", "0") != "1" and os.environ.get("HPF_ITEM_STREAM", "0") != "1"
         default_chunks = "2" if self.shard_mode == "scatter" else "3"
         nchunks = int(os.environ.get("HPF_AR_CHUNKS", default_chunks))
@@ -227,7 +227,12 @@ class FullBatchCavi:
         # rank at C3, 0.15-0.4 ms on xGMI depending on the rank count -- has something to hide under; bench.py's autotune
         # measures both on whatever links it runs on
         self.gather_early = self.shard_mode == "scatter" and not self.rs_alltoall and not self.item_stream and \
-            os.environ.get("HPF_GATHER_EARLY", "1") == "1"
+            os.environ.get("HPF_GATHER_EARLY", "1") in ("1", "2")
+        # HPF_GATHER_EARLY=2, "gather-carried" (C-issued iteration only; opt-in until it has run on real links): the
+        # exchange of iteration t runs on into iteration t+1 -- range j's apply half is carried to just ahead of that
+        # range's next item sweep, so its all-gather has a whole iteration to hide under; needs a second communicator
+        # for the k-float all-reduces (include/hpf_hip.h, HPF_SCHEDULE_GATHER_CARRIED)
+        self.gather_carried = self.gather_early and os.environ.get("HPF_GATHER_EARLY", "1") == "2"
         if self.gather_early:
             self.ag_packed = False
         # scatter mode on RCCL: the whole iteration issued by ONE C call (hpf_hip_shard_iterate) on a communicator of
@@ -583,7 +588,7 @@ class FullBatchCavi:
         # (gather-early: the apply kernel streams ALL item rows -- twice the finalize grid keeps 32 waves per CU in flight)
         grid = ops.finalize_grid(fin_rows)
         if self.gather_early:      # (gx blocks for each rank's block of the gathered buffer: a multiple of the world size)
-            grid = W * max(1, -(-2 * ops.finalize_grid(self.nI) // W))
+            grid = W * max(len(self.item_chunks), -(-2 * ops.finalize_grid(self.nI) // W))
         self.csB_part_sc = torch.zeros((grid, ld), **f32)
         self._csT_ready = torch.cuda.Event() if cuda else None
         self._sc_fresh = True
@@ -604,7 +609,7 @@ class FullBatchCavi:
         plan, err = None, None
         try:
             from . import rccl, shard_native as sn
-            coll = comm = None
+            coll = comm = comm_small = None
             dry = 0
             keep = []
             if hasattr(dist, "native_collective"):
@@ -622,6 +627,13 @@ class FullBatchCavi:
                     comm = _DIRECT_COMMS[key]
                 if not comm.self_check():
                     raise RuntimeError("the communicator's self-check failed")
+                if self.gather_carried:     # a second communicator: the k-float all-reduces overtake the bulk collectives
+                    key = (str(self.device), self.world, self.rank, "small")
+                    if key not in _DIRECT_COMMS:
+                        _DIRECT_COMMS[key] = rccl.DirectComm(self.device, dist, self.rank, self.world)
+                    comm_small = _DIRECT_COMMS[key]
+                    if not comm_small.self_check():
+                        raise RuntimeError("the second communicator's self-check failed")
             else:
                 return None
             d = sn.ShardDesc()
@@ -649,6 +661,12 @@ class FullBatchCavi:
             d.ag_recv = self.acc_i.data_ptr() if self.ag_packed else None
             if self.gather_early:
                 d.schedule, d.ag_recv, d.shp_own = 1, self.ag_recv_all.data_ptr(), self.shp_own_all.data_ptr()
+            if self.gather_carried:
+                d.schedule = 2
+                d.comm_small = comm_small.handle if comm_small is not None else None
+                if getattr(self, "_ss", None) is None:     # colsum(Beta): reduced + summed under the last item sweep
+                    self._ss = torch.cuda.Stream(device=self.device, priority=-1)
+                d.sstream = self._ss.cuda_stream
             d.a, d.k_shp, d.add_k_rte = float(hy.a), float(hy.k_shp), float(hy.add_k_rte)
             d.c, d.t_shp, d.add_t_rte = float(hy.c), float(hy.t_shp), float(hy.add_t_rte)
             d.comm = comm.handle if comm is not None else None
@@ -659,7 +677,7 @@ class FullBatchCavi:
             if dry:      # (probes: hold the streams for the time real links would take, at an assumed bus bandwidth)
                 d.dry_run_busbw_GBps = float(getattr(dist, "native_dry_run_busbw", 0.0))
                 d.dry_run_latency_us = float(getattr(dist, "native_dry_run_latency_us", 0.0))
-            plan = sn.ShardPlan(d, keep=keep + [comm, views])
+            plan = sn.ShardPlan(d, keep=keep + [comm, comm_small, views])
         except Exception as exc:   # noqa: BLE001
             plan, err = None, "%s: %s" % (type(exc).__name__, str(exc)[:200])
         # all or none (a rank that issued its collectives through another communicator than its peers would hang them)

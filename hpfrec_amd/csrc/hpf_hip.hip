@@ -604,43 +604,68 @@ __global__ __launch_bounds__(BLOCK) void item_shape_kernel(const float *__restri
                                                            float *__restrict__ rs_prev, float prior_shp, float top_shp,
                                                            int k, const RowRanges rr, int64_t nrows) {
     // send rows: k numerators, the row's base rate at column k, zero up to the stride sld (a multiple of 4 floats, so
-    // that part 2 reads them as float4); shp_out rows: the padded table layout [.][LD]
+    // that part 2 reads them as float4); shp_out rows: the padded table layout [.][LD].
+    // SR rows per wave step, all their loads issued first: this kernel runs on the exchange stream BESIDE the sweeps, which
+    // leave it one wave slot per SIMD and a saturated memory system -- with one row in flight per wave it took 80-100 us
+    // there against 19 us on an idle GPU (profiles/r03_timeline_links_gather_carried_300GBps.txt)
     constexpr int CPL = (LD + WAVE - 1) / WAVE;
+    constexpr int SR = (CPL == 1) ? 4 : (CPL <= 4 ? 2 : 1);
     const int lane = threadIdx.x & (WAVE - 1);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * WPB;
-    for (int64_t v = (int64_t)blockIdx.x * WPB + wid; v < nrows; v += nwaves) {
-        int64_t t = rr.t_begin[0] + v, r = rr.row_begin[0] + v;
+    for (int64_t v0 = ((int64_t)blockIdx.x * WPB + wid) * SR; v0 < nrows; v0 += nwaves * SR) {
+        int64_t tt[SR], rr_[SR];
+        float a[SR][CPL], eo[SR][CPL], rs_old[SR];
+        bool live[SR];
 #pragma unroll
-        for (int i = 1; i < HPF_MAX_ROW_RANGES; i++)
-            if (i < rr.n && v >= rr.v_begin[i]) {
-                t = rr.t_begin[i] + (v - rr.v_begin[i]);
-                r = rr.row_begin[i] + (v - rr.v_begin[i]);
+        for (int i = 0; i < SR; i++) {
+            const int64_t v = v0 + i;
+            live[i] = v < nrows;
+            int64_t t = rr.t_begin[0] + v, r = rr.row_begin[0] + v;
+#pragma unroll
+            for (int q = 1; q < HPF_MAX_ROW_RANGES; q++)
+                if (q < rr.n && v >= rr.v_begin[q]) {
+                    t = rr.t_begin[q] + (v - rr.v_begin[q]);
+                    r = rr.row_begin[q] + (v - rr.v_begin[q]);
+                }
+            tt[i] = t;
+            rr_[i] = r;
+#pragma unroll
+            for (int q = 0; q < CPL; q++) {
+                const int c = lane + WAVE * q;
+                const bool valid = live[i] && c < k;
+                a[i][q] = valid ? acc[(size_t)t * k + c] : 0.f;
+                eo[i][q] = valid ? e_old[(size_t)r * LD + c] : 0.f;
             }
-        double ev[CPL];
-        float sh[CPL];
-        int ehi = 0;
-#pragma unroll
-        for (int q = 0; q < CPL; q++) {
-            const int c = lane + WAVE * q;
-            const bool valid = c < k;
-            const float a = valid ? acc[(size_t)t * k + c] : 0.f;
-            const float eo = valid ? e_old[(size_t)r * LD + c] : 0.f;
-            sh[q] = fmaf(eo, a, prior_shp);
-            ev[q] = valid ? expect_ratio(sh[q], 1.0f) : 0.0;       // exp(psi(shp))
-            ehi = max(ehi, __double2hiint(ev[q]));
+            rs_old[i] = live[i] ? rs[r] : 1.f;
         }
-        const double inv = row_pow2_scale(ehi);
-        const float rs_old = rs[r];
 #pragma unroll
-        for (int q = 0; q < CPL; q++) {
-            const int c = lane + WAVE * q;
-            if (c < LD) shp_out[(size_t)t * LD + c] = (c < k) ? sh[q] : 0.f;      // the shape row, for part 2
-            if (c < k) send[(size_t)t * sld + c] = (float)(ev[q] * inv);
+        for (int i = 0; i < SR; i++) {
+            if (!live[i]) continue;          // (wave-uniform)
+            const int64_t t = tt[i], r = rr_[i];
+            double ev[CPL];
+            float sh[CPL];
+            int ehi = 0;
+#pragma unroll
+            for (int q = 0; q < CPL; q++) {
+                const int c = lane + WAVE * q;
+                const bool valid = c < k;
+                sh[q] = fmaf(eo[i][q], a[i][q], prior_shp);
+                ev[q] = valid ? expect_ratio(sh[q], 1.0f) : 0.0;       // exp(psi(shp))
+                ehi = max(ehi, __double2hiint(ev[q]));
+            }
+            const double inv = row_pow2_scale(ehi);
+#pragma unroll
+            for (int q = 0; q < CPL; q++) {
+                const int c = lane + WAVE * q;
+                if (c < LD) shp_out[(size_t)t * LD + c] = (c < k) ? sh[q] : 0.f;      // the shape row, for part 2
+                if (c < k) send[(size_t)t * sld + c] = (float)(ev[q] * inv);
+            }
+            // the base rate and the zero tail of the payload row (sld - k <= 4 columns; with k == LD they lie past the
+            // table row)
+            if (lane < sld - k) send[(size_t)t * sld + k + lane] = (lane == 0) ? top_shp / rs_old[i] : 0.f;
+            if (lane == 0 && rs_prev) rs_prev[r] = rs_old[i];
         }
-        // the base rate and the zero tail of the payload row (sld - k <= 4 columns; with k == LD they lie past the table row)
-        if (lane < sld - k) send[(size_t)t * sld + k + lane] = (lane == 0) ? top_shp / rs_old : 0.f;
-        if (lane == 0 && rs_prev) rs_prev[r] = rs_old;
     }
 }
 

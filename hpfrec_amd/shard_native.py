@@ -49,6 +49,7 @@ class ShardDesc(ctypes.Structure):
         ("dry_run", _i32), ("schedule", _i32),
         ("shp_own", _vp),
         ("dry_run_busbw_GBps", _f32), ("dry_run_latency_us", _f32),
+        ("comm_small", _vp), ("sstream", _vp),
     ]
 
 

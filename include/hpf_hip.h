@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 14
+#define HPF_HIP_ABI_VERSION 15
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -437,12 +437,17 @@ typedef struct hpf_shard_desc {
     int32_t dry_run;               /* 1: this rank alone -- every collective is its one-rank form (local copy of the
                                       rank's slice) + a 1-element all-reduce on comm if given: the compute-only
                                       schedule of a rank, for probes and the bench's exposed-exchange figure */
-    int32_t schedule;              /* HPF_SCHEDULE_FINALIZE_THEN_GATHER (0) or HPF_SCHEDULE_GATHER_EARLY (1), below */
+    int32_t schedule;              /* HPF_SCHEDULE_FINALIZE_THEN_GATHER (0), _GATHER_EARLY (1) or _GATHER_CARRIED (2), below */
     float *shp_own;                /* gather-early: [sum of slice lengths][ld] shapes between the finalizer's halves */
     float dry_run_busbw_GBps;      /* dry run only, > 0: every collective additionally occupies its stream for
                                       latency + bytes * (world-1)/world / busbw -- one idle-spinning wavefront (the links
                                       do the work on a real node), so that a one-GPU probe shows what each schedule hides */
     float dry_run_latency_us;
+    void *comm_small;              /* schedule 2: a SECOND communicator for the two k-float all-reduces (RCCL executes the
+                                      operations of one communicator in issue order whatever their streams, so on `comm` they
+                                      would queue behind the bulk collectives they must overtake); NULL: `comm` */
+    void *sstream;                 /* schedule 2: a third stream for colsum(Beta) (reduce + all-reduce under the last item
+                                      sweep); NULL: the compute stream */
 } hpf_shard_desc;
 
 /* Two schedules of the same exchange.
@@ -455,9 +460,18 @@ typedef struct hpf_shard_desc {
  *    ld]) WHILE THE USER SWEEP RUNS, the shapes wait in shp_own ([sum of slice lengths][ld]); after the
  *    all-reduce of colsum(Theta) (on the compute stream: no stream hand-over) every rank applies the rates to all items
  *    locally.  csB_part then has the grid of the apply kernel (csB_part_rows blocks over nI rows).  The exchange leaves
- *    the critical path except for two k-float all-reduces. */
+ *    the critical path except for two k-float all-reduces.
+ * 2, gather-carried: gather-early with the exchange of iteration t running on INTO iteration t+1.  Range by range:
+ *    reduce-scatter, shape half, all-gather of that range's [numerators | base rate] rows (ag_recv: range j's block
+ *    [world][slice rows of j][payload ld] at row offset world * (slice rows of the ranges before j)); the apply half of
+ *    range j is CARRIED to the start of the next iteration, just ahead of that range's item sweep -- the only reader of
+ *    its E rows before the user side -- so the all-gather of range j has until then, not until the end of the user side,
+ *    and the links can stay busy for the whole iteration.  hpf_hip_shard_join applies what is pending (the state after a
+ *    join is the state after schedule 1).  The two k-float all-reduces must not queue behind the bulk collectives:
+ *    comm_small.  csB_part_rows (a multiple of world, >= world * nranges) is divided over the ranges' apply launches. */
 #define HPF_SCHEDULE_FINALIZE_THEN_GATHER 0
 #define HPF_SCHEDULE_GATHER_EARLY 1
+#define HPF_SCHEDULE_GATHER_CARRIED 2
 
 /* {sizeof(hpf_shard_desc), offsetof ranges, offsetof acc_i, offsetof dry_run}: lets a foreign-function binding check
  * its mirror of the struct against the compiled one. */

@@ -243,7 +243,8 @@ def test_row_finalize_ranges_op(ops, k):
     assert bool((fac.cpu()[~touched] == -1).all()) and bool((fac.cpu()[touched][:, :k] > 0).all())
 
 
-@pytest.mark.parametrize("k,world,rank", [(30, 2, 0), (50, 8, 5), (64, 3, 2), (200, 4, 1)])
+@pytest.mark.parametrize("k,world,rank", [(30, 2, 0), (50, 8, 5), (64, 3, 2), (100, 8, 0), (200, 4, 1), (300, 2, 1),
+                                          (600, 2, 0), (1024, 2, 1)])
 def test_item_split_finalize_ops(ops, k, world, rank):
     """The split item finalizer of the gather-early exchange (hpf_hip_item_shape_rows_f32 on every "rank's" slices, an
     emulated all-gather, hpf_hip_item_apply_rows_f32) against the numpy stand-in, and against the one-part finalizer
@@ -535,7 +536,7 @@ def test_fused_and_split_drivers_agree(hip_backend):
 @pytest.mark.parametrize("mode", ["scatter", "allreduce", "scatter-graph", "scatter-item-stream", "scatter-direct",
                                   "scatter-direct-graph", "scatter-native", "scatter-native-graph",
                                   "scatter-native-padded", "scatter-native-early", "scatter-native-early-graph",
-                                  "scatter-early"])
+                                  "scatter-early", "scatter-native-carried", "scatter-native-carried-graph"])
 def test_sharded_path_single_rank_nccl(mode):
     """The multi-GPU code path on one GPU with a real RCCL group: "scatter" = asynchronous reduce-scatter / dense
     finalize of the own slice / all-gather into the E table; "allreduce" = async packed all-reduce + deferred finalize.
@@ -552,7 +553,8 @@ def test_sharded_path_single_rank_nccl(mode):
     if mode == "scatter-native-padded":   # all-gather of ld-padded E rows straight into the table (no unpack launch)
         env["HPF_AG_PACKED"] = "0"
     # split item finalizer: the all-gather runs under the user sweep (the library default), or the one-part finalizer
-    env["HPF_GATHER_EARLY"] = "1" if "early" in mode else "0"
+    # ("carried": the apply half of a range carried into the next iteration, a second communicator for the small sums)
+    env["HPF_GATHER_EARLY"] = "2" if "carried" in mode else "1" if "early" in mode else "0"
     if mode.endswith("graph"):            # pairs of iterations replayed from a captured hipGraph (RCCL calls included)
         env["HPF_GRAPH"] = "1"
     if "direct" in mode:                  # the collectives on an RCCL communicator of our own (hpfrec_amd/rccl.py)
@@ -806,6 +808,7 @@ def test_tiny_shape_priors(hip_backend):
                                                (2, "scatter", "native-padded", 100), (3, "scatter", "packed", 50),
                                                (2, "scatter", "native-early", 20), (3, "scatter", "native-early", 100),
                                                (3, "scatter", "early", 50),
+                                               (2, "scatter", "native-carried", 20), (3, "scatter", "native-carried", 50),
                                                (2, "allreduce", "1", 20), (3, "allreduce", "1", 20),
                                                (2, "allreduce", "0", 20), (2, "allreduce", "1", 100)])
 def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypatch, world, mode, lazy, k):
@@ -822,7 +825,7 @@ def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypat
         lazy = "1"
     native = lazy.startswith("native")
     # split item finalizer, the all-gather under the user sweep (the library default) -- or the one-part finalizer
-    monkeypatch.setenv("HPF_GATHER_EARLY", "1" if lazy.endswith("early") else "0")
+    monkeypatch.setenv("HPF_GATHER_EARLY", "2" if lazy.endswith("carried") else "1" if lazy.endswith("early") else "0")
     if native:                                    # the whole iteration issued from C (hpf_hip_shard_iterate), gloo
         monkeypatch.setenv("HPF_TEST_NATIVE_GLOO", "1")     # standing in for RCCL through the collective callback
         monkeypatch.setenv("HPF_AG_PACKED", "0" if lazy == "native-padded" else "1")
@@ -896,7 +899,8 @@ def test_bench_multi_rank_path_selftest(ranks):
                HPF_BENCH_WATCHDOG_S="600")     # (8 gloo ranks SHARING one GPU are slow: not what the watchdog is for)
     for v in ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_FORCE_SHARDED"):
         env.pop(v, None)
-    for v in ("HPF_RS_ALLTOALL", "HPF_GRAPH", "HPF_NATIVE_SHARD", "HPF_AG_PACKED", "HPF_RCCL_DIRECT"):
+    for v in ("HPF_RS_ALLTOALL", "HPF_GRAPH", "HPF_NATIVE_SHARD", "HPF_AG_PACKED", "HPF_RCCL_DIRECT", "HPF_GATHER_EARLY",
+              "HPF_SHARD_SWEEP_BPC", "HPF_ITEM_SWEEP_BPC"):
         env.pop(v, None)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
                           "--master-addr", "127.0.0.1", "--master-port", str(29588 + ranks), os.path.join(root, "bench.py"),
@@ -908,7 +912,9 @@ def test_bench_multi_rank_path_selftest(ranks):
     assert d["n_gpus"] == ranks and d["steps"] == 2 and d["config"]["state_finite"] is True
     at = d["config"]["exchange_autotune"]
     assert {"scatter/2", "scatter/1", "allreduce/3", "allreduce/2", "scatter/2/item-stream", "scatter/2/all-to-all",
-            "scatter/2/native", "scatter/2/native/packed-ag", "scatter/1/native/packed-ag", "scatter/1/native"} \
+            "scatter/2/native", "scatter/2/native/packed-ag", "scatter/1/native/packed-ag", "scatter/1/native",
+            "scatter/2/native/gather-early", "scatter/2/native/gather-carried", "scatter/3/native/gather-carried",
+            "scatter/2/room-3-6/native/gather-carried", "scatter/2/room-3-6/native/gather-early"} \
         <= set(at["ms_per_iteration"]), at
     assert at["chosen"] in at["ms_per_iteration"]
     # gloo: no communicator of our own, nothing to capture -- reported as failed candidates, not as timings
@@ -936,7 +942,8 @@ def test_bench_autotune_on_a_one_rank_rccl_group():
     env = dict(os.environ, HPF_FORCE_SHARDED="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                MASTER_PORT="29577")
     for v in ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_RS_ALLTOALL", "HPF_GRAPH", "HPF_RCCL_DIRECT",
-              "HPF_BENCH_SELFTEST_GLOO", "HPF_NATIVE_SHARD", "HPF_AG_PACKED"):
+              "HPF_BENCH_SELFTEST_GLOO", "HPF_NATIVE_SHARD", "HPF_AG_PACKED", "HPF_GATHER_EARLY", "HPF_SHARD_SWEEP_BPC",
+              "HPF_ITEM_SWEEP_BPC"):
         env.pop(v, None)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
                           "--workload", "small", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
@@ -947,7 +954,8 @@ def test_bench_autotune_on_a_one_rank_rccl_group():
     at = d["config"]["exchange_autotune"]
     assert at["failed"] == {}, at
     assert {"scatter/2/direct-rccl", "scatter/2/native", "scatter/2/native/packed-ag", "scatter/1/native/packed-ag",
-            "scatter/1/native"} <= set(at["ms_per_iteration"])
+            "scatter/1/native", "scatter/2/native/gather-early", "scatter/2/native/gather-carried",
+            "scatter/2/room-3-6/native/gather-carried"} <= set(at["ms_per_iteration"])
     assert any("/native" in key and key.endswith("/hipgraph") for key in at["ms_per_iteration"])
     assert d["config"]["state_finite"] is True and d["value"] > 0
     co = d["collective"]          # exchange alone / compute alone, on the real (one-rank) RCCL communicator

@@ -130,7 +130,7 @@ Beta = np.empty((nI, k), np.float32)
 init = backend.initialize_parameters(Theta, Beta, 123, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
 hy = cavi.Hyper(k, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
 for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
-    for r in sorted({0, world - 1}):
+    for r in ([int(x) for x in os.environ['PROBE_RANKS'].split(',')] if os.environ.get('PROBE_RANKS') else sorted({0, world - 1})):
         lu, li, ly, (u0, u1) = cavi.shard_users(iu, ii, y, nU, r, world)
         emu = EmulatedRank(r, world)
         cavi._dist = lambda: emu
@@ -166,6 +166,7 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
                 print("world %d rank %d [%s%s]: %d users, %d nnz: %.3f ms/iteration (all tables stored; host issue time %.3f ms); "
                       "kernels ms/iter %s%s" % (world, r, "native C issue" if m._plan is not None else "python issue",
                                                 ", packed all-gather" if getattr(m, "ag_packed", False) else
+                                                ", gather-carried" if getattr(m, "gather_carried", False) else
                                                 ", gather-early" if getattr(m, "gather_early", False) else "",
                                                 u1 - u0, m.nnz, dt, t_issue, ks,
                                                 " [hipGraph pairs: %s]" % ("ok" if m.__dict__.get("_graphs", {}).get(True) is not None
