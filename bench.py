@@ -452,6 +452,7 @@ def main():
                          # profiles/r03_shard_probe_gather_carried.txt); RCCL's kernels need slots in the same way
                          ("scatter", "2", "0", "0", "0", "0", "1", "0", "2", "3,32"),
                          ("scatter", "2", "0", "0", "0", "0", "1", "0", "2", "3,6"),
+                         ("scatter", "2", "0", "0", "0", "0", "1", "0", "1", "3,32"),
                          ("scatter", "2", "0", "0", "0", "0", "1", "0", "1", "3,6")):
                 key, env = candidate(*cand)
                 envs[key] = env
