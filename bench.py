@@ -368,15 +368,16 @@ def main():
         tune_iters = 6 if os.environ.get("HPF_BENCH_SELFTEST_GLOO") == "1" else 20
         watchdog_state["meta"]["tune_iters"] = tune_iters
 
-        def candidate(mode, chunks, istream, a2a, graph, direct="0", native="0", packed="0", early="0", room="4,32"):
-            # room: workgroups per CU of the user sweep / the item sweeps (the library defaults 4 / 32 fill every wave
-            # slot; 3 / 6 leave one wave slot per SIMD and a quarter of the registers to the exchange stream's kernels)
+        def candidate(mode, chunks, istream, a2a, graph, direct="0", native="0", packed="0", early="0", room="3,32"):
+            # room: workgroups per CU of the user sweep / the item sweeps (the library defaults 3 / 32 leave one wave
+            # slot per SIMD and a quarter of the registers beside the user sweep to the collectives' kernels; 4 / 32
+            # fills every slot; 3 / 6 also keeps the item sweeps at 6 of their 8 waves per SIMD)
             env = {"HPF_SHARD_MODE": mode, "HPF_AR_CHUNKS": chunks, "HPF_ITEM_STREAM": istream, "HPF_RS_ALLTOALL": a2a,
                    "HPF_GRAPH": graph, "HPF_RCCL_DIRECT": direct, "HPF_NATIVE_SHARD": native, "HPF_AG_PACKED": packed,
                    "HPF_GATHER_EARLY": early, "HPF_SHARD_SWEEP_BPC": room.split(",")[0],
                    "HPF_ITEM_SWEEP_BPC": room.split(",")[1]}
             os.environ.update(env)
-            key = "%s/%s%s%s%s%s%s%s%s%s" % (mode, chunks, "/room-%s" % room.replace(",", "-") if room != "4,32" else "",
+            key = "%s/%s%s%s%s%s%s%s%s%s" % (mode, chunks, "/room-%s" % room.replace(",", "-") if room != "3,32" else "",
                                            "/item-stream" if istream == "1" else "",
                                            "/all-to-all" if a2a == "1" else "", "/direct-rccl" if direct == "1" else "",
                                            "/native" if native == "1" else "", "/packed-ag" if packed == "1" else "",
@@ -447,12 +448,13 @@ def main():
         # should this hang): the gather-carried schedule, the exchange of an iteration running on into the next one
         if os.environ.get("HPF_BENCH_TRY_CARRIED", "1") == "1":
             for cand in (("scatter", "2", "0", "0", "0", "0", "1", "0", "2"), ("scatter", "3", "0", "0", "0", "0", "1", "0", "2"),
-                         # ... and with room left on every CU for the exchange stream's kernels: beside sweeps that fill
-                         # every wave slot the shape half ran 4x slower (a one-GPU probe with emulated link time,
-                         # profiles/r03_shard_probe_gather_carried.txt); RCCL's kernels need slots in the same way
-                         ("scatter", "2", "0", "0", "0", "0", "1", "0", "2", "3,32"),
+                         # ... and with less / more room left on every CU for the exchange stream's kernels: beside
+                         # sweeps that fill every wave slot the shape half ran 4x slower and a collective-sized stand-in
+                         # stretched the user sweep by 20 % (one-GPU probes with emulated link time,
+                         # profiles/r03_shard_probe_gather_carried.txt, r03_shard_probe_collective_footprint.txt)
+                         ("scatter", "2", "0", "0", "0", "0", "1", "0", "2", "4,32"),
                          ("scatter", "2", "0", "0", "0", "0", "1", "0", "2", "3,6"),
-                         ("scatter", "2", "0", "0", "0", "0", "1", "0", "1", "3,32"),
+                         ("scatter", "2", "0", "0", "0", "0", "1", "0", "1", "4,32"),
                          ("scatter", "2", "0", "0", "0", "0", "1", "0", "1", "3,6")):
                 key, env = candidate(*cand)
                 envs[key] = env

@@ -25,7 +25,7 @@ SVI_SRC_PATH = os.path.join(_PKG, "csrc", "hpf_svi_prep.hip") # index structures
 SOURCES = (SRC_PATH, SHARD_SRC_PATH, MT_SRC_PATH, SVI_SRC_PATH)
 INC_PATH = os.path.join(_ROOT, "include")
 
-HPF_HIP_ABI_VERSION = 15
+HPF_HIP_ABI_VERSION = 16
 
 #: every symbol include/hpf_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = (

@@ -139,10 +139,16 @@ class FullBatchCavi:
         self.nnz = self.users.nnz
         self.dist = _dist()
         # sweep grid of THIS model (the op set is shared): sharded launches cover short item ranges and want fewer,
-        # fatter blocks (16 per CU costs 3 % at N=8, gains 1 % at N=1)
+        # fatter blocks (16 per CU costs 3 % at N=8, gains 1 % at N=1).  THREE workgroups per CU, not the four that fill
+        # every wave slot the fused sweep's 104 VGPRs allow: the user sweep is the kernel the exchange hides under, and
+        # a collective's kernel (or the exchange stream's shape kernel) must become RESIDENT beside it.  With four, a
+        # stand-in of a collective kernel's footprint (32 workgroups x 256 threads, 128 VGPRs, 64 KB of LDS) took slots
+        # from the sweep's persistent grid and stretched it from 240 to 280-295 us; with three the sweep itself is 6 %
+        # slower and the 8-rank iteration at an emulated 300 GB/s 4-12 % faster in every schedule
+        # (profiles/r03_shard_probe_collective_footprint.txt)
         self.sweep_blocks = ops.sweep_blocks
         if self.dist and "HPF_SWEEP_BPC" not in os.environ and hasattr(ops, "cu_count"):
-            self.sweep_blocks = max(1, ops.cu_count) * int(os.environ.get("HPF_SHARD_SWEEP_BPC", "4"))
+            self.sweep_blocks = max(1, ops.cu_count) * int(os.environ.get("HPF_SHARD_SWEEP_BPC", "3"))
         # the sharded item pass is many short rows: more, smaller blocks even out its tail (tools/sweep_micro.py:
         # 203 us at 32 blocks per CU vs 220 at 8 for rank 0 of 8 at C3)
         self.item_sweep_blocks = max(1, getattr(ops, "cu_count", 1)) * int(os.environ.get("HPF_ITEM_SWEEP_BPC", "32")) \
@@ -677,6 +683,7 @@ class FullBatchCavi:
             if dry:      # (probes: hold the streams for the time real links would take, at an assumed bus bandwidth)
                 d.dry_run_busbw_GBps = float(getattr(dist, "native_dry_run_busbw", 0.0))
                 d.dry_run_latency_us = float(getattr(dist, "native_dry_run_latency_us", 0.0))
+                d.dry_run_footprint_blocks = int(getattr(dist, "native_dry_run_footprint_blocks", 0))
             plan = sn.ShardPlan(d, keep=keep + [comm, comm_small, views])
         except Exception as exc:   # noqa: BLE001
             plan, err = None, "%s: %s" % (type(exc).__name__, str(exc)[:200])

@@ -76,6 +76,17 @@ __global__ void link_time_kernel(long long ticks) {
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
+// the same with the footprint of a collective library's kernel: 256 threads, 128 VGPRs, 64 KB of LDS per workgroup -- it
+// starts only where a CU has that much free, which sweeps that fill every wave slot do not leave
+__global__ __launch_bounds__(256) void link_time_fat_kernel(long long ticks, int *sink) {
+    extern __shared__ int fat_lds[];
+    asm volatile("" ::: "v127");
+    fat_lds[threadIdx.x] = (int)threadIdx.x;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (ticks < 0) sink[threadIdx.x] = fat_lds[255 - threadIdx.x];
+}
+
 // one collective of the schedule.  `slice`: element offset of this rank's part inside the world-sized buffer
 int collective(Plan *p, int op, const float *send, float *recv, int64_t count, hipStream_t st, bool small = false) {
     const hpf_shard_desc &d = p->d;
@@ -90,7 +101,11 @@ int collective(Plan *p, int op, const float *send, float *recv, int64_t count, h
             // bytes a rank moves: (world-1)/world of the whole buffer (all-reduce: twice that)
             const double whole = (double)count * sizeof(float) * (op == HPF_COLL_ALL_REDUCE ? 2.0 : (double)d.world);
             const double us = d.dry_run_latency_us + whole * (d.world - 1) / d.world / (d.dry_run_busbw_GBps * 1e3);
-            hipLaunchKernelGGL(link_time_kernel, dim3(1), dim3(64), 0, st, (long long)(us * 100.0));
+            if (d.dry_run_footprint_blocks > 0 && op != HPF_COLL_ALL_REDUCE)
+                hipLaunchKernelGGL(link_time_fat_kernel, dim3(d.dry_run_footprint_blocks), dim3(256), 64 * 1024, st,
+                                   (long long)(us * 100.0), (int *)p->tiny);
+            else
+                hipLaunchKernelGGL(link_time_kernel, dim3(1), dim3(64), 0, st, (long long)(us * 100.0));
         }
         // ... plus a real (one-rank, one-element: identity) RCCL call, so that a launch of RCCL's is paid
         if (d.comm) {

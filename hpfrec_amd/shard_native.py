@@ -50,6 +50,7 @@ class ShardDesc(ctypes.Structure):
         ("shp_own", _vp),
         ("dry_run_busbw_GBps", _f32), ("dry_run_latency_us", _f32),
         ("comm_small", _vp), ("sstream", _vp),
+        ("dry_run_footprint_blocks", _i32), ("pad3", _i32),
     ]
 
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 15
+#define HPF_HIP_ABI_VERSION 16
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -448,6 +448,11 @@ typedef struct hpf_shard_desc {
                                       would queue behind the bulk collectives they must overtake); NULL: `comm` */
     void *sstream;                 /* schedule 2: a third stream for colsum(Beta) (reduce + all-reduce under the last item
                                       sweep); NULL: the compute stream */
+    int32_t dry_run_footprint_blocks;  /* dry run with busbw > 0: the stand-in of a bulk collective is this many workgroups
+                                      of 256 threads, 128 VGPRs and 64 KB of LDS each (what a collective library's
+                                      kernel needs to be RESIDENT beside the sweeps), each holding its slot for the link
+                                      time; 0: one wavefront */
+    int32_t pad3;
 } hpf_shard_desc;
 
 /* Two schedules of the same exchange.

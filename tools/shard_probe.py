@@ -79,6 +79,8 @@ class EmulatedRank:
     #: sleeping wavefront): what the iteration would take if the links delivered that, with the schedule's real dependencies
     native_dry_run_busbw = float(os.environ.get("PROBE_BUSBW", "0"))
     native_dry_run_latency_us = float(os.environ.get("PROBE_LAT_US", "20"))
+    # > 0: a bulk collective's stand-in is that many 256-thread workgroups with 128 VGPRs and 64 KB of LDS each
+    native_dry_run_footprint_blocks = int(os.environ.get("PROBE_FAT_BLOCKS", "0"))
 
     def direct_comm(self, device, raw=False):
         """HPF_RCCL_DIRECT=1: the collectives as calls on a one-rank communicator of our own + the same local copies.
