@@ -347,7 +347,8 @@ def main():
     # first and the fastest one -- by the slowest rank's clock -- is the configuration that is then benchmarked.
     autotune = None
     TUNED = ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_RS_ALLTOALL", "HPF_GRAPH", "HPF_RCCL_DIRECT",
-             "HPF_NATIVE_SHARD", "HPF_AG_PACKED", "HPF_GATHER_EARLY", "HPF_SHARD_SWEEP_BPC", "HPF_ITEM_SWEEP_BPC")
+             "HPF_NATIVE_SHARD", "HPF_AG_PACKED", "HPF_GATHER_EARLY", "HPF_SHARD_SWEEP_BPC", "HPF_ITEM_SWEEP_BPC",
+             "HPF_CARRIED_ONE_COMM")
     if os.environ.get("HPF_BENCH_SELFTEST_GLOO") == "1" and dist is not None:
         # the one-GPU self-test has no RCCL between its ranks: gloo stands in for it behind the C-issued iteration's
         # collective callback (tests/dist_worker.py), so that the native path and the `collective` block are exercised
@@ -372,16 +373,19 @@ def main():
             # room: workgroups per CU of the user sweep / the item sweeps (the library defaults 3 / 32 leave one wave
             # slot per SIMD and a quarter of the registers beside the user sweep to the collectives' kernels; 4 / 32
             # fills every slot; 3 / 6 also keeps the item sweeps at 6 of their 8 waves per SIMD)
+            one_comm = early == "2/one-comm"      # gather-carried with the k-float all-reduces on the bulk communicator
+            early = early.split("/")[0]
             env = {"HPF_SHARD_MODE": mode, "HPF_AR_CHUNKS": chunks, "HPF_ITEM_STREAM": istream, "HPF_RS_ALLTOALL": a2a,
                    "HPF_GRAPH": graph, "HPF_RCCL_DIRECT": direct, "HPF_NATIVE_SHARD": native, "HPF_AG_PACKED": packed,
                    "HPF_GATHER_EARLY": early, "HPF_SHARD_SWEEP_BPC": room.split(",")[0],
-                   "HPF_ITEM_SWEEP_BPC": room.split(",")[1]}
+                   "HPF_ITEM_SWEEP_BPC": room.split(",")[1], "HPF_CARRIED_ONE_COMM": "1" if one_comm else "0"}
             os.environ.update(env)
             key = "%s/%s%s%s%s%s%s%s%s%s" % (mode, chunks, "/room-%s" % room.replace(",", "-") if room != "3,32" else "",
                                            "/item-stream" if istream == "1" else "",
                                            "/all-to-all" if a2a == "1" else "", "/direct-rccl" if direct == "1" else "",
                                            "/native" if native == "1" else "", "/packed-ag" if packed == "1" else "",
-                                           "/gather-early" if early == "1" else "/gather-carried" if early == "2" else "",
+                                           "/gather-early" if early == "1" else
+                                           "/gather-carried-one-comm" if one_comm else "/gather-carried" if early == "2" else "",
                                            "/hipgraph" if graph == "1" else "")
             t_ms, err, m = None, None, None
 
@@ -440,7 +444,10 @@ def main():
         for cand in (("scatter", "2", "0", "0", "0", "0", "1", "0"), ("scatter", "2", "0", "0", "0", "0", "1", "1"),
                      ("scatter", "1", "0", "0", "0", "0", "1", "1"), ("scatter", "1", "0", "0", "0", "0", "1", "0"),
                      # the gather-early schedule (split item finalizer: the all-gather runs under the user sweep)
-                     ("scatter", "2", "0", "0", "0", "0", "1", "0", "1"), ("scatter", "1", "0", "0", "0", "0", "1", "0", "1")):
+                     ("scatter", "2", "0", "0", "0", "0", "1", "0", "1"), ("scatter", "1", "0", "0", "0", "0", "1", "0", "1"),
+                     # gather-carried on ONE communicator: nothing new to RCCL; as good as the two-communicator form
+                     # below only if RCCL lets a communicator's operations on different streams overtake each other
+                     ("scatter", "2", "0", "0", "0", "0", "1", "0", "2/one-comm")):
             key, env = candidate(*cand)
             envs[key] = env
         # LAST of the eager candidates (a second RCCL communicator is active beside the first -- never run with more
@@ -461,6 +468,7 @@ def main():
         # (not the gather-carried ones: three streams in one capture crashed the ROCm 7.0 runtime in round 2 with the
         # item-stream form, and a crash -- unlike a hang -- leaves no line at all)
         dr = {k_: v for k_, v in autotune.items() if "/native" in k_ and "gather-carried" not in k_}
+        # (envs[...] of the winner carries HPF_CARRIED_ONE_COMM too)
         if dr and os.environ.get("HPF_BENCH_SELFTEST_GLOO") != "1":
             base = envs[min(dr, key=dr.get)]
             key, env = candidate("scatter", base["HPF_AR_CHUNKS"], "0", "0", "1", "0", "1", base["HPF_AG_PACKED"],

@@ -633,7 +633,9 @@ class FullBatchCavi:
                     comm = _DIRECT_COMMS[key]
                 if not comm.self_check():
                     raise RuntimeError("the communicator's self-check failed")
-                if self.gather_carried:     # a second communicator: the k-float all-reduces overtake the bulk collectives
+                # a second communicator: the k-float all-reduces overtake the bulk collectives (HPF_CARRIED_ONE_COMM=1:
+                # all on one -- correct either way, slower if RCCL orders a communicator's operations across streams)
+                if self.gather_carried and os.environ.get("HPF_CARRIED_ONE_COMM", "0") != "1":
                     key = (str(self.device), self.world, self.rank, "small")
                     if key not in _DIRECT_COMMS:
                         _DIRECT_COMMS[key] = rccl.DirectComm(self.device, dist, self.rank, self.world)

@@ -900,7 +900,7 @@ def test_bench_multi_rank_path_selftest(ranks):
     for v in ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_FORCE_SHARDED"):
         env.pop(v, None)
     for v in ("HPF_RS_ALLTOALL", "HPF_GRAPH", "HPF_NATIVE_SHARD", "HPF_AG_PACKED", "HPF_RCCL_DIRECT", "HPF_GATHER_EARLY",
-              "HPF_SHARD_SWEEP_BPC", "HPF_ITEM_SWEEP_BPC"):
+              "HPF_SHARD_SWEEP_BPC", "HPF_ITEM_SWEEP_BPC", "HPF_CARRIED_ONE_COMM"):
         env.pop(v, None)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
                           "--master-addr", "127.0.0.1", "--master-port", str(29588 + ranks), os.path.join(root, "bench.py"),
@@ -914,6 +914,7 @@ def test_bench_multi_rank_path_selftest(ranks):
     assert {"scatter/2", "scatter/1", "allreduce/3", "allreduce/2", "scatter/2/item-stream", "scatter/2/all-to-all",
             "scatter/2/native", "scatter/2/native/packed-ag", "scatter/1/native/packed-ag", "scatter/1/native",
             "scatter/2/native/gather-early", "scatter/2/native/gather-carried", "scatter/3/native/gather-carried",
+            "scatter/2/native/gather-carried-one-comm", "scatter/2/room-4-32/native/gather-carried",
             "scatter/2/room-3-6/native/gather-carried", "scatter/2/room-3-6/native/gather-early"} \
         <= set(at["ms_per_iteration"]), at
     assert at["chosen"] in at["ms_per_iteration"]
@@ -943,7 +944,7 @@ def test_bench_autotune_on_a_one_rank_rccl_group():
                MASTER_PORT="29577")
     for v in ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_RS_ALLTOALL", "HPF_GRAPH", "HPF_RCCL_DIRECT",
               "HPF_BENCH_SELFTEST_GLOO", "HPF_NATIVE_SHARD", "HPF_AG_PACKED", "HPF_GATHER_EARLY", "HPF_SHARD_SWEEP_BPC",
-              "HPF_ITEM_SWEEP_BPC"):
+              "HPF_ITEM_SWEEP_BPC", "HPF_CARRIED_ONE_COMM"):
         env.pop(v, None)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
                           "--workload", "small", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
@@ -955,7 +956,8 @@ def test_bench_autotune_on_a_one_rank_rccl_group():
     assert at["failed"] == {}, at
     assert {"scatter/2/direct-rccl", "scatter/2/native", "scatter/2/native/packed-ag", "scatter/1/native/packed-ag",
             "scatter/1/native", "scatter/2/native/gather-early", "scatter/2/native/gather-carried",
-            "scatter/2/room-3-6/native/gather-carried"} <= set(at["ms_per_iteration"])
+            "scatter/2/native/gather-carried-one-comm", "scatter/2/room-3-6/native/gather-carried"} \
+        <= set(at["ms_per_iteration"])
     assert any("/native" in key and key.endswith("/hipgraph") for key in at["ms_per_iteration"])
     assert d["config"]["state_finite"] is True and d["value"] > 0
     co = d["collective"]          # exchange alone / compute alone, on the real (one-rank) RCCL communicator
