@@ -1302,6 +1302,122 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
     const int lane = threadIdx.x & (WAVE - 1);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * WPB;
+    if constexpr (LD >= 4 * WAVE) {
+        // rows of 256+ floats: a lane holds float4s (columns (v*64 + lane)*4 .. +3), VR rows in flight per wave.  With a
+        // dword per lane and load this pass spent ~50 instructions per element on addresses and predicates and was
+        // bound by instruction issue: the whole-table pass of a lazy user epoch (1 GB of shapes read, nothing stored)
+        // ran at 2.2 TB/s (profiles/r03_svi_c5_rocprofv3.txt before / after)
+        constexpr int VPL = LD / (4 * WAVE);
+        constexpr int VR = (VPL == 1) ? 4 : (VPL == 2 ? 2 : 1);
+        float4 cs4[VPL], acc4[VPL];
+        bool ok[VPL][4];
+#pragma unroll
+        for (int v = 0; v < VPL; v++) {
+            const int c = (v * WAVE + lane) * 4;
+#pragma unroll
+            for (int e2 = 0; e2 < 4; e2++) ok[v][e2] = c + e2 < k;
+            cs4[v] = make_float4(ok[v][0] ? cs_other[c] : 0.f, ok[v][1] ? cs_other[c + 1] : 0.f,
+                                 ok[v][2] ? cs_other[c + 2] : 0.f, ok[v][3] ? cs_other[c + 3] : 0.f);
+            acc4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        // A wave takes 64 CONSECUTIVE rows: their flags and row scalars are one coalesced load each (lane l holds row
+        // g + l's; a row's are read back with a wave-uniform shuffle) and the new scalars go out as one store -- per row
+        // they were three single-address loads and up to two single-lane stores next to one 1 KB row load.
+        for (int64_t g = ((int64_t)blockIdx.x * WPB + wid) * WAVE; g < nrows; g += nwaves * WAVE) {
+            const int64_t rl = g + lane;
+            const bool lv = rl < nrows;
+            const unsigned long long fmask = __ballot(lv && flag && flag[rl] != 0);
+            const float rs_l = lv ? rs[rl] : 1.f;
+            const float rsr_l = (lv && rs_rate) ? rs_rate[rl] : rs_l;
+            float rs_new_l = rs_l;
+            const int cnt = (int)min((int64_t)WAVE, nrows - g);
+            for (int b0 = 0; b0 < cnt; b0 += VR) {
+                float4 sv[VR][VPL], rv[VR][VPL], av[VR][VPL], ev[VR][VPL];
+                bool fl[VR], live[VR];
+#pragma unroll
+                for (int i = 0; i < VR; i++) {
+                    live[i] = b0 + i < cnt;
+                    fl[i] = live[i] && ((fmask >> (b0 + i)) & 1ull) != 0;
+                    const size_t o4 = (size_t)(live[i] ? g + b0 + i : 0) * (LD / 4) + lane;
+#pragma unroll
+                    for (int v = 0; v < VPL; v++) {
+                        sv[i][v] = live[i] ? reinterpret_cast<const float4 *>(shp)[o4 + v * WAVE] : zero4;
+                        rv[i][v] = (live[i] && rate_mode != 0) ? reinterpret_cast<const float4 *>(rte)[o4 + v * WAVE] : one4;
+                        av[i][v] = fl[i] ? reinterpret_cast<const float4 *>(acc)[o4 + v * WAVE] : zero4;
+                        ev[i][v] = fl[i] ? reinterpret_cast<const float4 *>(e)[o4 + v * WAVE] : zero4;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < VR; i++) {
+                    if (!live[i]) break;
+                    const int64_t r = g + b0 + i;
+                    const float rs_old = __shfl(rs_l, b0 + i);
+                    const float base = top / __shfl(rsr_l, b0 + i);
+                    const size_t o4 = (size_t)r * (LD / 4) + lane;
+                    float fsum = 0.f;
+#pragma unroll
+                    for (int v = 0; v < VPL; v++) {
+                        float s4[4] = {sv[i][v].x, sv[i][v].y, sv[i][v].z, sv[i][v].w};
+                        float r4[4] = {rv[i][v].x, rv[i][v].y, rv[i][v].z, rv[i][v].w};
+                        const float a4[4] = {av[i][v].x, av[i][v].y, av[i][v].z, av[i][v].w};
+                        const float e4[4] = {ev[i][v].x, ev[i][v].y, ev[i][v].z, ev[i][v].w};
+                        const float c4[4] = {cs4[v].x, cs4[v].y, cs4[v].z, cs4[v].w};
+                        float f4[4];
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; e2++) {
+                            float f = 0.f;
+                            if (ok[v][e2]) {
+                                float sx = s4[e2];
+                                if (fl[i]) {
+                                    const float fresh = fmaf(e4[e2], a4[e2], prior);
+                                    sx = (w_old == 0.f) ? w_new * fresh : w_new * fresh + w_old * sx;
+                                }
+                                float rt = r4[e2];
+                                if (rate_mode == 0)
+                                    rt = base + c4[e2];
+                                else if (fl[i])
+                                    rt = step * (base + c4[e2]) + step_prev * rt;
+                                f = sx / rt;
+                                s4[e2] = sx;
+                                r4[e2] = rt;
+                            } else {
+                                s4[e2] = 0.f;       // (pad columns: what the tables hold there)
+                                r4[e2] = 0.f;
+                            }
+                            f4[e2] = f;
+                            fsum += f;
+                        }
+                        acc4[v].x += f4[0];
+                        acc4[v].y += f4[1];
+                        acc4[v].z += f4[2];
+                        acc4[v].w += f4[3];
+                        if (fl[i]) reinterpret_cast<float4 *>(shp)[o4 + v * WAVE] = make_float4(s4[0], s4[1], s4[2], s4[3]);
+                        if (rte && (rate_mode == 0 || fl[i]))
+                            reinterpret_cast<float4 *>(rte)[o4 + v * WAVE] = make_float4(r4[0], r4[1], r4[2], r4[3]);
+                        if (fac) reinterpret_cast<float4 *>(fac)[o4 + v * WAVE] = make_float4(f4[0], f4[1], f4[2], f4[3]);
+                    }
+                    if (rs_mode == 2 || (rs_mode == 1 && fl[i])) {
+                        fsum = wave_sum(fsum);
+                        if (lane == b0 + i) rs_new_l = step * (add + fsum) + step_prev * rs_old;
+                    }
+                }
+            }
+            if (lv && rs_prev_out) rs_prev_out[rl] = rsr_l;
+            if (lv && (rs_mode == 2 || (rs_mode == 1 && ((fmask >> lane) & 1ull) != 0))) rs[rl] = rs_new_l;
+        }
+#pragma unroll
+        for (int v = 0; v < VPL; v++)
+            reinterpret_cast<float4 *>(&red[wid][0])[v * WAVE + lane] = acc4[v];
+        __syncthreads();
+        for (int c = threadIdx.x; c < LD; c += BLOCK) {
+            float t = red[0][c];
+#pragma unroll
+            for (int w2 = 1; w2 < WPB; w2++) t += red[w2][c];
+            cs_partial[(size_t)blockIdx.x * LD + c] = t;
+        }
+        return;
+    }
     float csl[CPL], csacc[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; q++) {
@@ -1314,12 +1430,17 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
         float sv[R][CPL], rv[R][CPL], av[R][CPL], ev[R][CPL], rs_old[R], rs_rt[R];
         bool fl[R];
 #pragma unroll
-        for (int i = 0; i < R; i++) {
+        for (int i = 0; i < R; i++) {       // (flags and scalars of all rows first: see the float4 path)
             const int64_t r = r0 + i * nwaves;
             const bool live = r < nrows;
             fl[i] = live && flag && flag[r] != 0;
             rs_old[i] = live ? rs[r] : 1.f;
             rs_rt[i] = (live && rs_rate) ? rs_rate[r] : rs_old[i];
+        }
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int64_t r = r0 + i * nwaves;
+            const bool live = r < nrows;
 #pragma unroll
             for (int q = 0; q < CPL; q++) {
                 const int c = lane + WAVE * q;
