@@ -919,9 +919,10 @@ struct ExpectIn {
 
 template <int LD>
 __device__ __forceinline__ void expect_load(const float *__restrict__ shp, const float *__restrict__ rte, int64_t r, int k,
-                                            int lane, const FactoredRate fr, ExpectIn<LD> &in) {
+                                            int lane, const FactoredRate fr, float rs_r, ExpectIn<LD> &in) {
+    // rs_r: fr.rs[r] (factored rate), fetched by the caller -- coalesced for 64 rows at a time where it can
     constexpr int CPL = ExpectIn<LD>::CPL;
-    const float base = fr.rs ? fr.top / fr.rs[r] : 0.f;
+    const float base = fr.rs ? fr.top / rs_r : 0.f;
 #pragma unroll
     for (int q = 0; q < CPL; q++) {
         const int c = lane + WAVE * q;
@@ -967,16 +968,17 @@ __global__ __launch_bounds__(BLOCK) void expect_kernel(const float *__restrict__
         for (int64_t g = ((int64_t)blockIdx.x * WPB + wid) * WAVE; g < nrows; g += nwaves * WAVE) {
             unsigned long long m = __ballot(g + lane < nrows && flag[g + lane] != 0);
             if (!m) continue;
+            const float rs_l = (fr.rs && g + lane < nrows) ? fr.rs[g + lane] : 1.f;   // the 64 rows' scalars, one load
             int b = __builtin_ctzll(m);
             m &= m - 1;
-            expect_load<LD>(shp, rte, g + b, k, lane, fr, cur);
+            expect_load<LD>(shp, rte, g + b, k, lane, fr, __shfl(rs_l, b), cur);
             while (true) {
                 const bool more = m != 0;
                 int b2 = 0;
                 if (more) {
                     b2 = __builtin_ctzll(m);
                     m &= m - 1;
-                    expect_load<LD>(shp, rte, g + b2, k, lane, fr, nxt);
+                    expect_load<LD>(shp, rte, g + b2, k, lane, fr, __shfl(rs_l, b2), nxt);
                 }
                 expect_finish<LD>(e, g + b, k, lane, cur);
                 if (!more) break;
@@ -999,10 +1001,10 @@ __global__ __launch_bounds__(BLOCK) void expect_kernel(const float *__restrict__
     };
     int64_t r = next_row(t);
     if (r < 0) return;
-    expect_load<LD>(shp, rte, r, k, lane, fr, cur);
+    expect_load<LD>(shp, rte, r, k, lane, fr, fr.rs ? fr.rs[r] : 1.f, cur);
     while (true) {
         const int64_t r2 = next_row(t);
-        if (r2 >= 0) expect_load<LD>(shp, rte, r2, k, lane, fr, nxt);
+        if (r2 >= 0) expect_load<LD>(shp, rte, r2, k, lane, fr, fr.rs ? fr.rs[r2] : 1.f, nxt);
         expect_finish<LD>(e, r, k, lane, cur);
         if (r2 < 0) break;
         cur = nxt;
@@ -1303,10 +1305,10 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * WPB;
     if constexpr (LD >= 4 * WAVE) {
-        // rows of 256+ floats: a lane holds float4s (columns (v*64 + lane)*4 .. +3), VR rows in flight per wave.  With a
-        // dword per lane and load this pass spent ~50 instructions per element on addresses and predicates and was
-        // bound by instruction issue: the whole-table pass of a lazy user epoch (1 GB of shapes read, nothing stored)
-        // ran at 2.2 TB/s (profiles/r03_svi_c5_rocprofv3.txt before / after)
+        // rows of 256+ floats: a lane holds float4s (columns (v*64 + lane)*4 .. +3), VR rows in flight per wave.  The
+        // whole-table pass of a lazy user epoch (1 GB of shapes read, nothing stored) ran at 2.2 TB/s; float4 loads
+        // alone changed nothing -- what it was waiting for were the per-row single-address loads and single-lane stores
+        // (below), tools/svi_side_probe.py: 0.46 -> 0.33 ms, a plain read of the table takes 0.27
         constexpr int VPL = LD / (4 * WAVE);
         constexpr int VR = (VPL == 1) ? 4 : (VPL == 2 ? 2 : 1);
         float4 cs4[VPL], acc4[VPL];
