@@ -809,6 +809,8 @@ def test_tiny_shape_priors(hip_backend):
                                                (2, "scatter", "native-early", 20), (3, "scatter", "native-early", 100),
                                                (3, "scatter", "early", 50),
                                                (2, "scatter", "native-carried", 20), (3, "scatter", "native-carried", 50),
+                                               (3, "scatter", "checks-native-carried", 20),
+                                               (2, "scatter", "checks-native-early", 20),
                                                (2, "allreduce", "1", 20), (3, "allreduce", "1", 20),
                                                (2, "allreduce", "0", 20), (2, "allreduce", "1", 100)])
 def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypatch, world, mode, lazy, k):
@@ -823,6 +825,9 @@ def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypat
     if lazy == "a2a":                             # scatter mode, reduce-scatter as all-to-all + local sum
         monkeypatch.setenv("HPF_RS_ALLTOALL", "1")
         lazy = "1"
+    if lazy.startswith("checks-"):                # llk checks every 2 iterations: joins (and carried applies) mid-fit
+        monkeypatch.setenv("HPF_TEST_CHECK_EVERY", "2")
+        lazy = lazy[len("checks-"):]
     native = lazy.startswith("native")
     # split item finalizer, the all-gather under the user sweep (the library default) -- or the one-part finalizer
     monkeypatch.setenv("HPF_GATHER_EARLY", "2" if lazy.endswith("carried") else "1" if lazy.endswith("early") else "0")
