@@ -4,6 +4,7 @@ host: slow, but it is the real sharded driver on the real kernels at C3 size -- 
 pad rows), a few iterations, every rank's tables against the single-process run.
 
     python tools/two_rank_c3_check.py [world=2] [mode=scatter|allreduce] [iterations=3] [workload=c3]
+    HPF_TEST_NATIVE_GLOO=1 HPF_GATHER_EARLY=2 python tools/two_rank_c3_check.py 8     (the C-issued gather-carried schedule)
 """
 import os
 import sys
@@ -52,6 +53,12 @@ def worker(rank, world, port, wl, its, mode, out):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HPF_SHARD_MODE=mode)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if os.environ.get("HPF_TEST_NATIVE_GLOO") == "1":
+        # the C-issued iteration (hpf_hip_shard_iterate; HPF_GATHER_EARLY = 0 / 1 / 2 picks its schedule) with gloo standing
+        # in for RCCL through the collective callback
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from dist_worker import gloo_collective
+        dist.native_collective = lambda model: gloo_collective(dist, model)
     st = fit(rank, world, wl, its)
     np.savez(os.path.join(out, "rank%d.npz" % rank), **{k: v for k, v in st.items()})
     dist.destroy_process_group()
