@@ -315,6 +315,15 @@ class FullBatchCavi:
         it = self.items
         deg = (it.indptr[1:] - it.indptr[:-1]).clone()
         self.dist.all_reduce(deg)
+        # HPF_RANGE_ROW_WEIGHT = w: a row counts as its nonzeros + w x the mean row's (0: equal nonzeros = equal sweep
+        # time, 18 % / 82 % of the rows at C3; large: equal rows = equal exchange bytes).  Scatter mode: 2 (31 % / 69 %
+        # of the nonzeros) -- the range swept first is the one with most rows, and with equal nonzeros its exchange (82 %
+        # of the bytes) ended after the iteration did: at an emulated 300 GB/s the 8-rank iteration went 0.87 -> 0.83 ms
+        # (finalize-then-gather), 0.80 -> 0.78 (gather-early), 0.72 -> 0.63 (gather-carried), at no cost without link
+        # time (profiles/r03_shard_probe_gather_carried.txt, "range split")
+        w = float(os.environ.get("HPF_RANGE_ROW_WEIGHT", "2" if self.shard_mode == "scatter" else "0"))
+        if w > 0 and self.nI > 0:
+            deg = deg + int(round(w * float(deg.sum().item()) / self.nI))
         gptr = torch.zeros(self.nI + 1, dtype=torch.int64, device=deg.device)
         torch.cumsum(deg, 0, out=gptr[1:])
         cuts = [lo for lo, _ in layout.nnz_balanced_ranges(gptr, max(1, nchunks))] + [self.nI]
