@@ -56,6 +56,18 @@ def _dist():
 
 
 _DIRECT_COMMS = {}
+# The side streams of the sharded iteration, ONE set per device for the life of the process: ROCm maps a new stream onto
+# a hardware queue by creation order, and the streams of a second model of a process landed on queues that collide with
+# the compute stream's (tools/shard_probe.py: its second model ran 0.64 -> 1.1 ms per iteration under gather-carried with
+# emulated link time).  Only one model iterates at a time, so models share them; bench.py builds ~25 models in a row.
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device, kind, priority=0):
+    key = (str(device), kind)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=priority)
+    return _SIDE_STREAMS[key]
 NATIVE_PLANS_CREATED = [0]      # how many models of this process run their sharded iteration from C (tests, bench)
 
 
@@ -682,7 +694,7 @@ class FullBatchCavi:
                 d.schedule = 2
                 d.comm_small = comm_small.handle if comm_small is not None else None
                 if getattr(self, "_ss", None) is None:     # colsum(Beta): reduced + summed under the last item sweep
-                    self._ss = torch.cuda.Stream(device=self.device, priority=-1)
+                    self._ss = _side_stream(self.device, "small", -1)
                 d.sstream = self._ss.cuda_stream
             d.a, d.k_shp, d.add_k_rte = float(hy.a), float(hy.k_shp), float(hy.add_k_rte)
             d.c, d.t_shp, d.add_t_rte = float(hy.c), float(hy.t_shp), float(hy.add_t_rte)
@@ -865,14 +877,14 @@ class FullBatchCavi:
             # queues in creation order; when the exchange stream landed on the compute stream's queue, a collective
             # that waits for the links held back the sweeps queued behind it (seen with tools/shard_probe.py
             # PROBE_BUSBW=...: the second model of a process ran 0.3 ms slower per iteration than the first)
-            self._xs = torch.cuda.Stream(device=self.device, priority=-1)
+            self._xs = _side_stream(self.device, "exchange", -1)
         return self._xs
 
     def _istream(self):
         if self.device.type != "cuda":
             return None
         if getattr(self, "_is", None) is None:
-            self._is = torch.cuda.Stream(device=self.device)
+            self._is = _side_stream(self.device, "item")
         return self._is
 
     def _event(self):
