@@ -25,7 +25,7 @@ import os
 import numpy as np
 import torch
 
-from . import _lib, layout
+from . import _lib, _streams, layout
 
 
 class Hyper:
@@ -56,18 +56,7 @@ def _dist():
 
 
 _DIRECT_COMMS = {}
-# The side streams of the sharded iteration, ONE set per device for the life of the process: ROCm maps a new stream onto
-# a hardware queue by creation order, and the streams of a second model of a process landed on queues that collide with
-# the compute stream's (tools/shard_probe.py: its second model ran 0.64 -> 1.1 ms per iteration under gather-carried with
-# emulated link time).  Only one model iterates at a time, so models share them; bench.py builds ~25 models in a row.
-_SIDE_STREAMS = {}
-
-
-def _side_stream(device, kind, priority=0):
-    key = (str(device), kind)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=priority)
-    return _SIDE_STREAMS[key]
+_side_stream = _streams.side_stream      # (process-wide side streams: hpfrec_amd/_streams.py)
 NATIVE_PLANS_CREATED = [0]      # how many models of this process run their sharded iteration from C (tests, bench)
 
 

@@ -20,7 +20,7 @@ import time
 import numpy as np
 import torch
 
-from . import cavi, layout, svi
+from . import _streams, cavi, layout, svi
 from .ops_hip import HipOps
 
 c_real_t = ctypes.c_float          # hpfrec/cython_float.pxi:9
@@ -265,7 +265,7 @@ def start_init_draw(ops, dist, random_seed, nU, nI, k):
         dist.broadcast(mt_state, 0)
     if dev.type != "cuda":
         return cavi.draw_init_words(ops, mt_state, nU, nI, k), None
-    side = torch.cuda.Stream(dev)
+    side = _streams.side_stream(dev, "initial-draw")
     side.wait_stream(torch.cuda.current_stream(dev))
     mt_state.record_stream(side)          # (the kernel leaves the stream's new position in it when it ends)
     with torch.cuda.stream(side):

@@ -18,7 +18,7 @@ import os
 import numpy as np
 import torch
 
-from . import _lib, layout
+from . import _lib, _streams, layout
 
 _NAMES = ("Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "Theta", "Beta")
 SVI_TIMINGS = {}      # HPF_TIMING=1: {"epochs": n, "seconds": wall time of the last fit's epoch loop}
@@ -445,7 +445,9 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
     # (HPF_SVI_LAZY=0: every batch stores the rate and mean tables the reference rewrites -- 2-3 GB per C5 batch that nothing
     # reads before the next check; kept as a switch so that a test can hold the lazy form against it bit for bit)
     lazy = os.environ.get("HPF_SVI_LAZY", "1") == "1"
-    prep_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+    # (one preparation stream per device for the life of the process, like the exchange streams of the sharded fit: a new
+    # stream per fit walks through the hardware queues, and some of them collide with the compute stream's)
+    prep_stream = _streams.side_stream(dev, "svi-prepare") if dev.type == "cuda" else None
     if prep_stream is not None:
         prep_stream.wait_stream(torch.cuda.current_stream(dev))      # the CSR / CSC built above
     workspaces = {}
