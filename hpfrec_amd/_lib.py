@@ -25,7 +25,7 @@ SVI_SRC_PATH = os.path.join(_PKG, "csrc", "hpf_svi_prep.hip") # index structures
 SOURCES = (SRC_PATH, SHARD_SRC_PATH, MT_SRC_PATH, SVI_SRC_PATH)
 INC_PATH = os.path.join(_ROOT, "include")
 
-HPF_HIP_ABI_VERSION = 16
+HPF_HIP_ABI_VERSION = 17
 
 #: every symbol include/hpf_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = (
@@ -37,7 +37,7 @@ SYMBOLS = (
     "hpf_hip_unpack_rows_f32", "hpf_hip_item_shape_rows_f32", "hpf_hip_item_apply_rows_f32", "hpf_hip_gather_payload_ld", "hpf_hip_rccl_open", "hpf_hip_rccl_unique_id", "hpf_hip_rccl_comm_init", "hpf_hip_rccl_comm_count",
     "hpf_hip_rccl_comm_destroy", "hpf_hip_rccl_all_reduce_f32", "hpf_hip_rccl_reduce_scatter_f32",
     "hpf_hip_rccl_all_gather_f32", "hpf_hip_shard_plan_create", "hpf_hip_shard_plan_destroy", "hpf_hip_shard_iterate",
-    "hpf_hip_shard_join", "hpf_hip_shard_exchange_only", "hpf_hip_shard_desc_layout",
+    "hpf_hip_shard_join", "hpf_hip_shard_exchange_only", "hpf_hip_shard_desc_layout", "hpf_hip_shard_trace",
     "hpf_hip_mt19937_scratch_words", "hpf_hip_mt19937_jump_poly",
 )
 
@@ -104,6 +104,7 @@ def lib():
     L.hpf_hip_shard_iterate.argtypes = [vp, vp, vp, ci, vp]
     L.hpf_hip_shard_join.argtypes = [vp, vp]
     L.hpf_hip_shard_exchange_only.argtypes = [vp, ci, ci, vp]
+    L.hpf_hip_shard_trace.argtypes = [vp, vp, i64, ctypes.POINTER(i64)]
     L.hpf_hip_colsum_reduce_f32.argtypes = [vp, ci, vp, ci, vp]
     L.hpf_hip_colsum_f32.argtypes = [vp, i64, ci, vp, ci, vp]
     L.hpf_hip_expect_f32.argtypes = [vp, vp, vp, vp, vp, i64, ci, ci, vp, vp, cf, vp]

@@ -15,6 +15,7 @@
 
 #include <mutex>
 #include <new>
+#include <vector>
 
 #include "hpf_hip.h"
 
@@ -48,7 +49,73 @@ inline int rccl_rc(ncclResult_t r) { return r == ncclSuccess ? 0 : HPF_ERCCL_BAS
         if (e__ != hipSuccess) return (int)e__;        \
     } while (0)
 
+// ---- trace mode (hpf_shard_desc.dry_run == 2): what an iteration ISSUES, in order, without a device --------------------
+// Every kernel launch, collective, event record / wait and copy of the schedule is appended to the plan's trace instead of
+// being issued (events and streams are opaque handles then).  tests/test_host_logic.py reads the traces of all ranks of a
+// job on a machine without a GPU and checks what a multi-rank run depends on: identical collective sequences on every
+// rank, every wait after its record, each schedule's order of kernels.
+struct Tracer {
+    std::vector<hpf_shard_trace_rec> recs;
+    void add(int kind, int id, const void *stream, int64_t arg) {
+        hpf_shard_trace_rec r;
+        r.kind = kind;
+        r.id = id;
+        r.stream = (int64_t)(intptr_t)stream;
+        r.arg = arg;
+        recs.push_back(r);
+    }
+};
+thread_local Tracer *g_tr = nullptr;
+struct TraceScope {       // the tracer of the plan being issued, for the wrappers below
+    Tracer *prev;
+    explicit TraceScope(Tracer *t) : prev(g_tr) { g_tr = t; }
+    ~TraceScope() { g_tr = prev; }
+};
+
+template <typename T>
+const void *last_arg(T v) { return (const void *)v; }
+template <typename T, typename... R>
+const void *last_arg(T, R... rest) { return last_arg(rest...); }
+
+inline hipError_t tr_event_record(hipEvent_t e, hipStream_t st) {
+    if (g_tr) {
+        g_tr->add(HPF_TRACE_RECORD, 0, st, (int64_t)(intptr_t)e);
+        return hipSuccess;
+    }
+    return hipEventRecord(e, st);
+}
+inline hipError_t tr_stream_wait(hipStream_t st, hipEvent_t e, unsigned flags) {
+    if (g_tr) {
+        g_tr->add(HPF_TRACE_WAIT, 0, st, (int64_t)(intptr_t)e);
+        return hipSuccess;
+    }
+    return hipStreamWaitEvent(st, e, flags);
+}
+inline hipError_t tr_memcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
+    if (g_tr) {
+        g_tr->add(HPF_TRACE_COPY, 0, st, (int64_t)bytes);
+        return hipSuccess;
+    }
+    return hipMemcpyAsync(dst, src, bytes, kind, st);
+}
+#define hipEventRecord tr_event_record
+#define hipStreamWaitEvent tr_stream_wait
+#define hipMemcpyAsync tr_memcpy
+// the kernels of the schedule are reached through the library's own C entries; their stream is the last argument
+#define TR_KERNEL(id, fn, ...) (g_tr ? (g_tr->add(HPF_TRACE_KERNEL, id, last_arg(__VA_ARGS__), 0), 0) : fn(__VA_ARGS__))
+#define hpf_hip_sweep_f32(...) TR_KERNEL(HPF_TRACE_K_SWEEP, (hpf_hip_sweep_f32), __VA_ARGS__)
+#define hpf_hip_segsum_f32(...) TR_KERNEL(HPF_TRACE_K_SEGSUM, (hpf_hip_segsum_f32), __VA_ARGS__)
+#define hpf_hip_sweep_finalize_f32(...) TR_KERNEL(HPF_TRACE_K_SWEEP_FINALIZE, (hpf_hip_sweep_finalize_f32), __VA_ARGS__)
+#define hpf_hip_row_finalize_f32(...) TR_KERNEL(HPF_TRACE_K_ROW_FINALIZE, (hpf_hip_row_finalize_f32), __VA_ARGS__)
+#define hpf_hip_row_finalize_ranges_f32(...) TR_KERNEL(HPF_TRACE_K_ROW_FINALIZE_RANGES, (hpf_hip_row_finalize_ranges_f32), __VA_ARGS__)
+#define hpf_hip_colsum_reduce_f32(...) TR_KERNEL(HPF_TRACE_K_COLSUM_REDUCE, (hpf_hip_colsum_reduce_f32), __VA_ARGS__)
+#define hpf_hip_item_shape_rows_f32(...) TR_KERNEL(HPF_TRACE_K_ITEM_SHAPE, (hpf_hip_item_shape_rows_f32), __VA_ARGS__)
+#define hpf_hip_item_apply_rows_f32(...) TR_KERNEL(HPF_TRACE_K_ITEM_APPLY, (hpf_hip_item_apply_rows_f32), __VA_ARGS__)
+#define hpf_hip_unpack_rows_f32(...) TR_KERNEL(HPF_TRACE_K_UNPACK, (hpf_hip_unpack_rows_f32), __VA_ARGS__)
+
 struct Plan {
+    Tracer tracer;
+    bool tracing;                     // dry_run == 2
     hpf_shard_desc d;
     hipStream_t xs;
     hipEvent_t sw_done[HPF_MAX_ROW_RANGES], ag_done[HPF_MAX_ROW_RANGES], csT_ready, start;
@@ -90,6 +157,10 @@ __global__ __launch_bounds__(256) void link_time_fat_kernel(long long ticks, int
 // one collective of the schedule.  `slice`: element offset of this rank's part inside the world-sized buffer
 int collective(Plan *p, int op, const float *send, float *recv, int64_t count, hipStream_t st, bool small = false) {
     const hpf_shard_desc &d = p->d;
+    if (p->tracing) {
+        p->tracer.add(HPF_TRACE_COLLECTIVE, op | (small ? 0x100 : 0), st, count);
+        return 0;
+    }
     if (d.dry_run) {
         // this rank alone: the one-rank form of the collective on this rank's slice ...
         const size_t bytes = (size_t)count * sizeof(float);
@@ -328,7 +399,8 @@ int hpf_hip_shard_plan_create(const hpf_shard_desc *desc, void **plan) {
     p->pending_store = 0;
     p->ss = (hipStream_t)d.sstream;
     p->tiny = nullptr;
-    if (d.dry_run && d.comm) {
+    p->tracing = d.dry_run == 2;
+    if (!p->tracing && d.dry_run && d.comm) {
         const hipError_t e = hipMalloc((void **)&p->tiny, 256);
         if (e != hipSuccess) {
             delete p;
@@ -391,6 +463,10 @@ int hpf_hip_shard_plan_create(const hpf_shard_desc *desc, void **plan) {
     evs[ne++] = &p->p2_done;
     evs[ne++] = &p->csB_done;
     for (int i = 0; i < ne; i++) {
+        if (p->tracing) {       // opaque handles: HPF_TRACE_EVENT_BASE + the event's index (sw_done j: 2j, ag_done j: 2j+1, ...)
+            *evs[i] = (hipEvent_t)(intptr_t)(HPF_TRACE_EVENT_BASE + i);
+            continue;
+        }
         const hipError_t e = hipEventCreateWithFlags(evs[i], hipEventDisableTiming);
         if (e != hipSuccess) {
             for (int q = 0; q < i; q++) (void)hipEventDestroy(*evs[q]);
@@ -407,6 +483,10 @@ int hpf_hip_shard_plan_create(const hpf_shard_desc *desc, void **plan) {
 int hpf_hip_shard_plan_destroy(void *plan) {
     if (!plan) return HPF_EINVAL;
     Plan *p = (Plan *)plan;
+    if (p->tracing) {
+        delete p;
+        return 0;
+    }
     for (int j = 0; j < p->d.nranges; j++) {
         (void)hipEventDestroy(p->sw_done[j]);
         (void)hipEventDestroy(p->ag_done[j]);
@@ -423,6 +503,7 @@ int hpf_hip_shard_plan_destroy(void *plan) {
 int hpf_hip_shard_join(void *plan, void *stream) {
     if (!plan) return HPF_EINVAL;
     Plan *p = (Plan *)plan;
+    TraceScope scope(p->tracing ? &p->tracer : nullptr);
     if (!p->fresh) {
         const hpf_shard_desc &d = p->d;
         hipStream_t st = (hipStream_t)stream;
@@ -567,6 +648,7 @@ static int iterate_gather_carried(Plan *p, const float *eT, float *eT_next, int 
 int hpf_hip_shard_iterate(void *plan, const float *eT, float *eT_next, int store, void *compute_stream) {
     if (!plan || !eT || !eT_next || eT == eT_next) return HPF_EINVAL;
     Plan *p = (Plan *)plan;
+    TraceScope scope(p->tracing ? &p->tracer : nullptr);
     if (p->d.schedule == HPF_SCHEDULE_GATHER_EARLY)
         return iterate_gather_early(p, eT, eT_next, store, (hipStream_t)compute_stream);
     if (p->d.schedule == HPF_SCHEDULE_GATHER_CARRIED)
@@ -629,6 +711,7 @@ int hpf_hip_shard_iterate(void *plan, const float *eT, float *eT_next, int store
 int hpf_hip_shard_exchange_only(void *plan, int op, int range, void *stream) {
     if (!plan) return HPF_EINVAL;
     Plan *p = (Plan *)plan;
+    TraceScope scope(p->tracing ? &p->tracer : nullptr);
     const hpf_shard_desc &d = p->d;
     hipStream_t st = (hipStream_t)stream;
     if (range < 0) {
@@ -645,6 +728,18 @@ int hpf_hip_shard_exchange_only(void *plan, int op, int range, void *stream) {
         return all_gather_range(p, range, st);   // (idempotent: e_own still holds the rows)
     }
     return HPF_EINVAL;
+}
+
+int hpf_hip_shard_trace(void *plan, hpf_shard_trace_rec *out, int64_t cap, int64_t *n) {
+    if (!plan || !n || cap < 0 || (cap > 0 && !out)) return HPF_EINVAL;
+    Plan *p = (Plan *)plan;
+    if (!p->tracing) return HPF_EINVAL;
+    const int64_t have = (int64_t)p->tracer.recs.size();
+    *n = have;
+    if (cap < have) return 0;         // (size query: nothing is consumed)
+    for (int64_t i = 0; i < have; i++) out[i] = p->tracer.recs[(size_t)i];
+    p->tracer.recs.clear();
+    return 0;
 }
 
 }  // extern "C"

@@ -54,6 +54,17 @@ class ShardDesc(ctypes.Structure):
     ]
 
 
+class TraceRec(ctypes.Structure):
+    """hpf_shard_trace_rec: one issued operation of a traced plan (desc.dry_run = 2)."""
+    _fields_ = [("kind", _i32), ("id", _i32), ("stream", _i64), ("arg", _i64)]
+
+
+TRACE_KERNEL, TRACE_COLLECTIVE, TRACE_RECORD, TRACE_WAIT, TRACE_COPY = 1, 2, 3, 4, 5
+TRACE_KERNELS = {1: "sweep", 2: "segsum", 3: "sweep_finalize", 4: "row_finalize", 5: "row_finalize_ranges", 6: "colsum_reduce",
+                 7: "item_shape", 8: "item_apply", 9: "unpack"}
+TRACE_EVENT_BASE = 0x1000
+
+
 class ShardPlan:
     """Owns one hpf_shard plan.  `keep`: whatever must outlive the plan on the Python side (tensors whose pointers the
     descriptor holds, the callback object of a stand-in collective)."""
@@ -78,6 +89,20 @@ class ShardPlan:
     def exchange_only(self, op, rng, stream):
         _lib.check(self.L.hpf_hip_shard_exchange_only(self.handle, int(op), int(rng), stream),
                    "hpf_hip_shard_exchange_only")
+
+    def iterate_raw(self, eT, eT_next, store, stream):
+        """iterate() on raw pointer values (a traced plan: nothing is dereferenced)."""
+        _lib.check(self.L.hpf_hip_shard_iterate(self.handle, eT, eT_next, int(bool(store)), stream), "hpf_hip_shard_iterate")
+
+    def trace(self):
+        """The operations a traced plan (desc.dry_run = 2) has issued since the last call, in order: a list of
+        (kind, id, stream, arg) tuples (include/hpf_hip.h, HPF_TRACE_*)."""
+        n = ctypes.c_int64(0)
+        _lib.check(self.L.hpf_hip_shard_trace(self.handle, None, 0, ctypes.byref(n)), "hpf_hip_shard_trace")
+        buf = (TraceRec * max(1, n.value))()
+        _lib.check(self.L.hpf_hip_shard_trace(self.handle, ctypes.addressof(buf), n.value, ctypes.byref(n)),
+                   "hpf_hip_shard_trace")
+        return [(r.kind, r.id, r.stream, r.arg) for r in buf[: n.value]]
 
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle.value:

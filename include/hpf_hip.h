@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 16
+#define HPF_HIP_ABI_VERSION 17
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -477,6 +477,36 @@ typedef struct hpf_shard_desc {
 #define HPF_SCHEDULE_FINALIZE_THEN_GATHER 0
 #define HPF_SCHEDULE_GATHER_EARLY 1
 #define HPF_SCHEDULE_GATHER_CARRIED 2
+
+/* dry_run == 2, "trace": nothing is issued and no device is needed -- every kernel launch, collective, event record /
+ * wait and copy of hpf_hip_shard_iterate / _join / _exchange_only is appended to the plan's trace instead, in issue order
+ * (table pointers are never dereferenced, streams are opaque values, comm / coll are ignored).  What a multi-rank run
+ * depends on -- identical collective sequences on all ranks, every wait after its record -- can then be checked on any
+ * machine (tests/test_host_logic.py). */
+#define HPF_TRACE_KERNEL 1      /* id = HPF_TRACE_K_*                                              */
+#define HPF_TRACE_COLLECTIVE 2  /* id = HPF_COLL_* (| 0x100: a k-float all-reduce), arg = count    */
+#define HPF_TRACE_RECORD 3      /* arg = event                                                     */
+#define HPF_TRACE_WAIT 4        /* arg = event                                                     */
+#define HPF_TRACE_COPY 5        /* arg = bytes                                                     */
+#define HPF_TRACE_K_SWEEP 1
+#define HPF_TRACE_K_SEGSUM 2
+#define HPF_TRACE_K_SWEEP_FINALIZE 3
+#define HPF_TRACE_K_ROW_FINALIZE 4
+#define HPF_TRACE_K_ROW_FINALIZE_RANGES 5
+#define HPF_TRACE_K_COLSUM_REDUCE 6
+#define HPF_TRACE_K_ITEM_SHAPE 7
+#define HPF_TRACE_K_ITEM_APPLY 8
+#define HPF_TRACE_K_UNPACK 9
+/* events of a traced plan: HPF_TRACE_EVENT_BASE + 2j (range j swept), + 2j + 1 (range j's all-gather done), then, after the
+ * 2 * nranges of them: colsum(Theta) ready, iteration start, apply done, colsum(Beta) done */
+#define HPF_TRACE_EVENT_BASE 0x1000
+typedef struct hpf_shard_trace_rec {
+    int32_t kind, id;
+    int64_t stream;     /* the stream argument as given (compute stream of the call, xstream, sstream) */
+    int64_t arg;
+} hpf_shard_trace_rec;
+/* *n = records waiting; when cap >= *n they are copied to out and the trace is emptied (cap < *n: a size query) */
+int hpf_hip_shard_trace(void *plan, hpf_shard_trace_rec *out, int64_t cap, int64_t *n);
 
 /* {sizeof(hpf_shard_desc), offsetof ranges, offsetof acc_i, offsetof dry_run}: lets a foreign-function binding check
  * its mirror of the struct against the compiled one. */

@@ -444,3 +444,103 @@ def test_backend_accepts_what_the_reference_class_passes(cpu_ops_backend):
                 assert out.shape == named["ix_u"].shape and out.dtype == np.float32
             else:
                 assert len(out) == 6 and out[0].shape == named["Theta"].shape
+
+
+def _traced_plan(world, rank, schedule, nranges=2, k=50, nI=1003, small_comm=True):
+    """A C-issued iteration plan in trace mode (hpf_shard_desc.dry_run = 2): nothing is dereferenced or issued, so the
+    table pointers are arbitrary non-null values and no GPU is needed."""
+    from hpfrec_amd import shard_native as sn
+    ld = _lib.ld_for_k(k)
+    d = sn.ShardDesc()
+    d.world, d.rank, d.k, d.ld, d.nU, d.nI = world, rank, k, ld, 500, nI
+    fake = iter(range(0x10000, 0x7fffffff, 0x10000))
+    for n in ("u_segs", "u_idx", "u_y", "u_row_seg_ptr", "u_multi_rows", "i_segs", "i_idx", "i_y", "i_row_seg_ptr", "eB", "part_u",
+              "part_i", "Gamma_shp", "Theta", "k_rte", "k_rte_prev", "Lambda_shp", "Beta", "t_rte", "t_rte_prev", "csT", "csB",
+              "csB_used", "csT_part", "csB_part", "acc_i", "acc_own", "e_own", "ag_recv", "shp_own"):
+        setattr(d, n, next(fake))
+    d.u_nseg, d.u_nmulti = 700, 3
+    # item ranges: multiples of the world size, the last one ends in pad rows; issue order NOT ascending
+    rows = -(-nI // world) * world
+    cut = (rows // (2 * world)) * world if nranges > 1 else rows
+    bounds = [(cut, rows), (0, cut)][: nranges] if nranges == 2 else [(0, rows)]
+    d.nranges = len(bounds)
+    seg = 0
+    for j, (lo, hi) in enumerate(bounds):
+        r = d.ranges[j]
+        r.lo, r.hi, r.seg_lo, r.nseg, r.nmulti, r.short_rows = lo, hi, seg, hi - lo, 2, j & 1
+        r.multi_rows = next(fake)
+        seg += hi - lo
+    d.csT_part_rows, d.user_sweep_grid, d.user_multi_grid = 64, 48, 4
+    d.csB_part_rows, d.item_sweep_grid = 8 * world, 256
+    d.e_own_ld = ld if schedule == 0 else (k + 4) // 4 * 4
+    d.a = d.k_shp = d.add_k_rte = d.c = d.t_shp = d.add_t_rte = 0.3
+    d.xstream, d.sstream = 0xE0, 0x50 if schedule == 2 else None
+    d.dry_run, d.schedule = 2, schedule
+    plan = sn.ShardPlan(d)
+    return plan, sn
+
+
+@pytest.mark.parametrize("schedule", [0, 1, 2])
+@pytest.mark.parametrize("world,nranges", [(8, 2), (3, 2), (2, 1)])
+def test_c_issued_iteration_traces(schedule, world, nranges):
+    """What a multi-rank run of the C-issued iteration depends on, checked WITHOUT a GPU on the operations each rank's plan
+    issues (trace mode of hpf_hip_shard_iterate / _join): every rank issues the SAME sequence of collectives (kind and
+    element count -- a mismatch is a hang on real links), every stream wait names an event recorded before it, each
+    range's reduce-scatter follows its sweep and precedes its all-gather, the user side is issued once per iteration,
+    and a join leaves nothing pending (gather-carried: the carried apply halves are issued by the join)."""
+    CS = 0xC0
+    traces = []
+    for rank in range(world):
+        plan, sn = _traced_plan(world, rank, schedule, nranges)
+        ops = []
+        for it in range(3):
+            plan.iterate_raw(0x100 + (it & 1), 0x101 - (it & 1), it == 2, CS)
+            ops.append(plan.trace())
+        plan.join(CS)
+        ops.append(plan.trace())
+        plan.close()
+        traces.append(ops)
+    KER = sn.TRACE_KERNELS
+    coll = lambda tr: [(i, a) for kind, i, st, a in tr if kind == sn.TRACE_COLLECTIVE]    # noqa: E731
+    for step in range(4):
+        assert all(coll(traces[r][step]) == coll(traces[0][step]) for r in range(world)), (schedule, step)
+    for rank in range(world):
+        recorded = set()
+        for step, tr in enumerate(traces[rank]):
+            names = [KER[i] for kind, i, st, a in tr if kind == sn.TRACE_KERNEL]
+            for kind, i, st, a in tr:
+                if kind == sn.TRACE_RECORD:
+                    recorded.add(a)
+                elif kind == sn.TRACE_WAIT:
+                    assert a in recorded, (schedule, rank, step, hex(a))
+            if step == 3:       # the join
+                assert ("item_apply" in names) == (schedule == 2) and "sweep" not in names
+                continue
+            assert names.count("sweep_finalize") == 1 and names.count("sweep") == nranges
+            c = coll(tr)
+            n_rs = sum(1 for i, a in c if i == sn.COLL_REDUCE_SCATTER)
+            n_ag = sum(1 for i, a in c if i == sn.COLL_ALL_GATHER)
+            n_small = sum(1 for i, a in c if i == (sn.COLL_ALL_REDUCE | 0x100) or i == sn.COLL_ALL_REDUCE)
+            assert n_rs == nranges and n_ag == (1 if schedule == 1 else nranges)
+            # (gather-carried: colsum(Beta) of an iteration is summed at the start of the next one, or by the join)
+            assert n_small == (2 if schedule != 2 or step > 0 else 1)
+            # a range's reduce-scatter after its sweep, its all-gather after its reduce-scatter
+            kinds = [("sweep", None) if (kind == sn.TRACE_KERNEL and KER[i] == "sweep") else
+                     ("rs", a) if (kind == sn.TRACE_COLLECTIVE and i == sn.COLL_REDUCE_SCATTER) else
+                     ("ag", a) if (kind == sn.TRACE_COLLECTIVE and i == sn.COLL_ALL_GATHER) else None
+                     for kind, i, st, a in tr]
+            kinds = [x for x in kinds if x]
+            seen_sweeps = seen_rs = 0
+            for what, a in kinds:
+                if what == "sweep":
+                    seen_sweeps += 1
+                elif what == "rs":
+                    seen_rs += 1
+                    assert seen_rs <= seen_sweeps
+                else:
+                    assert seen_rs >= 1
+            if schedule == 2 and step > 0:      # the carried apply of a range just ahead of that range's sweep
+                order = [n for n in names if n in ("item_apply", "sweep")]
+                assert order == ["item_apply", "sweep"] * nranges, order
+            elif schedule == 1:                 # apply of all ranges after the user side
+                assert names.index("item_apply") > names.index("sweep_finalize")
