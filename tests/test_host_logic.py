@@ -544,3 +544,22 @@ def test_c_issued_iteration_traces(schedule, world, nranges):
                 assert order == ["item_apply", "sweep"] * nranges, order
             elif schedule == 1:                 # apply of all ranges after the user side
                 assert names.index("item_apply") > names.index("sweep_finalize")
+
+
+@pytest.mark.parametrize("schedule", [0, 1, 2])
+def test_c_issued_iteration_traces_with_fewer_items_than_ranks(schedule):
+    """5 items over 8 ranks: ranks 5-7 own pad rows only -- they launch no item finalizer (or shape half), yet take part in
+    every collective with the same element counts as everybody else."""
+    seqs, finalizers = [], []
+    for rank in range(8):
+        plan, sn = _traced_plan(8, rank, schedule, 1, nI=5)
+        for it in range(2):
+            plan.iterate_raw(0x100 + (it & 1), 0x101 - (it & 1), True, 0xC0)
+        plan.join(0xC0)
+        tr = plan.trace()
+        plan.close()
+        seqs.append([(i, a) for kind, i, st, a in tr if kind == sn.TRACE_COLLECTIVE])
+        finalizers.append(sum(1 for kind, i, st, a in tr if kind == sn.TRACE_KERNEL and
+                              sn.TRACE_KERNELS[i] in ("item_shape", "row_finalize_ranges")))
+    assert all(s == seqs[0] for s in seqs) and len(seqs[0]) > 0
+    assert finalizers == [2] * 5 + [0] * 3
