@@ -22,10 +22,12 @@ SRC_PATH = os.path.join(_PKG, "csrc", "hpf_hip.hip")          # the kernels + th
 SHARD_SRC_PATH = os.path.join(_PKG, "csrc", "hpf_shard.hip")  # host code: one rank's sharded iteration, RCCL binding
 MT_SRC_PATH = os.path.join(_PKG, "csrc", "hpf_mt19937.hip")   # the MT19937 stream of the initial draws (jump-ahead)
 SVI_SRC_PATH = os.path.join(_PKG, "csrc", "hpf_svi_prep.hip") # index structures of a stochastic batch, on the device
-SOURCES = (SRC_PATH, SHARD_SRC_PATH, MT_SRC_PATH, SVI_SRC_PATH)
+P2P_SRC_PATH = os.path.join(_PKG, "csrc", "hpf_p2p.hip")      # peer-mapped exchange regions (hipIpc*) + their primitives
+SOURCES = (SRC_PATH, SHARD_SRC_PATH, MT_SRC_PATH, SVI_SRC_PATH, P2P_SRC_PATH)
+HEADERS = (os.path.join(_PKG, "csrc", "hpf_p2p_dev.h"),)
 INC_PATH = os.path.join(_ROOT, "include")
 
-HPF_HIP_ABI_VERSION = 17
+HPF_HIP_ABI_VERSION = 18
 
 #: every symbol include/hpf_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = (
@@ -39,6 +41,10 @@ SYMBOLS = (
     "hpf_hip_rccl_all_gather_f32", "hpf_hip_shard_plan_create", "hpf_hip_shard_plan_destroy", "hpf_hip_shard_iterate",
     "hpf_hip_shard_join", "hpf_hip_shard_exchange_only", "hpf_hip_shard_desc_layout", "hpf_hip_shard_trace",
     "hpf_hip_mt19937_scratch_words", "hpf_hip_mt19937_jump_poly",
+    "hpf_hip_p2p_ctrl_bytes", "hpf_hip_p2p_region_create", "hpf_hip_p2p_region_handles", "hpf_hip_p2p_region_connect",
+    "hpf_hip_p2p_region_data", "hpf_hip_p2p_region_set_timeout", "hpf_hip_p2p_region_next_epoch",
+    "hpf_hip_p2p_region_status", "hpf_hip_p2p_region_destroy", "hpf_hip_p2p_signal", "hpf_hip_p2p_wait",
+    "hpf_hip_p2p_allreduce_vec_f32", "hpf_hip_p2p_pull_f32",
 )
 
 _lib = None
@@ -51,7 +57,7 @@ class HpfHipError(RuntimeError):
 def build(force=False, verbose=False):
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     if (not force) and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= max(
-            max(os.path.getmtime(p) for p in SOURCES), os.path.getmtime(os.path.join(INC_PATH, "hpf_hip.h"))):
+            max(os.path.getmtime(p) for p in SOURCES + HEADERS), os.path.getmtime(os.path.join(INC_PATH, "hpf_hip.h"))):
         return SO_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I" + INC_PATH,
            "-o", SO_PATH] + list(SOURCES) + ["-ldl"]
@@ -128,8 +134,23 @@ def lib():
     L.hpf_hip_svi_side_f32.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, cf, cf, cf, ci, ci, ci, ci,
                                        ci, vp, vp, vp]
     L.hpf_hip_svi_rate_rows_f32.argtypes = [vp, i64, vp, vp, vp, vp, cf, cf, cf, cf, ci, ci, ci, vp]
+    u32 = ctypes.c_uint32
+    L.hpf_hip_p2p_ctrl_bytes.argtypes = [ci]
+    L.hpf_hip_p2p_region_create.argtypes = [ci, ci, ci, i64, ctypes.POINTER(vp)]
+    L.hpf_hip_p2p_region_handles.argtypes = [vp, vp]
+    L.hpf_hip_p2p_region_connect.argtypes = [vp, vp]
+    L.hpf_hip_p2p_region_data.argtypes = [vp, ci, ctypes.POINTER(vp)]
+    L.hpf_hip_p2p_region_set_timeout.argtypes = [vp, cf]
+    L.hpf_hip_p2p_region_next_epoch.argtypes = [vp, ctypes.POINTER(u32)]
+    L.hpf_hip_p2p_region_status.argtypes = [vp, ctypes.POINTER(u32)]
+    L.hpf_hip_p2p_region_destroy.argtypes = [vp]
+    L.hpf_hip_p2p_signal.argtypes = [vp, ci, u32, vp]
+    L.hpf_hip_p2p_wait.argtypes = [vp, ci, u32, u32, vp]
+    L.hpf_hip_p2p_allreduce_vec_f32.argtypes = [vp, ci, u32, vp, vp]
+    L.hpf_hip_p2p_pull_f32.argtypes = [vp, ci, u32, ci, i64, vp, i64, ci, vp]
     for s in SYMBOLS:
         getattr(L, s).restype = ci
+    L.hpf_hip_p2p_ctrl_bytes.restype = i64
     L.hpf_hip_mt19937_scratch_words.restype = i64
     L.hpf_hip_svi_prep_scratch_words.restype = i64
     L.hpf_hip_svi_batch_sizeof.restype = i64

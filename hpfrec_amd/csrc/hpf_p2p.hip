@@ -1,0 +1,265 @@
+// hpf_p2p.hip -- the direct (peer-mapped) exchange of the user-sharded iteration: memory regions every rank of a node
+// maps from every other rank (hipIpc*), and the primitive stream operations on them (include/hpf_hip.h, section
+// "Multi-GPU, direct exchange").
+//
+// What this replaces: nothing in the reference (single-node OpenMP, cython_loops.pxi:4, 227-259).  SURVEY.md section
+// 8(e) asks for a DIRECT reduce-scatter + all-gather of the item statistics over all seven xGMI links of a GPU instead
+// of a ring; here the "collectives" disappear into the kernels that consume their results: the owner of an item slice
+// PULLS the N partial accumulator rows from the N ranks' exchange buffers and sums them in rank order
+// (item_shape_kernel, hpf_hip.hip), every rank pulls the finished [numerators | base rate] rows from their owners
+// (item_apply_kernel), and the two k-float column sums travel as self-validating 8-byte granules.  No RCCL kernel
+// competes with the sweeps for compute units and no collective launch latency is paid.
+//
+// A region = one coarse-grained data allocation (caller-defined layout) + one fine-grained control block (error word,
+// flag words, vector slots; hpf_p2p_dev.h).  The library allocates and owns both for the life of the region handle; the
+// caller moves the 2 x 64 handle bytes between the ranks by its own means (torch.distributed here).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <new>
+
+#include "hpf_hip.h"
+#include "hpf_p2p_dev.h"
+
+namespace {
+
+#define HIP_TRY(expr)                           \
+    do {                                        \
+        const hipError_t e__ = (expr);          \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+
+struct Region {
+    int world, rank, ld;
+    int64_t data_bytes;
+    void *data[HPF_P2P_MAX_RANKS];       // every rank's data buffer as mapped in this process ([rank]: the local one)
+    uint32_t *ctrl[HPF_P2P_MAX_RANKS];
+    bool opened_data[HPF_P2P_MAX_RANKS], opened_ctrl[HPF_P2P_MAX_RANKS];
+    bool connected, local_only;
+    uint32_t epoch;                      // the last epoch handed out (monotonic for the life of the region)
+    float timeout_ms;
+};
+
+hpf_p2p::Peers peers_of(const Region *r) {
+    hpf_p2p::Peers pp;
+    pp.world = r->world;
+    pp.rank = r->rank;
+    for (int i = 0; i < HPF_P2P_MAX_RANKS; i++) pp.ctrl[i] = (i < r->world) ? r->ctrl[i] : nullptr;
+    pp.timeout_ticks = (long long)((double)r->timeout_ms * 1e5);      // wall_clock64: 100 MHz
+    pp.emulate = r->local_only ? 1 : 0;
+    return pp;
+}
+
+__global__ void p2p_signal_kernel(const hpf_p2p::Peers pp, int kind, uint32_t epoch) {
+    hpf_p2p::wave_signal(pp, kind, epoch);
+}
+
+__global__ void p2p_wait_kernel(const hpf_p2p::Peers pp, int kind, uint32_t epoch, uint32_t mask) {
+    hpf_p2p::block_acquire(pp, kind, epoch, mask);
+}
+
+// vec[c] <- sum over the ranks of vec[c], in rank order (identical floats on every rank); one thread per column
+__global__ void p2p_allreduce_vec_kernel(const hpf_p2p::Peers pp, int which, uint32_t epoch, float *vec, int ld) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ld) return;
+    hpf_p2p::vec_publish(pp, which, epoch, ld, c, vec[c]);
+    vec[c] = hpf_p2p::vec_collect(pp, which, epoch, ld, c);
+}
+
+// dst[i] = src[i], 16 bytes per lane, 8 loads in flight per lane: a peer's buffer into local memory (the gather of the
+// finished item rows ahead of the apply kernel, when it is to run under the user sweep instead of inside the apply)
+__global__ __launch_bounds__(256) void p2p_pull_kernel(const hpf_p2p::Peers pp, int kind, uint32_t epoch, int src_rank,
+                                                       const float4 *__restrict__ src, float4 *__restrict__ dst,
+                                                       int64_t n4) {
+    if (kind >= 0) hpf_p2p::block_acquire(pp, kind, epoch, 1u << src_rank);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 7 * stride < n4; i += 8 * stride) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; u++) dst[i + u * stride] = v[u];
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
+}
+
+}  // namespace
+
+// for hpf_shard.hip (same library, C++ linkage): the kernel-argument view of a region, and its mapped data buffers
+namespace hpf_p2p {
+bool region_view(void *region, Peers *pp, void **data /* [HPF_P2P_MAX_RANKS] */, int *world, int *rank, int *ld) {
+    if (!region) return false;
+    Region *r = (Region *)region;
+    if (!r->connected) return false;
+    *pp = peers_of(r);
+    for (int i = 0; i < HPF_P2P_MAX_RANKS; i++) data[i] = (i < r->world) ? r->data[i] : nullptr;
+    *world = r->world;
+    *rank = r->rank;
+    *ld = r->ld;
+    return true;
+}
+}  // namespace hpf_p2p
+
+extern "C" {
+
+int64_t hpf_hip_p2p_ctrl_bytes(int ld) { return ld > 0 ? (int64_t)hpf_p2p::ctrl_bytes(ld) : HPF_EINVAL; }
+
+int hpf_hip_p2p_region_create(int world, int rank, int ld, int64_t data_bytes, void **region) {
+    if (!region || world <= 0 || world > HPF_P2P_MAX_RANKS || rank < 0 || rank >= world || ld <= 0 || data_bytes <= 0)
+        return HPF_EINVAL;
+    Region *r = new (std::nothrow) Region();
+    if (!r) return (int)hipErrorOutOfMemory;
+    memset(r, 0, sizeof(*r));
+    r->world = world;
+    r->rank = rank;
+    r->ld = ld;
+    r->data_bytes = data_bytes;
+    r->timeout_ms = 20000.f;
+    void *d = nullptr, *c = nullptr;
+    hipError_t e = hipMalloc(&d, (size_t)data_bytes);
+    if (e == hipSuccess) {
+        // fine-grained: coherent with peers' stores while kernels run (flags and granules are polled)
+        e = hipExtMallocWithFlags(&c, hpf_p2p::ctrl_bytes(ld), hipDeviceMallocFinegrained);
+    }
+    if (e == hipSuccess) e = hipMemset(c, 0, hpf_p2p::ctrl_bytes(ld));
+    if (e == hipSuccess) e = hipMemset(d, 0, (size_t)data_bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        if (d) (void)hipFree(d);
+        if (c) (void)hipFree(c);
+        delete r;
+        return (int)e;
+    }
+    r->data[rank] = d;
+    r->ctrl[rank] = (uint32_t *)c;
+    *region = r;
+    return 0;
+}
+
+int hpf_hip_p2p_region_handles(void *region, uint8_t out[2 * HPF_P2P_HANDLE_BYTES]) {
+    if (!region || !out) return HPF_EINVAL;
+    Region *r = (Region *)region;
+    static_assert(sizeof(hipIpcMemHandle_t) == HPF_P2P_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipIpcGetMemHandle(&h, r->ctrl[r->rank]));
+    memcpy(out, &h, sizeof(h));
+    HIP_TRY(hipIpcGetMemHandle(&h, r->data[r->rank]));
+    memcpy(out + HPF_P2P_HANDLE_BYTES, &h, sizeof(h));
+    return 0;
+}
+
+int hpf_hip_p2p_region_connect(void *region, const uint8_t *handles) {
+    if (!region) return HPF_EINVAL;
+    Region *r = (Region *)region;
+    if (r->connected) return HPF_EINVAL;
+    if (!handles) {       // this rank alone (probes, the bench's compute-only twin): every peer is the local memory
+        for (int p = 0; p < r->world; p++) {
+            r->data[p] = r->data[r->rank];
+            r->ctrl[p] = r->ctrl[r->rank];
+        }
+        r->local_only = true;
+        r->connected = true;
+        return 0;
+    }
+    for (int p = 0; p < r->world; p++) {
+        if (p == r->rank) continue;
+        hipIpcMemHandle_t h;
+        void *ptr = nullptr;
+        memcpy(&h, handles + (size_t)p * 2 * HPF_P2P_HANDLE_BYTES, sizeof(h));
+        HIP_TRY(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+        r->ctrl[p] = (uint32_t *)ptr;
+        r->opened_ctrl[p] = true;
+        memcpy(&h, handles + (size_t)p * 2 * HPF_P2P_HANDLE_BYTES + HPF_P2P_HANDLE_BYTES, sizeof(h));
+        ptr = nullptr;
+        HIP_TRY(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+        r->data[p] = ptr;
+        r->opened_data[p] = true;
+    }
+    r->connected = true;
+    return 0;
+}
+
+int hpf_hip_p2p_region_data(void *region, int peer, void **ptr) {
+    if (!region || !ptr) return HPF_EINVAL;
+    Region *r = (Region *)region;
+    if (peer < 0 || peer >= r->world || !r->data[peer]) return HPF_EINVAL;
+    *ptr = r->data[peer];
+    return 0;
+}
+
+int hpf_hip_p2p_region_set_timeout(void *region, float timeout_ms) {
+    if (!region || !(timeout_ms > 0.f)) return HPF_EINVAL;
+    ((Region *)region)->timeout_ms = timeout_ms;
+    return 0;
+}
+
+int hpf_hip_p2p_region_next_epoch(void *region, uint32_t *epoch) {
+    if (!region || !epoch) return HPF_EINVAL;
+    Region *r = (Region *)region;
+    *epoch = ++r->epoch;
+    return 0;
+}
+
+int hpf_hip_p2p_region_status(void *region, uint32_t *err) {
+    if (!region || !err) return HPF_EINVAL;
+    Region *r = (Region *)region;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(err, r->ctrl[r->rank], sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return *err ? HPF_ETIMEOUT : 0;
+}
+
+int hpf_hip_p2p_region_destroy(void *region) {
+    if (!region) return HPF_EINVAL;
+    Region *r = (Region *)region;
+    (void)hipDeviceSynchronize();
+    for (int p = 0; p < r->world; p++) {
+        if (r->opened_ctrl[p]) (void)hipIpcCloseMemHandle(r->ctrl[p]);
+        if (r->opened_data[p]) (void)hipIpcCloseMemHandle(r->data[p]);
+    }
+    (void)hipFree(r->ctrl[r->rank]);
+    (void)hipFree(r->data[r->rank]);
+    delete r;
+    return 0;
+}
+
+int hpf_hip_p2p_signal(void *region, int kind, uint32_t epoch, void *stream) {
+    if (!region || kind < 0 || kind >= HPF_P2P_NKINDS) return HPF_EINVAL;
+    Region *r = (Region *)region;
+    if (!r->connected) return HPF_EINVAL;
+    hipLaunchKernelGGL(p2p_signal_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, peers_of(r), kind, epoch);
+    return (int)hipGetLastError();
+}
+
+int hpf_hip_p2p_wait(void *region, int kind, uint32_t epoch, uint32_t src_mask, void *stream) {
+    if (!region || kind < 0 || kind >= HPF_P2P_NKINDS) return HPF_EINVAL;
+    Region *r = (Region *)region;
+    if (!r->connected) return HPF_EINVAL;
+    hipLaunchKernelGGL(p2p_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, peers_of(r), kind, epoch, src_mask);
+    return (int)hipGetLastError();
+}
+
+int hpf_hip_p2p_allreduce_vec_f32(void *region, int which, uint32_t epoch, float *vec, void *stream) {
+    if (!region || which < 0 || which >= HPF_P2P_NVEC || !vec) return HPF_EINVAL;
+    Region *r = (Region *)region;
+    if (!r->connected) return HPF_EINVAL;
+    hipLaunchKernelGGL(p2p_allreduce_vec_kernel, dim3((r->ld + 255) / 256), dim3(256), 0, (hipStream_t)stream, peers_of(r),
+                       which, epoch, vec, r->ld);
+    return (int)hipGetLastError();
+}
+
+int hpf_hip_p2p_pull_f32(void *region, int kind, uint32_t epoch, int src_rank, int64_t src_offset_bytes, float *dst,
+                         int64_t n, int grid_blocks, void *stream) {
+    if (!region || !dst || n < 0 || (n & 3) || (src_offset_bytes & 15) || src_rank < 0 || kind >= HPF_P2P_NKINDS)
+        return HPF_EINVAL;
+    Region *r = (Region *)region;
+    if (!r->connected || src_rank >= r->world || src_offset_bytes + n * 4 > r->data_bytes) return HPF_EINVAL;
+    if (n == 0) return 0;
+    const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(r->data[src_rank]) + src_offset_bytes);
+    hipLaunchKernelGGL(p2p_pull_kernel, dim3(grid_blocks > 0 ? grid_blocks : 64), dim3(256), 0, (hipStream_t)stream,
+                       peers_of(r), kind, epoch, src_rank, src, reinterpret_cast<float4 *>(dst), n / 4);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

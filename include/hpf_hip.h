@@ -32,11 +32,12 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 17
+#define HPF_HIP_ABI_VERSION 18
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
 #define HPF_ENOLIB (-3)       /* RCCL entry points not bound (hpf_hip_rccl_open failed or was not called) */
+#define HPF_ETIMEOUT (-4)     /* direct exchange: a peer's flag did not arrive within the region's time-out */
 #define HPF_ERCCL_BASE (-1000) /* an RCCL call failed: the return value is HPF_ERCCL_BASE - ncclResult_t */
 
 /* A contiguous run of nonzeros belonging to one sparse row (CSR row of a user, or CSC
@@ -525,6 +526,55 @@ int hpf_hip_shard_join(void *plan, void *stream);
 /* 1 (one collective of op HPF_COLL_*) of `count` per-rank elements between scratch regions of the plan's buffers, on
  * `stream`: the exchange-only timing pass of bench.py.  range < 0: the k-float all-reduce. */
 int hpf_hip_shard_exchange_only(void *plan, int op, int range, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Multi-GPU, direct exchange (hpfrec_amd/csrc/hpf_p2p.hip, hpf_p2p_dev.h): the item statistics move between the GPUs
+ * of a node WITHOUT a collective library.  SURVEY.md section 8(e): "must use a direct reduce-scatter + all-gather ...
+ * all 7 links ... rather than a ring".  Every rank owns a REGION -- a data buffer (caller-defined layout; coarse-grained
+ * device memory) and a control block (flags, vector slots, an error word; fine-grained device memory) -- exports both
+ * (hipIpcGetMemHandle) and maps every peer's (hipIpcOpenMemHandle).  The kernels of the iteration then read the peers'
+ * buffers directly: data is only ever PULLED by its consumer after the producer's flag (a monotonic epoch) has arrived
+ * in the consumer's own control block; k-float vectors travel as 8-byte {value, epoch} granules.  Every wait is bounded
+ * by the region's time-out: a missing peer sets the error word (HPF_ETIMEOUT at the next status call), it cannot hang
+ * the GPU.  The reference has no counterpart (single-node OpenMP, cython_loops.pxi:4).
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define HPF_P2P_MAX_RANKS 16
+#define HPF_P2P_HANDLE_BYTES 64     /* sizeof(hipIpcMemHandle_t) */
+#define HPF_P2P_NKINDS 32           /* flag kinds per control block (the schedule's: HPF_P2P_FLAG_*) */
+#define HPF_P2P_NVEC 2              /* vector slots: HPF_P2P_VEC_CST, HPF_P2P_VEC_CSB */
+#define HPF_P2P_VEC_CST 0
+#define HPF_P2P_VEC_CSB 1
+#define HPF_P2P_FLAG_SWEPT(j) (j)                          /* item range j of this epoch is complete in the rank's acc buffer */
+#define HPF_P2P_FLAG_SHAPED(j) (HPF_MAX_ROW_RANGES + (j))  /* the rank's [numerators | base] rows of range j are complete */
+#define HPF_P2P_FLAG_USER 30                               /* free for callers (tests, probes) */
+int64_t hpf_hip_p2p_ctrl_bytes(int ld);
+/* Allocates the region of `rank` of `world` on the current device (data_bytes of zeroed data + the control block for
+ * vectors of ld floats). */
+int hpf_hip_p2p_region_create(int world, int rank, int ld, int64_t data_bytes, void **region);
+/* out: [control-block handle | data handle], 2 x HPF_P2P_HANDLE_BYTES */
+int hpf_hip_p2p_region_handles(void *region, uint8_t out[2 * HPF_P2P_HANDLE_BYTES]);
+/* handles: world x 2 x HPF_P2P_HANDLE_BYTES bytes, rank after rank (this rank's own entry is ignored).  NULL: this rank
+ * ALONE -- every peer is mapped to the local memory and no flag is ever waited for (probes; the compute-only twin of the
+ * bench).  Call once, after every rank has created its region. */
+int hpf_hip_p2p_region_connect(void *region, const uint8_t *handles);
+int hpf_hip_p2p_region_data(void *region, int peer, void **ptr);       /* peer's data buffer as mapped here */
+int hpf_hip_p2p_region_set_timeout(void *region, float timeout_ms);    /* default 20 s */
+int hpf_hip_p2p_region_next_epoch(void *region, uint32_t *epoch);      /* ++epoch (starts at 1; every rank counts alike) */
+/* synchronises the device and reads the error word: 0, or HPF_ETIMEOUT with *err = the bit set (bit f: a flag of kind
+ * f mod 16 never came; bit 16 + v: a vector granule) */
+int hpf_hip_p2p_region_status(void *region, uint32_t *err);
+int hpf_hip_p2p_region_destroy(void *region);
+/* primitive stream operations (tests, probes; the iteration has them fused into its kernels):
+ * signal: after everything queued on `stream` so far, flags[kind][this rank] = epoch in every rank's control block;
+ * wait:   `stream` continues once flags[kind][src] >= epoch for every src in src_mask;
+ * allreduce_vec: vec[0..ld) summed over the ranks in rank order (in place; every rank gets the same floats);
+ * pull:   dst[0..n) = n floats at src_offset_bytes of src_rank's data buffer, after flags[kind][src_rank] >= epoch
+ *         (kind < 0: no wait). */
+int hpf_hip_p2p_signal(void *region, int kind, uint32_t epoch, void *stream);
+int hpf_hip_p2p_wait(void *region, int kind, uint32_t epoch, uint32_t src_mask, void *stream);
+int hpf_hip_p2p_allreduce_vec_f32(void *region, int which, uint32_t epoch, float *vec, void *stream);
+int hpf_hip_p2p_pull_f32(void *region, int kind, uint32_t epoch, int src_rank, int64_t src_offset_bytes, float *dst,
+                         int64_t n, int grid_blocks, void *stream);
 
 #ifdef __cplusplus
 }

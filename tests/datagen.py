@@ -74,6 +74,19 @@ def synthetic_hpf_shaped(nusers, nitems, nnz, seed=1, item_power=2.5, sigma=1.0)
     return u[perm].astype(np.uint64), i[perm].astype(np.uint64), y[perm]
 
 
+def large_counts(nusers=200_000, nitems=50_000, nnz=5_400_000, seed=9):
+    """The large golden case (tests/golden/large_full.npz): the benchmark's shape of problem at 200k x 50k, >= 5M
+    nonzeros -- big enough that numpy's float32 column sums over the rows (cython_loops.pxi:236,255) carry visible
+    rounding noise, small enough for the real reference to run it in minutes.  The pair (nusers-1, nitems-1) is
+    appended so that reindex=False sees the full shape."""
+    u, i, y = synthetic_hpf_shaped(nusers, nitems, nnz, seed=seed)
+    if not np.any((u == nusers - 1) & (i == nitems - 1)):
+        u = np.concatenate([u, np.array([nusers - 1], np.uint64)])
+        i = np.concatenate([i, np.array([nitems - 1], np.uint64)])
+        y = np.concatenate([y, np.array([1.0], np.float32)])
+    return u, i, y, nusers, nitems
+
+
 def boundary_valset(nusers, nitems, n=400, seed=21):
     """A small validation set for the llk / RMSE fixtures of tests/golden/c1_boundary.npz."""
     rs = np.random.RandomState(seed)

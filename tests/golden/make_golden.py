@@ -112,6 +112,27 @@ def mid_full():
     print("mid_full", len(out))
 
 
+def large_full():
+    """200k x 50k, >= 5M nonzeros, k = 50 through the REAL extension: sub-sampled rows (every 400th user, every 100th
+    item) and float64 column sums of all eight arrays after 1, 3 and 5 iterations.  Pins the large-scale parity claim
+    (numpy's naive float32 axis-0 sums, PXI:236,255, are the noisy side) with the reference itself."""
+    u, i, y, nU, nI = datagen.large_counts()
+    df = pd.DataFrame({"UserId": u.astype(np.int64), "ItemId": i.astype(np.int64), "Count": y})
+    out = {"nnz": np.int64(df.shape[0])}
+    for it in (1, 3, 5):
+        m = fit_ref(df, 50, it)
+        assert m.Theta.shape == (nU, 50) and m.Beta.shape == (nI, 50)
+        for n, v in grab(m).items():
+            step = 400 if v.shape[0] == nU else 100
+            out["it%d_%s_rows" % (it, n)] = v[::step].copy()
+            out["it%d_%s_colsum64" % (it, n)] = v.astype(np.float64).sum(axis=0)
+        print("large_full it", it, flush=True)
+    m = fit_ref(df, 50, 5, verbose=True, check_every=5)
+    out["train_llk_it5"] = np.float64(m.train_llk)
+    np.savez_compressed(os.path.join(OUT, "large_full.npz"), **out)
+    print("large_full", len(out))
+
+
 def c1_partial_fit():
     batches, nU, nI = datagen.partial_fit_batches()
     m = HPF(k=30, reindex=False, keep_data=False, random_seed=123, ncores=1, use_float=True)
@@ -239,6 +260,7 @@ if __name__ == "__main__":
     c1_trick()
     c1_hyper()
     mid_full()
+    large_full()
     c1_partial_fit()
     c1_svi()
     c1_predict()

@@ -98,3 +98,20 @@ def test_svi_epochs_bit_exact(tag, upb, ipb):
     st = O.fit_svi(Y, iu, ii, st_ix_u, nU, nI, 30, 4, 123, upb, ipb)
     for n in O.State.names:
         assert np.array_equal(getattr(st, n), g["%s_%s" % (tag, n)]), (tag, n)
+
+
+def test_large_bit_exact():
+    """200k x 50k, 5.4M nonzeros, k = 50: the oracle against the REAL reference (tests/golden/large_full.npz, made by
+    make_golden.py large_full) where numpy's sequential float32 column sums over 2e5 rows (PXI:236,255) carry visible
+    rounding -- the size class the GPU path's 1e-4 claim is about.  Sub-sampled rows bit-exact, float64 column sums of
+    every array bit-exact, after 1, 3 and 5 iterations."""
+    u, i, y, nU, nI = datagen.large_counts()
+    g = np.load(os.path.join(GOLDEN, "large_full.npz"))
+    assert int(g["nnz"]) == y.shape[0] >= 5_000_000
+    st, caps = O.fit_full_batch(y, u, i, nU, nI, 50, 5, 123, capture_at=(1, 3, 5), nthreads=O.max_threads())
+    for it in (1, 3, 5):
+        for n in O.State.names:
+            step = 400 if caps[it][n].shape[0] == nU else 100
+            assert np.array_equal(caps[it][n][::step], g["it%d_%s_rows" % (it, n)]), (it, n)
+            assert np.array_equal(caps[it][n].astype(np.float64).sum(axis=0), g["it%d_%s_colsum64" % (it, n)]), (it, n)
+    assert abs(float(O.train_llk(st, y, u, i)[0]) / g["train_llk_it5"] - 1) < 1e-6
