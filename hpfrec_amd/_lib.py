@@ -32,14 +32,14 @@ HPF_HIP_ABI_VERSION = 18
 #: every symbol include/hpf_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = (
     "hpf_hip_abi_version", "hpf_hip_ld_for_k", "hpf_hip_device_info", "hpf_hip_sweep_f32",
-    "hpf_hip_sweep_finalize_f32", "hpf_hip_sweep_prefinalize_f32",
+    "hpf_hip_sweep_finalize_f32",
     "hpf_hip_row_finalize_f32", "hpf_hip_row_finalize_ranges_f32", "hpf_hip_colsum_reduce_f32", "hpf_hip_colsum_f32", "hpf_hip_expect_f32",
     "hpf_hip_segsum_f32", "hpf_hip_pair_llk_f32", "hpf_hip_llk_sweep_f32", "hpf_hip_pair_dot_f32", "hpf_hip_score_rows_f32", "hpf_hip_gather_probe_f32",
     "hpf_hip_svi_shape_rows_f32", "hpf_hip_svi_refresh_f32", "hpf_hip_svi_rate_rows_f32", "hpf_hip_svi_side_f32", "hpf_hip_mt19937_words", "hpf_hip_uniform_rows_f32", "hpf_hip_svi_batch_prepare", "hpf_hip_svi_prep_scratch_words", "hpf_hip_svi_batch_sizeof", "hpf_hip_segsum_desc_f32", "hpf_hip_fold_in_f32",
-    "hpf_hip_unpack_rows_f32", "hpf_hip_item_shape_rows_f32", "hpf_hip_item_apply_rows_f32", "hpf_hip_gather_payload_ld", "hpf_hip_rccl_open", "hpf_hip_rccl_unique_id", "hpf_hip_rccl_comm_init", "hpf_hip_rccl_comm_count",
+    "hpf_hip_item_shape_rows_f32", "hpf_hip_item_apply_rows_f32", "hpf_hip_gather_payload_ld", "hpf_hip_rccl_open", "hpf_hip_rccl_unique_id", "hpf_hip_rccl_comm_init", "hpf_hip_rccl_comm_count",
     "hpf_hip_rccl_comm_destroy", "hpf_hip_rccl_all_reduce_f32", "hpf_hip_rccl_reduce_scatter_f32",
     "hpf_hip_rccl_all_gather_f32", "hpf_hip_shard_plan_create", "hpf_hip_shard_plan_destroy", "hpf_hip_shard_iterate",
-    "hpf_hip_shard_join", "hpf_hip_shard_exchange_only", "hpf_hip_shard_desc_layout", "hpf_hip_shard_trace",
+    "hpf_hip_shard_join", "hpf_hip_shard_status", "hpf_hip_shard_exchange_only", "hpf_hip_shard_desc_layout", "hpf_hip_shard_trace",
     "hpf_hip_mt19937_scratch_words", "hpf_hip_mt19937_jump_poly",
     "hpf_hip_p2p_ctrl_bytes", "hpf_hip_p2p_region_create", "hpf_hip_p2p_region_handles", "hpf_hip_p2p_region_connect",
     "hpf_hip_p2p_region_data", "hpf_hip_p2p_region_set_timeout", "hpf_hip_p2p_region_next_epoch",
@@ -86,13 +86,10 @@ def lib():
     L.hpf_hip_sweep_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp]
     L.hpf_hip_sweep_finalize_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, ci,
                                              ci, ci, vp]
-    L.hpf_hip_sweep_prefinalize_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, cf,
-                                                cf, ci, ci, ci, vp]
     L.hpf_hip_row_finalize_f32.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, ci, ci, ci,
                                            ci, vp]
     L.hpf_hip_row_finalize_ranges_f32.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, ci,
                                                   ci, ci, ci, ci, vp]
-    L.hpf_hip_unpack_rows_f32.argtypes = [vp, vp, i64, ci, ci, vp]
     L.hpf_hip_gather_payload_ld.argtypes = [ci]
     L.hpf_hip_item_shape_rows_f32.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, vp]
     L.hpf_hip_item_apply_rows_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, i64, ci, vp, vp, ci, vp]
@@ -109,6 +106,7 @@ def lib():
     L.hpf_hip_shard_plan_destroy.argtypes = [vp]
     L.hpf_hip_shard_iterate.argtypes = [vp, vp, vp, ci, vp]
     L.hpf_hip_shard_join.argtypes = [vp, vp]
+    L.hpf_hip_shard_status.argtypes = [vp]
     L.hpf_hip_shard_exchange_only.argtypes = [vp, ci, ci, vp]
     L.hpf_hip_shard_trace.argtypes = [vp, vp, i64, ctypes.POINTER(i64)]
     L.hpf_hip_colsum_reduce_f32.argtypes = [vp, ci, vp, ci, vp]

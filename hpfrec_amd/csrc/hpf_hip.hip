@@ -1,7 +1,7 @@
 // hpf_hip.hip -- gfx950 (MI355X, CDNA4) kernels + C ABI for the HPF full-batch CAVI sweep.
 //
 // What is replaced (reference: /root/reference/hpfrec/cython_loops.pxi = "PXI"):
-//   sweep_kernel        <- update_phi PXI:551-591 fused with update_G_n_L_sh PXI:613-621; MODE 1/2 also
+//   sweep_kernel        <- update_phi PXI:551-591 fused with update_G_n_L_sh PXI:613-621; MODE 1 also
 //                          run the row finalizer for whole-row segments (epilogue / prologue)
 //   row_finalize_kernel <- numpy rate/shape statements of fit_hpf PXI:236-259 + the psi/log/exp
 //                          hoisted out of update_phi (PXI:588: they only depend on the row)
@@ -24,6 +24,8 @@
 #include <string.h>
 
 #include "hpf_hip.h"
+#include "hpf_internal.h"
+#include "hpf_p2p_dev.h"
 
 namespace {
 
@@ -180,23 +182,25 @@ __device__ __forceinline__ double expect_ratio(float shp, float rte) {
 // ----------------------------------------------------------------------------------------
 // sweep: one wavefront per segment
 // ----------------------------------------------------------------------------------------
-struct FinalizeArgs {  // the row-finalize operands when it is fused into the sweep (MODE 1 or 2)
+struct FinalizeArgs {  // the row-finalize operands when it is fused into the sweep (MODE 1)
     const float *cs_other;
     float *cs_partial, *e_new, *shp, *rte, *fac, *rs;
     float prior_shp, top_shp, add_rte;
     int k;
     float *rs_prev;   // optional: receives the row's OLD scalar rate (rte = top/rs_prev + cs_other is rank-1,
                       // so callers may keep this instead of the [rows][ld] rte table)
-    float *acc_rows;  // MODE 0/2: packed [rows][acc_ld] accumulator rows of whole-row segments (or null);
-                      // MODE 2 also reads last iteration's reduced statistics from it
+    float *acc_rows;  // MODE 0: packed [rows][acc_ld] accumulator rows of whole-row segments (or null)
     int acc_ld;
     const int64_t *nseg_dev;  // optional: the live segment count on the device (<= nseg; stochastic batches)
+    // direct exchange (hpf_p2p_dev.h): on entry, block 0 tells every peer that what the PREVIOUS launches of this stream
+    // wrote into this rank's exchange buffer is complete -- flags[sig_kind][rank] = sig_epoch (null: nothing)
+    const hpf_p2p::Peers *sig_peers;
+    int sig_kind;
+    uint32_t sig_epoch;
+    float *cs_other_copy;     // optional: block 0 keeps a copy of cs_other (the column sums this launch used)
 };
 
-// MODE: 0 = plain sweep; 1 = row finalize fused as EPILOGUE of whole-row segments (single GPU);
-//       2 = row finalize fused as PROLOGUE of whole-row segments from an already reduced accumulator row
-//           (sharded path: the previous iteration's all-reduced item statistics are turned into this
-//           iteration's E row by the very wave that then sweeps the row -- "deferred item finalize")
+// MODE: 0 = plain sweep; 1 = row finalize fused as EPILOGUE of whole-row segments
 template <int LPR, int VPL, int MODE, int UU = HPF_U>
 __global__ __launch_bounds__(BLOCK)
 __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUSED_MAX_WAVES : 8))) void sweep_kernel(const hpf_segment *__restrict__ segs, int64_t nseg,
@@ -216,6 +220,7 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * WPB;
     if (fa.nseg_dev) nseg = min(nseg, fa.nseg_dev[0]);   // (a batch whose size only the device knows)
+    if (fa.sig_peers && blockIdx.x == 0 && wid == 0) hpf_p2p::wave_signal(*fa.sig_peers, fa.sig_kind, fa.sig_epoch);
 
     // FUSE: after the cross-group fold every group holds the whole accumulator row, so the
     // finalize work is dealt out over ALL 64 lanes: lane (g,j) owns the NC factors q = g + t*NG of
@@ -230,6 +235,7 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
             colq[t] = (q < NQ) ? ((q >> 2) * LPR + j) * 4 + (q & 3) : LD;  // LD = "no column"
             csl[t] = (colq[t] < fa.k) ? fa.cs_other[colq[t]] : 0.f;
             csacc[t] = 0.f;
+            if (fa.cs_other_copy && blockIdx.x == 0 && wid == 0 && colq[t] < LD) fa.cs_other_copy[colq[t]] = csl[t];
         }
     }
 
@@ -287,28 +293,6 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
         const int32_t *ip = idx + sgm.begin;
         const float *yp = y + sgm.begin;
         const bool whole_row = (sgm.len & HPF_SEG_WHOLE_ROW) != 0;
-
-        if constexpr (MODE == 2) {
-            if (whole_row) {
-                // finish the row from last iteration's reduced accumulator, then sweep with the fresh E row
-                float a[NC], eo[NC], en[NC];
-#pragma unroll
-                for (int t = 0; t < NC; t++) {
-                    a[t] = (colq[t] < fa.acc_ld) ? fa.acc_rows[(size_t)sgm.row * fa.acc_ld + colq[t]] : 0.f;
-                    eo[t] = (colq[t] < LD) ? tab_self[(size_t)sgm.row * LD + colq[t]] : 0.f;
-                }
-                finish_row(a, eo, en, sgm.row);
-#pragma unroll
-                for (int q = 0; q < NQ; q++) {  // back to the float4-per-lane layout, in every group
-                    const float val = __shfl(en[(NQ >= NG) ? q / NG : 0], (q % NG) * LPR + j);
-                    float4 &dst = rv[q >> 2];
-                    if ((q & 3) == 0) dst.x = val;
-                    if ((q & 3) == 1) dst.y = val;
-                    if ((q & 3) == 2) dst.z = val;
-                    if ((q & 3) == 3) dst.w = val;
-                }
-            }
-        }
 
         for (int base = 0; base < len; base += WAVE) {
             const int n = min(WAVE, len - base);
@@ -597,12 +581,28 @@ __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
 //                                row also finishes Beta = shp/rte, tau = add + sum_k Beta and its colsum(Beta) partials.
 // Against the one-part finalizer E carries one more float32 rounding (num is rounded before the division).
 // ----------------------------------------------------------------------------------------------------------------
+// PULL (direct exchange, hpf_p2p_dev.h): instead of one reduce-scattered accumulator row, the owner of a row sums the
+// row's partial accumulators straight out of the N ranks' exchange buffers (peer-mapped memory), in rank order -- the
+// reduce-scatter happens inside this kernel's loads.  pull.acc[p]: rank p's packed [table rows][k] buffer as mapped here,
+// indexed by the TABLE row; pull.sum_mask: the ranks whose rows count (all of them; a single-process emulation reads
+// every slice but counts its own only); pull.wait_kinds: the flag kinds every peer must have raised to pull.epoch.
+struct PullSrc {
+    int n;                                        // 0: `acc` holds the reduced rows (no pull)
+    uint32_t sum_mask, wait_kinds, epoch;
+    const float *acc[HPF_P2P_MAX_RANKS];
+    hpf_p2p::Peers peers;
+};
+
 template <int LD>
 __global__ __launch_bounds__(BLOCK) void item_shape_kernel(const float *__restrict__ acc, const float *__restrict__ e_old,
                                                            float *__restrict__ shp_out, float *__restrict__ send,
                                                            int sld, const float *__restrict__ rs,
                                                            float *__restrict__ rs_prev, float prior_shp, float top_shp,
-                                                           int k, const RowRanges rr, int64_t nrows) {
+                                                           int k, const RowRanges rr, int64_t nrows, const PullSrc pull) {
+    if (pull.n > 0) {
+        for (int kind = 0; kind < HPF_P2P_NKINDS; kind++)
+            if ((pull.wait_kinds >> kind) & 1u) hpf_p2p::block_acquire(pull.peers, kind, pull.epoch, 0xFFFFFFFFu);
+    }
     // send rows: k numerators, the row's base rate at column k, zero up to the stride sld (a multiple of 4 floats, so
     // that part 2 reads them as float4); shp_out rows: the padded table layout [.][LD].
     // SR rows per wave step, all their loads issued first: this kernel runs on the exchange stream BESIDE the sweeps, which
@@ -634,7 +634,20 @@ __global__ __launch_bounds__(BLOCK) void item_shape_kernel(const float *__restri
             for (int q = 0; q < CPL; q++) {
                 const int c = lane + WAVE * q;
                 const bool valid = live[i] && c < k;
-                a[i][q] = valid ? acc[(size_t)t * k + c] : 0.f;
+                if (pull.n > 0) {
+                    // all N loads issued before the first add (unrolled: pull.acc[p] is a kernel-argument pointer), summed
+                    // in rank order: the same float on every run (x + 0.f is exact: uncounted ranks drop out)
+                    float v[HPF_P2P_MAX_RANKS];
+#pragma unroll
+                    for (int p = 0; p < HPF_P2P_MAX_RANKS; p++)
+                        v[p] = (p < pull.n && valid) ? pull.acc[p][(size_t)r * k + c] : 0.f;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int p = 0; p < HPF_P2P_MAX_RANKS; p++) sum += ((pull.sum_mask >> p) & 1u) ? v[p] : 0.f;
+                    a[i][q] = sum;
+                } else {
+                    a[i][q] = valid ? acc[(size_t)t * k + c] : 0.f;
+                }
                 eo[i][q] = valid ? e_old[(size_t)r * LD + c] : 0.f;
             }
             rs_old[i] = live[i] ? rs[r] : 1.f;
@@ -690,13 +703,24 @@ __device__ __forceinline__ float group_max(float v) {          // all lanes of a
 // A row is held by LPR lanes as one float4 each (VPL of them when ld > 256), 64/LPR rows per wave step, R steps in
 // flight -- the layout of the sweep; with one row per wavefront this kernel spent 340 instructions per row and was
 // bound by instruction issue at a third of its memory rate.  All loads, then all arithmetic, then all stores.
+// Direct exchange: the rows of owner o are read from own.block[o] -- that rank's send buffer as mapped here (the
+// all-gather happens inside this kernel's loads), or a local copy of it -- once flags[own.wait_kind][o] (own.local_flag:
+// [this rank]) has reached own.epoch; own.n == 0: the gathered buffer `recv`.
+struct OwnerBlocks {
+    int n, wait_kind, local_flag;                 // wait_kind < 0: nothing to wait for
+    uint32_t epoch;
+    const float *block[HPF_P2P_MAX_RANKS];
+    hpf_p2p::Peers peers;
+};
+
 template <int LPR, int VPL>
 __global__ __launch_bounds__(BLOCK) void item_apply_kernel(const float *__restrict__ recv, int sld,
                                                            const float *__restrict__ shp_own, float *__restrict__ e_tab,
                                                            float *__restrict__ shp, float *__restrict__ fac,
                                                            float *__restrict__ rs, const float *__restrict__ cs_other,
                                                            float *__restrict__ cs_partial, float add_rte, int k,
-                                                           int rank, int64_t nrows, const ApplyRanges ar) {
+                                                           int rank, int64_t nrows, const ApplyRanges ar,
+                                                           const OwnerBlocks own) {
     constexpr int LD = 4 * LPR * VPL;
     constexpr int NG = WAVE / LPR;
     constexpr int R = (VPL == 1) ? 4 : (VPL == 2 ? 2 : 1);
@@ -706,7 +730,13 @@ __global__ __launch_bounds__(BLOCK) void item_apply_kernel(const float *__restri
     const int wid = threadIdx.x >> 6;
     const int owner = blockIdx.y;
     const bool mine = owner == rank;
-    const float *block = recv + (size_t)owner * ar.total * sld;
+    if (own.n > 0 && own.wait_kind >= 0) {
+        if (own.local_flag || mine)       // (a rank raises its flags in its own control block too)
+            hpf_p2p::block_acquire_self(own.peers, own.wait_kind, own.epoch);
+        else
+            hpf_p2p::block_acquire(own.peers, own.wait_kind, own.epoch, 1u << owner);
+    }
+    const float *block = (own.n > 0) ? own.block[owner] : recv + (size_t)owner * ar.total * sld;
     const int sq = min(sld >> 2, LPR * VPL);                   // float4s of a gathered row that hold numerators
     float4 csl[VPL], csacc[VPL];
     bool valid[VPL][4];
@@ -867,8 +897,13 @@ __global__ __launch_bounds__(BLOCK) void colsum_kernel(const float *__restrict__
 }
 
 // cs_out[c] = sum_b cs_partial[b][c]; 16 interleaved double chains per column, folded in order
+// peers != null (direct exchange): the column sums of ALL ranks -- each rank publishes its value of a column as an
+// {value, epoch} granule in every peer's control block and sums the N granules it receives in rank order, so every rank
+// ends with the same floats (the k-float all-reduce of the iteration without a collective library)
 __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float *__restrict__ cs_partial, int nblk,
-                                                             float *__restrict__ cs_out, int ld) {
+                                                             float *__restrict__ cs_out, int ld,
+                                                             const hpf_p2p::Peers *__restrict__ peers, int which,
+                                                             uint32_t epoch) {
     __shared__ double red[16][WAVE];
     const int cl = threadIdx.x & (WAVE - 1);
     const int chunk = threadIdx.x >> 6;
@@ -899,7 +934,13 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float *__rest
         double t = red[0][cl];
 #pragma unroll
         for (int q = 1; q < 16; q++) t += red[q][cl];
-        cs_out[c] = (float)t;
+        float out = (float)t;
+        if (peers) {
+            const hpf_p2p::Peers pp = *peers;
+            hpf_p2p::vec_publish(pp, which, epoch, ld, c, out);
+            out = hpf_p2p::vec_collect(pp, which, epoch, ld, c);
+        }
+        cs_out[c] = out;
     }
 }
 
@@ -1812,29 +1853,6 @@ __global__ __launch_bounds__(BLOCK) void uniform_rows_kernel(const uint32_t *__r
     }
 }
 
-// dst[r][0:k] = src[r][0:k] for rows of a packed [n][k] table into a padded [n][ld] one (pad columns are not written):
-// the receive side of the sharded path's k-packed all-gather of new E rows.  vec: one thread per float4 (k % 4 == 0 and
-// 16-byte aligned bases), else one per float.
-__global__ __launch_bounds__(BLOCK) void unpack_rows_kernel(const float *__restrict__ src, float *__restrict__ dst,
-                                                            long long nrows, int k, int ld, int vec) {
-    if (vec) {
-        const int kq = k >> 2, ldq = ld >> 2;
-        const long long total = nrows * kq;
-        const float4 *s4 = reinterpret_cast<const float4 *>(src);
-        float4 *d4 = reinterpret_cast<float4 *>(dst);
-        for (long long t = (long long)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * BLOCK) {
-            const long long r = t / kq;
-            d4[r * ldq + (t - r * kq)] = s4[t];
-        }
-    } else {
-        const long long total = nrows * k;
-        for (long long t = (long long)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * BLOCK) {
-            const long long r = t / k;
-            dst[r * ld + (t - r * k)] = src[t];
-        }
-    }
-}
-
 inline int clamp_grid(int64_t want, int grid_blocks) {
     int64_t g = grid_blocks > 0 ? grid_blocks : 2048;
     if (want < g) g = want;
@@ -1898,19 +1916,21 @@ int hpf_hip_device_info(int *cu_count, char *arch, int arch_len) {
     return 0;
 }
 
-int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
-                      const float *tab_self, const float *tab_other, float *part, float *acc_rows, int acc_ld, int k,
-                      int ld, int short_rows, int grid_blocks, const int64_t *nseg_dev, void *stream) {
-    if (nseg == 0) return 0;
-    if (!segs || !idx || !y || !tab_self || !tab_other || !part || nseg < 0 || k <= 0 || ld != hpf_hip_ld_for_k(k))
-        return HPF_EINVAL;
+static int sweep_impl(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y, const float *tab_self,
+                      const float *tab_other, float *part, float *acc_rows, int acc_ld, int k, int ld, int short_rows,
+                      int grid_blocks, const int64_t *nseg_dev, hpf_direct::Signal sig, hipStream_t st) {
+    if (nseg == 0 && !sig.peers_dev) return 0;
+    if (nseg < 0 || k <= 0 || ld != hpf_hip_ld_for_k(k)) return HPF_EINVAL;
+    if (nseg > 0 && (!segs || !idx || !y || !tab_self || !tab_other || !part)) return HPF_EINVAL;
     if (acc_rows && (acc_ld < k || acc_ld > ld)) return HPF_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    const int grid = clamp_grid((nseg + WPB - 1) / WPB, grid_blocks);
+    const int grid = clamp_grid((nseg + WPB - 1) / WPB, grid_blocks);      // (>= 1: a launch that only signals)
     FinalizeArgs fa = {};
     fa.acc_rows = acc_rows;
     fa.acc_ld = acc_ld;
     fa.nseg_dev = nseg_dev;
+    fa.sig_peers = sig.peers_dev;
+    fa.sig_kind = sig.kind;
+    fa.sig_epoch = sig.epoch;
     // short rows (a batch or a shard of a many-rank run: ~16 nonzeros per row): half the gathers in flight per wave
     // fill just as well and the smaller register file buys occupancy (-15 % at N=8)
     constexpr int US = (HPF_U >= 8) ? HPF_U / 2 : HPF_U;
@@ -1926,18 +1946,29 @@ int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx,
     return last_error();
 }
 
-int hpf_hip_sweep_finalize_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
+int hpf_hip_sweep_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
+                      const float *tab_self, const float *tab_other, float *part, float *acc_rows, int acc_ld, int k,
+                      int ld, int short_rows, int grid_blocks, const int64_t *nseg_dev, void *stream) {
+    if (nseg > 0 && (!segs || !idx || !y || !tab_self || !tab_other || !part)) return HPF_EINVAL;
+    return sweep_impl(segs, nseg, idx, y, tab_self, tab_other, part, acc_rows, acc_ld, k, ld, short_rows, grid_blocks,
+                      nseg_dev, hpf_direct::Signal{nullptr, 0, 0}, (hipStream_t)stream);
+}
+
+static int sweep_finalize_impl(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
                                const float *tab_self, const float *tab_other, float *part, float *e_new, float *shp,
                                float *rte, float *fac, float *rs, float *rs_prev, const float *cs_other,
                                float *cs_partial, float prior_shp, float top_shp, float add_rte, int k, int ld,
-                               int grid_blocks, void *stream) {
+                               int grid_blocks, float *cs_other_copy, hpf_direct::Signal sig, hipStream_t st) {
     if (!segs || !idx || !y || !tab_self || !tab_other || !part || !e_new || !rs || !cs_other || !cs_partial ||
         nseg <= 0 || k <= 0 || ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0)
         return HPF_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
     // grid NOT clamped: every block writes its cs_partial row
-    const FinalizeArgs fa = {cs_other, cs_partial, e_new, shp, rte, fac, rs, prior_shp, top_shp, add_rte, k, rs_prev,
-                             nullptr, 0, nullptr};
+    FinalizeArgs fa = {cs_other, cs_partial, e_new, shp, rte, fac, rs, prior_shp, top_shp, add_rte, k, rs_prev,
+                       nullptr, 0, nullptr};
+    fa.sig_peers = sig.peers_dev;
+    fa.sig_kind = sig.kind;
+    fa.sig_epoch = sig.epoch;
+    fa.cs_other_copy = cs_other_copy;
 #define CALL(LPR, VPL)                                                                                            \
     hipLaunchKernelGGL((sweep_kernel<LPR, VPL, 1>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg, idx, y,    \
                        tab_self, tab_other, part, fa);
@@ -1946,24 +1977,14 @@ int hpf_hip_sweep_finalize_f32(const hpf_segment *segs, int64_t nseg, const int3
     return last_error();
 }
 
-int hpf_hip_sweep_prefinalize_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
-                                  float *tab_self, const float *tab_other, float *part, float *acc_rows, int acc_ld,
-                                  float *shp, float *rte, float *fac, float *rs, float *rs_prev,
-                                  const float *cs_other, float *cs_partial, float prior_shp, float top_shp,
-                                  float add_rte, int k, int ld, int grid_blocks, void *stream) {
-    if (!segs || !idx || !y || !tab_self || !tab_other || !part || !acc_rows || !rs || !cs_other || !cs_partial ||
-        nseg <= 0 || k <= 0 || ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0 || acc_ld < k || acc_ld > ld)
-        return HPF_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    // grid NOT clamped: every block writes its cs_partial row
-    const FinalizeArgs fa = {cs_other, cs_partial, tab_self, shp, rte, fac, rs, prior_shp, top_shp, add_rte, k,
-                             rs_prev, acc_rows, acc_ld, nullptr};
-#define CALL(LPR, VPL)                                                                                          \
-    hipLaunchKernelGGL((sweep_kernel<LPR, VPL, 2>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg, idx, y,    \
-                       (const float *)tab_self, tab_other, part, fa);
-    HPF_DISPATCH_LD(ld, CALL)
-#undef CALL
-    return last_error();
+int hpf_hip_sweep_finalize_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
+                               const float *tab_self, const float *tab_other, float *part, float *e_new, float *shp,
+                               float *rte, float *fac, float *rs, float *rs_prev, const float *cs_other,
+                               float *cs_partial, float prior_shp, float top_shp, float add_rte, int k, int ld,
+                               int grid_blocks, void *stream) {
+    return sweep_finalize_impl(segs, nseg, idx, y, tab_self, tab_other, part, e_new, shp, rte, fac, rs, rs_prev, cs_other,
+                               cs_partial, prior_shp, top_shp, add_rte, k, ld, grid_blocks, nullptr,
+                               hpf_direct::Signal{nullptr, 0, 0}, (hipStream_t)stream);
 }
 
 int hpf_hip_row_finalize_f32(const float *part, const int64_t *row_seg_ptr, const int64_t *row_list, int64_t nrows,
@@ -2022,6 +2043,18 @@ int hpf_hip_row_finalize_ranges_f32(const float *acc, int nranges, const int64_t
 
 int hpf_hip_gather_payload_ld(int k) { return k > 0 ? ((k + 1 + 3) / 4) * 4 : HPF_EINVAL; }
 
+static int item_shape_impl(const float *acc, const RowRanges &rr, int64_t nrows, const float *e_old, float *shp_out,
+                           float *send, const float *rs, float *rs_prev, float prior_shp, float top_shp, int k, int ld,
+                           int grid_blocks, const PullSrc &pull, hipStream_t st) {
+    const int sld = hpf_hip_gather_payload_ld(k);
+#define CALL(LD)                                                                                                      \
+    hipLaunchKernelGGL((item_shape_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, acc, e_old, shp_out, send, sld, \
+                       rs, rs_prev, prior_shp, top_shp, k, rr, nrows, pull);
+    HPF_DISPATCH_LD1(ld, CALL)
+#undef CALL
+    return last_error();
+}
+
 int hpf_hip_item_shape_rows_f32(const float *acc, int nranges, const int64_t *range_rows, const int64_t *range_acc_begin,
                                 const int64_t *range_row_begin, const float *e_old, float *shp_out, float *send,
                                 const float *rs, float *rs_prev, float prior_shp, float top_shp, int k, int ld,
@@ -2029,7 +2062,6 @@ int hpf_hip_item_shape_rows_f32(const float *acc, int nranges, const int64_t *ra
     if (!acc || !range_rows || !range_acc_begin || !range_row_begin || !e_old || !shp_out || !send || !rs || nranges <= 0 ||
         nranges > HPF_MAX_ROW_RANGES || k <= 0 || ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0)
         return HPF_EINVAL;
-    const int sld = hpf_hip_gather_payload_ld(k);
     RowRanges rr = {};
     rr.n = nranges;
     int64_t nrows = 0;
@@ -2041,22 +2073,18 @@ int hpf_hip_item_shape_rows_f32(const float *acc, int nranges, const int64_t *ra
         nrows += range_rows[i];
     }
     if (nrows == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-#define CALL(LD)                                                                                                      \
-    hipLaunchKernelGGL((item_shape_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, acc, e_old, shp_out, send, sld, \
-                       rs, rs_prev, prior_shp, top_shp, k, rr, nrows);
-    HPF_DISPATCH_LD1(ld, CALL)
-#undef CALL
-    return last_error();
+    PullSrc pull = {};
+    return item_shape_impl(acc, rr, nrows, e_old, shp_out, send, rs, rs_prev, prior_shp, top_shp, k, ld, grid_blocks, pull,
+                           (hipStream_t)stream);
 }
 
-int hpf_hip_item_apply_rows_f32(const float *recv, const float *shp_own, float *e_tab, float *shp, float *fac, float *rs,
-                                const float *cs_other, float *cs_partial, float add_rte, int k, int ld, int rank,
-                                int world, int64_t nrows, int nranges, const int64_t *range_lo, const int64_t *range_hi,
-                                int grid_blocks, void *stream) {
-    if (!recv || !shp_own || !e_tab || !rs || !cs_other || !cs_partial || k <= 0 || ld != hpf_hip_ld_for_k(k) ||
-        rank < 0 || world <= 0 || rank >= world || nrows <= 0 || nranges <= 0 || nranges > HPF_MAX_ROW_RANGES ||
-        !range_lo || !range_hi || grid_blocks <= 0)
+static int item_apply_impl(const float *recv, const OwnerBlocks &own, const float *shp_own, float *e_tab, float *shp,
+                           float *fac, float *rs, const float *cs_other, float *cs_partial, float add_rte, int k, int ld,
+                           int rank, int world, int64_t nrows, int nranges, const int64_t *range_lo,
+                           const int64_t *range_hi, int grid_blocks, hipStream_t st) {
+    if ((!recv && own.n <= 0) || !shp_own || !e_tab || !rs || !cs_other || !cs_partial || k <= 0 ||
+        ld != hpf_hip_ld_for_k(k) || rank < 0 || world <= 0 || rank >= world || nrows <= 0 || nranges <= 0 ||
+        nranges > HPF_MAX_ROW_RANGES || !range_lo || !range_hi || grid_blocks <= 0)
         return HPF_EINVAL;
     if (grid_blocks % world != 0) return HPF_EINVAL;     // (gx blocks per rank's block of the gathered buffer)
     ApplyRanges ar = {};
@@ -2070,21 +2098,30 @@ int hpf_hip_item_apply_rows_f32(const float *recv, const float *shp_own, float *
         t += ar.m[i];
     }
     ar.total = t;
-    hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)(grid_blocks / world), (unsigned)world);
     const int sld = hpf_hip_gather_payload_ld(k);
 #define CALL(LPR, VPL)                                                                                                \
     hipLaunchKernelGGL((item_apply_kernel<LPR, VPL>), grid, dim3(BLOCK), 0, st, recv, sld, shp_own, e_tab, shp, fac,   \
-                       rs, cs_other, cs_partial, add_rte, k, rank, nrows, ar);
+                       rs, cs_other, cs_partial, add_rte, k, rank, nrows, ar, own);
     HPF_DISPATCH_LD(ld, CALL)
 #undef CALL
     return last_error();
 }
 
+int hpf_hip_item_apply_rows_f32(const float *recv, const float *shp_own, float *e_tab, float *shp, float *fac, float *rs,
+                                const float *cs_other, float *cs_partial, float add_rte, int k, int ld, int rank,
+                                int world, int64_t nrows, int nranges, const int64_t *range_lo, const int64_t *range_hi,
+                                int grid_blocks, void *stream) {
+    if (!recv) return HPF_EINVAL;
+    OwnerBlocks own = {};
+    return item_apply_impl(recv, own, shp_own, e_tab, shp, fac, rs, cs_other, cs_partial, add_rte, k, ld, rank, world,
+                           nrows, nranges, range_lo, range_hi, grid_blocks, (hipStream_t)stream);
+}
+
 int hpf_hip_colsum_reduce_f32(const float *cs_partial, int nblk, float *cs_out, int ld, void *stream) {
     if (!cs_partial || !cs_out || nblk <= 0 || ld < 32) return HPF_EINVAL;
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((ld + WAVE - 1) / WAVE), dim3(1024), 0, (hipStream_t)stream,
-                       cs_partial, nblk, cs_out, ld);
+                       cs_partial, nblk, cs_out, ld, (const hpf_p2p::Peers *)nullptr, 0, 0u);
     return last_error();
 }
 
@@ -2243,18 +2280,6 @@ int hpf_hip_svi_rate_rows_f32(const int64_t *row_list, int64_t nrows, float *rte
     return last_error();
 }
 
-int hpf_hip_unpack_rows_f32(const float *src, float *dst, int64_t nrows, int k, int ld, void *stream) {
-    if (nrows == 0) return 0;
-    if (!src || !dst || nrows < 0 || k <= 0 || ld < k || (ld & 3)) return HPF_EINVAL;
-    // float4 path: both row starts must be 16-byte aligned (k % 4 == 0 and an aligned base), else the scalar path
-    const bool vec = ((k & 3) == 0) && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
-    const int64_t work = nrows * (vec ? (k >> 2) : k);
-    const int grid = clamp_grid((work + BLOCK - 1) / BLOCK, 8192);
-    hipLaunchKernelGGL(unpack_rows_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, src, dst,
-                       (long long)nrows, k, ld, vec ? 1 : 0);
-    return last_error();
-}
-
 int hpf_hip_gather_probe_f32(const int32_t *idx, int64_t n, const float *tab, float *sink, int grid_blocks,
                              void *stream) {
     if (!idx || !tab || !sink || n <= 0 || grid_blocks <= 0) return HPF_EINVAL;
@@ -2303,3 +2328,78 @@ int hpf_hip_uniform_rows_f32(const uint32_t *raw, float *out, const float *den, 
 }
 
 }  // extern "C"
+
+// ---- direct-exchange forms (hpf_internal.h; used by hpf_shard.hip) -------------------------------------------------------
+namespace hpf_direct {
+
+int sweep(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y, const float *tab_self,
+          const float *tab_other, float *part, float *acc_rows, int acc_ld, int k, int ld, int short_rows, int grid_blocks,
+          Signal sig, hipStream_t st) {
+    return sweep_impl(segs, nseg, idx, y, tab_self, tab_other, part, acc_rows, acc_ld, k, ld, short_rows, grid_blocks,
+                      nullptr, sig, st);
+}
+
+int sweep_finalize(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y, const float *tab_self,
+                   const float *tab_other, float *part, float *e_new, float *shp, float *rte, float *fac, float *rs,
+                   float *rs_prev, const float *cs_other, float *cs_partial, float prior_shp, float top_shp,
+                   float add_rte, int k, int ld, int grid_blocks, float *cs_other_copy, Signal sig, hipStream_t st) {
+    return sweep_finalize_impl(segs, nseg, idx, y, tab_self, tab_other, part, e_new, shp, rte, fac, rs, rs_prev, cs_other,
+                               cs_partial, prior_shp, top_shp, add_rte, k, ld, grid_blocks, cs_other_copy, sig, st);
+}
+
+int item_shape_pull(const float *const *acc_peers, int npeers, uint32_t sum_mask, uint32_t wait_kinds, uint32_t epoch,
+                    const hpf_p2p::Peers &pp, int64_t rows, int64_t send_row0, int64_t table_row0, const float *e_old,
+                    float *shp_out, float *send, const float *rs, float *rs_prev, float prior_shp, float top_shp, int k,
+                    int ld, int grid_blocks, hipStream_t st) {
+    if (!acc_peers || npeers <= 0 || npeers > HPF_P2P_MAX_RANKS || rows < 0 || send_row0 < 0 || table_row0 < 0 || !e_old ||
+        !shp_out || !send || !rs || k <= 0 || ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0)
+        return HPF_EINVAL;
+    PullSrc pull = {};
+    pull.n = npeers;
+    pull.sum_mask = sum_mask;
+    pull.wait_kinds = wait_kinds;
+    pull.epoch = epoch;
+    for (int p = 0; p < npeers; p++) {
+        if (!acc_peers[p]) return HPF_EINVAL;
+        pull.acc[p] = acc_peers[p];
+    }
+    pull.peers = pp;
+    RowRanges rr = {};
+    rr.n = 1;
+    rr.t_begin[0] = send_row0;
+    rr.row_begin[0] = table_row0;
+    // (rows == 0 -- a slice of pad rows only -- still launches: the flags are consumed in step with the peers)
+    return item_shape_impl(nullptr, rr, rows, e_old, shp_out, send, rs, rs_prev, prior_shp, top_shp, k, ld,
+                           rows > 0 ? grid_blocks : 1, pull, st);
+}
+
+int item_apply_blocks(const float *const *blocks, int nblocks, int wait_kind, int local_flag, uint32_t epoch,
+                      const hpf_p2p::Peers &pp, const float *shp_own, float *e_tab, float *shp, float *fac, float *rs,
+                      const float *cs_other, float *cs_partial, float add_rte, int k, int ld, int rank, int world,
+                      int64_t nrows, int nranges, const int64_t *range_lo, const int64_t *range_hi, int grid_blocks,
+                      hipStream_t st) {
+    if (!blocks || nblocks != world || world > HPF_P2P_MAX_RANKS) return HPF_EINVAL;
+    OwnerBlocks own = {};
+    own.n = nblocks;
+    own.wait_kind = wait_kind;
+    own.local_flag = local_flag;
+    own.epoch = epoch;
+    for (int p = 0; p < nblocks; p++) {
+        if (!blocks[p]) return HPF_EINVAL;
+        own.block[p] = blocks[p];
+    }
+    own.peers = pp;
+    return item_apply_impl(nullptr, own, shp_own, e_tab, shp, fac, rs, cs_other, cs_partial, add_rte, k, ld, rank, world,
+                           nrows, nranges, range_lo, range_hi, grid_blocks, st);
+}
+
+int colsum_reduce_allreduce(const float *cs_partial, int nblk, float *cs_out, int ld, const hpf_p2p::Peers *peers_dev,
+                            int which, uint32_t epoch, hipStream_t st) {
+    if (!cs_partial || !cs_out || nblk <= 0 || ld < 32 || !peers_dev || which < 0 || which >= HPF_P2P_NVEC)
+        return HPF_EINVAL;
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((ld + WAVE - 1) / WAVE), dim3(1024), 0, st, cs_partial, nblk, cs_out, ld,
+                       peers_dev, which, epoch);
+    return last_error();
+}
+
+}  // namespace hpf_direct

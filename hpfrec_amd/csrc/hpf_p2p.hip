@@ -20,6 +20,7 @@
 #include <new>
 
 #include "hpf_hip.h"
+#include "hpf_internal.h"
 #include "hpf_p2p_dev.h"
 
 namespace {
@@ -39,6 +40,8 @@ struct Region {
     bool connected, local_only;
     uint32_t epoch;                      // the last epoch handed out (monotonic for the life of the region)
     float timeout_ms;
+    hpf_p2p::Peers *peers_dev;           // this rank's Peers in (plain) device memory, for kernels that take a pointer
+    uint32_t *counters;                  // plain device words: arrival counters of "last block" epilogues (zero at rest)
 };
 
 hpf_p2p::Peers peers_of(const Region *r) {
@@ -85,6 +88,48 @@ __global__ __launch_bounds__(256) void p2p_pull_kernel(const hpf_p2p::Peers pp, 
     for (; i < n4; i += stride) dst[i] = src[i];
 }
 
+// The all-gather of the direct exchange as ONE launch, grid (gx, world): the blocks of column o copy owner o's finished
+// rows (n4 float4s at src[o]) into block o of the local gathered buffer.  On entry block (0,0) tells every peer that THIS
+// rank's rows are complete (earlier launches of this stream wrote them); the blocks of column o wait for o's flag.  The
+// last block to finish raises this rank's own `done_kind` flag, which the apply kernel on the compute stream polls.
+struct GatherSrc {
+    const float4 *src[HPF_P2P_MAX_RANKS];
+};
+__global__ __launch_bounds__(256) void p2p_gather_kernel(const hpf_p2p::Peers pp, const GatherSrc gs, float4 *__restrict__ dst,
+                                                         int64_t n4, int signal_kind, int done_kind, uint32_t epoch,
+                                                         uint32_t *__restrict__ counter) {
+    const int owner = blockIdx.y;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) hpf_p2p::wave_signal(pp, signal_kind, epoch);
+    hpf_p2p::block_acquire(pp, signal_kind, epoch, 1u << owner);
+    const float4 *__restrict__ src = gs.src[owner];
+    float4 *__restrict__ out = dst + (size_t)owner * n4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 7 * stride < n4; i += 8 * stride) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; u++) out[i + u * stride] = v[u];
+    }
+    for (; i < n4; i += stride) out[i] = src[i];
+    // last block: everything is in local memory -> raise this rank's own flag (release at agent scope is enough: the
+    // reader is a kernel of this device)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t total = gridDim.x * gridDim.y;
+        const uint32_t seen = atomicAdd(counter, 1u);
+        if (seen == total - 1) {
+            *counter = 0;       // (at rest again; the next launch of this kernel is stream-ordered after this one)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            hpf_p2p::st_sys(pp.ctrl[pp.rank] + hpf_p2p::flag_word(done_kind, pp.rank), epoch);
+        }
+    }
+}
+
 }  // namespace
 
 // for hpf_shard.hip (same library, C++ linkage): the kernel-argument view of a region, and its mapped data buffers
@@ -99,6 +144,24 @@ bool region_view(void *region, Peers *pp, void **data /* [HPF_P2P_MAX_RANKS] */,
     *rank = r->rank;
     *ld = r->ld;
     return true;
+}
+
+const Peers *region_peers_dev(void *region) {
+    return region ? ((Region *)region)->peers_dev : nullptr;
+}
+
+int gather_pull(void *region, int64_t src_offset_bytes, float *dst, int64_t floats_per_rank, int signal_kind, int done_kind,
+                uint32_t epoch, int gx, hipStream_t st) {
+    if (!region || !dst || floats_per_rank <= 0 || (floats_per_rank & 3) || (src_offset_bytes & 15) || gx <= 0)
+        return HPF_EINVAL;
+    Region *r = (Region *)region;
+    if (!r->connected || src_offset_bytes + floats_per_rank * 4 > r->data_bytes) return HPF_EINVAL;
+    GatherSrc gs = {};
+    for (int p = 0; p < r->world; p++)
+        gs.src[p] = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(r->data[p]) + src_offset_bytes);
+    hipLaunchKernelGGL(p2p_gather_kernel, dim3((unsigned)gx, (unsigned)r->world), dim3(256), 0, st, peers_of(r), gs,
+                       reinterpret_cast<float4 *>(dst), floats_per_rank / 4, signal_kind, done_kind, epoch, r->counters);
+    return (int)hipGetLastError();
 }
 }  // namespace hpf_p2p
 
@@ -150,6 +213,19 @@ int hpf_hip_p2p_region_handles(void *region, uint8_t out[2 * HPF_P2P_HANDLE_BYTE
     return 0;
 }
 
+static int finish_connect(Region *r) {
+    // (after every ctrl[] entry is known) this rank's Peers and the arrival counters, in plain device memory
+    void *pd = nullptr, *cn = nullptr;
+    HIP_TRY(hipMalloc(&pd, sizeof(hpf_p2p::Peers)));
+    r->peers_dev = (hpf_p2p::Peers *)pd;
+    HIP_TRY(hipMalloc(&cn, 64));
+    r->counters = (uint32_t *)cn;
+    HIP_TRY(hipMemset(cn, 0, 64));
+    const hpf_p2p::Peers pp = peers_of(r);
+    HIP_TRY(hipMemcpy(pd, &pp, sizeof(pp), hipMemcpyHostToDevice));
+    return 0;
+}
+
 int hpf_hip_p2p_region_connect(void *region, const uint8_t *handles) {
     if (!region) return HPF_EINVAL;
     Region *r = (Region *)region;
@@ -161,7 +237,7 @@ int hpf_hip_p2p_region_connect(void *region, const uint8_t *handles) {
         }
         r->local_only = true;
         r->connected = true;
-        return 0;
+        return finish_connect(r);
     }
     for (int p = 0; p < r->world; p++) {
         if (p == r->rank) continue;
@@ -178,7 +254,7 @@ int hpf_hip_p2p_region_connect(void *region, const uint8_t *handles) {
         r->opened_data[p] = true;
     }
     r->connected = true;
-    return 0;
+    return finish_connect(r);
 }
 
 int hpf_hip_p2p_region_data(void *region, int peer, void **ptr) {
@@ -191,7 +267,13 @@ int hpf_hip_p2p_region_data(void *region, int peer, void **ptr) {
 
 int hpf_hip_p2p_region_set_timeout(void *region, float timeout_ms) {
     if (!region || !(timeout_ms > 0.f)) return HPF_EINVAL;
-    ((Region *)region)->timeout_ms = timeout_ms;
+    Region *r = (Region *)region;
+    r->timeout_ms = timeout_ms;
+    if (r->peers_dev) {      // (the device copy carries the budget too)
+        const hpf_p2p::Peers pp = peers_of(r);
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(r->peers_dev, &pp, sizeof(pp), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -220,6 +302,8 @@ int hpf_hip_p2p_region_destroy(void *region) {
     }
     (void)hipFree(r->ctrl[r->rank]);
     (void)hipFree(r->data[r->rank]);
+    if (r->peers_dev) (void)hipFree(r->peers_dev);
+    if (r->counters) (void)hipFree(r->counters);
     delete r;
     return 0;
 }

@@ -91,6 +91,23 @@ __device__ __forceinline__ void block_acquire(const Peers &pp, int kind, uint32_
     __syncthreads();
 }
 
+// the same for a flag this rank raises for ITSELF (a kernel on another stream of this process is the producer)
+__device__ __forceinline__ void block_acquire_self(const Peers &pp, int kind, uint32_t epoch) {
+    if (threadIdx.x == 0) {      // (also in a single-process emulation: the producer is a stream of this process)
+        const uint32_t *f = pp.ctrl[pp.rank] + flag_word(kind, pp.rank);
+        const long long t0 = wall_clock64();
+        while ((int32_t)(ld_sys(f) - epoch) < 0) {
+            if (wall_clock64() - t0 > pp.timeout_ticks) {
+                atomicOr(pp.ctrl[pp.rank], 1u << (kind & 15));
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    __syncthreads();
+}
+
 // Producer side, by ONE wavefront whose block's (or whose predecessors' on the stream) stores are complete: system-scope
 // release, then lane p stores the epoch into peer p's flags[kind][rank] (the local block included: a rank also
 // "signals itself", so consumers need not special-case their own data)

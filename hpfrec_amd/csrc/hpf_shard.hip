@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "hpf_hip.h"
+#include "hpf_internal.h"
 
 namespace {
 
@@ -111,7 +112,6 @@ inline hipError_t tr_memcpy(void *dst, const void *src, size_t bytes, hipMemcpyK
 #define hpf_hip_colsum_reduce_f32(...) TR_KERNEL(HPF_TRACE_K_COLSUM_REDUCE, (hpf_hip_colsum_reduce_f32), __VA_ARGS__)
 #define hpf_hip_item_shape_rows_f32(...) TR_KERNEL(HPF_TRACE_K_ITEM_SHAPE, (hpf_hip_item_shape_rows_f32), __VA_ARGS__)
 #define hpf_hip_item_apply_rows_f32(...) TR_KERNEL(HPF_TRACE_K_ITEM_APPLY, (hpf_hip_item_apply_rows_f32), __VA_ARGS__)
-#define hpf_hip_unpack_rows_f32(...) TR_KERNEL(HPF_TRACE_K_UNPACK, (hpf_hip_unpack_rows_f32), __VA_ARGS__)
 
 struct Plan {
     Tracer tracer;
@@ -134,6 +134,11 @@ struct Plan {
     int apply_grid[HPF_MAX_ROW_RANGES], apply_g0[HPF_MAX_ROW_RANGES];   // blocks of range j's apply launch; first csB_part row
     hipStream_t ss;                   // stream of the colsum(Beta) reduction (nullptr: the compute stream)
     float *tiny;                      // dry runs with a communicator: the element of the stand-in RCCL call (plan-owned)
+    // direct schedule: the rank's connected exchange region as the kernels see it
+    hpf_p2p::Peers pp;
+    const hpf_p2p::Peers *peers_dev;
+    void *peer_data[HPF_P2P_MAX_RANKS];
+    uint32_t epoch;                   // of the iteration in flight (hpf_hip_p2p_region_next_epoch)
 };
 
 // dry runs with an assumed bus bandwidth: the stream is held for the time the links would take by ONE wavefront that
@@ -204,19 +209,11 @@ int collective(Plan *p, int op, const float *send, float *recv, int64_t count, h
     return HPF_EINVAL;
 }
 
-int all_gather_range(Plan *p, int j, hipStream_t st) {
+int all_gather_range(Plan *p, int j, hipStream_t st) {       // padded rows straight into the replicated E table
     const hpf_shard_desc &d = p->d;
     const hpf_shard_range &r = d.ranges[j];
-    const int64_t m = p->m[j];
-    if (d.e_own_ld == d.ld)     // padded rows straight into the replicated E table
-        return collective(p, HPF_COLL_ALL_GATHER, d.e_own + (size_t)p->t0[j] * d.ld, d.eB + (size_t)r.lo * d.ld,
-                          m * d.ld, st);
-    // k-packed rows into the receive buffer, then back to the padded layout the sweeps gather from
-    HPF_TRY(collective(p, HPF_COLL_ALL_GATHER, d.e_own + (size_t)p->t0[j] * d.e_own_ld,
-                       d.ag_recv + (size_t)r.lo * d.e_own_ld, m * d.e_own_ld, st));
-    if (d.e_own_ld != d.k) return HPF_EINVAL;
-    return hpf_hip_unpack_rows_f32(d.ag_recv + (size_t)r.lo * d.k, d.eB + (size_t)r.lo * d.ld, r.hi - r.lo, d.k, d.ld,
-                                   (void *)st);
+    return collective(p, HPF_COLL_ALL_GATHER, d.e_own + (size_t)p->t0[j] * d.ld, d.eB + (size_t)r.lo * d.ld,
+                      p->m[j] * d.ld, st);
 }
 
 int reduce_scatter_range(Plan *p, int j, hipStream_t st) {
@@ -249,6 +246,62 @@ int apply_range(Plan *p, int j, int store, hipStream_t st) {
                                        store ? d.Beta : nullptr, d.t_rte, d.csT, d.csB_part + (size_t)p->apply_g0[j] * d.ld,
                                        d.add_t_rte, d.k, d.ld, d.rank, d.world, d.nI, 1, &p->lo[j], &p->hi[j],
                                        p->apply_grid[j], (void *)st);
+}
+
+// ---- direct schedule: the kernels that carry the exchange (hpf_internal.h), traced like the others ------------------------
+// sig_kind >= 0: the launch raises flags[sig_kind][rank] = epoch in every peer on entry; < 0: no signal
+inline hpf_direct::Signal raise(Plan *p, int sig_kind) {
+    return sig_kind >= 0 ? hpf_direct::Signal{p->peers_dev, sig_kind, p->epoch} : hpf_direct::Signal{nullptr, 0, 0};
+}
+
+// an emulated link time for a pull of `bytes` (dry runs with dry_run_busbw_GBps > 0; one sleeping wavefront)
+int pull_link_time(Plan *p, double bytes, hipStream_t st) {
+    const hpf_shard_desc &d = p->d;
+    if (!d.dry_run || p->tracing || !(d.dry_run_busbw_GBps > 0.f)) return 0;
+    const double us = d.dry_run_latency_us + bytes / (d.dry_run_busbw_GBps * 1e3);
+    hipLaunchKernelGGL(link_time_kernel, dim3(1), dim3(64), 0, st, (long long)(us * 100.0));
+    return (int)hipGetLastError();
+}
+
+int direct_item_sweep(Plan *p, int j, const float *eT, int sig_kind, hipStream_t cs) {
+    const hpf_shard_desc &d = p->d;
+    const hpf_shard_range &r = d.ranges[j];
+    if (g_tr) {
+        g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_SWEEP, cs, sig_kind >= 0 ? 1 + sig_kind : 0);
+        return 0;
+    }
+    return hpf_direct::sweep(d.i_segs + r.seg_lo, r.nseg, d.i_idx, d.i_y, d.eB, eT, d.part_i + (size_t)r.seg_lo * d.ld,
+                             d.acc_i, d.k, d.k, d.ld, r.short_rows, d.item_sweep_grid, raise(p, sig_kind), cs);
+}
+
+int direct_shape_pull(Plan *p, int j, hipStream_t xs) {
+    const hpf_shard_desc &d = p->d;
+    const uint32_t wait = 1u << HPF_P2P_FLAG_SWEPT(j);
+    if (g_tr) {
+        g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_ITEM_SHAPE_PULL, xs, (int64_t)wait);
+        return 0;
+    }
+    const int64_t o0 = p->lo[j] + (int64_t)d.rank * p->m[j];
+    int64_t n_real = d.nI - o0;
+    if (n_real > p->m[j]) n_real = p->m[j];
+    if (n_real < 0) n_real = 0;
+    const float *acc[HPF_P2P_MAX_RANKS];
+    for (int q = 0; q < d.world; q++)
+        acc[q] = reinterpret_cast<const float *>(reinterpret_cast<const char *>(p->peer_data[q]) + d.p2p_acc_offset);
+    // a single-process emulation reads every rank's slice (the traffic) and counts its own (the value)
+    const uint32_t mask = p->pp.emulate ? (1u << d.rank) : ((d.world >= 32) ? 0xFFFFFFFFu : ((1u << d.world) - 1u));
+    HPF_TRY(hpf_direct::item_shape_pull(acc, d.world, mask, wait, p->epoch, p->pp, n_real, p->t0[j], o0, d.eB, d.shp_own,
+                                        d.e_own, d.t_rte, d.t_rte_prev, d.c, d.t_shp, d.k, d.ld,
+                                        d.csB_part_rows, xs));
+    return pull_link_time(p, (double)p->m[j] * d.k * 4.0 * (d.world - 1), xs);
+}
+
+int direct_colsum_allreduce(Plan *p, const float *part, int rows, float *out, int which, hipStream_t st) {
+    if (g_tr) {
+        g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_COLSUM_ALLREDUCE, st, which);
+        return 0;
+    }
+    return hpf_direct::colsum_reduce_allreduce(part, rows, out, p->d.ld, p->peers_dev, which, p->epoch, st);
 }
 
 }  // namespace
@@ -351,9 +404,11 @@ int hpf_hip_shard_plan_create(const hpf_shard_desc *desc, void **plan) {
     if (d.world <= 0 || d.rank < 0 || d.rank >= d.world || d.k <= 0 || d.ld != hpf_hip_ld_for_k(d.k) || d.nU <= 0 ||
         d.nI <= 0 || d.nranges <= 0 || d.nranges > HPF_MAX_ROW_RANGES)
         return HPF_EINVAL;
-    if (!d.u_segs || d.u_nseg <= 0 || !d.u_idx || !d.u_y || !d.u_row_seg_ptr || (d.u_nmulti > 0 && !d.u_multi_rows) ||
-        !d.i_segs || !d.i_idx || !d.i_y || !d.i_row_seg_ptr)
+    // (a rank may hold no nonzeros at all -- fewer users than ranks, or one user with most of them: u_nseg == 0 and every
+    //  row is finished by the row finalizer over u_multi_rows; zero-length arrays have null pointers then)
+    if (d.u_nseg < 0 || !d.u_row_seg_ptr || (d.u_nmulti > 0 && !d.u_multi_rows) || !d.i_row_seg_ptr)
         return HPF_EINVAL;
+    if (d.u_nseg > 0 && (!d.u_segs || !d.u_idx || !d.u_y || !d.i_segs || !d.i_idx || !d.i_y)) return HPF_EINVAL;
     if (!d.eB || !d.part_u || !d.part_i || !d.Gamma_shp || !d.Theta || !d.k_rte || !d.k_rte_prev || !d.Lambda_shp ||
         !d.Beta || !d.t_rte || !d.t_rte_prev || !d.csT || !d.csB || !d.csB_used || !d.csT_part || !d.csB_part ||
         !d.acc_i || !d.acc_own || !d.e_own || !d.xstream)
@@ -361,17 +416,35 @@ int hpf_hip_shard_plan_create(const hpf_shard_desc *desc, void **plan) {
     if (d.user_sweep_grid <= 0 || d.user_multi_grid <= 0 || d.user_sweep_grid + d.user_multi_grid > d.csT_part_rows ||
         d.csB_part_rows <= 0 || d.item_sweep_grid <= 0)
         return HPF_EINVAL;
-    if (d.schedule == HPF_SCHEDULE_GATHER_EARLY || d.schedule == HPF_SCHEDULE_GATHER_CARRIED) {
+    const bool tracing = d.dry_run == 2;
+    hpf_p2p::Peers pp = {};
+    void *peer_data[HPF_P2P_MAX_RANKS] = {};
+    if (d.schedule == HPF_SCHEDULE_DIRECT) {
+        if (d.e_own_ld != hpf_hip_gather_payload_ld(d.k) || !d.shp_own || (d.direct_prefetch && !d.ag_recv) ||
+            d.world > HPF_P2P_MAX_RANKS || d.nranges > HPF_MAX_ROW_RANGES || d.csB_part_rows % d.world != 0)
+            return HPF_EINVAL;
+        if (!tracing) {
+            int w = 0, r = 0, ld = 0;
+            if (!hpf_p2p::region_view(d.p2p_region, &pp, peer_data, &w, &r, &ld)) return HPF_EINVAL;
+            if (w != d.world || r != d.rank || ld != d.ld || (d.p2p_acc_offset & 15) || (d.p2p_send_offset & 15) ||
+                (const char *)d.acc_i != (const char *)peer_data[r] + d.p2p_acc_offset ||
+                (const char *)d.e_own != (const char *)peer_data[r] + d.p2p_send_offset)
+                return HPF_EINVAL;
+            if (d.dry_run && !pp.emulate) return HPF_EINVAL;      // (a dry run stands alone: a region connected to itself)
+        }
+    } else if (d.schedule == HPF_SCHEDULE_GATHER_EARLY || d.schedule == HPF_SCHEDULE_GATHER_CARRIED) {
         if (d.e_own_ld != hpf_hip_gather_payload_ld(d.k) || !d.ag_recv || !d.shp_own) return HPF_EINVAL;
         if (d.schedule == HPF_SCHEDULE_GATHER_CARRIED &&
             (d.csB_part_rows % d.world != 0 || d.csB_part_rows < d.world * d.nranges))
             return HPF_EINVAL;
     } else if (d.schedule != HPF_SCHEDULE_FINALIZE_THEN_GATHER) {
         return HPF_EINVAL;
-    } else if (d.e_own_ld != d.ld && (d.e_own_ld != d.k || !d.ag_recv)) {
+    } else if (d.e_own_ld != d.ld) {
         return HPF_EINVAL;
     }
-    if (d.dry_run) {
+    if (d.schedule == HPF_SCHEDULE_DIRECT) {
+        // no communicator, no callback: the exchange is in the kernels
+    } else if (d.dry_run) {
         if (d.comm) {   // the stand-in call of a dry run must be an identity: a one-rank communicator
             int n = 0;
             HPF_TRY(hpf_hip_rccl_comm_count(d.comm, &n));
@@ -400,7 +473,11 @@ int hpf_hip_shard_plan_create(const hpf_shard_desc *desc, void **plan) {
     p->ss = (hipStream_t)d.sstream;
     p->tiny = nullptr;
     p->tracing = d.dry_run == 2;
-    if (!p->tracing && d.dry_run && d.comm) {
+    p->pp = pp;
+    p->peers_dev = (d.schedule == HPF_SCHEDULE_DIRECT && !p->tracing) ? hpf_p2p::region_peers_dev(d.p2p_region) : nullptr;
+    for (int q = 0; q < HPF_P2P_MAX_RANKS; q++) p->peer_data[q] = peer_data[q];
+    p->epoch = 0;
+    if (!p->tracing && d.dry_run && d.comm && d.schedule != HPF_SCHEDULE_DIRECT) {
         const hipError_t e = hipMalloc((void **)&p->tiny, 256);
         if (e != hipSuccess) {
             delete p;
@@ -523,7 +600,9 @@ int hpf_hip_shard_join(void *plan, void *stream) {
         }
         // the exchange stream is in order: the last thing on it is the last range's all-gather (+ unpack), or -- gather-
         // early -- the all-reduce of colsum(Beta)
-        hipEvent_t last = (d.schedule == HPF_SCHEDULE_GATHER_EARLY) ? p->csB_done : p->ag_done[d.nranges - 1];
+        hipEvent_t last = (d.schedule == HPF_SCHEDULE_GATHER_EARLY) ? p->csB_done
+                          : (d.schedule == HPF_SCHEDULE_DIRECT)     ? p->ag_done[0]
+                                                                     : p->ag_done[d.nranges - 1];
         HIP_TRY(hipStreamWaitEvent(st, last, 0));
         p->fresh = true;
     }
@@ -566,7 +645,8 @@ static int iterate_gather_early(Plan *p, const float *eT, float *eT_next, int st
     if (!fresh) HIP_TRY(hipStreamWaitEvent(cs, p->csB_done, 0));
     if (store) HIP_TRY(hipMemcpyAsync(d.csB_used, d.csB, (size_t)ld * sizeof(float), hipMemcpyDeviceToDevice, cs));
     float *shp = store ? d.Gamma_shp : nullptr, *fac = store ? d.Theta : nullptr;
-    HPF_TRY(hpf_hip_sweep_finalize_f32(d.u_segs, d.u_nseg, d.u_idx, d.u_y, eT, d.eB, d.part_u, eT_next, shp, nullptr, fac,
+    if (d.u_nseg > 0)
+        HPF_TRY(hpf_hip_sweep_finalize_f32(d.u_segs, d.u_nseg, d.u_idx, d.u_y, eT, d.eB, d.part_u, eT_next, shp, nullptr, fac,
                                        d.k_rte, d.k_rte_prev, d.csB, d.csT_part, d.a, d.k_shp, d.add_k_rte, k, ld,
                                        d.user_sweep_grid, (void *)cs));
     HPF_TRY(hpf_hip_row_finalize_f32(d.part_u, d.u_row_seg_ptr, d.u_multi_rows, d.u_nmulti, eT, eT_next, shp, nullptr, fac,
@@ -632,7 +712,8 @@ static int iterate_gather_carried(Plan *p, const float *eT, float *eT_next, int 
     if (carried && ss != cs) HIP_TRY(hipStreamWaitEvent(cs, p->csB_done, 0));
     if (store) HIP_TRY(hipMemcpyAsync(d.csB_used, d.csB, (size_t)ld * sizeof(float), hipMemcpyDeviceToDevice, cs));
     float *shp = store ? d.Gamma_shp : nullptr, *fac = store ? d.Theta : nullptr;
-    HPF_TRY(hpf_hip_sweep_finalize_f32(d.u_segs, d.u_nseg, d.u_idx, d.u_y, eT, d.eB, d.part_u, eT_next, shp, nullptr, fac,
+    if (d.u_nseg > 0)
+        HPF_TRY(hpf_hip_sweep_finalize_f32(d.u_segs, d.u_nseg, d.u_idx, d.u_y, eT, d.eB, d.part_u, eT_next, shp, nullptr, fac,
                                        d.k_rte, d.k_rte_prev, d.csB, d.csT_part, d.a, d.k_shp, d.add_k_rte, k, ld,
                                        d.user_sweep_grid, (void *)cs));
     HPF_TRY(hpf_hip_row_finalize_f32(d.part_u, d.u_row_seg_ptr, d.u_multi_rows, d.u_nmulti, eT, eT_next, shp, nullptr, fac,
@@ -645,10 +726,115 @@ static int iterate_gather_carried(Plan *p, const float *eT, float *eT_next, int 
     return 0;
 }
 
+// The direct schedule (include/hpf_hip.h, HPF_SCHEDULE_DIRECT).  Per iteration, epoch e:
+//   compute stream:  sweep(range 0) . [segsum] . sweep(range 1; on entry: SWEPT(0) = e) . [segsum] . ... .
+//                    user sweep + finalize (on entry: SWEPT(last) = e) . split user rows . colsum(Theta) over ALL ranks .
+//                    apply (after GATHERED / the owners' SHAPED flags) . colsum(Beta) over all ranks
+//   exchange stream: per range j, after this rank's sweep of j:  shape half with the slice's rows PULLED from all ranks
+//                    (waits for every peer's SWEPT(j) = e);  then ONE pull of every owner's finished rows (on entry:
+//                    SHAPED = e; last block: GATHERED = e) -- or, without prefetch, a launch that only raises SHAPED.
+// Why no buffer is overwritten while a peer still reads it: a rank's sweep of epoch e+1 follows its apply of e, which has
+// seen every owner's SHAPED(e), raised after that owner's pulls of e; a rank's shape half of e+1 waits for every peer's
+// SWEPT(e+1), raised after that peer's apply of e (which read this rank's rows of e, directly or through its pull).
+static int iterate_direct(Plan *p, const float *eT, float *eT_next, int store, hipStream_t cs) {
+    const hpf_shard_desc &d = p->d;
+    hipStream_t xs = p->xs;
+    const int k = d.k, ld = d.ld;
+    if (p->tracing) {
+        p->epoch++;
+    } else {
+        HPF_TRY(hpf_hip_p2p_region_next_epoch(d.p2p_region, &p->epoch));
+    }
+    if (p->fresh) {
+        HIP_TRY(hipEventRecord(p->start, cs));
+        HIP_TRY(hipStreamWaitEvent(xs, p->start, 0));
+    }
+    p->fresh = false;
+    for (int j = 0; j < d.nranges; j++) {
+        const hpf_shard_range &r = d.ranges[j];
+        // (a range without local nonzeros still launches when it carries the previous range's flag)
+        if (r.nseg > 0 || j > 0) HPF_TRY(direct_item_sweep(p, j, eT, j > 0 ? HPF_P2P_FLAG_SWEPT(j - 1) : -1, cs));
+        if (r.nmulti > 0)
+            HPF_TRY(hpf_hip_segsum_f32(d.part_i, d.i_row_seg_ptr, r.multi_rows, r.nmulti, d.acc_i, ld, k, 1, (void *)cs));
+        HIP_TRY(hipEventRecord(p->sw_done[j], cs));
+        HIP_TRY(hipStreamWaitEvent(xs, p->sw_done[j], 0));
+        HPF_TRY(direct_shape_pull(p, j, xs));
+    }
+    // exchange stream, under the user side: this rank's rows are complete -> SHAPED; every owner's rows -> ag_recv
+    const double gather_bytes = (double)p->total * d.e_own_ld * 4.0 * (d.world - 1);
+    if (d.direct_prefetch) {
+        if (g_tr) {
+            g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_GATHER_PULL, xs, HPF_P2P_FLAG_SHAPED(0) | (HPF_P2P_FLAG_GATHERED << 8));
+        } else {
+            HPF_TRY(hpf_p2p::gather_pull(d.p2p_region, d.p2p_send_offset, d.ag_recv, p->total * d.e_own_ld,
+                                         HPF_P2P_FLAG_SHAPED(0), HPF_P2P_FLAG_GATHERED, p->epoch, 16, xs));
+            HPF_TRY(pull_link_time(p, gather_bytes, xs));
+        }
+    } else if (g_tr) {
+        g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_SIGNAL, xs, HPF_P2P_FLAG_SHAPED(0));
+    } else {
+        HPF_TRY(hpf_hip_p2p_signal(d.p2p_region, HPF_P2P_FLAG_SHAPED(0), p->epoch, (void *)xs));
+    }
+    HIP_TRY(hipEventRecord(p->ag_done[0], xs));          // (what hpf_hip_shard_join waits for)
+    // user side; the launch that follows the last item sweep raises its flag
+    const int last_flag = HPF_P2P_FLAG_SWEPT(d.nranges - 1);
+    float *shp = store ? d.Gamma_shp : nullptr, *fac = store ? d.Theta : nullptr;
+    if (d.u_nseg > 0) {
+        if (g_tr) {
+            g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_SWEEP_FINALIZE, cs, 1 + last_flag);
+        } else {
+            HPF_TRY(hpf_direct::sweep_finalize(d.u_segs, d.u_nseg, d.u_idx, d.u_y, eT, d.eB, d.part_u, eT_next, shp, nullptr,
+                                               fac, d.k_rte, d.k_rte_prev, d.csB, d.csT_part, d.a, d.k_shp, d.add_k_rte, k,
+                                               ld, d.user_sweep_grid, store ? d.csB_used : nullptr,
+                                               raise(p, last_flag), cs));
+        }
+    } else {
+        if (g_tr) {
+            g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_SIGNAL, cs, last_flag);
+        } else {
+            HPF_TRY(hpf_hip_p2p_signal(d.p2p_region, last_flag, p->epoch, (void *)cs));
+            if (store) HIP_TRY(hipMemcpyAsync(d.csB_used, d.csB, (size_t)ld * sizeof(float), hipMemcpyDeviceToDevice, cs));
+        }
+    }
+    HPF_TRY(hpf_hip_row_finalize_f32(d.part_u, d.u_row_seg_ptr, d.u_multi_rows, d.u_nmulti, eT, eT_next, shp, nullptr, fac,
+                                     d.k_rte, d.k_rte_prev, d.csB, d.csT_part + (size_t)d.user_sweep_grid * ld, d.a,
+                                     d.k_shp, d.add_k_rte, k, ld, ld, d.user_multi_grid, (void *)cs));
+    HPF_TRY(direct_colsum_allreduce(p, d.csT_part, d.csT_part_rows, d.csT, HPF_P2P_VEC_CST, cs));
+    // the rates applied to ALL items, from the gathered rows (or straight from the owners' buffers)
+    if (g_tr) {
+        g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_ITEM_APPLY, cs,
+                  1 + (d.direct_prefetch ? HPF_P2P_FLAG_GATHERED : HPF_P2P_FLAG_SHAPED(0)));
+    } else {
+        const float *blocks[HPF_P2P_MAX_RANKS];
+        for (int q = 0; q < d.world; q++)
+            blocks[q] = d.direct_prefetch
+                            ? d.ag_recv + (size_t)q * p->total * d.e_own_ld
+                            : reinterpret_cast<const float *>(reinterpret_cast<const char *>(p->peer_data[q]) +
+                                                              d.p2p_send_offset);
+        HPF_TRY(hpf_direct::item_apply_blocks(blocks, d.world, d.direct_prefetch ? HPF_P2P_FLAG_GATHERED : HPF_P2P_FLAG_SHAPED(0),
+                                              d.direct_prefetch ? 1 : 0, p->epoch, p->pp, d.shp_own, d.eB,
+                                              store ? d.Lambda_shp : nullptr, store ? d.Beta : nullptr, d.t_rte, d.csT,
+                                              d.csB_part, d.add_t_rte, k, ld, d.rank, d.world, d.nI, d.nranges, p->lo, p->hi,
+                                              d.csB_part_rows, cs));
+        if (!d.direct_prefetch) HPF_TRY(pull_link_time(p, gather_bytes, cs));
+    }
+    HPF_TRY(direct_colsum_allreduce(p, d.csB_part, d.csB_part_rows, d.csB, HPF_P2P_VEC_CSB, cs));
+    return 0;
+}
+
+int hpf_hip_shard_status(void *plan) {
+    if (!plan) return HPF_EINVAL;
+    Plan *p = (Plan *)plan;
+    if (p->tracing || p->d.schedule != HPF_SCHEDULE_DIRECT) return 0;
+    uint32_t err = 0;
+    return hpf_hip_p2p_region_status(p->d.p2p_region, &err);
+}
+
 int hpf_hip_shard_iterate(void *plan, const float *eT, float *eT_next, int store, void *compute_stream) {
     if (!plan || !eT || !eT_next || eT == eT_next) return HPF_EINVAL;
     Plan *p = (Plan *)plan;
     TraceScope scope(p->tracing ? &p->tracer : nullptr);
+    if (p->d.schedule == HPF_SCHEDULE_DIRECT) return iterate_direct(p, eT, eT_next, store, (hipStream_t)compute_stream);
     if (p->d.schedule == HPF_SCHEDULE_GATHER_EARLY)
         return iterate_gather_early(p, eT, eT_next, store, (hipStream_t)compute_stream);
     if (p->d.schedule == HPF_SCHEDULE_GATHER_CARRIED)
@@ -680,7 +866,8 @@ int hpf_hip_shard_iterate(void *plan, const float *eT, float *eT_next, int store
     // user side under the exchange: fused sweep + finalizer, the split / empty rows, colsum(Theta) of this rank
     if (store) HIP_TRY(hipMemcpyAsync(d.csB_used, d.csB, (size_t)ld * sizeof(float), hipMemcpyDeviceToDevice, cs));
     float *shp = store ? d.Gamma_shp : nullptr, *fac = store ? d.Theta : nullptr;
-    HPF_TRY(hpf_hip_sweep_finalize_f32(d.u_segs, d.u_nseg, d.u_idx, d.u_y, eT, d.eB, d.part_u, eT_next, shp, nullptr, fac,
+    if (d.u_nseg > 0)
+        HPF_TRY(hpf_hip_sweep_finalize_f32(d.u_segs, d.u_nseg, d.u_idx, d.u_y, eT, d.eB, d.part_u, eT_next, shp, nullptr, fac,
                                        d.k_rte, d.k_rte_prev, d.csB, d.csT_part, d.a, d.k_shp, d.add_k_rte, k, ld,
                                        d.user_sweep_grid, (void *)cs));
     HPF_TRY(hpf_hip_row_finalize_f32(d.part_u, d.u_row_seg_ptr, d.u_multi_rows, d.u_nmulti, eT, eT_next, shp, nullptr, fac,
@@ -714,6 +901,36 @@ int hpf_hip_shard_exchange_only(void *plan, int op, int range, void *stream) {
     TraceScope scope(p->tracing ? &p->tracer : nullptr);
     const hpf_shard_desc &d = p->d;
     hipStream_t st = (hipStream_t)stream;
+    if (d.schedule == HPF_SCHEDULE_DIRECT) {
+        // the pulls on their own, every rank in step: a fresh epoch, this rank's flag, then the kernel that carries the
+        // exchange (scratch results: the state is not meaningful afterwards)
+        if (range >= d.nranges) return HPF_EINVAL;
+        if (p->tracing) {
+            p->epoch++;
+        } else {
+            HPF_TRY(hpf_hip_p2p_region_next_epoch(d.p2p_region, &p->epoch));
+        }
+        if (range < 0) return direct_colsum_allreduce(p, d.csT_part, d.csT_part_rows, d.csT, HPF_P2P_VEC_CST, st);
+        if (op == HPF_COLL_REDUCE_SCATTER) {
+            if (g_tr) {
+                g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_SIGNAL, st, HPF_P2P_FLAG_SWEPT(range));
+            } else {
+                HPF_TRY(hpf_hip_p2p_signal(d.p2p_region, HPF_P2P_FLAG_SWEPT(range), p->epoch, (void *)st));
+            }
+            return direct_shape_pull(p, range, st);
+        }
+        if (op == HPF_COLL_ALL_GATHER) {
+            if (range != 0) return 0;         // (one pull for all ranges: counted with range 0)
+            if (g_tr) {
+                g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_GATHER_PULL, st, HPF_P2P_FLAG_SHAPED(0) | (HPF_P2P_FLAG_GATHERED << 8));
+                return 0;
+            }
+            if (!d.ag_recv) return HPF_EINVAL;
+            return hpf_p2p::gather_pull(d.p2p_region, d.p2p_send_offset, d.ag_recv, p->total * d.e_own_ld,
+                                        HPF_P2P_FLAG_SHAPED(0), HPF_P2P_FLAG_GATHERED, p->epoch, 64, st);
+        }
+        return HPF_EINVAL;
+    }
     if (range < 0) {
         if (op != HPF_COLL_ALL_REDUCE) return HPF_EINVAL;
         // scratch between iterations: the reduce-scatter outputs are rewritten before the finalizer reads them

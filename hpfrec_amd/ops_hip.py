@@ -80,17 +80,6 @@ class HipOps:
                                                      float(top_shp), float(add_rte), k, ld, cs_partial.shape[0],
                                                      self._stream()), "hpf_hip_sweep_finalize_f32")
 
-    def sweep_prefinalize(self, side, tab_self, tab_other, part, acc_rows, acc_ld, shp, rte, fac, rs, cs_other,
-                          cs_partial, prior_shp, top_shp, add_rte, k, ld, rs_prev=None):
-        """sharded item pass: whole-row segments first finish their row from acc_rows (last iteration's reduced
-        statistics), then sweep it and leave this iteration's local accumulator in acc_rows."""
-        _lib.check(self.L.hpf_hip_sweep_prefinalize_f32(
-            _ptr(side.segs), side.nseg, _ptr(side.idx), _ptr(side.y), _ptr(tab_self), _ptr(tab_other), _ptr(part),
-            _ptr(acc_rows), int(acc_ld), _ptr(shp), _ptr(rte), _ptr(fac), _ptr(rs), _ptr(rs_prev), _ptr(cs_other),
-            _ptr(cs_partial),
-            float(prior_shp), float(top_shp), float(add_rte), k, ld, cs_partial.shape[0], self._stream()),
-            "hpf_hip_sweep_prefinalize_f32")
-
     def finalize_grid(self, nrows):
         return int(max(1, min(self.finalize_blocks, (nrows + 3) // 4)))
 
@@ -152,11 +141,6 @@ class HipOps:
             _ptr(recv), _ptr(shp_own), _ptr(e_tab), _ptr(shp), _ptr(fac), _ptr(rs), _ptr(cs_other), _ptr(cs_partial),
             float(add_rte), k, ld, int(rank), int(world), int(nrows), n, ctypes.addressof(lo), ctypes.addressof(hi),
             cs_partial.shape[0], self._stream()), "hpf_hip_item_apply_rows_f32")
-
-    def unpack_rows(self, src, dst, nrows, k, ld):
-        """dst[r, :k] = src[r, :k]: a packed [nrows, k] table into a padded [nrows, ld] one."""
-        _lib.check(self.L.hpf_hip_unpack_rows_f32(_ptr(src), _ptr(dst), int(nrows), k, ld, self._stream()),
-                   "hpf_hip_unpack_rows_f32")
 
     def colsum_reduce(self, cs_partial, cs_out, ld):
         _lib.check(self.L.hpf_hip_colsum_reduce_f32(_ptr(cs_partial), cs_partial.shape[0], _ptr(cs_out), ld,

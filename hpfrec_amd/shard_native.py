@@ -1,10 +1,11 @@
 """ctypes binding of the "one rank's whole sharded iteration from C" entries of include/hpf_hip.h
 (hpf_hip_shard_plan_create / _iterate / _join / _exchange_only; hpfrec_amd/csrc/hpf_shard.hip).
 
-cavi.FullBatchCavi builds a ShardPlan over its own device tensors when its exchange mode is "scatter" and the job runs
-on RCCL: an iteration is then ONE host call instead of ~30 (kernel launches through ctypes, torch.distributed
-collectives, stream and event operations).  The Python form of the same schedule (cavi._iterate_scatter) stays as the
-path for gloo / CPU stand-in runs and as the fallback when a plan cannot be created on every rank.
+cavi.FullBatchCavi (hpfrec_amd/shard.py) builds a ShardPlan over its own device tensors whenever the job runs on a GPU:
+an iteration is then ONE host call instead of ~30 (kernel launches through ctypes, torch.distributed collectives, stream
+and event operations).  The call-by-call Python forms of the schedules (shard.ShardedMixin) stay as the path of gloo /
+CPU stand-in runs, as the checker of the first C-issued iteration, and as the fallback when a plan cannot be created on
+every rank.
 """
 import ctypes
 
@@ -50,7 +51,8 @@ class ShardDesc(ctypes.Structure):
         ("shp_own", _vp),
         ("dry_run_busbw_GBps", _f32), ("dry_run_latency_us", _f32),
         ("comm_small", _vp), ("sstream", _vp),
-        ("dry_run_footprint_blocks", _i32), ("pad3", _i32),
+        ("dry_run_footprint_blocks", _i32), ("direct_prefetch", _i32),
+        ("p2p_region", _vp), ("p2p_acc_offset", _i64), ("p2p_send_offset", _i64),
     ]
 
 
@@ -61,7 +63,8 @@ class TraceRec(ctypes.Structure):
 
 TRACE_KERNEL, TRACE_COLLECTIVE, TRACE_RECORD, TRACE_WAIT, TRACE_COPY = 1, 2, 3, 4, 5
 TRACE_KERNELS = {1: "sweep", 2: "segsum", 3: "sweep_finalize", 4: "row_finalize", 5: "row_finalize_ranges", 6: "colsum_reduce",
-                 7: "item_shape", 8: "item_apply", 9: "unpack"}
+                 7: "item_shape", 8: "item_apply", 10: "item_shape_pull", 11: "gather_pull", 12: "colsum_allreduce",
+                 13: "signal"}
 TRACE_EVENT_BASE = 0x1000
 
 
@@ -85,6 +88,12 @@ class ShardPlan:
 
     def join(self, stream):
         _lib.check(self.L.hpf_hip_shard_join(self.handle, stream), "hpf_hip_shard_join")
+
+    def status(self):
+        """Direct schedule: synchronises the device and raises when a wait for a peer's flag ran out (no-op otherwise)."""
+        rc = self.L.hpf_hip_shard_status(self.handle)
+        if rc != 0:
+            raise _lib.HpfHipError("hpfrec_amd: the direct exchange timed out waiting for a peer (code %d)" % rc)
 
     def exchange_only(self, op, rng, stream):
         _lib.check(self.L.hpf_hip_shard_exchange_only(self.handle, int(op), int(rng), stream),

@@ -100,22 +100,6 @@ int hpf_hip_sweep_finalize_f32(const hpf_segment *segs, int64_t nseg, const int3
                                int grid_blocks, void *stream);
 
 /*
- * The sharded (multi-GPU) item pass with the row finalizer fused in as a PROLOGUE ("deferred item finalize"):
- * acc_rows[row][0:acc_ld] holds LAST iteration's all-reduced accumulator of every row.  The wavefront that owns
- * a whole-row segment first finishes that row from it (shp/rte/fac/rs/tab_self[row] updated exactly as
- * hpf_hip_row_finalize_f32 would, cs_other = colsum of the other side's means), then sweeps the row with the
- * fresh E row and overwrites acc_rows[row] with THIS iteration's local accumulator (the all-reduce payload).
- * Split rows must have been finished beforehand (hpf_hip_row_finalize_f32 with their row_list, part = acc_rows,
- * part_ld = acc_ld); their segments write part[] as usual.  cs_partial: grid_blocks rows, all written.
- * This removes the replicated item finalizer launch from the multi-GPU critical path.
- */
-int hpf_hip_sweep_prefinalize_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y,
-                                  float *tab_self, const float *tab_other, float *part, float *acc_rows, int acc_ld,
-                                  float *shp, float *rte, float *fac, float *rs, float *rs_prev,
-                                  const float *cs_other, float *cs_partial, float prior_shp, float top_shp,
-                                  float add_rte, int k, int ld, int grid_blocks, void *stream);
-
-/*
  * Closed-form updates for the rows of one side.  Replaces the numpy statements of
  * fit_hpf PXI:236-259 (and the psi/log/exp hoisted out of update_phi, PXI:588):
  *
@@ -147,8 +131,8 @@ int hpf_hip_row_finalize_f32(const float *part, const int64_t *row_seg_ptr, cons
  * buffer).  The multi-GPU "scatter" exchange leaves each rank with one slice of every item range (the
  * reduce-scatter outputs, concatenated in acc); this finishes all of them at once.  The three range arrays are
  * HOST arrays of nranges <= HPF_MAX_ROW_RANGES entries, read during the call.  cs_partial: grid_blocks rows, all
- * written.  e_new_ld: row stride of e_new -- ld, or k <= e_new_ld < ld when the send buffer is packed (only the first
- * e_new_ld columns are written; hpf_hip_unpack_rows_f32 restores the padded layout on the receiving side).
+ * written.  e_new_ld: row stride of e_new -- ld, or k <= e_new_ld < ld for a packed send buffer (only the first
+ * e_new_ld columns are written).
  */
 #define HPF_MAX_ROW_RANGES 8
 int hpf_hip_row_finalize_ranges_f32(const float *acc, int nranges, const int64_t *range_rows,
@@ -186,9 +170,6 @@ int hpf_hip_item_apply_rows_f32(const float *recv, const float *shp_own, float *
                                 int world, int64_t nrows, int nranges, const int64_t *range_lo, const int64_t *range_hi,
                                 int grid_blocks, void *stream);
 
-/* dst[r][0:k] = src[r][0:k], r < nrows: a packed [nrows][k] table into a padded [nrows][ld] one (pad columns are left
- * as they are -- zero in an E table).  The receive side of a k-packed all-gather of E rows. */
-int hpf_hip_unpack_rows_f32(const float *src, float *dst, int64_t nrows, int k, int ld, void *stream);
 
 /* cs_out[c] = sum_b cs_partial[b][c], fixed order, double accumulation (Beta.sum(axis=0), PXI:236,255). */
 int hpf_hip_colsum_reduce_f32(const float *cs_partial, int nblk, float *cs_out, int ld, void *stream);
@@ -429,8 +410,9 @@ typedef struct hpf_shard_desc {
     float *acc_i;                  /* [ranges[last].hi][k] packed exchange buffer (reduce-scatter input) */
     float *acc_own;                /* [sum of slice lengths][k] reduce-scatter outputs, range after range */
     float *e_own;                  /* [sum of slice lengths][e_own_ld] new E rows of the slices (all-gather input) */
-    int32_t e_own_ld, item_sweep_grid;   /* e_own_ld = ld: all-gather straight into eB; = k: packed, see ag_recv */
-    float *ag_recv;                /* packed all-gather: [ranges[last].hi][k] receive buffer (may alias acc_i) */
+    int32_t e_own_ld, item_sweep_grid;   /* e_own_ld = ld (schedule 0: all-gather straight into eB) or
+                                            hpf_hip_gather_payload_ld(k) (schedules 1-3: [numerators | base] rows) */
+    float *ag_recv;                /* schedules 1-3: [world][sum of slice lengths][e_own_ld] gathered rows */
     float a, k_shp, add_k_rte, c, t_shp, add_t_rte;
     void *comm;                    /* ncclComm_t (hpf_hip_rccl_comm_init), or NULL */
     hpf_collective_fn coll; void *coll_ctx;   /* used instead of RCCL when coll != NULL */
@@ -438,7 +420,7 @@ typedef struct hpf_shard_desc {
     int32_t dry_run;               /* 1: this rank alone -- every collective is its one-rank form (local copy of the
                                       rank's slice) + a 1-element all-reduce on comm if given: the compute-only
                                       schedule of a rank, for probes and the bench's exposed-exchange figure */
-    int32_t schedule;              /* HPF_SCHEDULE_FINALIZE_THEN_GATHER (0), _GATHER_EARLY (1) or _GATHER_CARRIED (2), below */
+    int32_t schedule;              /* HPF_SCHEDULE_FINALIZE_THEN_GATHER (0), _GATHER_EARLY (1), _GATHER_CARRIED (2), _DIRECT (3) */
     float *shp_own;                /* gather-early: [sum of slice lengths][ld] shapes between the finalizer's halves */
     float dry_run_busbw_GBps;      /* dry run only, > 0: every collective additionally occupies its stream for
                                       latency + bytes * (world-1)/world / busbw -- one idle-spinning wavefront (the links
@@ -453,10 +435,15 @@ typedef struct hpf_shard_desc {
                                       of 256 threads, 128 VGPRs and 64 KB of LDS each (what a collective library's
                                       kernel needs to be RESIDENT beside the sweeps), each holding its slot for the link
                                       time; 0: one wavefront */
-    int32_t pad3;
+    int32_t direct_prefetch;       /* schedule 3: 1 = the peers' finished rows are copied into ag_recv by ONE pull launch
+                                      on the exchange stream (under the user sweep) and the apply kernel reads local
+                                      memory; 0 = the apply kernel reads the owners' buffers itself */
+    void *p2p_region;              /* schedule 3: the rank's connected exchange region (hpf_hip_p2p_region_create /
+                                      _connect); acc_i and e_own must lie INSIDE its data buffer, at the offsets below */
+    int64_t p2p_acc_offset, p2p_send_offset;   /* bytes from the start of the region's data buffer */
 } hpf_shard_desc;
 
-/* Two schedules of the same exchange.
+/* Four schedules of the same exchange.
  * 0, finalize-then-gather: after the user side, all-reduce colsum(Theta), finish this rank's item slices
  *    (hpf_hip_row_finalize_ranges_f32), all-gather the new E rows range by range; the next iteration's sweep of a range waits
  *    for that range's all-gather -- the all-gather hides only under the item sweeps of the other ranges.
@@ -474,17 +461,26 @@ typedef struct hpf_shard_desc {
  *    its E rows before the user side -- so the all-gather of range j has until then, not until the end of the user side,
  *    and the links can stay busy for the whole iteration.  hpf_hip_shard_join applies what is pending (the state after a
  *    join is the state after schedule 1).  The two k-float all-reduces must not queue behind the bulk collectives:
- *    comm_small.  csB_part_rows (a multiple of world, >= world * nranges) is divided over the ranges' apply launches. */
+ *    comm_small.  csB_part_rows (a multiple of world, >= world * nranges) is divided over the ranges' apply launches.
+ * 3, direct: gather-early WITHOUT collectives (section "Multi-GPU, direct exchange" below).  acc_i and e_own live in the
+ *    rank's peer-mapped region.  Compute stream: item sweeps (the launch after a range's sweep tells the peers, on entry,
+ *    that the range is complete), user side, colsum(Theta) summed over the ranks inside its reduction kernel (granules),
+ *    the apply half, colsum(Beta) the same way.  Exchange stream, per range: the shape half PULLS the slice's N partial
+ *    accumulator rows out of the N ranks' buffers and sums them in rank order (the reduce-scatter), then either one pull
+ *    launch copies every owner's finished rows into ag_recv under the user sweep (direct_prefetch) or the apply kernel
+ *    reads them from the owners' buffers itself (the all-gather).  No RCCL call, no collective kernel beside the sweeps.
+ *    comm / coll are not used; a dry run is a region connected to itself (hpf_hip_p2p_region_connect(region, NULL)). */
 #define HPF_SCHEDULE_FINALIZE_THEN_GATHER 0
 #define HPF_SCHEDULE_GATHER_EARLY 1
 #define HPF_SCHEDULE_GATHER_CARRIED 2
+#define HPF_SCHEDULE_DIRECT 3
 
 /* dry_run == 2, "trace": nothing is issued and no device is needed -- every kernel launch, collective, event record /
  * wait and copy of hpf_hip_shard_iterate / _join / _exchange_only is appended to the plan's trace instead, in issue order
  * (table pointers are never dereferenced, streams are opaque values, comm / coll are ignored).  What a multi-rank run
  * depends on -- identical collective sequences on all ranks, every wait after its record -- can then be checked on any
  * machine (tests/test_host_logic.py). */
-#define HPF_TRACE_KERNEL 1      /* id = HPF_TRACE_K_*                                              */
+#define HPF_TRACE_KERNEL 1      /* id = HPF_TRACE_K_*; arg = 1 + flag kind when the launch raises a flag on entry */
 #define HPF_TRACE_COLLECTIVE 2  /* id = HPF_COLL_* (| 0x100: a k-float all-reduce), arg = count    */
 #define HPF_TRACE_RECORD 3      /* arg = event                                                     */
 #define HPF_TRACE_WAIT 4        /* arg = event                                                     */
@@ -497,7 +493,10 @@ typedef struct hpf_shard_desc {
 #define HPF_TRACE_K_COLSUM_REDUCE 6
 #define HPF_TRACE_K_ITEM_SHAPE 7
 #define HPF_TRACE_K_ITEM_APPLY 8
-#define HPF_TRACE_K_UNPACK 9
+#define HPF_TRACE_K_ITEM_SHAPE_PULL 10   /* arg = the flag kinds waited for (bit mask)                  */
+#define HPF_TRACE_K_GATHER_PULL 11       /* arg = signal kind | done kind << 8                              */
+#define HPF_TRACE_K_COLSUM_ALLREDUCE 12  /* arg = HPF_P2P_VEC_*                                             */
+#define HPF_TRACE_K_SIGNAL 13            /* arg = flag kind (a launch that only raises a flag)              */
 /* events of a traced plan: HPF_TRACE_EVENT_BASE + 2j (range j swept), + 2j + 1 (range j's all-gather done), then, after the
  * 2 * nranges of them: colsum(Theta) ready, iteration start, apply done, colsum(Beta) done */
 #define HPF_TRACE_EVENT_BASE 0x1000
@@ -523,6 +522,9 @@ int hpf_hip_shard_iterate(void *plan, const float *eT, float *eT_next, int store
 /* `stream` waits for everything the plan has in flight on its exchange stream (call before reading the item tables,
  * before work of ANOTHER communicator, and before destroying the plan); the next iterate re-synchronises. */
 int hpf_hip_shard_join(void *plan, void *stream);
+/* schedule 3: synchronises the device and returns HPF_ETIMEOUT when a wait of this rank ran out (0 otherwise, and for
+ * the other schedules) */
+int hpf_hip_shard_status(void *plan);
 /* 1 (one collective of op HPF_COLL_*) of `count` per-rank elements between scratch regions of the plan's buffers, on
  * `stream`: the exchange-only timing pass of bench.py.  range < 0: the k-float all-reduce. */
 int hpf_hip_shard_exchange_only(void *plan, int op, int range, void *stream);
@@ -546,6 +548,7 @@ int hpf_hip_shard_exchange_only(void *plan, int op, int range, void *stream);
 #define HPF_P2P_VEC_CSB 1
 #define HPF_P2P_FLAG_SWEPT(j) (j)                          /* item range j of this epoch is complete in the rank's acc buffer */
 #define HPF_P2P_FLAG_SHAPED(j) (HPF_MAX_ROW_RANGES + (j))  /* the rank's [numerators | base] rows of range j are complete */
+#define HPF_P2P_FLAG_GATHERED 29                           /* (local) every owner's rows of this epoch are in ag_recv */
 #define HPF_P2P_FLAG_USER 30                               /* free for callers (tests, probes) */
 int64_t hpf_hip_p2p_ctrl_bytes(int ld);
 /* Allocates the region of `rank` of `world` on the current device (data_bytes of zeroed data + the control block for
