@@ -16,9 +16,10 @@ Prints ONE JSON line on rank 0 (see the bench contract in the task): metric/valu
                   committed rocprofv3 --pmc passes, null when they were measured on another kernel source;
   "cpu_baseline": the CPU oracle (oracle/, a port of the reference's Cython loops) timed on this
                   node's host cores on a bounded sample of the same workload (rank 0, N=1 only).
-N>1: the exchange configuration (all-reduce / reduce-scatter form, item ranges, streams, torch.distributed or an
-RCCL communicator of our own, hipGraph replay) is autotuned first, every rank taking the same decision
-(config.exchange_autotune); a watchdog reports the best completed candidate should a later one hang.
+N>1: the LIBRARY DEFAULT (HPF_SCHEDULE=auto: the direct, peer-mapped exchange) is timed first and its line is held; then at
+most five alternatives run 20 iterations each (--autotune-all: the long list), every rank taking the same decision, and
+only a candidate that beats the default by more than 2 % is benchmarked in its place (config.exchange_autotune); a
+watchdog reports the held line should anything after it stop making progress.
 """
 import argparse
 import json
@@ -36,6 +37,17 @@ from hpfrec_amd import cavi, cython_loops_float as backend  # noqa: E402
 from hpfrec_amd.ops_hip import HipOps  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+SCHEDULE_TEXT = {   # config.parallelism of an N>1 line: (world, item ranges)
+    "direct": "users sharded x%d; item statistics in %d ranges PULLED from the peers' mapped exchange buffers by the shape "
+              "half of the item finalizer (rank-order sum), finished rows pulled back under the user sweep; no collective library",
+    "gather-early": "users sharded x%d; item statistics reduce-scattered in %d pipelined ranges (RCCL), split item finalizer, "
+                    "[numerators | base rate] rows all-gathered under the user sweep",
+    "gather-carried": "users sharded x%d; item statistics reduce-scattered in %d ranges (RCCL), the all-gather of a range "
+                      "carried into the next iteration",
+    "finalize-then-gather": "users sharded x%d; item statistics reduce-scattered in %d pipelined ranges (RCCL), each rank "
+                            "finalizes 1/N of the items, new E rows all-gathered under the next item sweep",
+}
 
 WORKLOADS = {
     # name: (nU, nI, target nnz, k, label)
@@ -128,17 +140,30 @@ class TimedOps(HipOps):
         return out
 
 
-def cpu_baseline(nU, nI, k, nnz_full, sample_users=200_000, iters=4, device=None):
-    """The CPU oracle (port of the reference's loops: materialised phi, per-nonzero double
-    psi/log/exp, serial scatter, numpy rate updates) on this node's host cores, on a bounded sample:
-    the first `sample_users` users of a same-shaped matrix (all items kept).  Extrapolated linearly
-    in nnz to the full workload (the reference's cost is per nonzero)."""
+def cpu_baseline(nU, nI, k, nnz_full, sample_users=200_000, iters=4, device=None, triplets=None):
+    """The CPU oracle (port of the reference's loops: materialised phi, per-nonzero double psi/log/exp, serial scatter,
+    numpy rate updates) on this node's host cores.  With `triplets` (the benchmark's own matrix, host arrays) and enough
+    host memory for phi (nnz*k*4 bytes: 9.7 GB at C3) the FULL workload is timed: 1 warm + 3 timed iterations
+    (BASELINE.md section 4.3).  Otherwise a bounded sample: the first `sample_users` users of a same-shaped matrix (all
+    items kept), extrapolated linearly in nnz (the reference's cost is per nonzero)."""
     from oracle import hpf_oracle as O
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import datagen
-    sample_users = min(sample_users, nU)
-    nnz_s = int(nnz_full * (sample_users / nU))
-    iu, ii, Y = datagen.synthetic_hpf_shaped(sample_users, nI, nnz_s, seed=1)
+    full = False
+    if triplets is not None:
+        try:
+            import psutil
+            need = triplets[2].shape[0] * k * 4 * 1.25 + (nU + nI) * k * 4 * 24
+            full = psutil.virtual_memory().available > need + (8 << 30)
+        except Exception:   # noqa: BLE001
+            full = False
+    if full:
+        iu, ii, Y = triplets
+        sample_users, iters = nU, 3
+    else:
+        sample_users = min(sample_users, nU)
+        nnz_s = int(nnz_full * (sample_users / nU))
+        iu, ii, Y = datagen.synthetic_hpf_shaped(sample_users, nI, nnz_s, seed=1)
     cores = O.max_threads()
     hy = O.Hyper(k, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
     st = O.State(sample_users, nI, hy, 123)
@@ -160,8 +185,11 @@ def cpu_baseline(nU, nI, k, nnz_full, sample_users=200_000, iters=4, device=None
     snaps[total_its] = {n: getattr(st, n) for n in ("Theta", "Beta")}
     per_full = dt * (nnz_full / Y.shape[0])
     out = {"value": 1.0 / per_full, "unit": "iters/s", "cores": cores, "kind": "port",
-           "sample": "%d users x %d items, %d nnz, k=%d, %d timed iterations at %.2f s/iter; scaled by nnz to %d nnz"
-                     % (sample_users, nI, Y.shape[0], k, iters, dt, nnz_full)}
+           "sample": ("the FULL workload: %d users x %d items, %d nnz, k=%d, %d timed iterations at %.2f s/iter (after 1 warm "
+                      "iteration; phi materialised: %.1f GB)" % (sample_users, nI, Y.shape[0], k, iters, dt,
+                                                                 Y.shape[0] * k * 4 / 1e9)) if full else
+                     ("%d users x %d items, %d nnz, k=%d, %d timed iterations at %.2f s/iter; scaled by nnz to %d nnz"
+                      % (sample_users, nI, Y.shape[0], k, iters, dt, nnz_full))}
     # the oracle is the checker: the HIP path on the same sample, same start, same numbers of iterations
     if device is not None:
         hyd = cavi.Hyper(k, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
@@ -181,16 +209,20 @@ def cpu_baseline(nU, nI, k, nnz_full, sample_users=200_000, iters=4, device=None
             return max(float(np.max(np.abs(a[n] - b[n]) / np.abs(b[n]))) for n in ("Theta", "Beta"))
         # numpy's float32 row-by-row column sums (PXI:236,255), which the port reproduces bit for bit, are themselves
         # ~1e-4 off at 10^5..10^6 rows; the same port with float64 column sums shows what is left without that
-        st64 = O.State(sample_users, nI, hy, 123)
         snaps64 = {}
-        for i in range(total_its):
-            O.cavi_iteration(st64, hy, Yc, iuc, iic, phi, 0, cores, exact_colsums=True)
-            if i + 1 in snaps:
-                snaps64[i + 1] = {n: getattr(st64, n).copy() for n in ("Theta", "Beta")}
+        if not full:        # (a diagnostic, bounded to the sample: the same port with float64 column sums)
+            st64 = O.State(sample_users, nI, hy, 123)
+            for i in range(total_its):
+                O.cavi_iteration(st64, hy, Yc, iuc, iic, phi, 0, cores, exact_colsums=True)
+                if i + 1 in snaps:
+                    snaps64[i + 1] = {n: getattr(st64, n).copy() for n in ("Theta", "Beta")}
         out["parity_vs_gpu_on_sample"] = {
-            "max_rel_dev_Theta_Beta": {"after_%d_iterations" % n: {
-                "vs_port": worst(got[n], snaps[n]), "vs_port_with_float64_column_sums": worst(got[n], snaps64[n])}
+            "max_rel_dev_Theta_Beta": {"after_%d_iterations" % n: dict(
+                vs_port=worst(got[n], snaps[n]),
+                **({"vs_port_with_float64_column_sums": worst(got[n], snaps64[n])} if n in snaps64 else {}))
                 for n in sorted(snaps)},
+            "pinned_by": "tests/golden/large_full.npz (the real reference at 200k x 50k, 5.4M nnz; oracle bit-exact, GPU "
+                         "within 1e-4: tests/test_oracle.py::test_large_bit_exact, test_hip_parity.py::test_large_vs_golden)",
             "note": "element-wise parity is a short-horizon property (rounding noise grows ~x1.2 per iteration); the port "
                     "reproduces numpy's float32 row-by-row column sums of the reference (PXI:236,255), whose own error is "
                     "~1e-4 at 1e5..1e6 rows (SURVEY.md section 7); the GPU sums them in fp64 trees"}
@@ -270,10 +302,10 @@ def main():
                     help="skip the untimed extras (lean-iteration and llk-pass timings); used under rocprofv3 so that "
                          "per-kernel averages cover exactly the warm-up + timed iterations")
     ap.add_argument("--no-fuse", action="store_true", help="separate sweep and row-finalize launches")
-    ap.add_argument("--try-hipgraph", action="store_true",
-                    help="N>1: also try the fastest scatter configuration with hipGraph replay of iteration pairs (HPF_GRAPH=1)")
     ap.add_argument("--no-autotune", action="store_true",
-                    help="N>1: do not try the exchange configurations first, use the defaults of hpfrec_amd.cavi")
+                    help="N>1: time the library default only")
+    ap.add_argument("--autotune-all", action="store_true",
+                    help="N>1: also try gather-carried (two RCCL communicators) and the sweep-grid variants")
     ap.add_argument("--lean", action="store_true",
                     help="skip the stores of the six [n,k] output tables in the timed iterations")
     args = ap.parse_args()
@@ -331,6 +363,9 @@ def main():
     ops = TimedOps(device)
     hy = cavi.Hyper(k, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
     lu, li, ly, (u0, u1) = cavi.shard_users(iu, ii, y, nU, rank, world)
+    host_triplets = None
+    if world == 1 and not args.no_cpu_baseline:      # the CPU baseline times the SAME matrix (host copies: 1 GB at C3)
+        host_triplets = (iu.cpu().numpy(), ii.cpu().numpy(), y.cpu().numpy())
     del iu, ii, y
     Theta = np.empty((nU, k), np.float32)
     Beta = np.empty((nI, k), np.float32)
@@ -342,176 +377,139 @@ def main():
         m.load_state(init[0][s], init[1][s], init[2], init[3], init[4][s], init[5], Theta[s], Beta)
         return m
 
-    # N>1: the exchange mode / number of pipelined item ranges that is fastest depends on what the links and RCCL
-    # deliver on this node, so (unless the environment pins them) each candidate runs a few untimed iterations
-    # first and the fastest one -- by the slowest rank's clock -- is the configuration that is then benchmarked.
+    # N>1: the library default goes FIRST and its measurement is held (watchdog); a few alternatives follow.
     autotune = None
-    TUNED = ("HPF_SHARD_MODE", "HPF_AR_CHUNKS", "HPF_ITEM_STREAM", "HPF_RS_ALLTOALL", "HPF_GRAPH", "HPF_RCCL_DIRECT",
-             "HPF_NATIVE_SHARD", "HPF_AG_PACKED", "HPF_GATHER_EARLY", "HPF_SHARD_SWEEP_BPC", "HPF_ITEM_SWEEP_BPC",
-             "HPF_CARRIED_ONE_COMM")
+    TUNED = ("HPF_SCHEDULE", "HPF_ITEM_RANGES", "HPF_DIRECT_PREFETCH", "HPF_SHARD_SWEEP_BPC", "HPF_ITEM_SWEEP_BPC",
+             "HPF_NATIVE_SHARD")
     if os.environ.get("HPF_BENCH_SELFTEST_GLOO") == "1" and dist is not None:
         # the one-GPU self-test has no RCCL between its ranks: gloo stands in for it behind the C-issued iteration's
-        # collective callback (tests/dist_worker.py), so that the native path and the `collective` block are exercised
+        # collective callback (tests/dist_worker.py), so that the RCCL-shaped candidates are exercised too
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from dist_worker import gloo_collective
         dist.native_collective = lambda model_: gloo_collective(dist, model_)
     sharded = dist is not None and (world > 1 or os.environ.get("HPF_FORCE_SHARDED") == "1")
-    if sharded and not args.no_autotune and not any(v in os.environ for v in TUNED):
-        autotune, failed = {}, {}
-        # Safety net: this multi-rank path could only be exercised with gloo ranks on one GPU (and a one-rank RCCL
-        # group) before the driver's run.  If anything after a completed candidate stops making progress, rank 0
-        # still reports that candidate's barrier-bracketed 20-iteration measurement (flagged as a fallback).
-        watchdog_state["autotune"], watchdog_state["meta"] = autotune, dict(
-            workload=label, users=nU, items=nI, nnz=nnz, k=k, world=world, rank=rank, workload_key=args.workload)
+    store = not args.lean
+
+    def joined_barrier(m):
+        # the model's exchange stream may still have work in flight: join it before another communicator's barrier
+        if m is not None and getattr(m, "dist", None):
+            m._sync_scatter_streams()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def describe(m):
+        m._scatter_views()                   # (the exchange is set up on first use: schedule, ranges, plan)
+        sched = getattr(m, "schedule", None)
+        return "%s/%d%s%s" % (sched, len(m.item_chunks or []),
+                              "/no-prefetch" if sched == "direct" and os.environ.get("HPF_DIRECT_PREFETCH", "1") != "1" else "",
+                              "" if m._plan is not None else "/python-issued")
+
+    CANDIDATES = [   # (label, environment on top of the defaults) -- the default itself is not in the list
+        ("direct, one item range", {"HPF_SCHEDULE": "direct", "HPF_ITEM_RANGES": "1"}),
+        ("direct, the apply kernel pulls (no prefetch)", {"HPF_SCHEDULE": "direct", "HPF_DIRECT_PREFETCH": "0"}),
+        ("gather-early on RCCL", {"HPF_SCHEDULE": "gather-early"}),
+        ("finalize-then-gather on RCCL", {"HPF_SCHEDULE": "finalize-then-gather"}),
+        ("direct, user sweep 4 workgroups per CU", {"HPF_SCHEDULE": "direct", "HPF_SHARD_SWEEP_BPC": "4"}),
+    ]
+    CANDIDATES_ALL = [
+        ("gather-early on RCCL, one item range", {"HPF_SCHEDULE": "gather-early", "HPF_ITEM_RANGES": "1"}),
+        ("direct, item sweeps 6 workgroups per CU", {"HPF_SCHEDULE": "direct", "HPF_ITEM_SWEEP_BPC": "6"}),
+        ("direct, three item ranges", {"HPF_SCHEDULE": "direct", "HPF_ITEM_RANGES": "3"}),
+        # LAST: a second RCCL communicator active beside the first -- never run with more than one rank before
+        ("gather-carried on RCCL (two communicators)", {"HPF_SCHEDULE": "gather-carried"}),
+    ]
+    pinned = [v for v in TUNED if v in os.environ]
+    model = build_model()
+    if sharded and not args.no_autotune and not pinned:
+        tune_iters = 6 if os.environ.get("HPF_BENCH_SELFTEST_GLOO") == "1" else 20
+        times, failed, labels = {}, {}, {}
+        watchdog_state["autotune"], watchdog_state["meta"] = times, dict(
+            workload=label, users=nU, items=nI, nnz=nnz, k=k, world=world, rank=rank, workload_key=args.workload,
+            tune_iters=tune_iters)
         _arm_watchdog(float(os.environ.get("HPF_BENCH_WATCHDOG_S", "240")))
 
-        # (the one-GPU self-test of this code path -- N gloo ranks sharing a GPU -- times 6 iterations per candidate)
-        tune_iters = 6 if os.environ.get("HPF_BENCH_SELFTEST_GLOO") == "1" else 20
-        watchdog_state["meta"]["tune_iters"] = tune_iters
+        def short_run(m):
+            m.iterate_many(4, store)
+            joined_barrier(m)
+            t0 = time.perf_counter()
+            m.iterate_many(tune_iters, store)
+            joined_barrier(m)
+            return (time.perf_counter() - t0) / tune_iters * 1e3
 
-        def candidate(mode, chunks, istream, a2a, graph, direct="0", native="0", packed="0", early="0", room="3,32"):
-            # room: workgroups per CU of the user sweep / the item sweeps (the library defaults 3 / 32 leave one wave
-            # slot per SIMD and a quarter of the registers beside the user sweep to the collectives' kernels; 4 / 32
-            # fills every slot; 3 / 6 also keeps the item sweeps at 6 of their 8 waves per SIMD)
-            one_comm = early == "2/one-comm"      # gather-carried with the k-float all-reduces on the bulk communicator
-            early = early.split("/")[0]
-            env = {"HPF_SHARD_MODE": mode, "HPF_AR_CHUNKS": chunks, "HPF_ITEM_STREAM": istream, "HPF_RS_ALLTOALL": a2a,
-                   "HPF_GRAPH": graph, "HPF_RCCL_DIRECT": direct, "HPF_NATIVE_SHARD": native, "HPF_AG_PACKED": packed,
-                   "HPF_GATHER_EARLY": early, "HPF_SHARD_SWEEP_BPC": room.split(",")[0],
-                   "HPF_ITEM_SWEEP_BPC": room.split(",")[1], "HPF_CARRIED_ONE_COMM": "1" if one_comm else "0"}
-            os.environ.update(env)
-            key = "%s/%s%s%s%s%s%s%s%s%s" % (mode, chunks, "/room-%s" % room.replace(",", "-") if room != "3,32" else "",
-                                           "/item-stream" if istream == "1" else "",
-                                           "/all-to-all" if a2a == "1" else "", "/direct-rccl" if direct == "1" else "",
-                                           "/native" if native == "1" else "", "/packed-ag" if packed == "1" else "",
-                                           "/gather-early" if early == "1" else
-                                           "/gather-carried-one-comm" if one_comm else "/gather-carried" if early == "2" else "",
-                                           "/hipgraph" if graph == "1" else "")
-            t_ms, err, m = None, None, None
-
-            def joined_barrier():
-                # the model's own-communicator collectives may still be in flight on the exchange stream: join it
-                # before ANOTHER communicator's barrier (never two communicators with concurrent work on one device)
-                if getattr(m, "shard_mode", None) == "scatter":
-                    m._sync_scatter_streams()
-                torch.cuda.synchronize()
-                dist.barrier()
-                torch.cuda.synchronize()
-            try:
-                m = build_model()
-                m.iterate_many(4, not args.lean)         # (graph candidates: 2 eager + the capture + 1 replayed pair)
-                joined_barrier()
-                t0 = time.perf_counter()
-                m.iterate_many(tune_iters, not args.lean)
-                joined_barrier()
-                t_ms = (time.perf_counter() - t0) / tune_iters * 1e3
-                if graph == "1" and not any(g is not None for g in m.__dict__.get("_graphs", {}).values()):
-                    err, t_ms = "no hipGraph captured: %s" % getattr(m, "_graph_error", "backend not capturable"), None
-                if direct == "1" and getattr(m, "comm", None) is None:
-                    err, t_ms = "no communicator of our own (backend is not RCCL)", None
-                if native == "1" and getattr(m, "_plan", None) is None:
-                    err, t_ms = "no C-issued plan: %s" % (getattr(m, "native_error", None) or "backend has no RCCL"), None
-                m.flush_items()
-            except Exception as exc:   # noqa: BLE001
-                err = "%s: %s" % (type(exc).__name__, str(exc)[:200])
-            # every rank takes the same decision: a candidate counts only if it ran on ALL ranks
+        def agreed(t_ms):
+            # every rank takes the same decision: a candidate counts only if it ran on ALL ranks; slowest rank's time
             flag = torch.tensor([0.0 if t_ms is None else 1.0, t_ms or 0.0], dtype=torch.float64, device=device)
             ok = flag[:1].clone()
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             dist.all_reduce(flag[1:], op=dist.ReduceOp.MAX)
+            return float(flag[1].item()) if float(ok.item()) > 0 else None
+
+        # 1. the library default, held
+        default_key = "default: " + describe(model)
+        t = agreed(short_run(model))
+        if t is not None:
+            times[default_key] = t
+        watchdog_progress()
+        # 2. the alternatives
+        envs = {default_key: {}}
+        for lab, env in CANDIDATES + (CANDIDATES_ALL if args.autotune_all else []):
+            t_ms, err, m = None, None, None
+            os.environ.update(env)
+            try:
+                m = build_model()
+                key = describe(m) + ("" if all(v in ("HPF_SCHEDULE", "HPF_ITEM_RANGES", "HPF_DIRECT_PREFETCH") for v in env)
+                                     else "/" + ",".join("%s=%s" % kv for kv in sorted(env.items()) if "BPC" in kv[0]))
+                if m.schedule != env["HPF_SCHEDULE"]:
+                    err = "fell back to %s (%s)" % (m.schedule, m.native_error)
+                elif m._scatter_views() is not None and m._plan is None:
+                    err = "no C-issued plan (%s)" % (m.native_error or "backend without RCCL")
+                else:
+                    t_ms = short_run(m)
+                    m.flush_items()
+            except Exception as exc:   # noqa: BLE001
+                key = lab
+                err = "%s: %s" % (type(exc).__name__, str(exc)[:200])
+            t = agreed(t_ms)
             del m
             torch.cuda.empty_cache()
-            if float(ok.item()) > 0:
-                autotune[key] = float(flag[1].item())
+            for v in env:
+                os.environ.pop(v, None)
+            labels[key] = lab
+            if t is not None:
+                times[key] = t
+                envs[key] = env
             else:
                 failed[key] = err or "failed on another rank"
             watchdog_progress()
-            return key, env
-
-        envs = {}
-        # the plain all-reduce configurations go first: they are the most conservative use of RCCL
-        for cand in (("allreduce", "3", "0", "0", "0"), ("allreduce", "2", "0", "0", "0"), ("scatter", "2", "0", "0", "0"),
-                     ("scatter", "1", "0", "0", "0"), ("scatter", "2", "1", "0", "0"), ("scatter", "2", "0", "1", "0")):
-            key, env = candidate(*cand)
-            envs[key] = env
-        # the collectives on an RCCL communicator of our own (hpfrec_amd/rccl.py), still issued call by call from Python
-        key, env = candidate("scatter", "2", "0", "0", "0", "1")
-        envs[key] = env
-        # the library default on RCCL: the whole iteration issued by one C call on that communicator
-        # (hpf_hip_shard_iterate), with the new E rows all-gathered ld-padded or k-packed, in 2 ranges or 1; then the
-        # fastest of them replayed from captured hipGraphs (nothing of torch's polls that communicator's work, so the
-        # capture is safe)
-        for cand in (("scatter", "2", "0", "0", "0", "0", "1", "0"), ("scatter", "2", "0", "0", "0", "0", "1", "1"),
-                     ("scatter", "1", "0", "0", "0", "0", "1", "1"), ("scatter", "1", "0", "0", "0", "0", "1", "0"),
-                     # the gather-early schedule (split item finalizer: the all-gather runs under the user sweep)
-                     ("scatter", "2", "0", "0", "0", "0", "1", "0", "1"), ("scatter", "1", "0", "0", "0", "0", "1", "0", "1"),
-                     # gather-carried on ONE communicator: nothing new to RCCL; as good as the two-communicator form
-                     # below only if RCCL lets a communicator's operations on different streams overtake each other
-                     ("scatter", "2", "0", "0", "0", "0", "1", "0", "2/one-comm")):
-            key, env = candidate(*cand)
-            envs[key] = env
-        # LAST of the eager candidates (a second RCCL communicator is active beside the first -- never run with more
-        # than one rank before the driver's run; everything above has completed by now and the watchdog reports it
-        # should this hang): the gather-carried schedule, the exchange of an iteration running on into the next one
-        if os.environ.get("HPF_BENCH_TRY_CARRIED", "1") == "1":
-            for cand in (("scatter", "2", "0", "0", "0", "0", "1", "0", "2"), ("scatter", "3", "0", "0", "0", "0", "1", "0", "2"),
-                         # ... and with less / more room left on every CU for the exchange stream's kernels: beside
-                         # sweeps that fill every wave slot the shape half ran 4x slower and a collective-sized stand-in
-                         # stretched the user sweep by 20 % (one-GPU probes with emulated link time,
-                         # profiles/r03_shard_probe_gather_carried.txt, r03_shard_probe_collective_footprint.txt)
-                         ("scatter", "2", "0", "0", "0", "0", "1", "0", "2", "4,32"),
-                         ("scatter", "2", "0", "0", "0", "0", "1", "0", "2", "3,6"),
-                         ("scatter", "2", "0", "0", "0", "0", "1", "0", "1", "4,32"),
-                         ("scatter", "2", "0", "0", "0", "0", "1", "0", "1", "3,6")):
-                key, env = candidate(*cand)
-                envs[key] = env
-        # (not the gather-carried ones: three streams in one capture crashed the ROCm 7.0 runtime in round 2 with the
-        # item-stream form, and a crash -- unlike a hang -- leaves no line at all)
-        dr = {k_: v for k_, v in autotune.items() if "/native" in k_ and "gather-carried" not in k_}
-        # (envs[...] of the winner carries HPF_CARRIED_ONE_COMM too)
-        if dr and os.environ.get("HPF_BENCH_SELFTEST_GLOO") != "1":
-            base = envs[min(dr, key=dr.get)]
-            key, env = candidate("scatter", base["HPF_AR_CHUNKS"], "0", "0", "1", "0", "1", base["HPF_AG_PACKED"],
-                                 base["HPF_GATHER_EARLY"], base["HPF_SHARD_SWEEP_BPC"] + "," + base["HPF_ITEM_SWEEP_BPC"])
-            envs[key] = env
-        sc = {k_: v for k_, v in autotune.items() if k_.startswith("scatter") and "item-stream" not in k_
-              and "direct-rccl" not in k_ and "/native" not in k_}
-        # The fastest torch.distributed scatter configuration replayed from captured hipGraphs -- only on request
-        # (--try-hipgraph): in ~1 of 50 captures on this image torch's RCCL watchdog thread queried an event recorded
-        # into the capture (hipErrorCapturedEvent) and aborted the process (profiles/r02_hipgraph_watchdog_abort.txt); a
-        # benchmark line must not depend on that.
-        if sc and args.try_hipgraph:
-            base = envs[min(sc, key=sc.get)]
-            key, env = candidate(base["HPF_SHARD_MODE"], base["HPF_AR_CHUNKS"], "0", base["HPF_RS_ALLTOALL"], "1")
-            envs[key] = env
-        # ^ (legacy Python-issued candidates pin HPF_NATIVE_SHARD=0 / HPF_AG_PACKED=0 through candidate()'s defaults)
-        if autotune:
-            best = min(autotune, key=autotune.get)
+        best = min(times, key=times.get) if times else None
+        # only a clear win displaces the default (2 %: run-to-run noise of a 20-iteration measurement)
+        if best is not None and best != default_key and default_key in times and times[best] > 0.98 * times[default_key]:
+            best = default_key
+        autotune = {"ms_per_iteration": dict(times), "chosen": best, "default": default_key, "failed": failed,
+                    "candidates": 1 + len(labels), "labels": labels}
+        if best is not None and best != default_key:
+            model.flush_items()
+            del model
+            torch.cuda.empty_cache()
             os.environ.update(envs[best])
-        else:       # nothing completed everywhere: the library defaults
-            best = None
-            for v in TUNED:
-                os.environ.pop(v, None)
-        autotune = {"ms_per_iteration": autotune, "chosen": best, "failed": failed}
-    model = build_model()
+            model = build_model()
     del lu, li, ly, init, Theta, Beta
     torch.cuda.empty_cache()
 
     if args.no_fuse:
         model.set_fused(False)
-    store = not args.lean
 
     def fence():
         watchdog_progress()
         if dist:
-            if getattr(model, "shard_mode", None) == "scatter":
-                model._sync_scatter_streams()     # (exchange stream joined before another communicator's barrier)
+            model._sync_scatter_streams()     # (exchange stream joined before another communicator's barrier)
             dist.barrier()
         torch.cuda.synchronize()
 
-    # (iterate_many: plain iterate() calls, or -- N>1 with HPF_GRAPH=1 -- pairs replayed from a captured hipGraph)
-    model.iterate_many(max(args.warmup, 4 if os.environ.get("HPF_GRAPH") == "1" else 1), store)   # untimed: code-object
-    fence()                                                                   # load, first touch, graph capture
+    model.iterate_many(max(args.warmup, 1), store)   # untimed: code-object load, first touch
+    fence()
     # N=1: every launch of the timed region is bracketed with HIP events (roofline.achieved comes from them).
     # N>1: an iteration is ~10 short launches, and two event records per launch cost ~9 % of it (measured with
     # tools/shard_probe.py), so the event-bracketed iterations are a separate pass right after the timed region.
@@ -589,6 +587,8 @@ def main():
     if sharded:
         try:
             collective = exchange_report(model, dist, world, device, dt / args.steps * 1e3, store, fence)
+            if "ranks" in collective:       # the exchange really spans the job: N ranks, as the carrier itself reports
+                collective["ranks_equal_n_gpus"] = bool(collective["ranks"] == world)
         except Exception as exc:   # noqa: BLE001  (the line must survive)
             collective = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
 
@@ -608,7 +608,7 @@ def main():
                 # both sides run sweep_kernel with the row finalizer fused in (sharded: the item side in ranges,
                 # as prologue): one user-side launch + the item-side launches own this rank's iteration bytes
                 # (scatter mode: this rank finalizes only its 1/N slice of the item rows)
-                ni_rank = model.nI / world if getattr(model, "shard_mode", None) == "scatter" else model.nI
+                ni_rank = model.nI / world
                 b_rank = n_loc * (8 + 8 * k) + model.nU * (12 + 20 * k) + ni_rank * (4 + 24 * k)
                 fused = [ksum[n] for n in ("sweep_finalize", "sweep_prefinalize", "sweep") if n in ksum]
                 t_both = sum(v["total_ms"] for v in fused) / ev_steps * 1e-3     # per iteration, both sides
@@ -661,26 +661,14 @@ def main():
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": label, "users": nU, "items": nI, "nnz": nnz, "k": k, "ld": model.ld,
-                       "parallelism": (("users sharded x%d; item statistics reduce-scattered in %d pipelined ranges (RCCL), "
-                                        "each rank finalizes 1/%d of the items, new E rows all-gathered under the next "
-                                        "item sweep" % (world, len(model.item_chunks), world))
-                                       if model.shard_mode == "scatter" else
-                                       ("users sharded x%d; item statistics all-reduced per iteration in %d pipelined "
-                                        "ranges (RCCL), item finalize deferred into the next item sweep"
-                                        % (world, len(model.item_chunks)))) if world > 1 else "1 GPU",
+                       "parallelism": SCHEDULE_TEXT.get(getattr(model, "schedule", None), "%s") % (
+                           world, len(model.item_chunks or [])) if sharded else "1 GPU",
+                       "schedule": getattr(model, "schedule", None) if sharded else None,
                        "exchange_autotune": autotune,
-                       "hipgraph_pairs": any(g is not None for g in model.__dict__.get("_graphs", {}).values()),
-                       "direct_rccl_communicator": getattr(model, "comm", None) is not None,
                        "iteration_issued_by": ("one C call (hpf_hip_shard_iterate)" if getattr(model, "_plan", None)
                                                is not None else "python, call by call") if sharded else None,
                        "native_plan_error": getattr(model, "native_error", None) if sharded else None,
-                       "e_rows_all_gathered": ("[k numerators | base rate] rows range by range, applied at the start of "
-                                               "the next iteration" if getattr(model, "gather_carried", False) else
-                                               "[k numerators | base rate] rows in one collective, under the user sweep"
-                                               if getattr(model, "gather_early", False) else
-                                               "k-packed + unpack launch" if getattr(model, "ag_packed", False)
-                                               else "ld-padded, straight into the table") if sharded and
-                       getattr(model, "shard_mode", None) == "scatter" else None,
+                       "first_iteration_check": getattr(model, "first_check", None) if sharded else None,
                        "seg_cap": cavi.layout.SEG_CAP, "fused_finalize": model.fused and world == 1,
                        "stores_all_state_tables": store, "state_finite": finite},
             "roofline": roof,
@@ -695,7 +683,7 @@ def main():
             line["train_llk_after_run"] = llk_val
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(nU, nI, k, nnz, device=device)
+                line["cpu_baseline"] = cpu_baseline(nU, nI, k, nnz, device=device, triplets=host_triplets)
             except Exception as e:  # the bench line must survive a broken host toolchain
                 line["cpu_baseline"] = {"value": None, "error": repr(e)}
         else:
@@ -716,28 +704,30 @@ def main():
 
 
 def exchange_report(model, dist, world, device, ms_per_step, store, fence, reps=10):
-    """N>1: the `collective` block of the line.  (1) The exchange ALONE: the iteration's reduce-scatters, all-gathers
-    (+ unpack) and k-float all-reduces issued back to back with nothing else on the GPU, HIP events around each group,
-    slowest rank reported -- bytes per rank, ms, algorithm and bus GB/s (nccl-tests' convention: bytes * (n-1)/n / t).
-    (2) The compute ALONE: the same iterations with every collective replaced by its one-rank form (the plan's dry run:
-    this rank's slice copied locally), barrier-bracketed -> exposed_ms = iteration - compute_only: what the schedule
-    failed to hide.  Needs the C-issued plan (RCCL, or the self-test's gloo callback); the state is garbage afterwards."""
-    from hpfrec_amd import shard_native as sn
+    """N>1: the `collective` block of the line.  (1) The exchange ALONE, with nothing else on the GPU, HIP events around
+    each group, slowest rank reported: RCCL schedules -- the iteration's reduce-scatters, all-gathers and k-float
+    all-reduces back to back; direct schedule -- the kernels that carry it: the pulling shape halves, the pull of the
+    finished rows, the granule all-reduce.  Bytes per rank, ms, algorithm and bus GB/s (nccl-tests' convention: bytes *
+    (n-1)/n / t; for the pulls that IS the traffic on the links).  (2) The compute ALONE: the same iterations with the
+    exchange emulated locally (the plan's dry run: this rank alone), barrier-bracketed -> exposed_ms = iteration -
+    compute_only: what the schedule failed to hide.  Needs the C-issued plan; the state is garbage afterwards."""
+    import ctypes
+    from hpfrec_amd import p2p, shard_native as sn
+    model._scatter_views()
     plan = getattr(model, "_plan", None)
-    if plan is None and getattr(model, "shard_mode", None) == "scatter":
-        model._scatter_views()
-        plan = model._plan
     if plan is None:
-        return {"skipped": "no C-issued plan on this configuration (%s)" %
-                (getattr(model, "native_error", None) or "exchange mode %s" % getattr(model, "shard_mode", None))}
+        return {"skipped": "no C-issued plan on this configuration (%s)" % getattr(model, "native_error", None)}
     k, ld, W = model.k, model.ld, world
     views = model._chunk_views
     rows = sum(c["hi"] - c["lo"] for c in views)
     e_ld = int(model.e_own_all.shape[1])
-    comm = None
-    for c in list(cavi._DIRECT_COMMS.values()):
-        comm = c
-    ranks = comm.count() if comm is not None else None
+    direct = model.schedule == "direct"
+    if direct:
+        ranks, ranks_src = model._region.world, "ranks of the peer-mapped region (every one of them mapped by this rank)"
+    elif model.comm is not None:
+        ranks, ranks_src = model.comm.count(), "ncclCommCount of the iteration's communicator"
+    else:
+        ranks, ranks_src = W, "torch.distributed world size (no RCCL communicator: gloo callback)"
     cur = lambda: torch.cuda.current_stream(device).cuda_stream   # noqa: E731
     fence()
 
@@ -756,16 +746,24 @@ def exchange_report(model, dist, world, device, ms_per_step, store, fence, reps=
     rs_ms = timed(lambda: [plan.exchange_only(sn.COLL_REDUCE_SCATTER, j, cur()) for j in range(len(views))])
     ag_ms = timed(lambda: [plan.exchange_only(sn.COLL_ALL_GATHER, j, cur()) for j in range(len(views))])
     ar_ms = timed(lambda: [plan.exchange_only(sn.COLL_ALL_REDUCE, -1, cur()) for _ in range(2)])
-    rs_bytes, ag_bytes = rows * k * 4, rows * e_ld * 4           # the whole buffer a collective spans, per rank
+    if direct:
+        plan.status()
+    rs_bytes, ag_bytes = rows * k * 4, rows * e_ld * 4           # the whole buffer an exchange step spans, per rank
     bus = (W - 1) / W
 
-    # compute only: a dry-run twin of the plan over the same tensors
-    import ctypes
+    # compute only: a dry-run twin of the plan over the same tensors (direct: over a region connected to itself)
     d = sn.ShardDesc()
     ctypes.memmove(ctypes.byref(d), ctypes.byref(plan.desc), ctypes.sizeof(d))
     d.dry_run, d.comm, d.comm_small, d.coll_ctx = 1, None, None, None
     d.coll = sn.COLLECTIVE_FN()
-    dry = sn.ShardPlan(d, keep=plan.keep)
+    keep = list(plan.keep)
+    if direct:
+        twin = p2p.PeerRegion(device, model._region.data_bytes, ld, rank=model.rank, world=W, local=True)
+        d.p2p_region = twin.handle.value
+        d.acc_i = twin.data_ptr() + d.p2p_acc_offset
+        d.e_own = twin.data_ptr() + d.p2p_send_offset
+        keep.append(twin)
+    dry = sn.ShardPlan(d, keep=keep)
     fence()
     its = 20
     stream = cur()
@@ -785,24 +783,19 @@ def exchange_report(model, dist, world, device, ms_per_step, store, fence, reps=
     dist.all_reduce(comp, op=dist.ReduceOp.MAX)
     comp_ms = float(comp.item())
     dry.close()
-    return {"ranks": ranks if ranks is not None else W,
-            "ranks_source": "ncclCommCount of the iteration's communicator" if ranks is not None
-            else "torch.distributed world size (no RCCL communicator: gloo callback)",
-            "ranges": len(views),
+    return {"ranks": ranks, "ranks_source": ranks_src, "ranges": len(views),
+            "carried_by": "kernels of the iteration pulling peer-mapped memory (no collective library)" if direct
+            else "RCCL collectives on a communicator of our own" if model.comm is not None else "gloo behind the plan's callback",
             "bytes_per_rank": {"reduce_scatter_buffer": rs_bytes, "all_gather_buffer": ag_bytes,
                                "sent_and_received_per_rank": (rs_bytes + ag_bytes) * bus, "small_all_reduces": 2 * ld * 4},
-            "schedule": "gather-carried (range by range; the apply half carried into the next iteration)"
-            if getattr(model, "gather_carried", False) else
-            "gather-early (all-gather under the user sweep)" if getattr(model, "gather_early", False)
-            else "finalize-then-gather",
-            "rs_ms": rs_ms, "ag_ms": ag_ms, "ag_includes_unpack": bool(getattr(model, "ag_packed", False)),
-            "small_allreduce_ms_each": ar_ms / 2,
+            "schedule": model.schedule,
+            "rs_ms": rs_ms, "ag_ms": ag_ms, "small_allreduce_ms_each": ar_ms / 2,
             "algbw_GBps": {"reduce_scatter": rs_bytes / rs_ms / 1e6, "all_gather": ag_bytes / ag_ms / 1e6},
             "busbw_GBps": {"reduce_scatter": rs_bytes * bus / rs_ms / 1e6, "all_gather": ag_bytes * bus / ag_ms / 1e6},
             "exchange_alone_ms": rs_ms + ag_ms + ar_ms, "compute_only_ms": comp_ms, "iteration_ms": ms_per_step,
             "exposed_ms": ms_per_step - comp_ms,
-            "note": "exchange alone: back-to-back collectives, nothing else running; compute only: every collective "
-                    "replaced by the local copy of this rank's slice (state not meaningful afterwards)"}
+            "note": "exchange alone: back to back, nothing else running (direct: rs = the pulling shape halves, ag = the "
+                    "pull of the finished rows); compute only: the exchange emulated locally (state not meaningful afterwards)"}
 
 
 def kernel_source_sha16():

@@ -194,9 +194,10 @@ class FullBatchCavi(ShardedMixin):
         mine = slice(u0 * k, (u0 + nU) * k)          # this rank's rows of a user table's words
         draws = (raw[: nUg * k][mine], raw[nUg * k: (nUg + nI) * k],
                  raw[(nUg + nI) * k: (2 * nUg + nI) * k][mine], raw[(2 * nUg + nI) * k:])
-        ops.uniform_rows(draws[0], self.Gamma_rte, nU, k, ld, hy.a_prime, 0.01)
+        if nU > 0:
+            ops.uniform_rows(draws[0], self.Gamma_rte, nU, k, ld, hy.a_prime, 0.01)
+            ops.uniform_rows(draws[2], self.Gamma_shp, nU, k, ld, hy.a_prime, 0.01, den=self.Gamma_rte, ratio=self.Theta)
         ops.uniform_rows(draws[1], self.Lambda_rte, nI, k, ld, hy.c_prime, 0.01)
-        ops.uniform_rows(draws[2], self.Gamma_shp, nU, k, ld, hy.a_prime, 0.01, den=self.Gamma_rte, ratio=self.Theta)
         ops.uniform_rows(draws[3], self.Lambda_shp, nI, k, ld, hy.c_prime, 0.01, den=self.Lambda_rte, ratio=self.Beta)
         self.k_rte.fill_(float(hy.b_prime))
         self.t_rte[: self.nI].fill_(float(hy.d_prime))
@@ -208,7 +209,8 @@ class FullBatchCavi(ShardedMixin):
 
     def refresh_expectations(self):
         ops, k, ld = self.ops, self.k, self.ld
-        ops.expect(self.Gamma_shp, self.Gamma_rte, self.eT, self.nU, k, ld)
+        if self.nU > 0:
+            ops.expect(self.Gamma_shp, self.Gamma_rte, self.eT, self.nU, k, ld)
         ops.expect(self.Lambda_shp, self.Lambda_rte, self.eB, self.nI, k, ld)
         ops.colsum(self.Beta, self.nI, ld, self.cs_scratch)
         ops.colsum_reduce(self.cs_scratch, self.csB, ld)
@@ -228,6 +230,8 @@ class FullBatchCavi(ShardedMixin):
         are finished by a small follow-up launch over side.multi_rows."""
         ops, k, ld = self.ops, self.k, self.ld
         shp, fac = (shp, fac) if store else (None, None)
+        if nrows == 0:          # (a rank without users: its column-sum partial rows stay zero)
+            return
         if self.fused and side.nseg > 0:
             ops.sweep_finalize(side, e_self, e_other, part, e_new, shp, None, fac, rs, cs_other, cs_part[:gs],
                                prior, top, add, k, ld, rs_prev=rs_prev)
@@ -271,7 +275,10 @@ class FullBatchCavi(ShardedMixin):
     def llk_terms(self, full_llk=False):
         """Global (all-reduced) float64 [sum y*log(yhat)(-lgamma), sum sq.err, sum yhat, nnz] over the training nonzeros."""
         self.flush_items()
-        t = self.ops.llk_sweep(self.users, self.Theta, self.Beta, self.k, self.ld, full_llk)
+        if self.nU > 0:
+            t = self.ops.llk_sweep(self.users, self.Theta, self.Beta, self.k, self.ld, full_llk)
+        else:                   # (a rank without users contributes nothing)
+            t = torch.zeros(3, dtype=torch.float64, device=self.device)
         out = torch.cat([t.to(torch.float64), torch.tensor([float(self.nnz)], dtype=torch.float64,
                                                            device=t.device)])
         if self.dist:
@@ -292,8 +299,11 @@ class FullBatchCavi(ShardedMixin):
         """(sum_u Theta) . (sum_i Beta) in float32, the subtrahend of the train llk (PXI:78)."""
         self.flush_items()
         if self.niter_done == 0:
-            self.ops.colsum(self.Theta, self.nU, self.ld, self.cs_scratch)
-            self.ops.colsum_reduce(self.cs_scratch, self.csT, self.ld)
+            if self.nU > 0:
+                self.ops.colsum(self.Theta, self.nU, self.ld, self.cs_scratch)
+                self.ops.colsum_reduce(self.cs_scratch, self.csT, self.ld)
+            else:
+                self.csT.zero_()
             if self.dist:
                 self.dist.all_reduce(self.csT)
         a = self.csT[: self.k].cpu().numpy()

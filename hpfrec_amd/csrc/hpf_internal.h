@@ -56,6 +56,9 @@ int colsum_reduce_allreduce(const float *cs_partial, int nblk, float *cs_out, in
 namespace hpf_p2p {
 int gather_pull(void *region, int64_t src_offset_bytes, float *dst, int64_t floats_per_rank, int signal_kind, int done_kind,
                 uint32_t epoch, int gx, hipStream_t st);
+// `st` continues once every peer in src_mask has raised every flag kind of the bit mask `kinds` to epoch and (self_kind >= 0)
+// this rank its own flag self_kind: ONE waiting wavefront.  Put in front of every consumer with a large grid.
+int wait_flags(void *region, uint32_t kinds, uint32_t epoch, uint32_t src_mask, int self_kind, hipStream_t st);
 // this rank's Peers in device memory (plan-lifetime copy inside the region's control block header is not possible:
 // the block is fine-grained; a small plain allocation owned by the region)
 const Peers *region_peers_dev(void *region);

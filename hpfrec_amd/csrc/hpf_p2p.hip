@@ -58,8 +58,13 @@ __global__ void p2p_signal_kernel(const hpf_p2p::Peers pp, int kind, uint32_t ep
     hpf_p2p::wave_signal(pp, kind, epoch);
 }
 
-__global__ void p2p_wait_kernel(const hpf_p2p::Peers pp, int kind, uint32_t epoch, uint32_t mask) {
-    hpf_p2p::block_acquire(pp, kind, epoch, mask);
+// ONE wavefront waits; the kernels behind it on the stream then find their flags raised.  Consumers with large grids never
+// wait themselves: hundreds of polling workgroups would take the wave slots the PRODUCER of the flag needs to start -- its
+// flag is raised on entry of a launch of this rank's other stream (or, on a shared GPU, of another process).
+__global__ void p2p_wait_kernel(const hpf_p2p::Peers pp, uint32_t kinds, uint32_t epoch, uint32_t mask, int self_kind) {
+    for (int kind = 0; kind < HPF_P2P_NKINDS; kind++)
+        if ((kinds >> kind) & 1u) hpf_p2p::block_acquire(pp, kind, epoch, mask);
+    if (self_kind >= 0) hpf_p2p::block_acquire_self(pp, self_kind, epoch);
 }
 
 // vec[c] <- sum over the ranks of vec[c], in rank order (identical floats on every rank); one thread per column
@@ -144,6 +149,14 @@ bool region_view(void *region, Peers *pp, void **data /* [HPF_P2P_MAX_RANKS] */,
     *rank = r->rank;
     *ld = r->ld;
     return true;
+}
+
+int wait_flags(void *region, uint32_t kinds, uint32_t epoch, uint32_t src_mask, int self_kind, hipStream_t st) {
+    if (!region) return HPF_EINVAL;
+    Region *r = (Region *)region;
+    if (!r->connected || self_kind >= HPF_P2P_NKINDS) return HPF_EINVAL;
+    hipLaunchKernelGGL(p2p_wait_kernel, dim3(1), dim3(64), 0, st, peers_of(r), kinds, epoch, src_mask, self_kind);
+    return (int)hipGetLastError();
 }
 
 const Peers *region_peers_dev(void *region) {
@@ -320,7 +333,8 @@ int hpf_hip_p2p_wait(void *region, int kind, uint32_t epoch, uint32_t src_mask, 
     if (!region || kind < 0 || kind >= HPF_P2P_NKINDS) return HPF_EINVAL;
     Region *r = (Region *)region;
     if (!r->connected) return HPF_EINVAL;
-    hipLaunchKernelGGL(p2p_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, peers_of(r), kind, epoch, src_mask);
+    hipLaunchKernelGGL(p2p_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, peers_of(r), 1u << kind, epoch, src_mask,
+                       -1);
     return (int)hipGetLastError();
 }
 

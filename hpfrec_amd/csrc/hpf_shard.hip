@@ -290,6 +290,9 @@ int direct_shape_pull(Plan *p, int j, hipStream_t xs) {
         acc[q] = reinterpret_cast<const float *>(reinterpret_cast<const char *>(p->peer_data[q]) + d.p2p_acc_offset);
     // a single-process emulation reads every rank's slice (the traffic) and counts its own (the value)
     const uint32_t mask = p->pp.emulate ? (1u << d.rank) : ((d.world >= 32) ? 0xFFFFFFFFu : ((1u << d.world) - 1u));
+    // ONE wavefront waits for the peers' flags; the shape kernel's workgroups then only take the acquire (a grid of
+    // polling workgroups would sit on the wave slots this rank's next compute-stream launch needs to raise ITS flag)
+    HPF_TRY(hpf_p2p::wait_flags(d.p2p_region, wait, p->epoch, 0xFFFFFFFFu, -1, xs));
     HPF_TRY(hpf_direct::item_shape_pull(acc, d.world, mask, wait, p->epoch, p->pp, n_real, p->t0[j], o0, d.eB, d.shp_own,
                                         d.e_own, d.t_rte, d.t_rte_prev, d.c, d.t_shp, d.k, d.ld,
                                         d.csB_part_rows, xs));
@@ -401,18 +404,19 @@ int hpf_hip_shard_desc_layout(int64_t out[4]) {
 int hpf_hip_shard_plan_create(const hpf_shard_desc *desc, void **plan) {
     if (!desc || !plan) return HPF_EINVAL;
     const hpf_shard_desc &d = *desc;
-    if (d.world <= 0 || d.rank < 0 || d.rank >= d.world || d.k <= 0 || d.ld != hpf_hip_ld_for_k(d.k) || d.nU <= 0 ||
+    if (d.world <= 0 || d.rank < 0 || d.rank >= d.world || d.k <= 0 || d.ld != hpf_hip_ld_for_k(d.k) || d.nU < 0 ||
         d.nI <= 0 || d.nranges <= 0 || d.nranges > HPF_MAX_ROW_RANGES)
-        return HPF_EINVAL;
+        return HPF_EINVAL;          // (nU == 0: a rank without a single user still takes part in every exchange step)
     // (a rank may hold no nonzeros at all -- fewer users than ranks, or one user with most of them: u_nseg == 0 and every
     //  row is finished by the row finalizer over u_multi_rows; zero-length arrays have null pointers then)
     if (d.u_nseg < 0 || !d.u_row_seg_ptr || (d.u_nmulti > 0 && !d.u_multi_rows) || !d.i_row_seg_ptr)
         return HPF_EINVAL;
     if (d.u_nseg > 0 && (!d.u_segs || !d.u_idx || !d.u_y || !d.i_segs || !d.i_idx || !d.i_y)) return HPF_EINVAL;
-    if (!d.eB || !d.part_u || !d.part_i || !d.Gamma_shp || !d.Theta || !d.k_rte || !d.k_rte_prev || !d.Lambda_shp ||
+    if (!d.eB || !d.part_u || !d.part_i || !d.Lambda_shp ||
         !d.Beta || !d.t_rte || !d.t_rte_prev || !d.csT || !d.csB || !d.csB_used || !d.csT_part || !d.csB_part ||
         !d.acc_i || !d.acc_own || !d.e_own || !d.xstream)
         return HPF_EINVAL;
+    if (d.nU > 0 && (!d.Gamma_shp || !d.Theta || !d.k_rte || !d.k_rte_prev)) return HPF_EINVAL;
     if (d.user_sweep_grid <= 0 || d.user_multi_grid <= 0 || d.user_sweep_grid + d.user_multi_grid > d.csT_part_rows ||
         d.csB_part_rows <= 0 || d.item_sweep_grid <= 0)
         return HPF_EINVAL;
@@ -649,7 +653,8 @@ static int iterate_gather_early(Plan *p, const float *eT, float *eT_next, int st
         HPF_TRY(hpf_hip_sweep_finalize_f32(d.u_segs, d.u_nseg, d.u_idx, d.u_y, eT, d.eB, d.part_u, eT_next, shp, nullptr, fac,
                                        d.k_rte, d.k_rte_prev, d.csB, d.csT_part, d.a, d.k_shp, d.add_k_rte, k, ld,
                                        d.user_sweep_grid, (void *)cs));
-    HPF_TRY(hpf_hip_row_finalize_f32(d.part_u, d.u_row_seg_ptr, d.u_multi_rows, d.u_nmulti, eT, eT_next, shp, nullptr, fac,
+    if (d.u_nmulti > 0)      // (its column-sum partial rows stay zero otherwise: never written)
+        HPF_TRY(hpf_hip_row_finalize_f32(d.part_u, d.u_row_seg_ptr, d.u_multi_rows, d.u_nmulti, eT, eT_next, shp, nullptr, fac,
                                      d.k_rte, d.k_rte_prev, d.csB, d.csT_part + (size_t)d.user_sweep_grid * ld, d.a,
                                      d.k_shp, d.add_k_rte, k, ld, ld, d.user_multi_grid, (void *)cs));
     HPF_TRY(hpf_hip_colsum_reduce_f32(d.csT_part, d.csT_part_rows, d.csT, ld, (void *)cs));
@@ -716,7 +721,8 @@ static int iterate_gather_carried(Plan *p, const float *eT, float *eT_next, int 
         HPF_TRY(hpf_hip_sweep_finalize_f32(d.u_segs, d.u_nseg, d.u_idx, d.u_y, eT, d.eB, d.part_u, eT_next, shp, nullptr, fac,
                                        d.k_rte, d.k_rte_prev, d.csB, d.csT_part, d.a, d.k_shp, d.add_k_rte, k, ld,
                                        d.user_sweep_grid, (void *)cs));
-    HPF_TRY(hpf_hip_row_finalize_f32(d.part_u, d.u_row_seg_ptr, d.u_multi_rows, d.u_nmulti, eT, eT_next, shp, nullptr, fac,
+    if (d.u_nmulti > 0)      // (its column-sum partial rows stay zero otherwise: never written)
+        HPF_TRY(hpf_hip_row_finalize_f32(d.part_u, d.u_row_seg_ptr, d.u_multi_rows, d.u_nmulti, eT, eT_next, shp, nullptr, fac,
                                      d.k_rte, d.k_rte_prev, d.csB, d.csT_part + (size_t)d.user_sweep_grid * ld, d.a,
                                      d.k_shp, d.add_k_rte, k, ld, ld, d.user_multi_grid, (void *)cs));
     HPF_TRY(hpf_hip_colsum_reduce_f32(d.csT_part, d.csT_part_rows, d.csT, ld, (void *)cs));
@@ -796,7 +802,8 @@ static int iterate_direct(Plan *p, const float *eT, float *eT_next, int store, h
             if (store) HIP_TRY(hipMemcpyAsync(d.csB_used, d.csB, (size_t)ld * sizeof(float), hipMemcpyDeviceToDevice, cs));
         }
     }
-    HPF_TRY(hpf_hip_row_finalize_f32(d.part_u, d.u_row_seg_ptr, d.u_multi_rows, d.u_nmulti, eT, eT_next, shp, nullptr, fac,
+    if (d.u_nmulti > 0)      // (its column-sum partial rows stay zero otherwise: never written)
+        HPF_TRY(hpf_hip_row_finalize_f32(d.part_u, d.u_row_seg_ptr, d.u_multi_rows, d.u_nmulti, eT, eT_next, shp, nullptr, fac,
                                      d.k_rte, d.k_rte_prev, d.csB, d.csT_part + (size_t)d.user_sweep_grid * ld, d.a,
                                      d.k_shp, d.add_k_rte, k, ld, ld, d.user_multi_grid, (void *)cs));
     HPF_TRY(direct_colsum_allreduce(p, d.csT_part, d.csT_part_rows, d.csT, HPF_P2P_VEC_CST, cs));
@@ -805,6 +812,12 @@ static int iterate_direct(Plan *p, const float *eT, float *eT_next, int store, h
         g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_ITEM_APPLY, cs,
                   1 + (d.direct_prefetch ? HPF_P2P_FLAG_GATHERED : HPF_P2P_FLAG_SHAPED(0)));
     } else {
+        // (one waiting wavefront ahead of the apply's large grid: GATHERED of this rank, or every owner's SHAPED)
+        if (d.direct_prefetch)
+            HPF_TRY(hpf_p2p::wait_flags(d.p2p_region, 0u, p->epoch, 0u, HPF_P2P_FLAG_GATHERED, cs));
+        else
+            HPF_TRY(hpf_p2p::wait_flags(d.p2p_region, 1u << HPF_P2P_FLAG_SHAPED(0), p->epoch, 0xFFFFFFFFu,
+                                        HPF_P2P_FLAG_SHAPED(0), cs));
         const float *blocks[HPF_P2P_MAX_RANKS];
         for (int q = 0; q < d.world; q++)
             blocks[q] = d.direct_prefetch
@@ -831,8 +844,9 @@ int hpf_hip_shard_status(void *plan) {
 }
 
 int hpf_hip_shard_iterate(void *plan, const float *eT, float *eT_next, int store, void *compute_stream) {
-    if (!plan || !eT || !eT_next || eT == eT_next) return HPF_EINVAL;
+    if (!plan) return HPF_EINVAL;
     Plan *p = (Plan *)plan;
+    if (p->d.nU > 0 && (!eT || !eT_next || eT == eT_next)) return HPF_EINVAL;
     TraceScope scope(p->tracing ? &p->tracer : nullptr);
     if (p->d.schedule == HPF_SCHEDULE_DIRECT) return iterate_direct(p, eT, eT_next, store, (hipStream_t)compute_stream);
     if (p->d.schedule == HPF_SCHEDULE_GATHER_EARLY)
@@ -870,7 +884,8 @@ int hpf_hip_shard_iterate(void *plan, const float *eT, float *eT_next, int store
         HPF_TRY(hpf_hip_sweep_finalize_f32(d.u_segs, d.u_nseg, d.u_idx, d.u_y, eT, d.eB, d.part_u, eT_next, shp, nullptr, fac,
                                        d.k_rte, d.k_rte_prev, d.csB, d.csT_part, d.a, d.k_shp, d.add_k_rte, k, ld,
                                        d.user_sweep_grid, (void *)cs));
-    HPF_TRY(hpf_hip_row_finalize_f32(d.part_u, d.u_row_seg_ptr, d.u_multi_rows, d.u_nmulti, eT, eT_next, shp, nullptr, fac,
+    if (d.u_nmulti > 0)      // (its column-sum partial rows stay zero otherwise: never written)
+        HPF_TRY(hpf_hip_row_finalize_f32(d.part_u, d.u_row_seg_ptr, d.u_multi_rows, d.u_nmulti, eT, eT_next, shp, nullptr, fac,
                                      d.k_rte, d.k_rte_prev, d.csB, d.csT_part + (size_t)d.user_sweep_grid * ld, d.a,
                                      d.k_shp, d.add_k_rte, k, ld, ld, d.user_multi_grid, (void *)cs));
     HPF_TRY(hpf_hip_colsum_reduce_f32(d.csT_part, d.csT_part_rows, d.csT, ld, (void *)cs));

@@ -472,7 +472,9 @@ int hpf_hip_svi_batch_prepare(const hpf_svi_batch *b, void *stream) {
         return HPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     auto grid_for = [](int64_t n, int per) { int64_t g = (n + per - 1) / per; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); };
-    hipError_t e = hipMemsetAsync(b->sizes, 0, 8 * sizeof(int64_t), st);
+    // sizes[0..6] are this batch's; sizes[7], the overflow flag, is STICKY: the driver reads it once after all epochs, and
+    // a truncated segment list of an earlier batch must not be forgotten (the workspace zeroes it at allocation)
+    hipError_t e = hipMemsetAsync(b->sizes, 0, 7 * sizeof(int64_t), st);
     if (e != hipSuccess) return (int)e;
     if (b->nprev > 0)
         hipLaunchKernelGGL(svi_mark_kernel, dim3(grid_for(b->nprev, BLOCK)), dim3(BLOCK), 0, st, b->prev_ids, b->nprev,

@@ -36,6 +36,7 @@ _EARLY = ("direct", "gather-early", "gather-carried")      # split item finalize
 _DIRECT_COMMS = {}
 _VERIFIED = {}                  # (schedule, world, device) -> bool: the first-iteration check of this process
 NATIVE_PLANS_CREATED = [0]      # how many models of this process run their sharded iteration from C (tests, bench)
+LAST_SCHEDULE = [None]          # "<schedule>" / "<schedule>, call by call" of the last model that set its exchange up
 _side_stream = _streams.side_stream
 
 
@@ -163,6 +164,7 @@ class ShardedMixin:
             raise RuntimeError("hpfrec_amd: the %s schedule is C-issued only and no plan could be created (%s)"
                                % (self.schedule, "; ".join(errors) or "HPF_NATIVE_SHARD=0 / unfused"))
         self.native_error = "; ".join(errors) if errors else None
+        LAST_SCHEDULE[0] = self.schedule + ("" if self._plan is not None else ", call by call")
         if errors:
             warnings.warn("hpfrec_amd: sharded schedule fell back to %s%s (%s)"
                           % (self.schedule, "" if self._plan is not None else ", call by call from Python", self.native_error))

@@ -281,7 +281,8 @@ int hpf_hip_fold_in_f32(const int32_t *idx, const float *y, int64_t n, const flo
  *               them (ascending own-side ids: stable, no sort): o_idx = own-side row id, o_y = count, o_segs / o_multi as
  *               above with `begin` indexing o_idx / o_y; flag_oth[row] = 1 for rows present, 0 for all others.
  * sizes[0..8) (device int64): segments own, split rows own, segments other, split rows other, nonzeros, rows other, -,
- * overflow (a capacity was too small; never with capacities from the side's largest rows).  Nothing is read back: the
+ * overflow (a capacity was too small; never with capacities from the side's largest rows; STICKY: entries 0..6 are reset
+ * by every call, the overflow flag only by the caller, so one read after many batches sees any of them).  Nothing is read back: the
  * consumers take their counts from `sizes` (hpf_hip_sweep_f32 nseg_dev, hpf_hip_segsum_desc_f32, hpf_hip_expect_f32 flag).
  * How: the own side is a stable compaction of its segment list; the other side is the other side's flat nonzero array
  * (already grouped by its rows, own-side ids ascending inside a row) filtered by flag_own -- a keep-bitmask pass, prefix

@@ -81,7 +81,13 @@ def _run(rank, world, port, out_dir, k, its, case, device="cpu"):
     seed = 123
     if case.endswith("-entropy"):       # random_seed <= 0: OS entropy (PXI:127) -- every rank must end up with rank 0's
         case, seed = case[: -len("-entropy")], 0
-    if case == "c4small":     # BASELINE C4's shape of problem at 2M nonzeros (tests/test_full_size.py)
+    if case == "few":         # 3 users x 40 items over more ranks than users: some ranks hold NO user at all
+        rs = np.random.RandomState(5)
+        nU, nI = 3, 40
+        iu = np.repeat(np.arange(3), (30, 3, 12)).astype(np.uint64)
+        ii = np.concatenate([rs.choice(40, n, replace=False) for n in (30, 3, 12)]).astype(np.uint64)
+        Y = (rs.gamma(1, 1, size=iu.shape[0]) + 1).astype(np.int32).astype(np.float32)
+    elif case == "c4small":     # BASELINE C4's shape of problem at 2M nonzeros (tests/test_full_size.py)
         nU, nI = 100_000, 30_000
         iu, ii, Y = datagen.synthetic_hpf_shaped(nU, nI, 2_000_000, seed=4)
     else:
@@ -98,11 +104,9 @@ def _run(rank, world, port, out_dir, k, its, case, device="cpu"):
     i, temp, llk = be.fit_hpf(0.3, 0.3, 1.0, 0.3, 0.3, 1.0, Y, iu, ii, Theta, Beta, its, "maxiter", check_every, 1e-3, 0, 0,
                               None, 0, np.zeros(1, np.uint64), "", seed, 1, 1, 0, 0, np.empty(0, np.float32),
                               np.empty(0, np.uint64), np.empty(0, np.uint64), 0, 1, 0)
-    native = 0
-    if os.environ.get("HPF_TEST_NATIVE_GLOO") == "1":
-        from hpfrec_amd import cavi
-        native = int(cavi.NATIVE_PLANS_CREATED[0])
+    from hpfrec_amd import shard
+    native = int(shard.NATIVE_PLANS_CREATED[0])
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), Theta=Theta, Beta=Beta, Gamma_shp=temp[0], Gamma_rte=temp[1],
              Lambda_shp=temp[2], Lambda_rte=temp[3], k_rte=temp[4], t_rte=temp[5], llk=np.float64(llk), niter=i,
-             native_plans=native)
+             native_plans=native, schedule=str(shard.LAST_SCHEDULE[0]))
     dist.destroy_process_group()

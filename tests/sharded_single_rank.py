@@ -1,6 +1,6 @@
 """Run by tests/test_hip_parity.py::test_sharded_path_single_rank_nccl under torch.distributed.run with
-one rank and HPF_FORCE_SHARDED=1: the RCCL process group, the async packed all-reduce and the
-packed-stride kernels run on real hardware; results must equal the ordinary single-GPU path."""
+one rank and HPF_FORCE_SHARDED=1: the RCCL process group, the exchange schedules and the packed-stride kernels run on
+real hardware; results must equal the ordinary single-GPU path."""
 import os
 import sys
 
@@ -15,7 +15,7 @@ import datagen  # noqa: E402
 from hpfrec_amd import cython_loops_float as be  # noqa: E402
 
 
-ITS = 12 if os.environ.get("HPF_GRAPH") == "1" else 5     # graph mode: 11 lean iterations = 2 eager + 4 replayed pairs + 1
+ITS = 5
 
 
 def fit():
@@ -37,21 +37,16 @@ if __name__ == "__main__":
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     os.environ["HPF_FORCE_SHARDED"] = "1"
     from hpfrec_amd import cavi
-    replays = [0]
-    if os.environ.get("HPF_GRAPH") == "1":
-        orig = cavi.FullBatchCavi._pair_graph
+    seen = []
+    orig = cavi.FullBatchCavi._scatter_views
 
-        def counted(self, store):
-            g = orig(self, store)
-            if g is not None:
-                replays[0] += 1
-            elif getattr(self, "_graph_failed", False):
-                print("GRAPH_CAPTURE_FAILED", self._graph_error)
-            return g
-        cavi.FullBatchCavi._pair_graph = counted
+    def noted(self):
+        v = orig(self)
+        seen.append(self.schedule)
+        return v
+    cavi.FullBatchCavi._scatter_views = noted
     sharded, llk1 = fit()
-    if replays[0] > 0:
-        print("GRAPH_PAIRS_REPLAYED")
+    print("SCHEDULE %s" % (seen[-1] if seen else None))
     if cavi._DIRECT_COMMS:
         print("DIRECT_RCCL_USED")
     if cavi.NATIVE_PLANS_CREATED[0] > 0:
@@ -59,5 +54,5 @@ if __name__ == "__main__":
     dist.destroy_process_group()
     worst = max(float(np.max(np.abs(a - b) / np.abs(b))) for a, b in zip(sharded, plain))
     print("SHARDED_VS_PLAIN max-rel %.3e llk-rel %.3e" % (worst, abs(llk1 / llk0 - 1)))
-    assert worst < (3e-5 if ITS > 5 else 1e-5) and abs(llk1 / llk0 - 1) < 1e-6
+    assert worst < 1e-5 and abs(llk1 / llk0 - 1) < 1e-6
     print("SHARDED_OK")

@@ -113,13 +113,16 @@ def test_c4_invariants_full_size(ops):
     assert abs(res["fused"][2][0] / res["split"][2][0] - 1) < 1e-7
 
 
-@pytest.mark.parametrize("mode", ["scatter", "allreduce"])
-def test_c4_two_ranks_sharded_vs_oracle(tmp_path, monkeypatch, mode):
-    """C4's configuration -- k=100, users sharded, item statistics exchanged per iteration -- on 2 ranks sharing the
-    GPU (gloo), 2M nonzeros, 3 iterations, against the oracle (PXI:227-259) and between replicas."""
+@pytest.mark.parametrize("mode,world", [("direct", 2), ("direct", 4), ("gather-early", 2), ("finalize-then-gather", 2)])
+def test_c4_two_ranks_sharded_vs_oracle(tmp_path, monkeypatch, mode, world):
+    """C4's configuration -- k=100, users sharded, item statistics exchanged per iteration -- on 2 (4) ranks sharing the
+    GPU, 2M nonzeros, 3 iterations, against the oracle (PXI:227-259) and between replicas.  "direct": the C-issued
+    iteration with the peer-mapped exchange between the processes (hipIpc; gloo is the control plane only); the other
+    two: the call-by-call forms over gloo."""
     import dist_worker
-    monkeypatch.setenv("HPF_SHARD_MODE", mode)
-    k, its, world = 100, 3, 2
+    monkeypatch.setenv("HPF_SCHEDULE", mode)
+    monkeypatch.setenv("HPF_DIRECT_TIMEOUT_MS", "60000")
+    k, its = 100, 3
     iu, ii, Y = datagen.synthetic_hpf_shaped(100_000, 30_000, 2_000_000, seed=4)
     nU, nI = 100_000, 30_000
     st, _ = O.fit_full_batch(Y, iu, ii, nU, nI, k, its, 123, nthreads=O.max_threads())

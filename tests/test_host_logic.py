@@ -563,3 +563,75 @@ def test_c_issued_iteration_traces_with_fewer_items_than_ranks(schedule):
                               sn.TRACE_KERNELS[i] in ("item_shape", "row_finalize_ranges")))
     assert all(s == seqs[0] for s in seqs) and len(seqs[0]) > 0
     assert finalizers == [2] * 5 + [0] * 3
+
+
+@pytest.mark.parametrize("prefetch", [1, 0])
+@pytest.mark.parametrize("world,nranges", [(8, 2), (3, 2), (2, 1), (8, 1)])
+def test_direct_schedule_traces_have_no_collective(world, nranges, prefetch):
+    """The direct (peer-mapped) schedule, HPF_SCHEDULE_DIRECT, in trace mode: NO collective of any kind is issued -- the
+    exchange is inside the kernels -- and the flag protocol is consistent on every rank: range j's SWEPT flag is raised on
+    entry of the launch that FOLLOWS the range's sweep on the compute stream (never by the sweep itself), the shape half of
+    range j (exchange stream, after the local sweep's event) waits for exactly that kind, SHAPED is raised once per
+    iteration on the exchange stream after the last shape half, and the apply waits for GATHERED (prefetch) or SHAPED.
+    An empty user shard (u_nseg = 0) still raises the last SWEPT flag through a signal-only launch."""
+    from hpfrec_amd import shard_native as sn
+    CS, XS = 0xC0, 0xE0
+    SWEPT = lambda j: j                   # noqa: E731  (HPF_P2P_FLAG_SWEPT)
+    SHAPED, GATHERED = 8, 29              # HPF_P2P_FLAG_SHAPED(0), HPF_P2P_FLAG_GATHERED
+    per_rank = []
+    for rank in range(world):
+        for empty_users in ((False, True) if rank == world - 1 else (False,)):
+            plan, _ = _traced_plan(world, rank, 3, nranges)
+            plan.close()
+            # (rebuild with the direct fields set: _traced_plan leaves them at zero)
+            d = plan.desc
+            d.direct_prefetch = prefetch
+            if empty_users:
+                d.u_nseg = 0
+            plan = sn.ShardPlan(d)
+            seq = []
+            for it in range(3):
+                plan.iterate_raw(0x100 + (it & 1), 0x101 - (it & 1), it == 2, CS)
+                tr = plan.trace()
+                assert not [1 for kind, i, st, a in tr if kind == sn.TRACE_COLLECTIVE], "a collective in the direct schedule"
+                ker = [(sn.TRACE_KERNELS[i], st, a) for kind, i, st, a in tr if kind == sn.TRACE_KERNEL]
+                names = [n for n, _, _ in ker]
+                assert names.count("sweep") == nranges and names.count("item_shape_pull") == nranges
+                assert names.count("colsum_allreduce") == 2 and names.count("item_apply") == 1
+                assert names.count("sweep_finalize") == (0 if empty_users else 1)
+                # flags raised on the compute stream, in order: SWEPT(0) .. SWEPT(last), each by the launch after its sweep
+                raised = [a - 1 for n, st, a in ker if st == CS and n in ("sweep", "sweep_finalize") and a > 0] + \
+                         [a for n, st, a in ker if st == CS and n == "signal"]
+                assert raised == [SWEPT(j) for j in range(nranges)], raised
+                sweeps = [a for n, st, a in ker if n == "sweep"]
+                assert sweeps[0] == 0                                   # the first sweep raises nothing
+                # the shape halves wait for their own range's flag, on the exchange stream
+                waits = [a for n, st, a in ker if n == "item_shape_pull" and st == XS]
+                assert waits == [1 << SWEPT(j) for j in range(nranges)]
+                # SHAPED: once, on the exchange stream, after the last shape half
+                if prefetch:
+                    g = [(a & 0xFF, a >> 8) for n, st, a in ker if n == "gather_pull" and st == XS]
+                    assert g == [(SHAPED, GATHERED)]
+                    assert names.index("gather_pull") > max(i for i, n in enumerate(names) if n == "item_shape_pull")
+                else:
+                    assert [a for n, st, a in ker if n == "signal" and st == XS] == [SHAPED] and "gather_pull" not in names
+                apply_wait = [a - 1 for n, st, a in ker if n == "item_apply"]
+                assert apply_wait == [GATHERED if prefetch else SHAPED]
+                # the apply follows colsum(Theta) and precedes colsum(Beta)
+                ia = names.index("item_apply")
+                cs_pos = [i for i, n in enumerate(names) if n == "colsum_allreduce"]
+                assert cs_pos[0] < ia < cs_pos[1]
+                # every stream wait names an event recorded before it
+                rec = set()
+                for kind, i, st, a in tr:
+                    if kind == sn.TRACE_RECORD:
+                        rec.add(a)
+                    elif kind == sn.TRACE_WAIT:
+                        assert a in rec
+                seq.append([(n, a) for n, st, a in ker if n in ("item_shape_pull", "gather_pull", "colsum_allreduce", "item_apply")])
+            plan.join(CS)
+            assert not [1 for kind, i, st, a in plan.trace() if kind in (sn.TRACE_COLLECTIVE, sn.TRACE_KERNEL)]
+            plan.close()
+            per_rank.append(seq)
+    # what every rank waits for / publishes is the same sequence on every rank (a mismatch is a time-out on real links)
+    assert all(s == per_rank[0] for s in per_rank)

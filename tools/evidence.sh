@@ -21,13 +21,12 @@ has svi && run svi_c5.txt python tools/svi_c5.py 10
 has serving && run serving_latency.txt python tools/serving_latency.py
 has e2e && run e2e_fit.txt python tools/e2e_fit.py c3 100
 if has shard; then
-  run shard_probe_c3.txt env HPF_SHARD_MODE=scatter PROBE_EVENTS=0 python tools/shard_probe.py 8
-  run shard_probe_c4.txt env PROBE_WORKLOAD=c4 HPF_SHARD_MODE=scatter PROBE_EVENTS=0 python tools/shard_probe.py 8
-  run shard_probe_c3_graph1.txt env HPF_GRAPH=1 HPF_AR_CHUNKS=1 HPF_SHARD_MODE=scatter PROBE_EVENTS=0 python tools/shard_probe.py 8
-  run shard_probe_c4_graph1.txt env PROBE_WORKLOAD=c4 HPF_GRAPH=1 HPF_AR_CHUNKS=1 HPF_SHARD_MODE=scatter PROBE_EVENTS=0 python tools/shard_probe.py 8
-  run shard_probe_c3_graph2.txt env HPF_GRAPH=1 HPF_AR_CHUNKS=2 HPF_SHARD_MODE=scatter PROBE_EVENTS=0 python tools/shard_probe.py 8
-  run shard_probe_c3_all_n.txt env HPF_GRAPH=1 PROBE_EVENTS=0 python tools/shard_probe.py 1 2 4 8
-  run shard_probe_c3_allreduce_n.txt env HPF_SHARD_MODE=allreduce PROBE_EVENTS=0 python tools/shard_probe.py 2 4
+  run shard_probe_c3.txt env PROBE_EVENTS=0 python tools/shard_probe.py 8
+  run shard_probe_c4.txt env PROBE_WORKLOAD=c4 PROBE_EVENTS=0 python tools/shard_probe.py 8
+  for sc in direct gather-early finalize-then-gather; do
+    run shard_probe_c3_$sc.txt env HPF_SCHEDULE=$sc PROBE_EVENTS=0 python tools/shard_probe.py 8
+  done
+  run shard_probe_c3_all_n.txt env PROBE_EVENTS=0 python tools/shard_probe.py 1 2 4 8
 fi
 if has default; then
   run bench_c3_default.json python bench.py

@@ -16,7 +16,7 @@ run
 run --no-fuse
 run --lean
 
-ENVV="HPF_FORCE_SHARDED=1 HPF_SHARD_MODE=scatter" run --no-autotune
+ENVV="HPF_FORCE_SHARDED=1" run --no-autotune
 run --workload c2
 run --workload c4
 if [ -d "$V" ]; then

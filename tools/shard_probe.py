@@ -72,8 +72,9 @@ class EmulatedRank:
         return dist.all_reduce(t, async_op=async_op) or _Done()
 
     #: HPF_NATIVE_SHARD=1 (the library default): the whole iteration issued by hpf_hip_shard_iterate in its dry-run
-    #: form -- this rank alone, every collective = the local copy of the rank's slice + a one-element call on a one-rank
-    #: RCCL communicator (the same stand-in as the Python paths below use)
+    #: form -- this rank alone.  HPF_SCHEDULE=direct (the default): the exchange region is connected to itself, the pulls
+    #: read local memory (every rank's slice is read, the own one counted); the RCCL-shaped schedules: every collective =
+    #: the local copy of the rank's slice + a one-element call on a one-rank RCCL communicator
     native_dry_run = True
     #: PROBE_BUSBW (GB/s) > 0: every emulated collective also holds its stream for latency + bytes*(N-1)/N / busbw (one
     #: sleeping wavefront): what the iteration would take if the links delivered that, with the schedule's real dependencies
@@ -82,30 +83,12 @@ class EmulatedRank:
     # > 0: a bulk collective's stand-in is that many 256-thread workgroups with 128 VGPRs and 64 KB of LDS each
     native_dry_run_footprint_blocks = int(os.environ.get("PROBE_FAT_BLOCKS", "0"))
 
-    def direct_comm(self, device, raw=False):
-        """HPF_RCCL_DIRECT=1: the collectives as calls on a one-rank communicator of our own + the same local copies.
-        raw: the communicator itself (for the native plan's dry run)."""
-        emu = self
+    def direct_comm(self, device, raw=True):
+        """The one-rank RCCL communicator the dry run of an RCCL-shaped plan pays its launches on."""
         if not hasattr(EmulatedRank, "_comm"):
             from hpfrec_amd import rccl
             EmulatedRank._comm = rccl.DirectComm(device)
-        if raw:
-            return EmulatedRank._comm
-
-        class Direct:
-            def all_reduce(self, t):
-                EmulatedRank._comm.all_reduce(t)
-
-            def reduce_scatter(self, out, inp):
-                m = out.shape[0]
-                out.copy_(inp[emu.rank * m: (emu.rank + 1) * m])
-                EmulatedRank._comm.all_reduce(emu.tiny)
-
-            def all_gather(self, out, inp):
-                m = inp.shape[0]
-                out[emu.rank * m: (emu.rank + 1) * m].copy_(inp)
-                EmulatedRank._comm.all_reduce(emu.tiny)
-        return Direct()
+        return EmulatedRank._comm
 
     def all_reduce(self, t, op=None, async_op=False):
         return self._call(t, async_op)
@@ -144,18 +127,11 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
             for _ in range(3):
                 m.iterate(store)
             torch.cuda.synchronize()
-            many = os.environ.get("HPF_GRAPH") == "1"
-            if many:
-                m.iterate_many(4, store)      # capture
-                torch.cuda.synchronize()
             ops.events, ops.recording = {}, store and os.environ.get('PROBE_EVENTS', '1') == '1'
             t0 = time.perf_counter()
             steps = 30
-            if many:
-                m.iterate_many(steps, store)
-            else:
-                for _ in range(steps):
-                    m.iterate(store)
+            for _ in range(steps):
+                m.iterate(store)
             t_issue = (time.perf_counter() - t0) / steps * 1e3
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps * 1e3
@@ -165,14 +141,10 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
                 if EmulatedRank.native_dry_run_busbw > 0 and m._plan is not None:
                     print("(collectives hold their stream as %.0f GB/s of bus bandwidth + %.0f us would)"
                           % (EmulatedRank.native_dry_run_busbw, EmulatedRank.native_dry_run_latency_us))
-                print("world %d rank %d [%s%s]: %d users, %d nnz: %.3f ms/iteration (all tables stored; host issue time %.3f ms); "
-                      "kernels ms/iter %s%s" % (world, r, "native C issue" if m._plan is not None else "python issue",
-                                                ", packed all-gather" if getattr(m, "ag_packed", False) else
-                                                ", gather-carried" if getattr(m, "gather_carried", False) else
-                                                ", gather-early" if getattr(m, "gather_early", False) else "",
-                                                u1 - u0, m.nnz, dt, t_issue, ks,
-                                                " [hipGraph pairs: %s]" % ("ok" if m.__dict__.get("_graphs", {}).get(True) is not None
-                                                                           else getattr(m, "_graph_error", "off")) if many else ""), flush=True)
+                print("world %d rank %d [%s, %s, %d item ranges]: %d users, %d nnz: %.3f ms/iteration (all tables stored; host "
+                      "issue time %.3f ms); kernels ms/iter %s"
+                      % (world, r, "native C issue" if m._plan is not None else "python issue", m.schedule,
+                         len(m.item_chunks), u1 - u0, m.nnz, dt, t_issue, ks), flush=True)
             else:
                 print("world %d rank %d: %.3f ms/iteration without the output-table stores (host issue time %.3f ms)"
                       % (world, r, dt, t_issue), flush=True)

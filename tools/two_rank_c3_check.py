@@ -3,8 +3,8 @@
 host: slow, but it is the real sharded driver on the real kernels at C3 size -- split popular rows, 64-bit offsets,
 pad rows), a few iterations, every rank's tables against the single-process run.
 
-    python tools/two_rank_c3_check.py [world=2] [mode=scatter|allreduce] [iterations=3] [workload=c3]
-    HPF_TEST_NATIVE_GLOO=1 HPF_GATHER_EARLY=2 python tools/two_rank_c3_check.py 8     (the C-issued gather-carried schedule)
+    python tools/two_rank_c3_check.py [world=2] [HPF_SCHEDULE=direct|gather-early|...] [iterations=3] [workload=c3]
+    HPF_TEST_NATIVE_GLOO=1 python tools/two_rank_c3_check.py 8 gather-carried     (C-issued, gloo behind the callback)
 """
 import os
 import sys
@@ -51,10 +51,10 @@ def fit(rank, world, wl, its):
 
 def worker(rank, world, port, wl, its, mode, out):
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HPF_SHARD_MODE=mode)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HPF_SCHEDULE=mode)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     if os.environ.get("HPF_TEST_NATIVE_GLOO") == "1":
-        # the C-issued iteration (hpf_hip_shard_iterate; HPF_GATHER_EARLY = 0 / 1 / 2 picks its schedule) with gloo standing
+        # the C-issued iteration (hpf_hip_shard_iterate) with gloo standing
         # in for RCCL through the collective callback
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from dist_worker import gloo_collective
@@ -66,7 +66,7 @@ def worker(rank, world, port, wl, its, mode, out):
 
 if __name__ == "__main__":
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-    mode = sys.argv[2] if len(sys.argv) > 2 else "scatter"
+    mode = sys.argv[2] if len(sys.argv) > 2 else "direct"
     its = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     wl = sys.argv[4] if len(sys.argv) > 4 else "c3"
     out = "/tmp/two_rank_check"
@@ -76,7 +76,7 @@ if __name__ == "__main__":
     print("single process: %.1f s" % (time.time() - t0), flush=True)
     t0 = time.time()
     mp.spawn(worker, args=(world, 29641, wl, its, mode, out), nprocs=world, join=True)
-    print("%d gloo ranks (%s mode): %.1f s" % (world, mode, time.time() - t0), flush=True)
+    print("%d ranks sharing the GPU (HPF_SCHEDULE=%s): %.1f s" % (world, mode, time.time() - t0), flush=True)
     worst = {}
     for r in range(world):
         d = np.load(os.path.join(out, "rank%d.npz" % r))
