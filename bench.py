@@ -642,6 +642,8 @@ def main():
                 roof["per_side"] = {"user_launch_ms": side(0), "item_launch_ms": side(1),
                                     "user_frac_of_hbm_peak": bu / (side(0) * 1e-3) / HBM_PEAK,
                                     "item_frac_of_hbm_peak": bi / (side(1) * 1e-3) / HBM_PEAK}
+            if traffic and _PMC_EXTRA:
+                roof.update(_PMC_EXTRA)      # hbm_bytes (DRAM-destined share of `traffic`), mall_hit_rate (not measurable)
             if traffic:
                 # the PMC bytes over the live launch duration.  FETCH_SIZE / WRITE_SIZE count at the L2 <-> fabric
                 # boundary, so Infinity-Cache hits (the 97 MB item table is MALL-resident) are included: this is a
@@ -808,6 +810,9 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
+_PMC_EXTRA = {}      # hbm_bytes / mall_hit_rate of the committed PMC summary (filled by _pmc_traffic)
+
+
 def _pmc_traffic(workload, world):
     """(HBM bytes per sweep launch, provenance) from the rocprofv3 --pmc passes committed under profiles/ (collected
     in separate runs, never in the timed one; tools/gpu_profile.sh + tools/pmc_json.py).  The summary names the
@@ -824,6 +829,8 @@ def _pmc_traffic(workload, world):
     have, want = d.get("kernel_source_sha16"), kernel_source_sha16()
     if have != want:
         return None, "%s was measured on kernel source %s, this run uses %s: stale" % (rel, have, want)
+    _PMC_EXTRA.update({kk: d.get(kk) for kk in ("hbm_bytes", "hbm_bytes_note", "mall_hit_rate", "mall_hit_rate_note",
+                                                "read_requests_per_launch", "write_requests_per_launch") if kk in d})
     return d.get("sweep_kernel_hbm_bytes_per_launch"), "%s (%s; kernel source %s)" % (rel, d.get("source"), have)
 
 

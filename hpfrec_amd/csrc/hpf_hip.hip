@@ -581,28 +581,12 @@ __global__ __launch_bounds__(BLOCK) void row_finalize_kernel(
 //                                row also finishes Beta = shp/rte, tau = add + sum_k Beta and its colsum(Beta) partials.
 // Against the one-part finalizer E carries one more float32 rounding (num is rounded before the division).
 // ----------------------------------------------------------------------------------------------------------------
-// PULL (direct exchange, hpf_p2p_dev.h): instead of one reduce-scattered accumulator row, the owner of a row sums the
-// row's partial accumulators straight out of the N ranks' exchange buffers (peer-mapped memory), in rank order -- the
-// reduce-scatter happens inside this kernel's loads.  pull.acc[p]: rank p's packed [table rows][k] buffer as mapped here,
-// indexed by the TABLE row; pull.sum_mask: the ranks whose rows count (all of them; a single-process emulation reads
-// every slice but counts its own only); pull.wait_kinds: the flag kinds every peer must have raised to pull.epoch.
-struct PullSrc {
-    int n;                                        // 0: `acc` holds the reduced rows (no pull)
-    uint32_t sum_mask, wait_kinds, epoch;
-    const float *acc[HPF_P2P_MAX_RANKS];
-    hpf_p2p::Peers peers;
-};
-
 template <int LD>
 __global__ __launch_bounds__(BLOCK) void item_shape_kernel(const float *__restrict__ acc, const float *__restrict__ e_old,
                                                            float *__restrict__ shp_out, float *__restrict__ send,
                                                            int sld, const float *__restrict__ rs,
                                                            float *__restrict__ rs_prev, float prior_shp, float top_shp,
-                                                           int k, const RowRanges rr, int64_t nrows, const PullSrc pull) {
-    if (pull.n > 0) {
-        for (int kind = 0; kind < HPF_P2P_NKINDS; kind++)
-            if ((pull.wait_kinds >> kind) & 1u) hpf_p2p::block_acquire(pull.peers, kind, pull.epoch, 0xFFFFFFFFu);
-    }
+                                                           int k, const RowRanges rr, int64_t nrows) {
     // send rows: k numerators, the row's base rate at column k, zero up to the stride sld (a multiple of 4 floats, so
     // that part 2 reads them as float4); shp_out rows: the padded table layout [.][LD].
     // SR rows per wave step, all their loads issued first: this kernel runs on the exchange stream BESIDE the sweeps, which
@@ -634,20 +618,7 @@ __global__ __launch_bounds__(BLOCK) void item_shape_kernel(const float *__restri
             for (int q = 0; q < CPL; q++) {
                 const int c = lane + WAVE * q;
                 const bool valid = live[i] && c < k;
-                if (pull.n > 0) {
-                    // all N loads issued before the first add (unrolled: pull.acc[p] is a kernel-argument pointer), summed
-                    // in rank order: the same float on every run (x + 0.f is exact: uncounted ranks drop out)
-                    float v[HPF_P2P_MAX_RANKS];
-#pragma unroll
-                    for (int p = 0; p < HPF_P2P_MAX_RANKS; p++)
-                        v[p] = (p < pull.n && valid) ? pull.acc[p][(size_t)r * k + c] : 0.f;
-                    float sum = 0.f;
-#pragma unroll
-                    for (int p = 0; p < HPF_P2P_MAX_RANKS; p++) sum += ((pull.sum_mask >> p) & 1u) ? v[p] : 0.f;
-                    a[i][q] = sum;
-                } else {
-                    a[i][q] = valid ? acc[(size_t)t * k + c] : 0.f;
-                }
+                a[i][q] = valid ? acc[(size_t)t * k + c] : 0.f;
                 eo[i][q] = valid ? e_old[(size_t)r * LD + c] : 0.f;
             }
             rs_old[i] = live[i] ? rs[r] : 1.f;
@@ -903,7 +874,7 @@ __global__ __launch_bounds__(BLOCK) void colsum_kernel(const float *__restrict__
 __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float *__restrict__ cs_partial, int nblk,
                                                              float *__restrict__ cs_out, int ld,
                                                              const hpf_p2p::Peers *__restrict__ peers, int which,
-                                                             uint32_t epoch) {
+                                                             uint32_t epoch, uint32_t then_wait_kinds, int then_wait_self) {
     __shared__ double red[16][WAVE];
     const int cl = threadIdx.x & (WAVE - 1);
     const int chunk = threadIdx.x >> 6;
@@ -941,6 +912,15 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float *__rest
             out = hpf_p2p::vec_collect(pp, which, epoch, ld, c);
         }
         cs_out[c] = out;
+    }
+    // direct exchange: this small launch also does the waiting for the large-grid launch behind it on the stream (flag
+    // kinds of the bit mask from every peer, then_wait_self from this rank itself) -- a grid of polling workgroups would
+    // sit on the wave slots the flags' producers need
+    if (peers && (then_wait_kinds || then_wait_self >= 0)) {
+        const hpf_p2p::Peers pp = *peers;
+        for (int kind = 0; kind < HPF_P2P_NKINDS; kind++)
+            if ((then_wait_kinds >> kind) & 1u) hpf_p2p::block_acquire(pp, kind, epoch, 0xFFFFFFFFu);
+        if (then_wait_self >= 0) hpf_p2p::block_acquire_self(pp, then_wait_self, epoch);
     }
 }
 
@@ -2045,11 +2025,11 @@ int hpf_hip_gather_payload_ld(int k) { return k > 0 ? ((k + 1 + 3) / 4) * 4 : HP
 
 static int item_shape_impl(const float *acc, const RowRanges &rr, int64_t nrows, const float *e_old, float *shp_out,
                            float *send, const float *rs, float *rs_prev, float prior_shp, float top_shp, int k, int ld,
-                           int grid_blocks, const PullSrc &pull, hipStream_t st) {
+                           int grid_blocks, hipStream_t st) {
     const int sld = hpf_hip_gather_payload_ld(k);
 #define CALL(LD)                                                                                                      \
     hipLaunchKernelGGL((item_shape_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, acc, e_old, shp_out, send, sld, \
-                       rs, rs_prev, prior_shp, top_shp, k, rr, nrows, pull);
+                       rs, rs_prev, prior_shp, top_shp, k, rr, nrows);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
     return last_error();
@@ -2073,8 +2053,7 @@ int hpf_hip_item_shape_rows_f32(const float *acc, int nranges, const int64_t *ra
         nrows += range_rows[i];
     }
     if (nrows == 0) return 0;
-    PullSrc pull = {};
-    return item_shape_impl(acc, rr, nrows, e_old, shp_out, send, rs, rs_prev, prior_shp, top_shp, k, ld, grid_blocks, pull,
+    return item_shape_impl(acc, rr, nrows, e_old, shp_out, send, rs, rs_prev, prior_shp, top_shp, k, ld, grid_blocks,
                            (hipStream_t)stream);
 }
 
@@ -2121,7 +2100,7 @@ int hpf_hip_item_apply_rows_f32(const float *recv, const float *shp_own, float *
 int hpf_hip_colsum_reduce_f32(const float *cs_partial, int nblk, float *cs_out, int ld, void *stream) {
     if (!cs_partial || !cs_out || nblk <= 0 || ld < 32) return HPF_EINVAL;
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((ld + WAVE - 1) / WAVE), dim3(1024), 0, (hipStream_t)stream,
-                       cs_partial, nblk, cs_out, ld, (const hpf_p2p::Peers *)nullptr, 0, 0u);
+                       cs_partial, nblk, cs_out, ld, (const hpf_p2p::Peers *)nullptr, 0, 0u, 0u, -1);
     return last_error();
 }
 
@@ -2347,32 +2326,6 @@ int sweep_finalize(const hpf_segment *segs, int64_t nseg, const int32_t *idx, co
                                cs_partial, prior_shp, top_shp, add_rte, k, ld, grid_blocks, cs_other_copy, sig, st);
 }
 
-int item_shape_pull(const float *const *acc_peers, int npeers, uint32_t sum_mask, uint32_t wait_kinds, uint32_t epoch,
-                    const hpf_p2p::Peers &pp, int64_t rows, int64_t send_row0, int64_t table_row0, const float *e_old,
-                    float *shp_out, float *send, const float *rs, float *rs_prev, float prior_shp, float top_shp, int k,
-                    int ld, int grid_blocks, hipStream_t st) {
-    if (!acc_peers || npeers <= 0 || npeers > HPF_P2P_MAX_RANKS || rows < 0 || send_row0 < 0 || table_row0 < 0 || !e_old ||
-        !shp_out || !send || !rs || k <= 0 || ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0)
-        return HPF_EINVAL;
-    PullSrc pull = {};
-    pull.n = npeers;
-    pull.sum_mask = sum_mask;
-    pull.wait_kinds = wait_kinds;
-    pull.epoch = epoch;
-    for (int p = 0; p < npeers; p++) {
-        if (!acc_peers[p]) return HPF_EINVAL;
-        pull.acc[p] = acc_peers[p];
-    }
-    pull.peers = pp;
-    RowRanges rr = {};
-    rr.n = 1;
-    rr.t_begin[0] = send_row0;
-    rr.row_begin[0] = table_row0;
-    // (rows == 0 -- a slice of pad rows only -- still launches: the flags are consumed in step with the peers)
-    return item_shape_impl(nullptr, rr, rows, e_old, shp_out, send, rs, rs_prev, prior_shp, top_shp, k, ld,
-                           rows > 0 ? grid_blocks : 1, pull, st);
-}
-
 int item_apply_blocks(const float *const *blocks, int nblocks, int wait_kind, int local_flag, uint32_t epoch,
                       const hpf_p2p::Peers &pp, const float *shp_own, float *e_tab, float *shp, float *fac, float *rs,
                       const float *cs_other, float *cs_partial, float add_rte, int k, int ld, int rank, int world,
@@ -2394,11 +2347,11 @@ int item_apply_blocks(const float *const *blocks, int nblocks, int wait_kind, in
 }
 
 int colsum_reduce_allreduce(const float *cs_partial, int nblk, float *cs_out, int ld, const hpf_p2p::Peers *peers_dev,
-                            int which, uint32_t epoch, hipStream_t st) {
+                            int which, uint32_t epoch, uint32_t then_wait_kinds, int then_wait_self, hipStream_t st) {
     if (!cs_partial || !cs_out || nblk <= 0 || ld < 32 || !peers_dev || which < 0 || which >= HPF_P2P_NVEC)
         return HPF_EINVAL;
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((ld + WAVE - 1) / WAVE), dim3(1024), 0, st, cs_partial, nblk, cs_out, ld,
-                       peers_dev, which, epoch);
+                       peers_dev, which, epoch, then_wait_kinds, then_wait_self);
     return last_error();
 }
 

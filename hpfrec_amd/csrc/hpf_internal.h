@@ -28,13 +28,6 @@ int sweep_finalize(const hpf_segment *segs, int64_t nseg, const int32_t *idx, co
                    const float *tab_other, float *part, float *e_new, float *shp, float *rte, float *fac, float *rs,
                    float *rs_prev, const float *cs_other, float *cs_partial, float prior_shp, float top_shp,
                    float add_rte, int k, int ld, int grid_blocks, float *cs_other_copy, Signal sig, hipStream_t st);
-// hpf_hip_item_shape_rows_f32 for ONE slice whose accumulator rows are pulled from the npeers exchange buffers
-// (acc_peers[p]: rank p's packed [table rows][k] buffer as mapped here) once every peer has raised the flag kinds in
-// wait_kinds to `epoch`; rows of ranks outside sum_mask are read but not counted
-int item_shape_pull(const float *const *acc_peers, int npeers, uint32_t sum_mask, uint32_t wait_kinds, uint32_t epoch,
-                    const hpf_p2p::Peers &pp, int64_t rows, int64_t send_row0, int64_t table_row0, const float *e_old,
-                    float *shp_out, float *send, const float *rs, float *rs_prev, float prior_shp, float top_shp, int k,
-                    int ld, int grid_blocks, hipStream_t st);
 // hpf_hip_item_apply_rows_f32 with the rows of owner o read from blocks[o] (wait_kind >= 0: after flags[wait_kind][o],
 // or -- local_flag -- this rank's own flags[wait_kind][rank], has reached epoch)
 int item_apply_blocks(const float *const *blocks, int nblocks, int wait_kind, int local_flag, uint32_t epoch,
@@ -42,9 +35,11 @@ int item_apply_blocks(const float *const *blocks, int nblocks, int wait_kind, in
                       const float *cs_other, float *cs_partial, float add_rte, int k, int ld, int rank, int world,
                       int64_t nrows, int nranges, const int64_t *range_lo, const int64_t *range_hi, int grid_blocks,
                       hipStream_t st);
-// hpf_hip_colsum_reduce_f32 whose result is the sum over ALL ranks (granules, rank order; which = HPF_P2P_VEC_*)
+// hpf_hip_colsum_reduce_f32 whose result is the sum over ALL ranks (granules, rank order; which = HPF_P2P_VEC_*); the
+// launch then also WAITS (one workgroup) for the flag kinds of then_wait_kinds from every peer and for this rank's own
+// flag then_wait_self (-1: none), on behalf of the large-grid launch that follows it on the stream
 int colsum_reduce_allreduce(const float *cs_partial, int nblk, float *cs_out, int ld, const hpf_p2p::Peers *peers_dev,
-                            int which, uint32_t epoch, hipStream_t st);
+                            int which, uint32_t epoch, uint32_t then_wait_kinds, int then_wait_self, hipStream_t st);
 
 }  // namespace hpf_direct
 
@@ -56,6 +51,10 @@ int colsum_reduce_allreduce(const float *cs_partial, int nblk, float *cs_out, in
 namespace hpf_p2p {
 int gather_pull(void *region, int64_t src_offset_bytes, float *dst, int64_t floats_per_rank, int signal_kind, int done_kind,
                 uint32_t epoch, int gx, hipStream_t st);
+// dst[0..n) = the rank-order sum over the ranks of the n floats at src_offset_bytes of every rank's data buffer (ranks
+// outside sum_mask are read, not counted); wide loads when offset, n and dst allow.  Put wait_flags() ahead of it.
+int pull_reduce(void *region, int64_t src_offset_bytes, float *dst, int64_t n, uint32_t sum_mask, int grid_blocks,
+                hipStream_t st);
 // `st` continues once every peer in src_mask has raised every flag kind of the bit mask `kinds` to epoch and (self_kind >= 0)
 // this rank its own flag self_kind: ONE waiting wavefront.  Put in front of every consumer with a large grid.
 int wait_flags(void *region, uint32_t kinds, uint32_t epoch, uint32_t src_mask, int self_kind, hipStream_t st);

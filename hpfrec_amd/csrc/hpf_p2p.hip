@@ -93,6 +93,50 @@ __global__ __launch_bounds__(256) void p2p_pull_kernel(const hpf_p2p::Peers pp, 
     for (; i < n4; i += stride) dst[i] = src[i];
 }
 
+// The reduce-scatter of the direct exchange: dst[i] = sum over the ranks p (in rank order) of src[p][i], i < n floats --
+// this rank's slice of an item range summed straight out of the N ranks' exchange buffers.  Flat 16-byte loads, all N
+// peers' loads of a lane issued before the first add (what a link wants: many wide requests in flight); ranks outside
+// sum_mask are read but not counted (a single-process emulation reads every slice and counts its own).  No waiting in
+// here: a one-wave wait kernel runs ahead of it on the stream (wait_flags).
+struct ReduceSrc {
+    const float *src[HPF_P2P_MAX_RANKS];
+};
+__global__ __launch_bounds__(256) void p2p_pull_reduce_kernel(const hpf_p2p::Peers pp, const ReduceSrc rs, int npeers,
+                                                              uint32_t sum_mask, float *__restrict__ dst, int64_t n,
+                                                              int vec) {
+    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");     // (the peers' rows: not this device's memory)
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (vec) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            float4 v[HPF_P2P_MAX_RANKS];
+#pragma unroll
+            for (int p = 0; p < HPF_P2P_MAX_RANKS; p++)
+                v[p] = (p < npeers) ? reinterpret_cast<const float4 *>(rs.src[p])[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int p = 0; p < HPF_P2P_MAX_RANKS; p++) {
+                const bool on = (sum_mask >> p) & 1u;       // (x + 0.f is exact: uncounted ranks drop out)
+                s.x += on ? v[p].x : 0.f;
+                s.y += on ? v[p].y : 0.f;
+                s.z += on ? v[p].z : 0.f;
+                s.w += on ? v[p].w : 0.f;
+            }
+            reinterpret_cast<float4 *>(dst)[i] = s;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            float s = 0.f;
+            for (int p = 0; p < npeers; p++) {
+                const float v = rs.src[p][i];
+                s += ((sum_mask >> p) & 1u) ? v : 0.f;
+            }
+            dst[i] = s;
+        }
+    }
+}
+
 // The all-gather of the direct exchange as ONE launch, grid (gx, world): the blocks of column o copy owner o's finished
 // rows (n4 float4s at src[o]) into block o of the local gathered buffer.  On entry block (0,0) tells every peer that THIS
 // rank's rows are complete (earlier launches of this stream wrote them); the blocks of column o wait for o's flag.  The
@@ -156,6 +200,21 @@ int wait_flags(void *region, uint32_t kinds, uint32_t epoch, uint32_t src_mask, 
     Region *r = (Region *)region;
     if (!r->connected || self_kind >= HPF_P2P_NKINDS) return HPF_EINVAL;
     hipLaunchKernelGGL(p2p_wait_kernel, dim3(1), dim3(64), 0, st, peers_of(r), kinds, epoch, src_mask, self_kind);
+    return (int)hipGetLastError();
+}
+
+int pull_reduce(void *region, int64_t src_offset_bytes, float *dst, int64_t n, uint32_t sum_mask, int grid_blocks,
+                hipStream_t st) {
+    if (!region || !dst || n < 0 || (src_offset_bytes & 3) || grid_blocks <= 0) return HPF_EINVAL;
+    Region *r = (Region *)region;
+    if (!r->connected || src_offset_bytes + n * 4 > r->data_bytes) return HPF_EINVAL;
+    if (n == 0) return 0;
+    ReduceSrc rs = {};
+    for (int p = 0; p < r->world; p++)
+        rs.src[p] = reinterpret_cast<const float *>(reinterpret_cast<const char *>(r->data[p]) + src_offset_bytes);
+    const int vec = ((src_offset_bytes & 15) == 0 && (n & 3) == 0 && ((uintptr_t)dst & 15) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(p2p_pull_reduce_kernel, dim3((unsigned)grid_blocks), dim3(256), 0, st, peers_of(r), rs, r->world,
+                       sum_mask, dst, n, vec);
     return (int)hipGetLastError();
 }
 

@@ -274,37 +274,35 @@ int direct_item_sweep(Plan *p, int j, const float *eT, int sig_kind, hipStream_t
                              d.acc_i, d.k, d.k, d.ld, r.short_rows, d.item_sweep_grid, raise(p, sig_kind), cs);
 }
 
-int direct_shape_pull(Plan *p, int j, hipStream_t xs) {
+// range j on the exchange stream: ONE wavefront waits until every rank -- this one included: its flag is raised on entry of
+// the launch that follows the range's sweep on the compute stream, so no stream event is needed -- has range j complete
+// in its exchange buffer; then this rank's slice is summed straight out of the N buffers (the reduce-scatter)
+int direct_pull_reduce(Plan *p, int j, hipStream_t xs) {
     const hpf_shard_desc &d = p->d;
-    const uint32_t wait = 1u << HPF_P2P_FLAG_SWEPT(j);
+    const int kind = HPF_P2P_FLAG_SWEPT(j);
     if (g_tr) {
-        g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_ITEM_SHAPE_PULL, xs, (int64_t)wait);
+        g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_WAIT, xs, (int64_t)(1u << kind));
+        g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_PULL_REDUCE, xs, j);
         return 0;
     }
-    const int64_t o0 = p->lo[j] + (int64_t)d.rank * p->m[j];
-    int64_t n_real = d.nI - o0;
-    if (n_real > p->m[j]) n_real = p->m[j];
-    if (n_real < 0) n_real = 0;
-    const float *acc[HPF_P2P_MAX_RANKS];
-    for (int q = 0; q < d.world; q++)
-        acc[q] = reinterpret_cast<const float *>(reinterpret_cast<const char *>(p->peer_data[q]) + d.p2p_acc_offset);
     // a single-process emulation reads every rank's slice (the traffic) and counts its own (the value)
     const uint32_t mask = p->pp.emulate ? (1u << d.rank) : ((d.world >= 32) ? 0xFFFFFFFFu : ((1u << d.world) - 1u));
-    // ONE wavefront waits for the peers' flags; the shape kernel's workgroups then only take the acquire (a grid of
-    // polling workgroups would sit on the wave slots this rank's next compute-stream launch needs to raise ITS flag)
-    HPF_TRY(hpf_p2p::wait_flags(d.p2p_region, wait, p->epoch, 0xFFFFFFFFu, -1, xs));
-    HPF_TRY(hpf_direct::item_shape_pull(acc, d.world, mask, wait, p->epoch, p->pp, n_real, p->t0[j], o0, d.eB, d.shp_own,
-                                        d.e_own, d.t_rte, d.t_rte_prev, d.c, d.t_shp, d.k, d.ld,
-                                        d.csB_part_rows, xs));
+    HPF_TRY(hpf_p2p::wait_flags(d.p2p_region, 1u << kind, p->epoch, 0xFFFFFFFFu, kind, xs));
+    const int64_t o0 = p->lo[j] + (int64_t)d.rank * p->m[j];
+    HPF_TRY(hpf_p2p::pull_reduce(d.p2p_region, d.p2p_acc_offset + o0 * d.k * (int64_t)sizeof(float),
+                                 d.acc_own + (size_t)p->t0[j] * d.k, p->m[j] * d.k, mask, d.direct_pull_grid, xs));
     return pull_link_time(p, (double)p->m[j] * d.k * 4.0 * (d.world - 1), xs);
 }
 
-int direct_colsum_allreduce(Plan *p, const float *part, int rows, float *out, int which, hipStream_t st) {
+int direct_colsum_allreduce(Plan *p, const float *part, int rows, float *out, int which, uint32_t then_wait_kinds,
+                            int then_wait_self, hipStream_t st) {
     if (g_tr) {
-        g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_COLSUM_ALLREDUCE, st, which);
+        g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_COLSUM_ALLREDUCE, st,
+                  which | ((int64_t)(then_wait_self + 1) << 8) | ((int64_t)then_wait_kinds << 16));
         return 0;
     }
-    return hpf_direct::colsum_reduce_allreduce(part, rows, out, p->d.ld, p->peers_dev, which, p->epoch, st);
+    return hpf_direct::colsum_reduce_allreduce(part, rows, out, p->d.ld, p->peers_dev, which, p->epoch, then_wait_kinds,
+                                               then_wait_self, st);
 }
 
 }  // namespace
@@ -425,7 +423,8 @@ int hpf_hip_shard_plan_create(const hpf_shard_desc *desc, void **plan) {
     void *peer_data[HPF_P2P_MAX_RANKS] = {};
     if (d.schedule == HPF_SCHEDULE_DIRECT) {
         if (d.e_own_ld != hpf_hip_gather_payload_ld(d.k) || !d.shp_own || (d.direct_prefetch && !d.ag_recv) ||
-            d.world > HPF_P2P_MAX_RANKS || d.nranges > HPF_MAX_ROW_RANGES || d.csB_part_rows % d.world != 0)
+            d.world > HPF_P2P_MAX_RANKS || d.nranges > HPF_MAX_ROW_RANGES || d.csB_part_rows % d.world != 0 ||
+            !d.acc_own || d.direct_pull_grid <= 0 || d.direct_gather_gx <= 0)
             return HPF_EINVAL;
         if (!tracing) {
             int w = 0, r = 0, ld = 0;
@@ -733,15 +732,17 @@ static int iterate_gather_carried(Plan *p, const float *eT, float *eT_next, int 
 }
 
 // The direct schedule (include/hpf_hip.h, HPF_SCHEDULE_DIRECT).  Per iteration, epoch e:
-//   compute stream:  sweep(range 0) . [segsum] . sweep(range 1; on entry: SWEPT(0) = e) . [segsum] . ... .
-//                    user sweep + finalize (on entry: SWEPT(last) = e) . split user rows . colsum(Theta) over ALL ranks .
-//                    apply (after GATHERED / the owners' SHAPED flags) . colsum(Beta) over all ranks
-//   exchange stream: per range j, after this rank's sweep of j:  shape half with the slice's rows PULLED from all ranks
-//                    (waits for every peer's SWEPT(j) = e);  then ONE pull of every owner's finished rows (on entry:
-//                    SHAPED = e; last block: GATHERED = e) -- or, without prefetch, a launch that only raises SHAPED.
+//   compute stream:  sweep(range 0) . [split rows] . sweep(range 1; on entry: SWEPT(0) = e) . [split rows] . ... .
+//                    user sweep + finalize (on entry: SWEPT(last) = e) . split user rows .
+//                    colsum(Theta) over ALL ranks (this small launch then waits for GATHERED / the owners' SHAPED) .
+//                    apply . colsum(Beta) over all ranks
+//   exchange stream: per range j: a one-wave wait for every rank's SWEPT(j) = e (this rank's too: NO stream event ties the
+//                    two streams in steady state), the slice pulled out of the N buffers and summed;  the shape half of
+//                    all slices;  ONE pull of every owner's finished rows (on entry: SHAPED = e; last block: GATHERED = e)
+//                    -- or, without prefetch, a launch that only raises SHAPED.
 // Why no buffer is overwritten while a peer still reads it: a rank's sweep of epoch e+1 follows its apply of e, which has
-// seen every owner's SHAPED(e), raised after that owner's pulls of e; a rank's shape half of e+1 waits for every peer's
-// SWEPT(e+1), raised after that peer's apply of e (which read this rank's rows of e, directly or through its pull).
+// seen every owner's SHAPED(e), raised after that owner's pulls of e; a rank's pulls and shape half of e+1 wait for every
+// rank's SWEPT(e+1), raised after that rank's apply of e (which read the finished rows of e, directly or through its pull).
 static int iterate_direct(Plan *p, const float *eT, float *eT_next, int store, hipStream_t cs) {
     const hpf_shard_desc &d = p->d;
     hipStream_t xs = p->xs;
@@ -751,7 +752,7 @@ static int iterate_direct(Plan *p, const float *eT, float *eT_next, int store, h
     } else {
         HPF_TRY(hpf_hip_p2p_region_next_epoch(d.p2p_region, &p->epoch));
     }
-    if (p->fresh) {
+    if (p->fresh) {      // (first iteration after a join: the exchange stream orders itself after whatever the caller queued)
         HIP_TRY(hipEventRecord(p->start, cs));
         HIP_TRY(hipStreamWaitEvent(xs, p->start, 0));
     }
@@ -762,18 +763,20 @@ static int iterate_direct(Plan *p, const float *eT, float *eT_next, int store, h
         if (r.nseg > 0 || j > 0) HPF_TRY(direct_item_sweep(p, j, eT, j > 0 ? HPF_P2P_FLAG_SWEPT(j - 1) : -1, cs));
         if (r.nmulti > 0)
             HPF_TRY(hpf_hip_segsum_f32(d.part_i, d.i_row_seg_ptr, r.multi_rows, r.nmulti, d.acc_i, ld, k, 1, (void *)cs));
-        HIP_TRY(hipEventRecord(p->sw_done[j], cs));
-        HIP_TRY(hipStreamWaitEvent(xs, p->sw_done[j], 0));
-        HPF_TRY(direct_shape_pull(p, j, xs));
+        HPF_TRY(direct_pull_reduce(p, j, xs));
     }
-    // exchange stream, under the user side: this rank's rows are complete -> SHAPED; every owner's rows -> ag_recv
+    // exchange stream, under the user side: the shape half of this rank's slices; SHAPED; every owner's rows -> ag_recv
+    if (p->nfin > 0)
+        HPF_TRY(hpf_hip_item_shape_rows_f32(d.acc_own, p->nfin, p->fin_rows, p->fin_acc, p->fin_row0, d.eB, d.shp_own,
+                                            d.e_own, d.t_rte, d.t_rte_prev, d.c, d.t_shp, k, ld, d.csB_part_rows,
+                                            (void *)xs));
     const double gather_bytes = (double)p->total * d.e_own_ld * 4.0 * (d.world - 1);
     if (d.direct_prefetch) {
         if (g_tr) {
             g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_GATHER_PULL, xs, HPF_P2P_FLAG_SHAPED(0) | (HPF_P2P_FLAG_GATHERED << 8));
         } else {
             HPF_TRY(hpf_p2p::gather_pull(d.p2p_region, d.p2p_send_offset, d.ag_recv, p->total * d.e_own_ld,
-                                         HPF_P2P_FLAG_SHAPED(0), HPF_P2P_FLAG_GATHERED, p->epoch, 16, xs));
+                                         HPF_P2P_FLAG_SHAPED(0), HPF_P2P_FLAG_GATHERED, p->epoch, d.direct_gather_gx, xs));
             HPF_TRY(pull_link_time(p, gather_bytes, xs));
         }
     } else if (g_tr) {
@@ -803,35 +806,30 @@ static int iterate_direct(Plan *p, const float *eT, float *eT_next, int store, h
         }
     }
     if (d.u_nmulti > 0)      // (its column-sum partial rows stay zero otherwise: never written)
-        HPF_TRY(hpf_hip_row_finalize_f32(d.part_u, d.u_row_seg_ptr, d.u_multi_rows, d.u_nmulti, eT, eT_next, shp, nullptr, fac,
-                                     d.k_rte, d.k_rte_prev, d.csB, d.csT_part + (size_t)d.user_sweep_grid * ld, d.a,
-                                     d.k_shp, d.add_k_rte, k, ld, ld, d.user_multi_grid, (void *)cs));
-    HPF_TRY(direct_colsum_allreduce(p, d.csT_part, d.csT_part_rows, d.csT, HPF_P2P_VEC_CST, cs));
+        HPF_TRY(hpf_hip_row_finalize_f32(d.part_u, d.u_row_seg_ptr, d.u_multi_rows, d.u_nmulti, eT, eT_next, shp, nullptr,
+                                         fac, d.k_rte, d.k_rte_prev, d.csB, d.csT_part + (size_t)d.user_sweep_grid * ld,
+                                         d.a, d.k_shp, d.add_k_rte, k, ld, ld, d.user_multi_grid, (void *)cs));
+    // colsum(Theta) over all ranks; the same small launch waits for what the apply's large grid needs
+    const int apply_kind = d.direct_prefetch ? HPF_P2P_FLAG_GATHERED : HPF_P2P_FLAG_SHAPED(0);
+    HPF_TRY(direct_colsum_allreduce(p, d.csT_part, d.csT_part_rows, d.csT, HPF_P2P_VEC_CST,
+                                    d.direct_prefetch ? 0u : (1u << apply_kind), apply_kind, cs));
     // the rates applied to ALL items, from the gathered rows (or straight from the owners' buffers)
     if (g_tr) {
-        g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_ITEM_APPLY, cs,
-                  1 + (d.direct_prefetch ? HPF_P2P_FLAG_GATHERED : HPF_P2P_FLAG_SHAPED(0)));
+        g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_ITEM_APPLY, cs, 1 + apply_kind);
     } else {
-        // (one waiting wavefront ahead of the apply's large grid: GATHERED of this rank, or every owner's SHAPED)
-        if (d.direct_prefetch)
-            HPF_TRY(hpf_p2p::wait_flags(d.p2p_region, 0u, p->epoch, 0u, HPF_P2P_FLAG_GATHERED, cs));
-        else
-            HPF_TRY(hpf_p2p::wait_flags(d.p2p_region, 1u << HPF_P2P_FLAG_SHAPED(0), p->epoch, 0xFFFFFFFFu,
-                                        HPF_P2P_FLAG_SHAPED(0), cs));
         const float *blocks[HPF_P2P_MAX_RANKS];
         for (int q = 0; q < d.world; q++)
             blocks[q] = d.direct_prefetch
                             ? d.ag_recv + (size_t)q * p->total * d.e_own_ld
                             : reinterpret_cast<const float *>(reinterpret_cast<const char *>(p->peer_data[q]) +
                                                               d.p2p_send_offset);
-        HPF_TRY(hpf_direct::item_apply_blocks(blocks, d.world, d.direct_prefetch ? HPF_P2P_FLAG_GATHERED : HPF_P2P_FLAG_SHAPED(0),
-                                              d.direct_prefetch ? 1 : 0, p->epoch, p->pp, d.shp_own, d.eB,
-                                              store ? d.Lambda_shp : nullptr, store ? d.Beta : nullptr, d.t_rte, d.csT,
-                                              d.csB_part, d.add_t_rte, k, ld, d.rank, d.world, d.nI, d.nranges, p->lo, p->hi,
-                                              d.csB_part_rows, cs));
+        HPF_TRY(hpf_direct::item_apply_blocks(blocks, d.world, apply_kind, d.direct_prefetch ? 1 : 0, p->epoch, p->pp,
+                                              d.shp_own, d.eB, store ? d.Lambda_shp : nullptr, store ? d.Beta : nullptr,
+                                              d.t_rte, d.csT, d.csB_part, d.add_t_rte, k, ld, d.rank, d.world, d.nI,
+                                              d.nranges, p->lo, p->hi, d.csB_part_rows, cs));
         if (!d.direct_prefetch) HPF_TRY(pull_link_time(p, gather_bytes, cs));
     }
-    HPF_TRY(direct_colsum_allreduce(p, d.csB_part, d.csB_part_rows, d.csB, HPF_P2P_VEC_CSB, cs));
+    HPF_TRY(direct_colsum_allreduce(p, d.csB_part, d.csB_part_rows, d.csB, HPF_P2P_VEC_CSB, 0u, -1, cs));
     return 0;
 }
 
@@ -925,14 +923,14 @@ int hpf_hip_shard_exchange_only(void *plan, int op, int range, void *stream) {
         } else {
             HPF_TRY(hpf_hip_p2p_region_next_epoch(d.p2p_region, &p->epoch));
         }
-        if (range < 0) return direct_colsum_allreduce(p, d.csT_part, d.csT_part_rows, d.csT, HPF_P2P_VEC_CST, st);
+        if (range < 0) return direct_colsum_allreduce(p, d.csT_part, d.csT_part_rows, d.csT, HPF_P2P_VEC_CST, 0u, -1, st);
         if (op == HPF_COLL_REDUCE_SCATTER) {
             if (g_tr) {
                 g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_SIGNAL, st, HPF_P2P_FLAG_SWEPT(range));
             } else {
                 HPF_TRY(hpf_hip_p2p_signal(d.p2p_region, HPF_P2P_FLAG_SWEPT(range), p->epoch, (void *)st));
             }
-            return direct_shape_pull(p, range, st);
+            return direct_pull_reduce(p, range, st);
         }
         if (op == HPF_COLL_ALL_GATHER) {
             if (range != 0) return 0;         // (one pull for all ranges: counted with range 0)
@@ -942,7 +940,7 @@ int hpf_hip_shard_exchange_only(void *plan, int op, int range, void *stream) {
             }
             if (!d.ag_recv) return HPF_EINVAL;
             return hpf_p2p::gather_pull(d.p2p_region, d.p2p_send_offset, d.ag_recv, p->total * d.e_own_ld,
-                                        HPF_P2P_FLAG_SHAPED(0), HPF_P2P_FLAG_GATHERED, p->epoch, 64, st);
+                                        HPF_P2P_FLAG_SHAPED(0), HPF_P2P_FLAG_GATHERED, p->epoch, d.direct_gather_gx, st);
         }
         return HPF_EINVAL;
     }

@@ -107,8 +107,8 @@ class ShardedMixin:
         gptr = torch.zeros(self.nI + 1, dtype=torch.int64, device=deg.device)
         torch.cumsum(deg, 0, out=gptr[1:])
         cuts = [lo for lo, _ in layout.nnz_balanced_ranges(gptr, max(1, nchunks))] + [self.nI]
-        W, fixed = self.world, [0]
-        for c in cuts[1:-1]:
+        W, fixed = 4 * self.world, [0]      # (4 x world: a slice then starts on a 16-byte boundary of the packed [.][k]
+        for c in cuts[1:-1]:                #  buffer for every k -- the pull-reduce reads it with 16-byte loads)
             c = fixed[-1] + ((c - fixed[-1] + W - 1) // W) * W
             if fixed[-1] < c < self.nI:
                 fixed.append(c)
@@ -116,7 +116,7 @@ class ShardedMixin:
         return [(lo, hi) for lo, hi in zip(fixed[:-1], fixed[1:]) if hi > lo]
 
     def _item_chunks(self, early):
-        """[(row_lo, row_hi, SideView over the range's segments, its split/empty rows)] in issue order."""
+        """[(row_lo, row_hi, SideView over the range's segments, its split rows)] in issue order."""
         from .cavi import _SideView
         it = self.items
         rsp = it.row_seg_ptr.cpu()
@@ -124,7 +124,11 @@ class ShardedMixin:
         out = []
         for lo, hi in self.item_bounds:
             top = min(hi, self.nI)
-            multi = it.multi_rows[(it.multi_rows >= lo) & (it.multi_rows < top)].contiguous()
+            multi = it.multi_rows[(it.multi_rows >= lo) & (it.multi_rows < top)]
+            # only rows cut into SEVERAL segments need their partial rows summed into the exchange buffer; a row without
+            # local nonzeros (most tail items on a rank of many) keeps the zeros the buffer was allocated with -- nothing
+            # else ever writes a row of acc_i
+            multi = multi[(it.row_seg_ptr[multi + 1] - it.row_seg_ptr[multi]) >= 2].contiguous()
             out.append((lo, hi, _SideView(it, int(rsp[lo]), int(rsp[top]), nnz=int(ptr[top] - ptr[lo])), multi))
         if early:
             # MOST rows first: the whole exchange runs under what is left of the iteration, so the range with most of the
@@ -305,6 +309,11 @@ class ShardedMixin:
                 d.p2p_region = self._region.handle.value
                 d.p2p_acc_offset, d.p2p_send_offset = self._region_offsets
                 d.direct_prefetch = int(os.environ.get("HPF_DIRECT_PREFETCH", "1") == "1")
+                # the pulls run BESIDE the user sweep and are bound by the links, not by their grid: one workgroup per CU
+                # for a slice's pull-reduce; the pull of the finished rows polls per owner, so few workgroups per owner
+                cus = max(1, getattr(self.ops, "cu_count", 256))
+                d.direct_pull_grid = int(os.environ.get("HPF_DIRECT_PULL_GRID", cus))
+                d.direct_gather_gx = max(1, int(os.environ.get("HPF_DIRECT_GATHER_GRID", cus // 2)) // self.world)
             d.a, d.k_shp, d.add_k_rte = float(hy.a), float(hy.k_shp), float(hy.add_k_rte)
             d.c, d.t_shp, d.add_t_rte = float(hy.c), float(hy.t_shp), float(hy.add_t_rte)
             d.comm = comm.handle if comm is not None else None

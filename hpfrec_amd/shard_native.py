@@ -52,6 +52,7 @@ class ShardDesc(ctypes.Structure):
         ("dry_run_busbw_GBps", _f32), ("dry_run_latency_us", _f32),
         ("comm_small", _vp), ("sstream", _vp),
         ("dry_run_footprint_blocks", _i32), ("direct_prefetch", _i32),
+        ("direct_pull_grid", _i32), ("direct_gather_gx", _i32),
         ("p2p_region", _vp), ("p2p_acc_offset", _i64), ("p2p_send_offset", _i64),
     ]
 
@@ -63,8 +64,8 @@ class TraceRec(ctypes.Structure):
 
 TRACE_KERNEL, TRACE_COLLECTIVE, TRACE_RECORD, TRACE_WAIT, TRACE_COPY = 1, 2, 3, 4, 5
 TRACE_KERNELS = {1: "sweep", 2: "segsum", 3: "sweep_finalize", 4: "row_finalize", 5: "row_finalize_ranges", 6: "colsum_reduce",
-                 7: "item_shape", 8: "item_apply", 10: "item_shape_pull", 11: "gather_pull", 12: "colsum_allreduce",
-                 13: "signal"}
+                 7: "item_shape", 8: "item_apply", 10: "pull_reduce", 11: "gather_pull", 12: "colsum_allreduce",
+                 13: "signal", 14: "wait"}
 TRACE_EVENT_BASE = 0x1000
 
 

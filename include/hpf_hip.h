@@ -439,6 +439,8 @@ typedef struct hpf_shard_desc {
     int32_t direct_prefetch;       /* schedule 3: 1 = the peers' finished rows are copied into ag_recv by ONE pull launch
                                       on the exchange stream (under the user sweep) and the apply kernel reads local
                                       memory; 0 = the apply kernel reads the owners' buffers itself */
+    int32_t direct_pull_grid, direct_gather_gx;   /* schedule 3: workgroups of a slice's pull-reduce launch; workgroups per
+                                      OWNER of the pull of the finished rows (its workgroups poll: keep it small) */
     void *p2p_region;              /* schedule 3: the rank's connected exchange region (hpf_hip_p2p_region_create /
                                       _connect); acc_i and e_own must lie INSIDE its data buffer, at the offsets below */
     int64_t p2p_acc_offset, p2p_send_offset;   /* bytes from the start of the region's data buffer */
@@ -464,13 +466,14 @@ typedef struct hpf_shard_desc {
  *    join is the state after schedule 1).  The two k-float all-reduces must not queue behind the bulk collectives:
  *    comm_small.  csB_part_rows (a multiple of world, >= world * nranges) is divided over the ranges' apply launches.
  * 3, direct: gather-early WITHOUT collectives (section "Multi-GPU, direct exchange" below).  acc_i and e_own live in the
- *    rank's peer-mapped region.  Compute stream: item sweeps (the launch after a range's sweep tells the peers, on entry,
- *    that the range is complete), user side, colsum(Theta) summed over the ranks inside its reduction kernel (granules),
- *    the apply half, colsum(Beta) the same way.  Exchange stream, per range: the shape half PULLS the slice's N partial
- *    accumulator rows out of the N ranks' buffers and sums them in rank order (the reduce-scatter), then either one pull
- *    launch copies every owner's finished rows into ag_recv under the user sweep (direct_prefetch) or the apply kernel
- *    reads them from the owners' buffers itself (the all-gather).  No RCCL call, no collective kernel beside the sweeps.
- *    comm / coll are not used; a dry run is a region connected to itself (hpf_hip_p2p_region_connect(region, NULL)). */
+ *    rank's peer-mapped region.  Compute stream: item sweeps (the launch after a range's sweep tells every rank, on entry,
+ *    that the range is complete -- no stream event ties the two streams), user side, colsum(Theta) summed over the ranks
+ *    inside its reduction kernel (granules), the apply half, colsum(Beta) the same way.  Exchange stream, per range: one
+ *    wavefront waits for every rank's flag, then the slice's N partial accumulator rows are PULLED out of the N ranks'
+ *    buffers and summed in rank order into acc_own (the reduce-scatter); the shape half of all slices; then either one
+ *    pull launch copies every owner's finished rows into ag_recv under the user sweep (direct_prefetch) or the apply
+ *    kernel reads them from the owners' buffers itself (the all-gather).  No RCCL call, no collective kernel beside the
+ *    sweeps.  comm / coll are not used; a dry run is a region connected to itself (hpf_hip_p2p_region_connect(region, NULL)). */
 #define HPF_SCHEDULE_FINALIZE_THEN_GATHER 0
 #define HPF_SCHEDULE_GATHER_EARLY 1
 #define HPF_SCHEDULE_GATHER_CARRIED 2
@@ -494,10 +497,11 @@ typedef struct hpf_shard_desc {
 #define HPF_TRACE_K_COLSUM_REDUCE 6
 #define HPF_TRACE_K_ITEM_SHAPE 7
 #define HPF_TRACE_K_ITEM_APPLY 8
-#define HPF_TRACE_K_ITEM_SHAPE_PULL 10   /* arg = the flag kinds waited for (bit mask)                  */
+#define HPF_TRACE_K_PULL_REDUCE 10       /* arg = the item range whose slice is pulled and summed            */
 #define HPF_TRACE_K_GATHER_PULL 11       /* arg = signal kind | done kind << 8                              */
-#define HPF_TRACE_K_COLSUM_ALLREDUCE 12  /* arg = HPF_P2P_VEC_*                                             */
+#define HPF_TRACE_K_COLSUM_ALLREDUCE 12  /* arg = HPF_P2P_VEC_* | (1 + own flag kind waited for afterwards) << 8 | peer kinds << 16 */
 #define HPF_TRACE_K_SIGNAL 13            /* arg = flag kind (a launch that only raises a flag)              */
+#define HPF_TRACE_K_WAIT 14              /* arg = the flag kinds one wavefront waits for, from every rank    */
 /* events of a traced plan: HPF_TRACE_EVENT_BASE + 2j (range j swept), + 2j + 1 (range j's all-gather done), then, after the
  * 2 * nranges of them: colsum(Theta) ready, iteration start, apply done, colsum(Beta) done */
 #define HPF_TRACE_EVENT_BASE 0x1000

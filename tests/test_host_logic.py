@@ -476,6 +476,7 @@ def _traced_plan(world, rank, schedule, nranges=2, k=50, nI=1003, small_comm=Tru
     d.a = d.k_shp = d.add_k_rte = d.c = d.t_shp = d.add_t_rte = 0.3
     d.xstream, d.sstream = 0xE0, 0x50 if schedule == 2 else None
     d.dry_run, d.schedule = 2, schedule
+    d.direct_prefetch, d.direct_pull_grid, d.direct_gather_gx = 1, 256, 16      # (read by the direct schedule only)
     plan = sn.ShardPlan(d)
     return plan, sn
 
@@ -570,9 +571,10 @@ def test_c_issued_iteration_traces_with_fewer_items_than_ranks(schedule):
 def test_direct_schedule_traces_have_no_collective(world, nranges, prefetch):
     """The direct (peer-mapped) schedule, HPF_SCHEDULE_DIRECT, in trace mode: NO collective of any kind is issued -- the
     exchange is inside the kernels -- and the flag protocol is consistent on every rank: range j's SWEPT flag is raised on
-    entry of the launch that FOLLOWS the range's sweep on the compute stream (never by the sweep itself), the shape half of
-    range j (exchange stream, after the local sweep's event) waits for exactly that kind, SHAPED is raised once per
-    iteration on the exchange stream after the last shape half, and the apply waits for GATHERED (prefetch) or SHAPED.
+    entry of the launch that FOLLOWS the range's sweep on the compute stream (never by the sweep itself); on the exchange
+    stream a one-wave wait for exactly that kind precedes the range's pull-reduce; the shape half follows the last pull;
+    SHAPED is raised once per iteration after it; the colsum(Theta) launch does the waiting for the apply (GATHERED of this
+    rank with prefetch, every owner's SHAPED without).  In steady state NO stream event ties the two streams (the flags do).
     An empty user shard (u_nseg = 0) still raises the last SWEPT flag through a signal-only launch."""
     from hpfrec_amd import shard_native as sn
     CS, XS = 0xC0, 0xE0
@@ -585,7 +587,7 @@ def test_direct_schedule_traces_have_no_collective(world, nranges, prefetch):
             plan.close()
             # (rebuild with the direct fields set: _traced_plan leaves them at zero)
             d = plan.desc
-            d.direct_prefetch = prefetch
+            d.direct_prefetch, d.direct_pull_grid, d.direct_gather_gx = prefetch, 256, 16
             if empty_users:
                 d.u_nseg = 0
             plan = sn.ShardPlan(d)
@@ -596,39 +598,39 @@ def test_direct_schedule_traces_have_no_collective(world, nranges, prefetch):
                 assert not [1 for kind, i, st, a in tr if kind == sn.TRACE_COLLECTIVE], "a collective in the direct schedule"
                 ker = [(sn.TRACE_KERNELS[i], st, a) for kind, i, st, a in tr if kind == sn.TRACE_KERNEL]
                 names = [n for n, _, _ in ker]
-                assert names.count("sweep") == nranges and names.count("item_shape_pull") == nranges
+                assert names.count("sweep") == nranges and names.count("pull_reduce") == nranges
                 assert names.count("colsum_allreduce") == 2 and names.count("item_apply") == 1
-                assert names.count("sweep_finalize") == (0 if empty_users else 1)
+                assert names.count("item_shape") == 1 and names.count("sweep_finalize") == (0 if empty_users else 1)
                 # flags raised on the compute stream, in order: SWEPT(0) .. SWEPT(last), each by the launch after its sweep
                 raised = [a - 1 for n, st, a in ker if st == CS and n in ("sweep", "sweep_finalize") and a > 0] + \
                          [a for n, st, a in ker if st == CS and n == "signal"]
                 assert raised == [SWEPT(j) for j in range(nranges)], raised
-                sweeps = [a for n, st, a in ker if n == "sweep"]
-                assert sweeps[0] == 0                                   # the first sweep raises nothing
-                # the shape halves wait for their own range's flag, on the exchange stream
-                waits = [a for n, st, a in ker if n == "item_shape_pull" and st == XS]
-                assert waits == [1 << SWEPT(j) for j in range(nranges)]
-                # SHAPED: once, on the exchange stream, after the last shape half
-                if prefetch:
-                    g = [(a & 0xFF, a >> 8) for n, st, a in ker if n == "gather_pull" and st == XS]
-                    assert g == [(SHAPED, GATHERED)]
-                    assert names.index("gather_pull") > max(i for i, n in enumerate(names) if n == "item_shape_pull")
-                else:
-                    assert [a for n, st, a in ker if n == "signal" and st == XS] == [SHAPED] and "gather_pull" not in names
-                apply_wait = [a - 1 for n, st, a in ker if n == "item_apply"]
-                assert apply_wait == [GATHERED if prefetch else SHAPED]
-                # the apply follows colsum(Theta) and precedes colsum(Beta)
+                assert [a for n, st, a in ker if n == "sweep"][0] == 0          # the first sweep raises nothing
+                # exchange stream: wait(SWEPT j) . pull_reduce(j) per range, then the shape half, then SHAPED
+                xs_ops = [(n, a) for n, st, a in ker if st == XS]
+                want = []
+                for j in range(nranges):
+                    want += [("wait", 1 << SWEPT(j)), ("pull_reduce", j)]
+                want += [("item_shape", 0)]
+                want += [("gather_pull", SHAPED | (GATHERED << 8))] if prefetch else [("signal", SHAPED)]
+                assert xs_ops == want, xs_ops
+                # the colsum(Theta) launch waits for what the apply needs; the apply follows it and precedes colsum(Beta)
+                cs_ar = [a for n, st, a in ker if n == "colsum_allreduce"]
+                assert cs_ar[0] & 0xFF == 0 and cs_ar[1] == 1              # HPF_P2P_VEC_CST then _CSB (which waits for nothing)
+                assert (cs_ar[0] >> 8) & 0xFF == 1 + (GATHERED if prefetch else SHAPED)
+                assert (cs_ar[0] >> 16) == (0 if prefetch else 1 << SHAPED)
                 ia = names.index("item_apply")
                 cs_pos = [i for i, n in enumerate(names) if n == "colsum_allreduce"]
                 assert cs_pos[0] < ia < cs_pos[1]
-                # every stream wait names an event recorded before it
+                # steady state: nothing recorded on, or waited for by, the compute stream; every wait after its record
                 rec = set()
                 for kind, i, st, a in tr:
                     if kind == sn.TRACE_RECORD:
                         rec.add(a)
+                        assert st == XS or it == 0
                     elif kind == sn.TRACE_WAIT:
-                        assert a in rec
-                seq.append([(n, a) for n, st, a in ker if n in ("item_shape_pull", "gather_pull", "colsum_allreduce", "item_apply")])
+                        assert a in rec and it == 0
+                seq.append([(n, a) for n, st, a in ker if n in ("wait", "pull_reduce", "gather_pull", "colsum_allreduce", "item_apply")])
             plan.join(CS)
             assert not [1 for kind, i, st, a in plan.trace() if kind in (sn.TRACE_COLLECTIVE, sn.TRACE_KERNEL)]
             plan.close()

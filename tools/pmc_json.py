@@ -3,7 +3,11 @@
 WRITE_SIZE, separate runs): HBM-side bytes per launch of the dominant kernel, tied to the kernel source it was
 measured on (bench.py emits roofline.traffic = null when the library running is built from another source).
 
-usage: pmc_json.py <dir with FETCH_SIZE csv> <dir with WRITE_SIZE csv> <workload> <out.json> [kernel substring]"""
+usage: pmc_json.py <dir with FETCH_SIZE csv> <dir with WRITE_SIZE csv> <workload> <out.json> [kernel substring
+                   [dir with RDREQ + RDREQ_DRAM csv, dir with WRREQ + WRREQ_DRAM csv]]
+The optional last two passes split the L2's memory-side requests into those destined for DRAM and the rest (VERDICT r03
+item 7): `hbm_bytes` = the corrected bytes x that fraction.  The Infinity Cache is memory-side -- a DRAM-destined request can
+still be served by it -- and rocprofv3 lists no counter for it on gfx950, so `mall_hit_rate` is null."""
 import csv
 import glob
 import json
@@ -43,5 +47,25 @@ doc = {
     "sweep_kernel_hbm_bytes_per_launch": int((2.0 * fetch_kb + write_kb) * 1024),
     "kernel_source_sha16": bench.kernel_source_sha16(),
 }
+if len(sys.argv) > 7:
+    rd_dir, wr_dir = sys.argv[6], sys.argv[7]
+    try:
+        _, rd_all, _ = avg_counter(rd_dir, "TCC_EA0_RDREQ_sum", inst)
+        _, rd_dram, _ = avg_counter(rd_dir, "TCC_EA0_RDREQ_DRAM_sum", inst)
+        _, wr_all, _ = avg_counter(wr_dir, "TCC_EA0_WRREQ_sum", inst)
+        _, wr_dram, _ = avg_counter(wr_dir, "TCC_EA0_WRREQ_DRAM_sum", inst)
+        fr, fw = rd_dram / max(rd_all, 1.0), wr_dram / max(wr_all, 1.0)
+        doc.update({
+            "read_requests_per_launch": {"all": rd_all, "destined_for_dram": rd_dram, "fraction": fr},
+            "write_requests_per_launch": {"all": wr_all, "destined_for_dram": wr_dram, "fraction": fw},
+            "hbm_bytes": int((2.0 * fetch_kb * fr + write_kb * fw) * 1024),
+            "hbm_bytes_note": "the corrected FETCH_SIZE / WRITE_SIZE bytes x the fraction of the L2's memory-side requests "
+                              "destined for DRAM (TCC_EA0_RDREQ_DRAM / TCC_EA0_WRREQ_DRAM): an UPPER bound on what HBM itself "
+                              "moved -- the Infinity Cache sits on the memory side and serves part of them",
+            "mall_hit_rate": None,
+            "mall_hit_rate_note": "rocprofv3 (ROCm 7.2, gfx950) lists no Infinity-Cache / MALL counter "
+                                  "(profiles/r04_rocprofv3_memory_counters_available.txt)"})
+    except SystemExit as e:
+        doc["hbm_bytes"], doc["hbm_bytes_note"] = None, "DRAM-destined request passes missing: %s" % e
 json.dump(doc, open(out, "w"), indent=2)
 print(json.dumps(doc))
