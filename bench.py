@@ -190,6 +190,9 @@ def cpu_baseline(nU, nI, k, nnz_full, sample_users=200_000, iters=4, device=None
                                                                  Y.shape[0] * k * 4 / 1e9)) if full else
                      ("%d users x %d items, %d nnz, k=%d, %d timed iterations at %.2f s/iter; scaled by nnz to %d nnz"
                       % (sample_users, nI, Y.shape[0], k, iters, dt, nnz_full))}
+    out["calibration_vs_reference"] = ("the port runs 12-15 % FASTER than the real Cython extension (port / reference time per "
+                                       "iteration 0.85-0.88, timed side by side in the build container, 8 cores, 2M nnz: "
+                                       "profiles/r02_cpu_calibration.txt) -- the reference itself cannot run on the GPU box")
     # the oracle is the checker: the HIP path on the same sample, same start, same numbers of iterations
     if device is not None:
         hyd = cavi.Hyper(k, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)

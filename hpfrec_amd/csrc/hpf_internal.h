@@ -47,10 +47,11 @@ int colsum_reduce_allreduce(const float *cs_partial, int nblk, float *cs_out, in
 // (dst + o * rows_per_rank * row_floats for owner o), one launch, grid (gx, world).  Block (0, 0) first raises
 // flags[signal_kind][rank] = epoch in every peer (this rank's rows are complete: they were written by earlier launches of
 // this stream); the blocks of owner o then wait for o's flag.  The last block to finish raises this rank's OWN
-// flags[done_kind][rank] (the apply kernel on the compute stream polls it instead of a stream event).
+// flags[done_kind][rank] (the apply kernel on the compute stream polls it instead of a stream event).  copy_own = 0: this
+// rank's own rows are not copied (their reader takes them from the source buffer).
 namespace hpf_p2p {
 int gather_pull(void *region, int64_t src_offset_bytes, float *dst, int64_t floats_per_rank, int signal_kind, int done_kind,
-                uint32_t epoch, int gx, hipStream_t st);
+                uint32_t epoch, int gx, int copy_own, hipStream_t st);
 // dst[0..n) = the rank-order sum over the ranks of the n floats at src_offset_bytes of every rank's data buffer (ranks
 // outside sum_mask are read, not counted); wide loads when offset, n and dst allow.  Put wait_flags() ahead of it.
 int pull_reduce(void *region, int64_t src_offset_bytes, float *dst, int64_t n, uint32_t sum_mask, int grid_blocks,

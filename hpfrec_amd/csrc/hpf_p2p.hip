@@ -146,14 +146,15 @@ struct GatherSrc {
 };
 __global__ __launch_bounds__(256) void p2p_gather_kernel(const hpf_p2p::Peers pp, const GatherSrc gs, float4 *__restrict__ dst,
                                                          int64_t n4, int signal_kind, int done_kind, uint32_t epoch,
-                                                         uint32_t *__restrict__ counter) {
+                                                         uint32_t *__restrict__ counter, int copy_own) {
     const int owner = blockIdx.y;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) hpf_p2p::wave_signal(pp, signal_kind, epoch);
     hpf_p2p::block_acquire(pp, signal_kind, epoch, 1u << owner);
     const float4 *__restrict__ src = gs.src[owner];
     float4 *__restrict__ out = dst + (size_t)owner * n4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // (this rank's own rows are not copied: the apply kernel reads them where the shape half left them)
+    int64_t i = (owner == pp.rank && !copy_own) ? n4 : (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i + 7 * stride < n4; i += 8 * stride) {
         float4 v[8];
 #pragma unroll
@@ -223,7 +224,7 @@ const Peers *region_peers_dev(void *region) {
 }
 
 int gather_pull(void *region, int64_t src_offset_bytes, float *dst, int64_t floats_per_rank, int signal_kind, int done_kind,
-                uint32_t epoch, int gx, hipStream_t st) {
+                uint32_t epoch, int gx, int copy_own, hipStream_t st) {
     if (!region || !dst || floats_per_rank <= 0 || (floats_per_rank & 3) || (src_offset_bytes & 15) || gx <= 0)
         return HPF_EINVAL;
     Region *r = (Region *)region;
@@ -232,7 +233,8 @@ int gather_pull(void *region, int64_t src_offset_bytes, float *dst, int64_t floa
     for (int p = 0; p < r->world; p++)
         gs.src[p] = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(r->data[p]) + src_offset_bytes);
     hipLaunchKernelGGL(p2p_gather_kernel, dim3((unsigned)gx, (unsigned)r->world), dim3(256), 0, st, peers_of(r), gs,
-                       reinterpret_cast<float4 *>(dst), floats_per_rank / 4, signal_kind, done_kind, epoch, r->counters);
+                       reinterpret_cast<float4 *>(dst), floats_per_rank / 4, signal_kind, done_kind, epoch, r->counters,
+                       copy_own);
     return (int)hipGetLastError();
 }
 }  // namespace hpf_p2p

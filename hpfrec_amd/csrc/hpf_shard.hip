@@ -776,7 +776,7 @@ static int iterate_direct(Plan *p, const float *eT, float *eT_next, int store, h
             g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_GATHER_PULL, xs, HPF_P2P_FLAG_SHAPED(0) | (HPF_P2P_FLAG_GATHERED << 8));
         } else {
             HPF_TRY(hpf_p2p::gather_pull(d.p2p_region, d.p2p_send_offset, d.ag_recv, p->total * d.e_own_ld,
-                                         HPF_P2P_FLAG_SHAPED(0), HPF_P2P_FLAG_GATHERED, p->epoch, d.direct_gather_gx, xs));
+                                         HPF_P2P_FLAG_SHAPED(0), HPF_P2P_FLAG_GATHERED, p->epoch, d.direct_gather_gx, 0, xs));
             HPF_TRY(pull_link_time(p, gather_bytes, xs));
         }
     } else if (g_tr) {
@@ -819,7 +819,7 @@ static int iterate_direct(Plan *p, const float *eT, float *eT_next, int store, h
     } else {
         const float *blocks[HPF_P2P_MAX_RANKS];
         for (int q = 0; q < d.world; q++)
-            blocks[q] = d.direct_prefetch
+            blocks[q] = (d.direct_prefetch && q != d.rank)       // (own rows: where the shape half left them)
                             ? d.ag_recv + (size_t)q * p->total * d.e_own_ld
                             : reinterpret_cast<const float *>(reinterpret_cast<const char *>(p->peer_data[q]) +
                                                               d.p2p_send_offset);
@@ -940,7 +940,7 @@ int hpf_hip_shard_exchange_only(void *plan, int op, int range, void *stream) {
             }
             if (!d.ag_recv) return HPF_EINVAL;
             return hpf_p2p::gather_pull(d.p2p_region, d.p2p_send_offset, d.ag_recv, p->total * d.e_own_ld,
-                                        HPF_P2P_FLAG_SHAPED(0), HPF_P2P_FLAG_GATHERED, p->epoch, d.direct_gather_gx, st);
+                                        HPF_P2P_FLAG_SHAPED(0), HPF_P2P_FLAG_GATHERED, p->epoch, d.direct_gather_gx, 1, st);
         }
         return HPF_EINVAL;
     }

@@ -87,6 +87,8 @@ def _run(rank, world, port, out_dir, k, its, case, device="cpu"):
         iu = np.repeat(np.arange(3), (30, 3, 12)).astype(np.uint64)
         ii = np.concatenate([rs.choice(40, n, replace=False) for n in (30, 3, 12)]).astype(np.uint64)
         Y = (rs.gamma(1, 1, size=iu.shape[0]) + 1).astype(np.int32).astype(np.float32)
+    elif case == "large":     # the large golden's matrix (tests/golden/large_full.npz: the REAL reference at 200k x 50k)
+        iu, ii, Y, nU, nI = datagen.large_counts()
     elif case == "c4small":     # BASELINE C4's shape of problem at 2M nonzeros (tests/test_full_size.py)
         nU, nI = 100_000, 30_000
         iu, ii, Y = datagen.synthetic_hpf_shaped(nU, nI, 2_000_000, seed=4)
@@ -106,6 +108,17 @@ def _run(rank, world, port, out_dir, k, its, case, device="cpu"):
                               np.empty(0, np.uint64), np.empty(0, np.uint64), 0, 1, 0)
     from hpfrec_amd import shard
     native = int(shard.NATIVE_PLANS_CREATED[0])
+    if case == "large":       # compact: the golden's sub-sampled rows and float64 column sums
+        arrs = dict(zip(("Theta", "Beta", "Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "k_rte", "t_rte"),
+                        (Theta, Beta) + tuple(temp)))
+        out = {}
+        for n, v in arrs.items():
+            out[n + "_rows"] = v[::(400 if v.shape[0] == nU else 100)].copy()
+            out[n + "_colsum64"] = v.astype(np.float64).sum(axis=0)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), llk=np.float64(llk), niter=i, native_plans=native,
+                 schedule=str(shard.LAST_SCHEDULE[0]), **out)
+        dist.destroy_process_group()
+        return
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), Theta=Theta, Beta=Beta, Gamma_shp=temp[0], Gamma_rte=temp[1],
              Lambda_shp=temp[2], Lambda_rte=temp[3], k_rte=temp[4], t_rte=temp[5], llk=np.float64(llk), niter=i,
              native_plans=native, schedule=str(shard.LAST_SCHEDULE[0]))

@@ -30,6 +30,27 @@ def _maxrel(a, b):
     return float(np.max(np.abs(a - b) / np.abs(b)))
 
 
+def test_large_golden_two_ranks_direct(tmp_path, monkeypatch):
+    """The N>1 path against the REAL reference: the large golden's matrix (200k x 50k, 5.4M nonzeros, k=50,
+    tests/golden/large_full.npz) fitted by 2 processes sharing the GPU with the direct (peer-mapped) exchange, 3
+    iterations -- every rank's sub-sampled rows and float64 column sums of all eight arrays within north_star's 1e-4 of what
+    hpfrec itself computed, replicas bit-identical."""
+    import dist_worker
+    from conftest import GOLDEN, spawn_ranks
+    monkeypatch.setenv("HPF_SCHEDULE", "direct")
+    monkeypatch.setenv("HPF_DIRECT_TIMEOUT_MS", "60000")
+    g = np.load(os.path.join(GOLDEN, "large_full.npz"))
+    world, its = 2, 3
+    spawn_ranks(dist_worker.run, lambda port: (world, port, str(tmp_path), 50, its, "large", "cuda"), world, str(tmp_path))
+    outs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    for r in range(world):
+        assert str(outs[r]["schedule"]) == "direct" and int(outs[r]["native_plans"]) >= 1
+        for n in O.State.names:
+            assert _maxrel(outs[r][n + "_rows"], g["it%d_%s_rows" % (its, n)]) < 1e-4, (r, n)
+            assert float(np.max(np.abs(outs[r][n + "_colsum64"] / g["it%d_%s_colsum64" % (its, n)] - 1))) < 1e-4, (r, n)
+            assert np.array_equal(outs[r][n + "_rows"], outs[0][n + "_rows"]), (r, n)
+
+
 # ---------------------------------------------------------------------------------------------
 # C3: the north-star matrix, 3 iterations, HIP path vs the port of the reference on all host cores
 # ---------------------------------------------------------------------------------------------
