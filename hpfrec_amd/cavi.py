@@ -120,7 +120,12 @@ class FullBatchCavi(ShardedMixin):
         # (profiles/r03_shard_probe_collective_footprint.txt)
         self.sweep_blocks = ops.sweep_blocks
         if self.dist and "HPF_SWEEP_BPC" not in os.environ and hasattr(ops, "cu_count"):
-            self.sweep_blocks = max(1, ops.cu_count) * int(os.environ.get("HPF_SHARD_SWEEP_BPC", "3"))
+            # (the direct exchange's kernels are light -- no collective library's footprint to leave room for: 4 measured
+            #  0.588 vs 0.605 ms per 8-rank iteration, profiles/r04_shard_probe_direct.txt; the RCCL schedules keep 3)
+            from .shard import requested_schedule
+            direct = requested_schedule() in ("auto", "direct") and self.device.type == "cuda" and \
+                os.environ.get("HPF_NATIVE_SHARD", "1") == "1"
+            self.sweep_blocks = max(1, ops.cu_count) * int(os.environ.get("HPF_SHARD_SWEEP_BPC", "4" if direct else "3"))
         # the sharded item pass is many short rows: more, smaller blocks even out its tail (tools/sweep_micro.py:
         # 203 us at 32 blocks per CU vs 220 at 8 for rank 0 of 8 at C3)
         self.item_sweep_blocks = max(1, getattr(ops, "cu_count", 1)) * int(os.environ.get("HPF_ITEM_SWEEP_BPC", "32")) \

@@ -223,7 +223,8 @@ class ShardedMixin:
         self._range_rows = [(c["lo"], c["hi"]) for c in views]       # in issue order (= slice order inside a rank's block)
         grid = ops.finalize_grid(max(1, sum(n for n, _, _ in ranges)))
         if early:      # (the apply kernel streams ALL item rows: gx blocks for each rank's block, a multiple of the world size)
-            grid = W * max(len(self.item_chunks), -(-2 * ops.finalize_grid(self.nI) // W))
+            mult = float(os.environ.get("HPF_APPLY_GRID_MULT", "2"))          # (probe knob)
+            grid = W * max(len(self.item_chunks), -(-int(mult * ops.finalize_grid(self.nI)) // W))
         self.csB_part_sc = torch.zeros((grid, ld), **f32)
         self._csT_ready = torch.cuda.Event() if cuda else None
         self._sc_fresh = True
