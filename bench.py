@@ -674,6 +674,7 @@ def main():
                                                is not None else "python, call by call") if sharded else None,
                        "native_plan_error": getattr(model, "native_error", None) if sharded else None,
                        "first_iteration_check": getattr(model, "first_check", None) if sharded else None,
+                       "first_iteration_checks_failed": getattr(model, "first_checks_failed", None) if sharded else None,
                        "seg_cap": cavi.layout.SEG_CAP, "fused_finalize": model.fused and world == 1,
                        "stores_all_state_tables": store, "state_finite": finite},
             "roofline": roof,

@@ -35,6 +35,7 @@ SCHEDULES = ("direct", "gather-early", "finalize-then-gather", "gather-carried")
 _EARLY = ("direct", "gather-early", "gather-carried")      # split item finalizer: [numerators | base] payload rows
 _DIRECT_COMMS = {}
 _VERIFIED = {}                  # (schedule, world, device) -> bool: the first-iteration check of this process
+_FAILED = set()                 # the same keys: schedules whose check failed -- not set up again in this process
 NATIVE_PLANS_CREATED = [0]      # how many models of this process run their sharded iteration from C (tests, bench)
 LAST_SCHEDULE = [None]          # "<schedule>" / "<schedule>, call by call" of the last model that set its exchange up
 _side_stream = _streams.side_stream
@@ -152,6 +153,8 @@ class ShardedMixin:
         if native_wanted:      # what to fall back to when the preferred schedule cannot get a plan on every rank
             order += {"direct": ["gather-early", "finalize-then-gather"], "gather-carried": ["gather-early", "finalize-then-gather"],
                       "gather-early": ["finalize-then-gather"]}.get(self._want, [])
+        # (a schedule whose first-iteration check failed in this process is not tried again; the verdict was every rank's)
+        order = [s_ for s_ in order if (s_, self.world, str(self.device)) not in _FAILED] or ["finalize-then-gather"]
         errors = []
         for idx, sched in enumerate(order):
             self.schedule = sched
@@ -416,19 +419,35 @@ class ShardedMixin:
         ok = torch.tensor([0.0 if err else 1.0], device=self.device)
         self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
         good = float(ok.item()) > 0
+        if os.environ.get("HPF_TEST_FAIL_FIRST_CHECK") == self.schedule:     # (tests: the fall-back path)
+            good, err = False, "failure injected by HPF_TEST_FAIL_FIRST_CHECK"
         _VERIFIED[key] = good
         self.first_check = {"schedule": self.schedule, "max_rel_vs_call_by_call": worst, "passed": good}
-        if not good:
-            # every rank goes back to the call-by-call form, from the state the check started with
-            self.native = False
-            self.native_error = err or "the first-iteration check failed on another rank"
-            warnings.warn("hpfrec_amd: %s; continuing call by call" % self.native_error)
-            if self.niter_done != done0:
-                self.eT, self.eT_next = self.eT_next, self.eT
-                self.niter_done = done0
-            for n, v in snap.items():
-                getattr(self, n).copy_(v)
-            self._iterate_python(store)
+        if good:
+            return
+        # Every rank takes the same way out (the vote was uniform): back to the state the check started with; the schedule
+        # is struck for the rest of the process; the NEXT C-issued schedule is set up and gets its own check -- direct ->
+        # gather-early on RCCL -> finalize-then-gather -- and only the last resort is the call-by-call form
+        failed = self.schedule
+        _FAILED.add(key)
+        self.native_error = "%s: %s" % (failed, err or "the first-iteration check failed on another rank")
+        self.first_checks_failed = getattr(self, "first_checks_failed", []) + [self.native_error]
+        if self.niter_done != done0:
+            self.eT, self.eT_next = self.eT_next, self.eT
+            self.niter_done = done0
+        for n, v in snap.items():
+            getattr(self, n).copy_(v)
+        torch.cuda.synchronize(self.device)
+        nxt = {"direct": "gather-early", "gather-carried": "gather-early", "gather-early": "finalize-then-gather"}.get(failed)
+        if nxt is not None:
+            warnings.warn("hpfrec_amd: %s; switching every rank to %s" % (self.native_error, nxt))
+            self._plan.close()
+            self._plan, self._chunk_views, self._want = None, None, nxt
+            self._last_native, self._sc_fresh, self._tables_split = False, True, False
+            return self._iterate_scatter(store)
+        warnings.warn("hpfrec_amd: %s; continuing call by call" % self.native_error)
+        self.native = False
+        self._iterate_python(store)
 
     def _iterate_finalize_then_gather(self, store):
         """Call by call, overlapped.  Per item range (fewest rows first): sweep the local CSC slice into the packed exchange

@@ -841,6 +841,7 @@ def test_tiny_shape_priors(hip_backend):
     (2, "direct", "no-prefetch", 100), (3, "direct", "no-prefetch", 50), (3, "direct", "checks", 20),
     (3, "direct", "one-range", 50), (2, "direct", "verify", 20), (8, "direct", "tiny-no-prefetch", 20),
     (4, "direct", "few", 20), (4, "gather-early", "few-cb", 20),     # more ranks than users: empty user shards
+    (2, "direct", "verify-failinject-cb", 20),      # the first-iteration check of `direct` fails -> every rank on gather-early
     # the RCCL-shaped schedules issued from C, gloo standing in for RCCL through the collective callback
     (2, "gather-early", "cb", 20), (3, "gather-early", "cb", 100), (8, "gather-early", "tiny-cb", 20),
     (2, "gather-early", "checks-cb", 20), (2, "gather-early", "verify-cb", 50),
@@ -870,6 +871,10 @@ def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypat
         monkeypatch.setenv("HPF_ITEM_RANGES", "1")
     if "verify" in flags:                # the first C-issued iteration checked against the call-by-call form, all ranks voting
         monkeypatch.setenv("HPF_VERIFY_FIRST", "1")
+    expect_sched = sched
+    if "failinject" in flags:            # ... and reported as failed for `direct`: the ranks move on to the next C-issued schedule
+        monkeypatch.setenv("HPF_TEST_FAIL_FIRST_CHECK", "direct")
+        expect_sched = "gather-early"
     native = "py" not in flags
     monkeypatch.setenv("HPF_NATIVE_SHARD", "1" if native else "0")
     if "cb" in flags:                    # gloo behind hpf_shard_desc.coll
@@ -898,7 +903,7 @@ def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypat
     for r in range(world):
         assert int(outs[r]["niter"]) == i
         assert abs(float(outs[r]["llk"]) / float(llk) - 1) < 1e-6
-        assert str(outs[r]["schedule"]) == sched + ("" if native else ", call by call"), outs[r]["schedule"]
+        assert str(outs[r]["schedule"]) == expect_sched + ("" if native else ", call by call"), outs[r]["schedule"]
         assert (int(outs[r]["native_plans"]) >= 1) == native, "the iteration was not issued from C"
         for n in names:
             assert np.max(np.abs(outs[r][n] - single[n]) / np.abs(single[n])) < 1e-5, (r, n)
