@@ -181,6 +181,10 @@ __global__ __launch_bounds__(BLOCK) void svi_own_write_kernel(const hpf_segment 
 // Entry e is kept iff flag[idx[e]]; its output position is P(e) = kept entries before e, read off a bitmask + a prefix per
 // tile of 1024 entries: no pass over the nonzeros ever depends on a row's length.
 constexpr int CHUNKS_PER_TILE = 16;       // 64-entry chunks per tile
+#ifndef HPF_PREP_INFLIGHT
+#define HPF_PREP_INFLIGHT 8               // chunks whose id (and count) loads a wave keeps in flight in the mask / write passes
+#endif
+constexpr int PIF = HPF_PREP_INFLIGHT;    // (4: the id stream of the mask pass ran at 1.1 TB/s -- latency-bound)
 
 // (3a') the own side's flags as a bitset (a 1M-row side: 128 KB -- it fits the LDS of a CU, the byte table does not)
 __global__ __launch_bounds__(BLOCK) void svi_flag_bits_kernel(const uint8_t *__restrict__ flag, int64_t nrows,
@@ -220,17 +224,17 @@ __global__ __launch_bounds__(1024) void svi_oth_mask_kernel(const int32_t *__res
     for (int64_t t = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); t < ntiles; t += nwaves) {
         unsigned long long mine = 0;               // lane j < 16 ends up holding the mask of chunk j
 #pragma unroll
-        for (int j0 = 0; j0 < CHUNKS_PER_TILE; j0 += 4) {
-            int32_t id[4];
-            bool in[4];
+        for (int j0 = 0; j0 < CHUNKS_PER_TILE; j0 += PIF) {
+            int32_t id[PIF];
+            bool in[PIF];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < PIF; u++) {
                 const int64_t e = (t * CHUNKS_PER_TILE + j0 + u) * WAVE + lane;
                 in[u] = e < nnz;
                 id[u] = in[u] ? idx[e] : 0;
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < PIF; u++) {
                 const unsigned long long m = __ballot(in[u] && ((tab[id[u] >> 5] >> (id[u] & 31)) & 1u));
                 if (lane == j0 + u) mine = m;
             }
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(BLOCK) void svi_oth_layout_kernel(int64_t nrows, co
 }
 
 // (3e) other side: the kept nonzeros written in order -- o_idx = the own side's row id, o_y = the count.  One wavefront
-// per tile: the tile's 16 masks and prefixes arrive in one load each, four chunks' gathers are in flight at once
+// per tile: the tile's 16 masks and prefixes arrive in one load each, PIF chunks' gathers are in flight at once
 __global__ __launch_bounds__(BLOCK) void svi_oth_write_kernel(const int32_t *__restrict__ idx, const float *__restrict__ y,
                                                               int64_t nnz, const unsigned long long *__restrict__ mask,
                                                               const uint16_t *__restrict__ chunk_pre,
@@ -403,13 +407,13 @@ __global__ __launch_bounds__(BLOCK) void svi_oth_write_kernel(const int32_t *__r
             pre = chunk_pre[t * CHUNKS_PER_TILE + lane];
         }
 #pragma unroll
-        for (int j0 = 0; j0 < CHUNKS_PER_TILE; j0 += 4) {
-            int32_t id[4];
-            float yy[4];
-            long long pos[4];
-            bool keep[4];
+        for (int j0 = 0; j0 < CHUNKS_PER_TILE; j0 += PIF) {
+            int32_t id[PIF];
+            float yy[PIF];
+            long long pos[PIF];
+            bool keep[PIF];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < PIF; u++) {
                 const unsigned long long m = __shfl(mine, j0 + u);
                 const int p = __shfl(pre, j0 + u);
                 keep[u] = (m >> lane) & 1ull;
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(BLOCK) void svi_oth_write_kernel(const int32_t *__r
                 yy[u] = keep[u] ? y[e] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < PIF; u++) {
                 if (keep[u] && pos[u] < o_cap) {
                     o_idx[pos[u]] = id[u];
                     o_y[pos[u]] = yy[u];
