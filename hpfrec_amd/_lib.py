@@ -27,7 +27,7 @@ SOURCES = (SRC_PATH, SHARD_SRC_PATH, MT_SRC_PATH, SVI_SRC_PATH, P2P_SRC_PATH)
 HEADERS = (os.path.join(_PKG, "csrc", "hpf_p2p_dev.h"),)
 INC_PATH = os.path.join(_ROOT, "include")
 
-HPF_HIP_ABI_VERSION = 18
+HPF_HIP_ABI_VERSION = 19
 
 #: every symbol include/hpf_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = (
@@ -130,7 +130,7 @@ def lib():
     L.hpf_hip_svi_shape_rows_f32.argtypes = [vp, i64, vp, vp, vp, cf, cf, cf, ci, ci, ci, vp]
     L.hpf_hip_svi_refresh_f32.argtypes = [i64, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, ci, ci, ci, ci, ci, vp]
     L.hpf_hip_svi_side_f32.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, cf, cf, cf, ci, ci, ci, ci,
-                                       ci, vp, vp, vp]
+                                       ci, vp, vp, vp, vp]
     L.hpf_hip_svi_rate_rows_f32.argtypes = [vp, i64, vp, vp, vp, vp, cf, cf, cf, cf, ci, ci, ci, vp]
     u32 = ctypes.c_uint32
     L.hpf_hip_p2p_ctrl_bytes.argtypes = [ci]

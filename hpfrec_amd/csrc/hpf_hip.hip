@@ -1315,7 +1315,11 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                                                          float w_old, float top, float add, float step,
                                                          float step_prev, int rate_mode, int rs_mode, int k,
                                                          const float *__restrict__ rs_rate,
-                                                         float *__restrict__ rs_prev_out) {
+                                                         float *__restrict__ rs_prev_out, float *e_out) {
+    // e_out (may alias e): the step's rows also get their NEW E row, exp(psi(shp))/rte row-scaled, from the shape and rate
+    // just formed -- what expect_kernel would compute from the tables at the start of the next step (same function, same
+    // inputs, same bits), without reading them back; rows outside the step keep theirs (nothing of theirs changed in a
+    // rate_mode 1 pass), so a side whose E table was current for all rows stays current.
     // rte / fac may be null: the table is not stored (rate_mode 0 only for rte).  A batch side's rate is rank-1,
     // rte = top/rs + cs_other, and its means are read through their column sums only, so an epoch keeps the row scalar
     // (rs_prev_out[r] = the rs the rate was formed with) + cs_other instead of two [rows][ld] tables; rs_rate: form the
@@ -1419,6 +1423,30 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                         if (rte && (rate_mode == 0 || fl[i]))
                             reinterpret_cast<float4 *>(rte)[o4 + v * WAVE] = make_float4(r4[0], r4[1], r4[2], r4[3]);
                         if (fac) reinterpret_cast<float4 *>(fac)[o4 + v * WAVE] = make_float4(f4[0], f4[1], f4[2], f4[3]);
+                        if (e_out && fl[i]) {      // (kept for the E row below)
+                            sv[i][v] = make_float4(s4[0], s4[1], s4[2], s4[3]);
+                            rv[i][v] = make_float4(r4[0], r4[1], r4[2], r4[3]);
+                        }
+                    }
+                    if (e_out && fl[i]) {          // (wave-uniform)
+                        double en[VPL][4];
+                        int ehi = 0;
+#pragma unroll
+                        for (int v = 0; v < VPL; v++) {
+                            const float s4[4] = {sv[i][v].x, sv[i][v].y, sv[i][v].z, sv[i][v].w};
+                            const float r4[4] = {rv[i][v].x, rv[i][v].y, rv[i][v].z, rv[i][v].w};
+#pragma unroll
+                            for (int e2 = 0; e2 < 4; e2++) {
+                                en[v][e2] = ok[v][e2] ? expect_ratio(s4[e2], r4[e2]) : 0.0;
+                                ehi = max(ehi, __double2hiint(en[v][e2]));
+                            }
+                        }
+                        const double inv = row_pow2_scale(ehi);
+#pragma unroll
+                        for (int v = 0; v < VPL; v++)
+                            reinterpret_cast<float4 *>(e_out)[o4 + v * WAVE] =
+                                make_float4(ok[v][0] ? (float)(en[v][0] * inv) : 0.f, ok[v][1] ? (float)(en[v][1] * inv) : 0.f,
+                                            ok[v][2] ? (float)(en[v][2] * inv) : 0.f, ok[v][3] ? (float)(en[v][3] * inv) : 0.f);
                     }
                     if (rs_mode == 2 || (rs_mode == 1 && fl[i])) {
                         fsum = wave_sum(fsum);
@@ -1486,7 +1514,7 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                 const int c = lane + WAVE * q;
                 if (c < LD) {
                     const size_t o = (size_t)r * LD + c;
-                    float f = 0.f;
+                    float f = 0.f, s_new = 0.f, rt_new = 1.f;
                     if (c < k) {
                         float s = sv[i][q];
                         if (fl[i]) {
@@ -1503,10 +1531,32 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                             rte[o] = rt;
                         }
                         f = s / rt;
+                        s_new = s;
+                        rt_new = rt;
                     }
                     if (fac) fac[o] = f;
                     fsum += f;
                     csacc[q] += f;
+                    if (e_out && fl[i] && c < k) {     // (kept for the E row below)
+                        sv[i][q] = s_new;
+                        rv[i][q] = rt_new;
+                    }
+                }
+            }
+            if (e_out && fl[i]) {                      // (wave-uniform)
+                double en[CPL];
+                int ehi = 0;
+#pragma unroll
+                for (int q = 0; q < CPL; q++) {
+                    const int c = lane + WAVE * q;
+                    en[q] = (c < k) ? expect_ratio(sv[i][q], rv[i][q]) : 0.0;
+                    ehi = max(ehi, __double2hiint(en[q]));
+                }
+                const double inv = row_pow2_scale(ehi);
+#pragma unroll
+                for (int q = 0; q < CPL; q++) {
+                    const int c = lane + WAVE * q;
+                    if (c < LD) e_out[(size_t)r * LD + c] = (c < k) ? (float)(en[q] * inv) : 0.f;
                 }
             }
             if (rs_prev_out && lane == 0) rs_prev_out[r] = rs_rt[i];
@@ -2226,17 +2276,18 @@ int hpf_hip_svi_refresh_f32(int64_t nrows, const float *shp, float *rte, float *
 int hpf_hip_svi_side_f32(int64_t nrows, const uint8_t *flag, const float *acc, const float *e, float *shp, float *rte,
                          float *fac, float *rs, const float *cs_other, float *cs_partial, float prior, float w_new,
                          float w_old, float top, float add, float step, float step_prev, int rate_mode, int rs_mode,
-                         int k, int ld, int grid_blocks, const float *rs_rate, float *rs_prev_out, void *stream) {
+                         int k, int ld, int grid_blocks, const float *rs_rate, float *rs_prev_out, float *e_out,
+                         void *stream) {
     if (!shp || !rs || !cs_other || !cs_partial || (flag && (!acc || !e)) || nrows <= 0 || k <= 0 ||
         ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0 || (rate_mode != 0 && rate_mode != 1) || rs_mode < 0 ||
-        rs_mode > 2 || (rate_mode == 1 && !rte))
+        rs_mode > 2 || (rate_mode == 1 && !rte) || (e_out && !flag))
         return HPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     // grid not clamped: every block writes its cs_partial row
 #define CALL(LD)                                                                                                    \
     hipLaunchKernelGGL((svi_side_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, nrows, flag, acc, e, shp, rte, \
                        fac, rs, cs_other, cs_partial, prior, w_new, w_old, top, add, step, step_prev, rate_mode,    \
-                       rs_mode, k, rs_rate, rs_prev_out);
+                       rs_mode, k, rs_rate, rs_prev_out, e_out);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
     return last_error();

@@ -270,14 +270,15 @@ class HipOps:
                                                   ld, cs_partial.shape[0], self._stream()), "hpf_hip_svi_refresh_f32")
 
     def svi_side(self, nrows, flag, acc, e, shp, rte, fac, rs, cs_other, cs_partial, prior, w_new, w_old, top, add, step,
-                 step_prev, rate_mode, rs_mode, k, ld, rs_rate=None, rs_prev_out=None):
+                 step_prev, rate_mode, rs_mode, k, ld, rs_rate=None, rs_prev_out=None, e_out=None):
         """rte / fac None: not stored (rte: rate_mode 0 only); rs_prev_out: the scalar each row's rate was formed with;
-        rs_rate: form the rate from these scalars instead of rs (expanding a factored rate)."""
+        rs_rate: form the rate from these scalars instead of rs (expanding a factored rate); e_out: the flagged rows' new
+        E rows (what `expect` would compute from the tables afterwards)."""
         _lib.check(self.L.hpf_hip_svi_side_f32(nrows, _ptr(flag), _ptr(acc), _ptr(e), _ptr(shp), _ptr(rte), _ptr(fac),
                                                _ptr(rs), _ptr(cs_other), _ptr(cs_partial), float(prior), float(w_new),
                                                float(w_old), float(top), float(add), float(step), float(step_prev),
                                                int(rate_mode), int(rs_mode), k, ld, cs_partial.shape[0], _ptr(rs_rate),
-                                               _ptr(rs_prev_out), self._stream()),
+                                               _ptr(rs_prev_out), _ptr(e_out), self._stream()),
                    "hpf_hip_svi_side_f32")
 
     def svi_rate_rows(self, row_list, rte, fac, rs, cs_other, top, add, step, step_prev, mode, k, ld):

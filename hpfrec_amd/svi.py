@@ -171,6 +171,9 @@ class DeviceModel:
         # (materialize).  Same float32 operations as the stored form: bit-identical results.
         self.factored = {"u": None, "i": None}       # None: rate table current; else (rs_prev, cs_used, top)
         self.means_stale = {"u": False, "i": False}
+        # the E table (eT / eB) of a side is current for ALL of its rows: a lazy epoch keeps the OTHER side's so -- the
+        # whole-table pass of a step writes the new E rows of the rows it changed -- and skips that side's expectation pass
+        self.e_valid = {"u": False, "i": False}
         self._rs_prev = {"u": torch.zeros(self.nU, **f32), "i": torch.zeros(self.nI, **f32)}
         self.csT = torch.zeros(self.ld, **f32)      # Theta.sum(axis=0) / Beta.sum(axis=0): set by put(), kept
         self.csB = torch.zeros(self.ld, **f32)      # current by every step
@@ -186,6 +189,7 @@ class DeviceModel:
         """Upload one state array ([n,k] table or [n,1] scalar-rate vector) from the host."""
         dev = self.ops.device
         a = torch.from_numpy(np.ascontiguousarray(host, dtype=np.float32))
+        self.e_valid = {"u": False, "i": False}       # (whatever is uploaded, the E tables no longer describe it)
         if name in ("k_rte", "t_rte"):
             getattr(self, name).copy_(a.reshape(-1))
         else:
@@ -229,6 +233,7 @@ class DeviceModel:
                          ratio=self.Beta)
         self.k_rte.fill_(float(hy.b_prime))
         self.t_rte.fill_(float(hy.d_prime))
+        self.e_valid = {"u": False, "i": False}
         self.csT = self.colsum("Theta")
         self.csB = self.colsum("Beta")
 
@@ -275,15 +280,17 @@ class DeviceModel:
             self._part = torch.empty((rows, self.ld), dtype=torch.float32, device=self.ops.device)
         return self._part
 
-    def batch_phi_sums(self, su, si, flag_u, flag_i):
+    def batch_phi_sums(self, su, si, flag_u, flag_i, e_current=()):
         """Per touched row, sum_n w_n * (other side's E row) over the batch's nonzeros (update_phi[_csr] +
         update_G_n_L_sh[_csr] restricted to the batch; sum phi = E_row (*) this), from the CURRENT shapes/rates,
         left in acc_u[user] / acc_i[item] for the rows present in the batch.  su / si: the batch grouped by user / by
         item -- BatchSides (partial_fit: sizes known on the host) or DevSides (epochs: sizes on the device); flag_u /
         flag_i: one byte per row, the rows of the step."""
         ops, k, ld = self.ops, self.k, self.ld
-        ops.expect(self.Gamma_shp, self.Gamma_rte, self.eT, self.nU, k, ld, flag=flag_u, factored=self.factored["u"])
-        ops.expect(self.Lambda_shp, self.Lambda_rte, self.eB, self.nI, k, ld, flag=flag_i, factored=self.factored["i"])
+        if "u" not in e_current:         # (e_current: sides whose E table is up to date for every row already)
+            ops.expect(self.Gamma_shp, self.Gamma_rte, self.eT, self.nU, k, ld, flag=flag_u, factored=self.factored["u"])
+        if "i" not in e_current:
+            ops.expect(self.Lambda_shp, self.Lambda_rte, self.eB, self.nI, k, ld, flag=flag_i, factored=self.factored["i"])
         for side, e_self, e_other, acc in ((su, self.eT, self.eB, self.acc_u), (si, self.eB, self.eT, self.acc_i)):
             if side.nseg == 0:
                 continue
@@ -317,7 +324,20 @@ def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_
         m.materialize(means=False)            # (stored form: both rate tables are read and written in place)
     elif m.factored[ow] is not None:
         m.materialize((ow,), means=False)     # the other side's rate is BLENDED row by row (PXI:320 / 372): it needs the table
-    m.batch_phi_sums(su, si, flag_u, flag_i)                      # phi from the OLD parameters
+    e_current = ()
+    if lazy and os.environ.get("HPF_SVI_E_FOLD", "1") == "1":
+        # The other side's E rows change only where a step changes its shapes and rates -- the step's own rows, whose new E
+        # rows the whole-table pass below writes while it has them in registers.  So its E table only has to be made current
+        # once per epoch (the sides swap roles), not re-read for the touched rows (most of the side) every batch.
+        So = m._side(ow)
+        if not m.e_valid[ow]:
+            ops.expect(So["shp"], So["rte"], m.eB if ow == "i" else m.eT, So["n"], k, ld)
+            m.e_valid[ow] = True
+        e_current = (ow,)
+    m.e_valid[bw] = False                                          # (its rates change for every row below)
+    if not lazy:
+        m.e_valid[ow] = False
+    m.batch_phi_sums(su, si, flag_u, flag_i, e_current)            # phi from the OLD parameters
     U = dict(n=m.nU, flag=flag_u, shp=m.Gamma_shp, rte=m.Gamma_rte, fac=m.Theta, rs=m.k_rte, e=m.eT, acc=m.acc_u,
              prior=hy["a"], top=hy["k_shp"], add=hy["add_k_rte"], cs="csT")
     I = dict(n=m.nI, flag=flag_i, shp=m.Lambda_shp, rte=m.Lambda_rte, fac=m.Beta, rs=m.t_rte, e=m.eB, acc=m.acc_i,
@@ -343,7 +363,8 @@ def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_
     # ... other side: shapes and rates of the touched rows blended towards the step's estimate (the rates with the
     # batch side's NEW column sums), means of every row, scalar rates, column sums
     ops.svi_side(O["n"], O["flag"], O["acc"], O["e"], O["shp"], O["rte"], None if lazy else O["fac"], O["rs"], cs_batch,
-                 m._cs_part, O["prior"], w_other, step_prev, O["top"], O["add"], step, step_prev, 1, rs_mode, k, ld)
+                 m._cs_part, O["prior"], w_other, step_prev, O["top"], O["add"], step, step_prev, 1, rs_mode, k, ld,
+                 e_out=O["e"] if e_current else None)
     cs_o = torch.zeros(ld, dtype=torch.float32, device=ops.device)
     ops.colsum_reduce(m._cs_part, cs_o, ld)
     setattr(m, O["cs"], cs_o)

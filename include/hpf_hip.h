@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 18
+#define HPF_HIP_ABI_VERSION 19
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -245,11 +245,17 @@ int hpf_hip_svi_refresh_f32(int64_t nrows, const float *shp, float *rte, float *
  * rate_mode 0 rte may be NULL too and rs_prev_out[r] (optional, every row) receives the scalar the rate was formed with,
  * so that rte = top/rs_prev_out + cs_other can be expanded later: rs_rate (optional) forms the rate from THAT scalar
  * instead of rs[r] -- the expansion is this same call with flag = NULL, rs_mode 0, rs_rate = the kept scalars.
+ * e_out (optional; may be e): the flagged rows also get their NEW expectation row exp(psi(shp[r]))/rte[r], row-scaled,
+ * from the shape and rate just formed -- bit for bit what hpf_hip_expect_f32 would compute from the tables afterwards
+ * (the psi/log/exp hoisted out of update_phi, PXI:588), without reading them back.  In a rate_mode 1 pass nothing else of
+ * the side changes, so an E table that was current for all rows stays current and the next step needs no expectation pass
+ * over this side.
  */
 int hpf_hip_svi_side_f32(int64_t nrows, const uint8_t *flag, const float *acc, const float *e, float *shp, float *rte,
                          float *fac, float *rs, const float *cs_other, float *cs_partial, float prior, float w_new,
                          float w_old, float top, float add, float step, float step_prev, int rate_mode, int rs_mode,
-                         int k, int ld, int grid_blocks, const float *rs_rate, float *rs_prev_out, void *stream);
+                         int k, int ld, int grid_blocks, const float *rs_rate, float *rs_prev_out, float *e_out,
+                         void *stream);
 int hpf_hip_svi_rate_rows_f32(const int64_t *row_list, int64_t nrows, float *rte, const float *fac, float *rs,
                               const float *cs_other, float top, float add, float step, float step_prev, int mode,
                               int k, int ld, void *stream);

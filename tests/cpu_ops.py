@@ -444,9 +444,10 @@ class CpuOps:
         cp[0] = F.astype(np.float64).sum(axis=0).astype(np.float32)
 
     def svi_side(self, nrows, flag, acc, e, shp, rte, fac, rs, cs_other, cs_partial, prior, w_new, w_old, top, add, step,
-                 step_prev, rate_mode, rs_mode, k, ld, rs_rate=None, rs_prev_out=None):
+                 step_prev, rate_mode, rs_mode, k, ld, rs_rate=None, rs_prev_out=None, e_out=None):
         """hpf_hip_svi_side_f32 = the separate stand-in statements in the reference's order.  rte / fac None: computed
-        into scratch tables and dropped; rs_rate / rs_prev_out: the factored-rate plumbing of the lazy epochs."""
+        into scratch tables and dropped; rs_rate / rs_prev_out: the factored-rate plumbing of the lazy epochs; e_out: the
+        flagged rows' new E rows (= expect over them afterwards)."""
         rows = torch.nonzero(flag[:nrows] != 0).reshape(-1) if flag is not None else torch.empty(0, dtype=torch.int64)
         self.svi_shape_rows(rows, acc, e, shp, prior, w_new, w_old, k, ld, acc_by_row=True)
         rte_t = rte if rte is not None else torch.zeros_like(shp)
@@ -463,6 +464,8 @@ class CpuOps:
         if rs_mode == 1:
             assert torch.equal(rs, rs_before)
             self.svi_rate_rows(rows, None, fac_t, rs, None, 0.0, add, step, step_prev, 1, k, ld)
+        if e_out is not None:
+            self.expect(shp, rte_t, e_out, nrows, k, ld, flag=flag)
 
     def svi_rate_rows(self, row_list, rte, fac, rs, cs_other, top, add, step, step_prev, mode, k, ld):
         rows = _np(row_list).astype(np.int64)
