@@ -414,7 +414,8 @@ def main():
         ("direct, the apply kernel pulls (no prefetch)", {"HPF_SCHEDULE": "direct", "HPF_DIRECT_PREFETCH": "0"}),
         ("gather-early on RCCL", {"HPF_SCHEDULE": "gather-early"}),
         ("finalize-then-gather on RCCL", {"HPF_SCHEDULE": "finalize-then-gather"}),
-        ("direct, user sweep 4 workgroups per CU", {"HPF_SCHEDULE": "direct", "HPF_SHARD_SWEEP_BPC": "4"}),
+        ("direct, user sweep 3 workgroups per CU (room for the exchange stream's kernels)",
+         {"HPF_SCHEDULE": "direct", "HPF_SHARD_SWEEP_BPC": "3"}),
     ]
     CANDIDATES_ALL = [
         ("gather-early on RCCL, one item range", {"HPF_SCHEDULE": "gather-early", "HPF_ITEM_RANGES": "1"}),

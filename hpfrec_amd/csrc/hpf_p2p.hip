@@ -4,11 +4,12 @@
 //
 // What this replaces: nothing in the reference (single-node OpenMP, cython_loops.pxi:4, 227-259).  SURVEY.md section
 // 8(e) asks for a DIRECT reduce-scatter + all-gather of the item statistics over all seven xGMI links of a GPU instead
-// of a ring; here the "collectives" disappear into the kernels that consume their results: the owner of an item slice
+// of a ring; here the "collectives" are kernels of this library reading peer-mapped memory: the owner of an item slice
 // PULLS the N partial accumulator rows from the N ranks' exchange buffers and sums them in rank order
-// (item_shape_kernel, hpf_hip.hip), every rank pulls the finished [numerators | base rate] rows from their owners
-// (item_apply_kernel), and the two k-float column sums travel as self-validating 8-byte granules.  No RCCL kernel
-// competes with the sweeps for compute units and no collective launch latency is paid.
+// (p2p_pull_reduce_kernel: the reduce-scatter), every rank pulls the finished [numerators | base rate] rows from their
+// owners (p2p_gather_kernel under the user sweep, or item_apply_kernel itself: the all-gather), and the two k-float column
+// sums travel as self-validating 8-byte granules (colsum_reduce_kernel).  No RCCL kernel competes with the sweeps for
+// compute units and no collective launch latency is paid.
 //
 // A region = one coarse-grained data allocation (caller-defined layout) + one fine-grained control block (error word,
 // flag words, vector slots; hpf_p2p_dev.h).  The library allocates and owns both for the life of the region handle; the

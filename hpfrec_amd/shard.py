@@ -21,7 +21,8 @@ ONE switch, HPF_SCHEDULE, picks how the exchange is carried (DESIGN.md section 6
 
 On a GPU the whole iteration is issued by ONE C call (hpf_hip_shard_iterate; HPF_NATIVE_SHARD=0 or model.native = False:
 call by call from Python).  The first C-issued iteration of a process on real links is CHECKED against the call-by-call
-form on the same state (every rank votes); a mismatch disables the C-issued form for all ranks.
+form on the same state (every rank votes); a failure strikes the schedule for the process and moves every rank on to the
+next C-issued one (direct -> gather-early -> finalize-then-gather), the call-by-call form being the last resort.
 """
 import contextlib
 import os
@@ -94,7 +95,7 @@ class ShardedMixin:
 
     def _item_bounds(self, nchunks):
         """Contiguous item ranges [(lo, hi)], identical on every rank (cut on all-reduced degrees), each a multiple of
-        the world size long; the last one runs past nI into pad rows."""
+        4 x the world size long; the last one runs past nI into pad rows."""
         it = self.items
         deg = (it.indptr[1:] - it.indptr[:-1]).clone()
         self.dist.all_reduce(deg)
