@@ -814,8 +814,8 @@ static int iterate_direct(Plan *p, const float *eT, float *eT_next, int store, h
     HPF_TRY(direct_colsum_allreduce(p, d.csT_part, d.csT_part_rows, d.csT, HPF_P2P_VEC_CST,
                                     d.direct_prefetch ? 0u : (1u << apply_kind), apply_kind, cs));
     // the rates applied to ALL items, from the gathered rows (or straight from the owners' buffers)
-    if (g_tr) {
-        g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_ITEM_APPLY, cs, 1 + apply_kind);
+    if (g_tr) {      // (arg: 1 + the flag kind its own workgroups wait for; 0: none -- the colsum launch has waited)
+        g_tr->add(HPF_TRACE_KERNEL, HPF_TRACE_K_ITEM_APPLY, cs, d.direct_prefetch ? 0 : 1 + apply_kind);
     } else {
         const float *blocks[HPF_P2P_MAX_RANKS];
         for (int q = 0; q < d.world; q++)
@@ -823,7 +823,11 @@ static int iterate_direct(Plan *p, const float *eT, float *eT_next, int store, h
                             ? d.ag_recv + (size_t)q * p->total * d.e_own_ld
                             : reinterpret_cast<const float *>(reinterpret_cast<const char *>(p->peer_data[q]) +
                                                               d.p2p_send_offset);
-        HPF_TRY(hpf_direct::item_apply_blocks(blocks, d.world, apply_kind, d.direct_prefetch ? 1 : 0, p->epoch, p->pp,
+        // prefetch: everything the apply reads is LOCAL memory, complete before the colsum launch ahead of it on this stream
+        // saw GATHERED -- the launch boundary is the acquire, no workgroup polls or fences (a system-scope acquire in each
+        // of its 2048 workgroups cost the kernel 8 of its 55 us at C3 x 8)
+        const int in_kernel_wait = d.direct_prefetch ? -1 : apply_kind;
+        HPF_TRY(hpf_direct::item_apply_blocks(blocks, d.world, in_kernel_wait, d.direct_prefetch ? 1 : 0, p->epoch, p->pp,
                                               d.shp_own, d.eB, store ? d.Lambda_shp : nullptr, store ? d.Beta : nullptr,
                                               d.t_rte, d.csT, d.csB_part, d.add_t_rte, k, ld, d.rank, d.world, d.nI,
                                               d.nranges, p->lo, p->hi, d.csB_part_rows, cs));

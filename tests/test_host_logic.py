@@ -622,6 +622,8 @@ def test_direct_schedule_traces_have_no_collective(world, nranges, prefetch):
                 ia = names.index("item_apply")
                 cs_pos = [i for i, n in enumerate(names) if n == "colsum_allreduce"]
                 assert cs_pos[0] < ia < cs_pos[1]
+                # (prefetch: the apply reads local memory only and waits for nothing itself -- the colsum launch did)
+                assert ker[ia][2] == (0 if prefetch else 1 + SHAPED)
                 # steady state: nothing recorded on, or waited for by, the compute stream; every wait after its record
                 rec = set()
                 for kind, i, st, a in tr:
