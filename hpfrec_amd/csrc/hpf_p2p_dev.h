@@ -15,7 +15,8 @@
 //     {value, epoch} granules written by ONE atomic store each, so they need no fence and no separate flag.
 //   * Every poll is bounded by a wall-clock budget: on expiry the kernel sets the control block's error word and goes on
 //     (the results are garbage, the host reports HPF_ETIMEOUT at the next status check) -- a missing peer can cost a
-//     fit, never the GPU.
+//     fit, never the GPU.  Once the error word is set no later poll of this rank spins at all: a dead peer costs ONE budget,
+//     not one per wait of the iterations already queued.
 #ifndef HPF_P2P_DEV_H
 #define HPF_P2P_DEV_H
 #include <hip/hip_runtime.h>
@@ -70,6 +71,7 @@ __device__ __forceinline__ bool wait_flag(const Peers &pp, int kind, int src, ui
     if (pp.emulate) return true;
     const uint32_t *f = pp.ctrl[pp.rank] + flag_word(kind, src);
     if ((int32_t)(ld_sys(f) - epoch) >= 0) return true;
+    if (ld_sys(pp.ctrl[pp.rank]) != 0u) return false;        // (an earlier wait of this rank has timed out)
     const long long t0 = wall_clock64();
     while ((int32_t)(ld_sys(f) - epoch) < 0) {
         if (wall_clock64() - t0 > pp.timeout_ticks) {
@@ -96,7 +98,9 @@ __device__ __forceinline__ void block_acquire_self(const Peers &pp, int kind, ui
     if (threadIdx.x == 0) {      // (also in a single-process emulation: the producer is a stream of this process)
         const uint32_t *f = pp.ctrl[pp.rank] + flag_word(kind, pp.rank);
         const long long t0 = wall_clock64();
+        const bool failed = ld_sys(pp.ctrl[pp.rank]) != 0u;
         while ((int32_t)(ld_sys(f) - epoch) < 0) {
+            if (failed) break;
             if (wall_clock64() - t0 > pp.timeout_ticks) {
                 atomicOr(pp.ctrl[pp.rank], 1u << (kind & 15));
                 break;
@@ -135,11 +139,13 @@ __device__ __forceinline__ float vec_collect(const Peers &pp, int which, uint32_
         reinterpret_cast<const char *>(pp.ctrl[pp.rank]) + vec_base_bytes());
     float s = 0.f;
     const long long t0 = wall_clock64();
+    const bool failed = ld_sys(pp.ctrl[pp.rank]) != 0u;
     for (int src = 0; src < pp.world; src++) {
         // (emulation: this rank alone -- the "sum" is the local value, like an all-reduce on a one-rank communicator)
         const unsigned long long *slot = base + vec_granule(which, (int)(epoch & 1u), pp.emulate ? pp.rank : src, ld, c);
         unsigned long long g = ld_sys64(slot);
         while ((uint32_t)(g >> 32) != epoch) {
+            if (failed) break;
             if (wall_clock64() - t0 > pp.timeout_ticks) {
                 atomicOr(pp.ctrl[pp.rank], 1u << (16 + which));
                 break;

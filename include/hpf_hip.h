@@ -575,7 +575,9 @@ int hpf_hip_p2p_region_data(void *region, int peer, void **ptr);       /* peer's
 int hpf_hip_p2p_region_set_timeout(void *region, float timeout_ms);    /* default 20 s */
 int hpf_hip_p2p_region_next_epoch(void *region, uint32_t *epoch);      /* ++epoch (starts at 1; every rank counts alike) */
 /* synchronises the device and reads the error word: 0, or HPF_ETIMEOUT with *err = the bit set (bit f: a flag of kind
- * f mod 16 never came; bit 16 + v: a vector granule) */
+ * f mod 16 never came; bit 16 + v: a vector granule).  The word is sticky for the life of the region, and once it is set no
+ * later wait of this rank polls at all: the launches already queued drain at once (their results are garbage), so a dead
+ * peer costs one time-out budget, not one per queued wait. */
 int hpf_hip_p2p_region_status(void *region, uint32_t *err);
 int hpf_hip_p2p_region_destroy(void *region);
 /* primitive stream operations (tests, probes; the iteration has them fused into its kernels):
