@@ -841,6 +841,8 @@ def test_tiny_shape_priors(hip_backend):
     (2, "direct", "no-prefetch", 100), (3, "direct", "no-prefetch", 50), (3, "direct", "checks", 20),
     (3, "direct", "one-range", 50), (2, "direct", "verify", 20), (8, "direct", "tiny-no-prefetch", 20),
     (4, "direct", "few", 20), (4, "gather-early", "few-cb", 20),     # more ranks than users: empty user shards
+    # k == ld (the [numerators | base] row is 4 floats longer than a table row), the smallest ld, ld = 256
+    (2, "direct", "", 64), (3, "direct", "", 7), (2, "direct", "", 200), (2, "direct", "no-prefetch", 64),
     (2, "direct", "verify-failinject-cb", 20),      # the first-iteration check of `direct` fails -> every rank on gather-early
     # the RCCL-shaped schedules issued from C, gloo standing in for RCCL through the collective callback
     (2, "gather-early", "cb", 20), (3, "gather-early", "cb", 100), (8, "gather-early", "tiny-cb", 20),
