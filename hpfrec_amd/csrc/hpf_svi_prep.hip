@@ -190,11 +190,23 @@ constexpr int PIF = HPF_PREP_INFLIGHT;    // (4: the id stream of the mask pass 
 __global__ __launch_bounds__(BLOCK) void svi_flag_bits_kernel(const uint8_t *__restrict__ flag, int64_t nrows,
                                                               uint32_t *__restrict__ bits) {
     const int64_t nwords = (nrows + 31) / 32;
+    const bool wide = (reinterpret_cast<uintptr_t>(flag) & 15) == 0;
     for (int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < nwords; w += (int64_t)gridDim.x * BLOCK) {
         uint32_t v = 0;
-        for (int b = 0; b < 32; b++) {
-            const int64_t r = w * 32 + b;
-            if (r < nrows && flag[r]) v |= 1u << b;
+        if (wide && w * 32 + 32 <= nrows) {       // 32 flags = two 16-byte loads (one byte load each: 0.1 ms per C5 batch)
+            const uint4 q[2] = {reinterpret_cast<const uint4 *>(flag + w * 32)[0],
+                                reinterpret_cast<const uint4 *>(flag + w * 32)[1]};
+            const uint32_t d[8] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w};
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                    if ((d[i] >> (8 * b)) & 0xFFu) v |= 1u << (4 * i + b);
+        } else {
+            for (int b = 0; b < 32; b++) {
+                const int64_t r = w * 32 + b;
+                if (r < nrows && flag[r]) v |= 1u << b;
+            }
         }
         bits[w] = v;
     }

@@ -30,9 +30,10 @@ def _maxrel(a, b):
     return float(np.max(np.abs(a - b) / np.abs(b)))
 
 
-def test_large_golden_two_ranks_direct(tmp_path, monkeypatch):
+@pytest.mark.parametrize("world", [2, 8])
+def test_large_golden_ranks_direct(tmp_path, monkeypatch, world):
     """The N>1 path against the REAL reference: the large golden's matrix (200k x 50k, 5.4M nonzeros, k=50,
-    tests/golden/large_full.npz) fitted by 2 processes sharing the GPU with the direct (peer-mapped) exchange, 3
+    tests/golden/large_full.npz) fitted by 2 / 8 processes sharing the GPU with the direct (peer-mapped) exchange, 3
     iterations -- every rank's sub-sampled rows and float64 column sums of all eight arrays within north_star's 1e-4 of what
     hpfrec itself computed, replicas bit-identical."""
     import dist_worker
@@ -40,7 +41,7 @@ def test_large_golden_two_ranks_direct(tmp_path, monkeypatch):
     monkeypatch.setenv("HPF_SCHEDULE", "direct")
     monkeypatch.setenv("HPF_DIRECT_TIMEOUT_MS", "60000")
     g = np.load(os.path.join(GOLDEN, "large_full.npz"))
-    world, its = 2, 3
+    its = 3
     spawn_ranks(dist_worker.run, lambda port: (world, port, str(tmp_path), 50, its, "large", "cuda"), world, str(tmp_path))
     outs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     for r in range(world):
