@@ -9,6 +9,7 @@ plane), exactly like the ncclUniqueId of rccl.DirectComm.  The reference has no 
 /root/reference/hpfrec/cython_loops.pxi:4).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -51,21 +52,29 @@ class PeerRegion:
         self.data_bytes = int(data_bytes)
         h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            _check(self.L.hpf_hip_p2p_region_create(self.world, self.rank, self.ld, self.data_bytes, ctypes.byref(h)),
-                   "hpf_hip_p2p_region_create")
-            self.handle = h
-            if local or dist is None or self.world == 1:
+            alone = local or dist is None or self.world == 1
+            if os.environ.get("HPF_TEST_P2P_FAIL_CREATE") == str(self.rank) and not alone:    # (tests: one rank's failure)
+                rc = -2
+            else:
+                rc = self.L.hpf_hip_p2p_region_create(self.world, self.rank, self.ld, self.data_bytes, ctypes.byref(h))
+            if alone:
+                _check(rc, "hpf_hip_p2p_region_create")
+            self.handle = h if rc == 0 else None
+            if alone:
                 _check(self.L.hpf_hip_p2p_region_connect(self.handle, None), "hpf_hip_p2p_region_connect")
                 self.local = True
             else:
+                # every rank takes part in the exchange whatever happened locally (an allocation that failed on ONE rank
+                # must not leave the others waiting in the all-gather), and all connect or none does
                 mine = (ctypes.c_uint8 * (2 * HANDLE_BYTES))()
-                rc = self.L.hpf_hip_p2p_region_handles(self.handle, ctypes.addressof(mine))
-                # every rank takes part in the exchange whatever happened locally, and all connect or none does
+                if rc == 0:
+                    rc = self.L.hpf_hip_p2p_region_handles(self.handle, ctypes.addressof(mine))
                 got = [None] * self.world
                 dist.all_gather_object(got, (rc, bytes(mine)))
                 if any(r != 0 for r, _ in got):
                     self.close()
-                    raise P2PError("hipIpcGetMemHandle failed on a rank (codes %s)" % [r for r, _ in got])
+                    raise P2PError("the exchange region could not be created / exported on a rank (codes %s)"
+                                   % [r for r, _ in got])
                 blob = b"".join(b for _, b in got)
                 buf = (ctypes.c_uint8 * len(blob)).from_buffer_copy(blob)
                 rc = self.L.hpf_hip_p2p_region_connect(self.handle, ctypes.addressof(buf))

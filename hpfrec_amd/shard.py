@@ -30,7 +30,7 @@ import warnings
 
 import torch
 
-from . import _streams, layout
+from . import _streams, layout, p2p
 
 SCHEDULES = ("direct", "gather-early", "finalize-then-gather", "gather-carried")
 _EARLY = ("direct", "gather-early", "gather-carried")      # split item finalizer: [numerators | base] payload rows
@@ -159,7 +159,14 @@ class ShardedMixin:
         errors = []
         for idx, sched in enumerate(order):
             self.schedule = sched
-            self._chunk_views = self._alloc_exchange(sched)
+            try:
+                self._chunk_views = self._alloc_exchange(sched)
+            except p2p.P2PError as exc:      # (raised on every rank or on none: PeerRegion votes before it connects)
+                errors.append("%s: %s" % (sched, str(exc)[:200]))
+                self._plan = None
+                if idx + 1 == len(order):
+                    break
+                continue
             self._plan, err = self._make_plan(self._chunk_views) if native_wanted else (None, None)
             if err:
                 errors.append("%s: %s" % (sched, err))
@@ -192,7 +199,6 @@ class ShardedMixin:
             self._region = None
         if sched == "direct":
             # the packed accumulators and the finished rows live in ONE peer-mapped allocation
-            from . import p2p
             acc_bytes = ((nIa * k * 4 + 255) // 256) * 256
             send_bytes = ((total * e_ld * 4 + 255) // 256) * 256
             local = bool(getattr(self.dist, "native_dry_run", False)) or W == 1

@@ -844,6 +844,7 @@ def test_tiny_shape_priors(hip_backend):
     # k == ld (the [numerators | base] row is 4 floats longer than a table row), the smallest ld, ld = 256
     (2, "direct", "", 64), (3, "direct", "", 7), (2, "direct", "", 200), (2, "direct", "no-prefetch", 64),
     (2, "direct", "verify-failinject-cb", 20),      # the first-iteration check of `direct` fails -> every rank on gather-early
+    (3, "direct", "regionfail-cb", 20),             # ONE rank cannot create its exchange region -> every rank on gather-early
     # the RCCL-shaped schedules issued from C, gloo standing in for RCCL through the collective callback
     (2, "gather-early", "cb", 20), (3, "gather-early", "cb", 100), (8, "gather-early", "tiny-cb", 20),
     (2, "gather-early", "checks-cb", 20), (2, "gather-early", "verify-cb", 50),
@@ -876,6 +877,9 @@ def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypat
     expect_sched = sched
     if "failinject" in flags:            # ... and reported as failed for `direct`: the ranks move on to the next C-issued schedule
         monkeypatch.setenv("HPF_TEST_FAIL_FIRST_CHECK", "direct")
+        expect_sched = "gather-early"
+    if "regionfail" in flags:
+        monkeypatch.setenv("HPF_TEST_P2P_FAIL_CREATE", "1")
         expect_sched = "gather-early"
     native = "py" not in flags
     monkeypatch.setenv("HPF_NATIVE_SHARD", "1" if native else "0")
