@@ -137,6 +137,9 @@ class PeerRegion:
             raise P2PError("direct exchange: a peer's flag never arrived (error word 0x%x, code %d)" % (err.value, rc))
 
     def close(self):
+        """Frees the region.  No collective in here (it may run from a destructor): the caller closes only after a host-side
+        collective every rank entered with its device synchronised (the end of a fit, the first-iteration vote), so that no
+        peer's pull can still be reading this memory."""
         if getattr(self, "handle", None) is not None and self.handle.value:
             self.L.hpf_hip_p2p_region_destroy(self.handle)
             self.handle = None
