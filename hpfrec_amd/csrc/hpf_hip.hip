@@ -198,10 +198,14 @@ struct FinalizeArgs {  // the row-finalize operands when it is fused into the sw
     int sig_kind;
     uint32_t sig_epoch;
     float *cs_other_copy;     // optional: block 0 keeps a copy of cs_other (the column sums this launch used)
+    int nq4;                  // SKIP: float4s of a gathered row that hold columns < k, rounded up to whole 64-byte sectors
 };
 
-// MODE: 0 = plain sweep; 1 = row finalize fused as EPILOGUE of whole-row segments
-template <int LPR, int VPL, int MODE, int UU = HPF_U>
+// MODE: 0 = plain sweep; 1 = row finalize fused as EPILOGUE of whole-row segments.
+// SKIP: the zero padding of the gathered rows is not fetched -- lanes whose float4 lies in a 64-byte sector past column k
+// issue no load (k = 200 in ld = 256: 13 of a row's 16 sectors; k = 100 in ld = 128: 7 of 8).  Only instantiated for those k:
+// with k = 50 in ld = 64 every sector holds columns and the kernel is the unmasked one.
+template <int LPR, int VPL, int MODE, int UU = HPF_U, bool SKIP = false>
 __global__ __launch_bounds__(BLOCK)
 __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUSED_MAX_WAVES : 8))) void sweep_kernel(const hpf_segment *__restrict__ segs, int64_t nseg,
                                                       const int32_t *__restrict__ idx,
@@ -315,7 +319,12 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
                     yy[u] = __shfl(myy, src);
                     const float4 *op = reinterpret_cast<const float4 *>(tab_other + (size_t)cc[u] * LD);
 #pragma unroll
-                    for (int v = 0; v < VPL; v++) o[u][v] = op[v * LPR + j];
+                    for (int v = 0; v < VPL; v++) {
+                        if constexpr (SKIP)
+                            o[u][v] = (v * LPR + j < fa.nq4) ? op[v * LPR + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        else
+                            o[u][v] = op[v * LPR + j];
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < U; u++) {
@@ -1337,10 +1346,12 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
         constexpr int VPL = LD / (4 * WAVE);
         constexpr int VR = (VPL == 1) ? 4 : (VPL == 2 ? 2 : 1);
         float4 cs4[VPL], acc4[VPL];
-        bool ok[VPL][4];
+        bool ok[VPL][4], act[VPL];        // act: this lane's float4 lies in a 64-byte sector that holds columns (< k); the
+        const int nq4 = ((k + 15) / 16) * 4;   // sectors of pure padding are not READ (k = 200: 13 of a row's 16)
 #pragma unroll
         for (int v = 0; v < VPL; v++) {
             const int c = (v * WAVE + lane) * 4;
+            act[v] = v * WAVE + lane < nq4;
 #pragma unroll
             for (int e2 = 0; e2 < 4; e2++) ok[v][e2] = c + e2 < k;
             cs4[v] = make_float4(ok[v][0] ? cs_other[c] : 0.f, ok[v][1] ? cs_other[c + 1] : 0.f,
@@ -1369,10 +1380,11 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                     const size_t o4 = (size_t)(live[i] ? g + b0 + i : 0) * (LD / 4) + lane;
 #pragma unroll
                     for (int v = 0; v < VPL; v++) {
-                        sv[i][v] = live[i] ? reinterpret_cast<const float4 *>(shp)[o4 + v * WAVE] : zero4;
-                        rv[i][v] = (live[i] && rate_mode != 0) ? reinterpret_cast<const float4 *>(rte)[o4 + v * WAVE] : one4;
-                        av[i][v] = fl[i] ? reinterpret_cast<const float4 *>(acc)[o4 + v * WAVE] : zero4;
-                        ev[i][v] = fl[i] ? reinterpret_cast<const float4 *>(e)[o4 + v * WAVE] : zero4;
+                        sv[i][v] = (live[i] && act[v]) ? reinterpret_cast<const float4 *>(shp)[o4 + v * WAVE] : zero4;
+                        rv[i][v] = (live[i] && act[v] && rate_mode != 0) ? reinterpret_cast<const float4 *>(rte)[o4 + v * WAVE]
+                                                                         : one4;
+                        av[i][v] = (fl[i] && act[v]) ? reinterpret_cast<const float4 *>(acc)[o4 + v * WAVE] : zero4;
+                        ev[i][v] = (fl[i] && act[v]) ? reinterpret_cast<const float4 *>(e)[o4 + v * WAVE] : zero4;
                     }
                 }
 #pragma unroll
@@ -1946,6 +1958,9 @@ int hpf_hip_device_info(int *cu_count, char *arch, int arch_len) {
     return 0;
 }
 
+// float4s of a table row up to the end of the 64-byte sector that holds column k - 1
+static inline int sector_float4s(int k) { return ((k + 15) / 16) * 4; }
+
 static int sweep_impl(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y, const float *tab_self,
                       const float *tab_other, float *part, float *acc_rows, int acc_ld, int k, int ld, int short_rows,
                       int grid_blocks, const int64_t *nseg_dev, hpf_direct::Signal sig, hipStream_t st) {
@@ -1961,18 +1976,23 @@ static int sweep_impl(const hpf_segment *segs, int64_t nseg, const int32_t *idx,
     fa.sig_peers = sig.peers_dev;
     fa.sig_kind = sig.kind;
     fa.sig_epoch = sig.epoch;
+    fa.nq4 = sector_float4s(k);
+    const bool skip = fa.nq4 < ld / 4;
     // short rows (a batch or a shard of a many-rank run: ~16 nonzeros per row): half the gathers in flight per wave
     // fill just as well and the smaller register file buys occupancy (-15 % at N=8)
     constexpr int US = (HPF_U >= 8) ? HPF_U / 2 : HPF_U;
+#define LAUNCH(LPR, VPL, UU_, SKIP_)                                                                                \
+    hipLaunchKernelGGL((sweep_kernel<LPR, VPL, 0, UU_, SKIP_>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg, idx, y, \
+                       tab_self, tab_other, part, fa)
 #define CALL(LPR, VPL)                                                                                              \
-    if (short_rows)                                                                                                 \
-        hipLaunchKernelGGL((sweep_kernel<LPR, VPL, 0, US>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg, idx, y,     \
-                           tab_self, tab_other, part, fa);                                                          \
-    else                                                                                                            \
-        hipLaunchKernelGGL((sweep_kernel<LPR, VPL, 0>), dim3(grid), dim3(BLOCK), 0, st, segs, nseg, idx, y,         \
-                           tab_self, tab_other, part, fa);
+    if (short_rows) {                                                                                               \
+        if (skip) LAUNCH(LPR, VPL, US, true); else LAUNCH(LPR, VPL, US, false);                                     \
+    } else {                                                                                                        \
+        if (skip) LAUNCH(LPR, VPL, HPF_U, true); else LAUNCH(LPR, VPL, HPF_U, false);                               \
+    }
     HPF_DISPATCH_LD(ld, CALL)
 #undef CALL
+#undef LAUNCH
     return last_error();
 }
 
@@ -1999,9 +2019,15 @@ static int sweep_finalize_impl(const hpf_segment *segs, int64_t nseg, const int3
     fa.sig_kind = sig.kind;
     fa.sig_epoch = sig.epoch;
     fa.cs_other_copy = cs_other_copy;
+    fa.nq4 = sector_float4s(k);
+    const bool skip = fa.nq4 < ld / 4;
 #define CALL(LPR, VPL)                                                                                            \
-    hipLaunchKernelGGL((sweep_kernel<LPR, VPL, 1>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg, idx, y,    \
-                       tab_self, tab_other, part, fa);
+    if (skip)                                                                                                     \
+        hipLaunchKernelGGL((sweep_kernel<LPR, VPL, 1, HPF_U, true>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, \
+                           nseg, idx, y, tab_self, tab_other, part, fa);                                          \
+    else                                                                                                          \
+        hipLaunchKernelGGL((sweep_kernel<LPR, VPL, 1>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg, idx,   \
+                           y, tab_self, tab_other, part, fa);
     HPF_DISPATCH_LD(ld, CALL)
 #undef CALL
     return last_error();
