@@ -233,8 +233,8 @@ class ShardedMixin:
         self._range_rows = [(c["lo"], c["hi"]) for c in views]       # in issue order (= slice order inside a rank's block)
         grid = ops.finalize_grid(max(1, sum(n for n, _, _ in ranges)))
         if early:      # (the apply kernel streams ALL item rows: gx blocks for each rank's block, a multiple of the world size)
-            mult = float(os.environ.get("HPF_APPLY_GRID_MULT", "2"))          # (probe knob)
-            grid = W * max(len(self.item_chunks), -(-int(mult * ops.finalize_grid(self.nI)) // W))
+            # (2048 workgroups at C3: 1024 and 2048 are equal, 512 and 4096 slower -- tools/apply_probe.py)
+            grid = W * max(len(self.item_chunks), -(-2 * ops.finalize_grid(self.nI) // W))
         self.csB_part_sc = torch.zeros((grid, ld), **f32)
         self._csT_ready = torch.cuda.Event() if cuda else None
         self._sc_fresh = True
@@ -323,8 +323,8 @@ class ShardedMixin:
                 # the pulls run BESIDE the user sweep and are bound by the links, not by their grid: one workgroup per CU
                 # for a slice's pull-reduce; the pull of the finished rows polls per owner, so few workgroups per owner
                 cus = max(1, getattr(self.ops, "cu_count", 256))
-                d.direct_pull_grid = int(os.environ.get("HPF_DIRECT_PULL_GRID", cus))
-                d.direct_gather_gx = max(1, int(os.environ.get("HPF_DIRECT_GATHER_GRID", cus // 2)) // self.world)
+                d.direct_pull_grid = cus                                  # (64-512 workgroups measured alike)
+                d.direct_gather_gx = max(1, (cus // 2) // self.world)
             d.a, d.k_shp, d.add_k_rte = float(hy.a), float(hy.k_shp), float(hy.add_k_rte)
             d.c, d.t_shp, d.add_t_rte = float(hy.c), float(hy.t_shp), float(hy.add_t_rte)
             d.comm = comm.handle if comm is not None else None
