@@ -43,8 +43,6 @@ SCHEDULE_TEXT = {   # config.parallelism of an N>1 line: (world, item ranges)
               "half of the item finalizer (rank-order sum), finished rows pulled back under the user sweep; no collective library",
     "gather-early": "users sharded x%d; item statistics reduce-scattered in %d pipelined ranges (RCCL), split item finalizer, "
                     "[numerators | base rate] rows all-gathered under the user sweep",
-    "gather-carried": "users sharded x%d; item statistics reduce-scattered in %d ranges (RCCL), the all-gather of a range "
-                      "carried into the next iteration",
     "finalize-then-gather": "users sharded x%d; item statistics reduce-scattered in %d pipelined ranges (RCCL), each rank "
                             "finalizes 1/N of the items, new E rows all-gathered under the next item sweep",
 }
@@ -308,7 +306,7 @@ def main():
     ap.add_argument("--no-autotune", action="store_true",
                     help="N>1: time the library default only")
     ap.add_argument("--autotune-all", action="store_true",
-                    help="N>1: also try gather-carried (two RCCL communicators) and the sweep-grid variants")
+                    help="N>1: also try the one-range / three-range and sweep-grid variants")
     ap.add_argument("--lean", action="store_true",
                     help="skip the stores of the six [n,k] output tables in the timed iterations")
     args = ap.parse_args()
@@ -421,8 +419,6 @@ def main():
         ("gather-early on RCCL, one item range", {"HPF_SCHEDULE": "gather-early", "HPF_ITEM_RANGES": "1"}),
         ("direct, item sweeps 6 workgroups per CU", {"HPF_SCHEDULE": "direct", "HPF_ITEM_SWEEP_BPC": "6"}),
         ("direct, three item ranges", {"HPF_SCHEDULE": "direct", "HPF_ITEM_RANGES": "3"}),
-        # LAST: a second RCCL communicator active beside the first -- never run with more than one rank before
-        ("gather-carried on RCCL (two communicators)", {"HPF_SCHEDULE": "gather-carried"}),
     ]
     pinned = [v for v in TUNED if v in os.environ]
     model = build_model()

@@ -27,7 +27,7 @@ SOURCES = (SRC_PATH, SHARD_SRC_PATH, MT_SRC_PATH, SVI_SRC_PATH, P2P_SRC_PATH)
 HEADERS = (os.path.join(_PKG, "csrc", "hpf_p2p_dev.h"),)
 INC_PATH = os.path.join(_ROOT, "include")
 
-HPF_HIP_ABI_VERSION = 19
+HPF_HIP_ABI_VERSION = 20
 
 #: every symbol include/hpf_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = (

@@ -128,11 +128,6 @@ struct Plan {
     int nfin;                         // slices with at least one real (non-pad) row
     int64_t fin_rows[HPF_MAX_ROW_RANGES], fin_acc[HPF_MAX_ROW_RANGES], fin_row0[HPF_MAX_ROW_RANGES];
     bool fresh;                       // nothing of this plan in flight on the exchange stream
-    // gather-carried: the apply half of the last iteration is still to run (its all-gathers may be in flight)
-    bool pending;
-    int pending_store;
-    int apply_grid[HPF_MAX_ROW_RANGES], apply_g0[HPF_MAX_ROW_RANGES];   // blocks of range j's apply launch; first csB_part row
-    hipStream_t ss;                   // stream of the colsum(Beta) reduction (nullptr: the compute stream)
     float *tiny;                      // dry runs with a communicator: the element of the stand-in RCCL call (plan-owned)
     // direct schedule: the rank's connected exchange region as the kernels see it
     hpf_p2p::Peers pp;
@@ -197,7 +192,7 @@ int collective(Plan *p, int op, const float *send, float *recv, int64_t count, h
         return 0;
     }
     if (!g_rccl.ok) return HPF_ENOLIB;
-    ncclComm_t comm = (ncclComm_t)((small && d.comm_small) ? d.comm_small : d.comm);
+    ncclComm_t comm = (ncclComm_t)d.comm;
     switch (op) {
         case HPF_COLL_ALL_REDUCE:
             return rccl_rc(g_rccl.AllReduce(send, recv, (size_t)count, ncclFloat32, ncclSum, comm, st));
@@ -220,32 +215,6 @@ int reduce_scatter_range(Plan *p, int j, hipStream_t st) {
     const hpf_shard_desc &d = p->d;
     return collective(p, HPF_COLL_REDUCE_SCATTER, d.acc_i + (size_t)d.ranges[j].lo * d.k,
                       d.acc_own + (size_t)p->t0[j] * d.k, p->m[j] * d.k, st);
-}
-
-// gather-carried: range j's shape half, its all-gather, its apply half
-int shape_range(Plan *p, int j, hipStream_t st) {
-    const hpf_shard_desc &d = p->d;
-    for (int f = 0; f < p->nfin; f++)
-        if (p->fin_acc[f] == p->t0[j])
-            return hpf_hip_item_shape_rows_f32(d.acc_own, 1, &p->fin_rows[f], &p->fin_acc[f], &p->fin_row0[f], d.eB, d.shp_own,
-                                               d.e_own, d.t_rte, d.t_rte_prev, d.c, d.t_shp, d.k, d.ld,
-                                               p->apply_grid[j], (void *)st);
-    return 0;     // (a slice of pad rows only)
-}
-
-int all_gather_payload_range(Plan *p, int j, hipStream_t st) {
-    const hpf_shard_desc &d = p->d;
-    return collective(p, HPF_COLL_ALL_GATHER, d.e_own + (size_t)p->t0[j] * d.e_own_ld,
-                      d.ag_recv + (size_t)d.world * p->t0[j] * d.e_own_ld, p->m[j] * d.e_own_ld, st);
-}
-
-int apply_range(Plan *p, int j, int store, hipStream_t st) {
-    const hpf_shard_desc &d = p->d;
-    return hpf_hip_item_apply_rows_f32(d.ag_recv + (size_t)d.world * p->t0[j] * d.e_own_ld,
-                                       d.shp_own + (size_t)p->t0[j] * d.ld, d.eB, store ? d.Lambda_shp : nullptr,
-                                       store ? d.Beta : nullptr, d.t_rte, d.csT, d.csB_part + (size_t)p->apply_g0[j] * d.ld,
-                                       d.add_t_rte, d.k, d.ld, d.rank, d.world, d.nI, 1, &p->lo[j], &p->hi[j],
-                                       p->apply_grid[j], (void *)st);
 }
 
 // ---- direct schedule: the kernels that carry the exchange (hpf_internal.h), traced like the others ------------------------
@@ -435,11 +404,8 @@ int hpf_hip_shard_plan_create(const hpf_shard_desc *desc, void **plan) {
                 return HPF_EINVAL;
             if (d.dry_run && !pp.emulate) return HPF_EINVAL;      // (a dry run stands alone: a region connected to itself)
         }
-    } else if (d.schedule == HPF_SCHEDULE_GATHER_EARLY || d.schedule == HPF_SCHEDULE_GATHER_CARRIED) {
+    } else if (d.schedule == HPF_SCHEDULE_GATHER_EARLY) {
         if (d.e_own_ld != hpf_hip_gather_payload_ld(d.k) || !d.ag_recv || !d.shp_own) return HPF_EINVAL;
-        if (d.schedule == HPF_SCHEDULE_GATHER_CARRIED &&
-            (d.csB_part_rows % d.world != 0 || d.csB_part_rows < d.world * d.nranges))
-            return HPF_EINVAL;
     } else if (d.schedule != HPF_SCHEDULE_FINALIZE_THEN_GATHER) {
         return HPF_EINVAL;
     } else if (d.e_own_ld != d.ld) {
@@ -459,10 +425,6 @@ int hpf_hip_shard_plan_create(const hpf_shard_desc *desc, void **plan) {
         int n = 0;
         HPF_TRY(hpf_hip_rccl_comm_count(d.comm, &n));
         if (n != d.world) return HPF_EINVAL;
-        if (d.comm_small) {
-            HPF_TRY(hpf_hip_rccl_comm_count(d.comm_small, &n));
-            if (n != d.world) return HPF_EINVAL;
-        }
     }
     Plan *p = new (std::nothrow) Plan();
     if (!p) return (int)hipErrorOutOfMemory;
@@ -471,9 +433,6 @@ int hpf_hip_shard_plan_create(const hpf_shard_desc *desc, void **plan) {
     p->nevents = 0;
     p->nfin = 0;
     p->fresh = true;
-    p->pending = false;
-    p->pending_store = 0;
-    p->ss = (hipStream_t)d.sstream;
     p->tiny = nullptr;
     p->tracing = d.dry_run == 2;
     p->pp = pp;
@@ -514,24 +473,6 @@ int hpf_hip_shard_plan_create(const hpf_shard_desc *desc, void **plan) {
         t += m;
     }
     p->total = t;
-    if (d.schedule == HPF_SCHEDULE_GATHER_CARRIED) {
-        // the apply launches of the ranges share the csB_part blocks in proportion to their rows (each a multiple of world)
-        const int gx = d.csB_part_rows / d.world;
-        int used = 0, big = 0;
-        for (int j = 0; j < d.nranges; j++) {
-            int g = (int)((double)(gx - d.nranges) * (double)p->m[j] / (double)(t > 0 ? t : 1)) + 1;
-            p->apply_grid[j] = g;
-            used += g;
-            if (p->m[j] > p->m[big]) big = j;
-        }
-        p->apply_grid[big] += gx - used;      // (the remainder to the largest range)
-        int g0 = 0;
-        for (int j = 0; j < d.nranges; j++) {
-            p->apply_g0[j] = g0;
-            p->apply_grid[j] *= d.world;
-            g0 += p->apply_grid[j];
-        }
-    }
     hipEvent_t *evs[2 * HPF_MAX_ROW_RANGES + 4];
     int ne = 0;
     for (int j = 0; j < d.nranges; j++) {
@@ -587,20 +528,6 @@ int hpf_hip_shard_join(void *plan, void *stream) {
     if (!p->fresh) {
         const hpf_shard_desc &d = p->d;
         hipStream_t st = (hipStream_t)stream;
-        if (d.schedule == HPF_SCHEDULE_GATHER_CARRIED) {
-            // what the next iteration would have done first: the apply halves, colsum(Beta) summed over the ranks
-            if (p->pending) {
-                for (int j = 0; j < d.nranges; j++) {
-                    HIP_TRY(hipStreamWaitEvent(st, p->ag_done[j], 0));
-                    HPF_TRY(apply_range(p, j, p->pending_store, st));
-                }
-                HPF_TRY(hpf_hip_colsum_reduce_f32(d.csB_part, d.csB_part_rows, d.csB, d.ld, (void *)st));
-                HPF_TRY(collective(p, HPF_COLL_ALL_REDUCE, d.csB, d.csB, d.ld, st, true));
-                p->pending = false;
-            }
-            p->fresh = true;
-            return 0;
-        }
         // the exchange stream is in order: the last thing on it is the last range's all-gather (+ unpack), or -- gather-
         // early -- the all-reduce of colsum(Beta)
         hipEvent_t last = (d.schedule == HPF_SCHEDULE_GATHER_EARLY) ? p->csB_done
@@ -669,65 +596,6 @@ static int iterate_gather_early(Plan *p, const float *eT, float *eT_next, int st
     HPF_TRY(hpf_hip_colsum_reduce_f32(d.csB_part, d.csB_part_rows, d.csB, ld, (void *)xs));
     HPF_TRY(collective(p, HPF_COLL_ALL_REDUCE, d.csB, d.csB, ld, xs));
     HIP_TRY(hipEventRecord(p->csB_done, xs));
-    return 0;
-}
-
-static int iterate_gather_carried(Plan *p, const float *eT, float *eT_next, int store, hipStream_t cs) {
-    const hpf_shard_desc &d = p->d;
-    hipStream_t xs = p->xs, ss = p->ss ? p->ss : cs;
-    const int k = d.k, ld = d.ld;
-    if (p->fresh) {
-        HIP_TRY(hipEventRecord(p->start, cs));
-        HIP_TRY(hipStreamWaitEvent(xs, p->start, 0));
-    }
-    p->fresh = false;
-    const bool carried = p->pending;
-    for (int j = 0; j < d.nranges; j++) {
-        const hpf_shard_range &r = d.ranges[j];
-        if (carried) {
-            // the apply half of the LAST iteration for this range, just ahead of its only reader before the user side
-            HIP_TRY(hipStreamWaitEvent(cs, p->ag_done[j], 0));
-            HPF_TRY(apply_range(p, j, p->pending_store, cs));
-            if (j == d.nranges - 1) {
-                // colsum(Beta) -- read by the user side -- is reduced and summed over the ranks under the last item sweep
-                if (ss != cs) {
-                    HIP_TRY(hipEventRecord(p->p2_done, cs));
-                    HIP_TRY(hipStreamWaitEvent(ss, p->p2_done, 0));
-                }
-                HPF_TRY(hpf_hip_colsum_reduce_f32(d.csB_part, d.csB_part_rows, d.csB, ld, (void *)ss));
-                HPF_TRY(collective(p, HPF_COLL_ALL_REDUCE, d.csB, d.csB, ld, ss, true));
-                if (ss != cs) HIP_TRY(hipEventRecord(p->csB_done, ss));
-            }
-        }
-        if (r.nseg > 0)
-            HPF_TRY(hpf_hip_sweep_f32(d.i_segs + r.seg_lo, r.nseg, d.i_idx, d.i_y, d.eB, eT,
-                                      d.part_i + (size_t)r.seg_lo * ld, d.acc_i, k, k, ld, r.short_rows,
-                                      d.item_sweep_grid, nullptr, (void *)cs));
-        if (r.nmulti > 0)
-            HPF_TRY(hpf_hip_segsum_f32(d.part_i, d.i_row_seg_ptr, r.multi_rows, r.nmulti, d.acc_i, ld, k, 1, (void *)cs));
-        HIP_TRY(hipEventRecord(p->sw_done[j], cs));
-        // exchange stream: this range's reduce-scatter, the shape half of this rank's slice, the all-gather of its payload
-        HIP_TRY(hipStreamWaitEvent(xs, p->sw_done[j], 0));
-        HPF_TRY(reduce_scatter_range(p, j, xs));
-        HPF_TRY(shape_range(p, j, xs));
-        HPF_TRY(all_gather_payload_range(p, j, xs));
-        HIP_TRY(hipEventRecord(p->ag_done[j], xs));
-    }
-    if (carried && ss != cs) HIP_TRY(hipStreamWaitEvent(cs, p->csB_done, 0));
-    if (store) HIP_TRY(hipMemcpyAsync(d.csB_used, d.csB, (size_t)ld * sizeof(float), hipMemcpyDeviceToDevice, cs));
-    float *shp = store ? d.Gamma_shp : nullptr, *fac = store ? d.Theta : nullptr;
-    if (d.u_nseg > 0)
-        HPF_TRY(hpf_hip_sweep_finalize_f32(d.u_segs, d.u_nseg, d.u_idx, d.u_y, eT, d.eB, d.part_u, eT_next, shp, nullptr, fac,
-                                       d.k_rte, d.k_rte_prev, d.csB, d.csT_part, d.a, d.k_shp, d.add_k_rte, k, ld,
-                                       d.user_sweep_grid, (void *)cs));
-    if (d.u_nmulti > 0)      // (its column-sum partial rows stay zero otherwise: never written)
-        HPF_TRY(hpf_hip_row_finalize_f32(d.part_u, d.u_row_seg_ptr, d.u_multi_rows, d.u_nmulti, eT, eT_next, shp, nullptr, fac,
-                                     d.k_rte, d.k_rte_prev, d.csB, d.csT_part + (size_t)d.user_sweep_grid * ld, d.a,
-                                     d.k_shp, d.add_k_rte, k, ld, ld, d.user_multi_grid, (void *)cs));
-    HPF_TRY(hpf_hip_colsum_reduce_f32(d.csT_part, d.csT_part_rows, d.csT, ld, (void *)cs));
-    HPF_TRY(collective(p, HPF_COLL_ALL_REDUCE, d.csT, d.csT, ld, cs, true));
-    p->pending = true;
-    p->pending_store = store;
     return 0;
 }
 
@@ -853,8 +721,6 @@ int hpf_hip_shard_iterate(void *plan, const float *eT, float *eT_next, int store
     if (p->d.schedule == HPF_SCHEDULE_DIRECT) return iterate_direct(p, eT, eT_next, store, (hipStream_t)compute_stream);
     if (p->d.schedule == HPF_SCHEDULE_GATHER_EARLY)
         return iterate_gather_early(p, eT, eT_next, store, (hipStream_t)compute_stream);
-    if (p->d.schedule == HPF_SCHEDULE_GATHER_CARRIED)
-        return iterate_gather_carried(p, eT, eT_next, store, (hipStream_t)compute_stream);
     const hpf_shard_desc &d = p->d;
     hipStream_t cs = (hipStream_t)compute_stream, xs = p->xs;
     const int k = d.k, ld = d.ld;
@@ -956,7 +822,6 @@ int hpf_hip_shard_exchange_only(void *plan, int op, int range, void *stream) {
     if (range >= d.nranges) return HPF_EINVAL;
     if (op == HPF_COLL_REDUCE_SCATTER) return reduce_scatter_range(p, range, st);
     if (op == HPF_COLL_ALL_GATHER) {
-        if (d.schedule == HPF_SCHEDULE_GATHER_CARRIED) return all_gather_payload_range(p, range, st);
         if (d.schedule == HPF_SCHEDULE_GATHER_EARLY)     // one collective for all ranges: counted with range 0
             return range == 0 ? collective(p, HPF_COLL_ALL_GATHER, d.e_own, d.ag_recv, p->total * d.e_own_ld, st) : 0;
         return all_gather_range(p, range, st);   // (idempotent: e_own still holds the rows)

@@ -17,7 +17,6 @@ ONE switch, HPF_SCHEDULE, picks how the exchange is carried (DESIGN.md section 6
                         not available, and -- issued call by call, in order -- what gloo / CPU runs execute.
   finalize-then-gather  reduce-scatter, one-part finalizer after the user side, all-gather of the new E rows per range
                         (HPF_SCHEDULE_FINALIZE_THEN_GATHER); Python form: overlapped on an exchange stream.
-  gather-carried        gather-early with the exchange running on into the next iteration (opt-in; two RCCL communicators).
 
 On a GPU the whole iteration is issued by ONE C call (hpf_hip_shard_iterate; HPF_NATIVE_SHARD=0 or model.native = False:
 call by call from Python).  The first C-issued iteration of a process on real links is CHECKED against the call-by-call
@@ -32,8 +31,8 @@ import torch
 
 from . import _streams, layout, p2p
 
-SCHEDULES = ("direct", "gather-early", "finalize-then-gather", "gather-carried")
-_EARLY = ("direct", "gather-early", "gather-carried")      # split item finalizer: [numerators | base] payload rows
+SCHEDULES = ("direct", "gather-early", "finalize-then-gather")
+_EARLY = ("direct", "gather-early")      # split item finalizer: [numerators | base] payload rows
 _DIRECT_COMMS = {}
 _VERIFIED = {}                  # (schedule, world, device) -> bool: the first-iteration check of this process
 _FAILED = set()                 # the same keys: schedules whose check failed -- not set up again in this process
@@ -75,7 +74,7 @@ class ShardedMixin:
         c_issue = cuda and os.environ.get("HPF_NATIVE_SHARD", "1") == "1"
         if want == "auto":
             want = "direct" if c_issue else "gather-early"
-        if want in ("direct", "gather-carried") and not c_issue:
+        if want == "direct" and not c_issue:
             raise ValueError("HPF_SCHEDULE=%s is issued from C only: it needs a GPU and HPF_NATIVE_SHARD != 0" % want)
         self._want = want
         self.schedule = want
@@ -88,10 +87,6 @@ class ShardedMixin:
     @property
     def gather_early(self):
         return self.schedule in _EARLY
-
-    @property
-    def gather_carried(self):
-        return self.schedule == "gather-carried"
 
     def _item_bounds(self, nchunks):
         """Contiguous item ranges [(lo, hi)], identical on every rank (cut on all-reduced degrees), each a multiple of
@@ -152,7 +147,7 @@ class ShardedMixin:
         native_wanted = cuda and os.environ.get("HPF_NATIVE_SHARD", "1") == "1" and self.fused
         order = [self._want]
         if native_wanted:      # what to fall back to when the preferred schedule cannot get a plan on every rank
-            order += {"direct": ["gather-early", "finalize-then-gather"], "gather-carried": ["gather-early", "finalize-then-gather"],
+            order += {"direct": ["gather-early", "finalize-then-gather"],
                       "gather-early": ["finalize-then-gather"]}.get(self._want, [])
         # (a schedule whose first-iteration check failed in this process is not tried again; the verdict was every rank's)
         order = [s_ for s_ in order if (s_, self.world, str(self.device)) not in _FAILED] or ["finalize-then-gather"]
@@ -172,10 +167,10 @@ class ShardedMixin:
                 errors.append("%s: %s" % (sched, err))
             if self._plan is not None or idx + 1 == len(order):
                 break
-            if sched in ("direct", "gather-carried") or err:
+            if sched == "direct" or err:
                 continue        # C-issued only / a plan was expected and failed: the next preference (the last one,
             break               # finalize-then-gather, has the overlapped call-by-call form)
-        if self._plan is None and self.schedule in ("direct", "gather-carried"):
+        if self._plan is None and self.schedule == "direct":
             raise RuntimeError("hpfrec_amd: the %s schedule is C-issued only and no plan could be created (%s)"
                                % (self.schedule, "; ".join(errors) or "HPF_NATIVE_SHARD=0 / unfused"))
         self.native_error = "; ".join(errors) if errors else None
@@ -260,7 +255,7 @@ class ShardedMixin:
         plan, err = None, None
         try:
             from . import rccl, shard_native as sn
-            coll = comm = comm_small = None
+            coll = comm = None
             dry = 0
             keep = []
             if sched == "direct":
@@ -278,14 +273,6 @@ class ShardedMixin:
                 comm = self.comm = _DIRECT_COMMS[key]
                 if not comm.self_check():
                     raise RuntimeError("the communicator's self-check failed")
-                # gather-carried: a second communicator lets the k-float all-reduces overtake the bulk collectives
-                if sched == "gather-carried":
-                    key = key + ("small",)
-                    if key not in _DIRECT_COMMS:
-                        _DIRECT_COMMS[key] = rccl.DirectComm(self.device, dist, self.rank, self.world)
-                    comm_small = _DIRECT_COMMS[key]
-                    if not comm_small.self_check():
-                        raise RuntimeError("the second communicator's self-check failed")
             d = sn.ShardDesc()
             hy, u, it = self.hy, self.users, self.items
             d.world, d.rank, d.k, d.ld, d.nU, d.nI = self.world, self.rank, self.k, self.ld, self.nU, self.nI
@@ -308,14 +295,9 @@ class ShardedMixin:
             d.csB_part, d.csB_part_rows = self.csB_part_sc.data_ptr(), int(self.csB_part_sc.shape[0])
             d.acc_own, d.e_own = self.acc_own_all.data_ptr(), self.e_own_all.data_ptr()
             d.e_own_ld, d.item_sweep_grid = int(self.e_own_all.shape[1]), int(self.item_sweep_blocks)
-            d.schedule = {"finalize-then-gather": 0, "gather-early": 1, "gather-carried": 2, "direct": 3}[sched]
+            d.schedule = {"finalize-then-gather": 0, "gather-early": 1, "direct": 3}[sched]
             if sched in _EARLY:
                 d.ag_recv, d.shp_own = self.ag_recv_all.data_ptr(), self.shp_own_all.data_ptr()
-            if sched == "gather-carried":
-                d.comm_small = comm_small.handle if comm_small is not None else None
-                if getattr(self, "_ss", None) is None:     # colsum(Beta): reduced + summed under the last item sweep
-                    self._ss = _side_stream(self.device, "small", -1)
-                d.sstream = self._ss.cuda_stream
             if sched == "direct":
                 d.p2p_region = self._region.handle.value
                 d.p2p_acc_offset, d.p2p_send_offset = self._region_offsets
@@ -336,7 +318,7 @@ class ShardedMixin:
                 d.dry_run_busbw_GBps = float(getattr(dist, "native_dry_run_busbw", 0.0))
                 d.dry_run_latency_us = float(getattr(dist, "native_dry_run_latency_us", 0.0))
                 d.dry_run_footprint_blocks = int(getattr(dist, "native_dry_run_footprint_blocks", 0))
-            plan = sn.ShardPlan(d, keep=keep + [comm, comm_small, views, self._region])
+            plan = sn.ShardPlan(d, keep=keep + [comm, views, self._region])
         except Exception as exc:   # noqa: BLE001
             plan, err = None, "%s: %s" % (type(exc).__name__, str(exc)[:200])
         # all or none (a rank that issued its exchange in another form than its peers would hang them)
@@ -445,7 +427,7 @@ class ShardedMixin:
         for n, v in snap.items():
             getattr(self, n).copy_(v)
         torch.cuda.synchronize(self.device)
-        nxt = {"direct": "gather-early", "gather-carried": "gather-early", "gather-early": "finalize-then-gather"}.get(failed)
+        nxt = {"direct": "gather-early", "gather-early": "finalize-then-gather"}.get(failed)
         if nxt is not None:
             warnings.warn("hpfrec_amd: %s; switching every rank to %s" % (self.native_error, nxt))
             self._plan.close()

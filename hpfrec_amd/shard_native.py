@@ -50,7 +50,6 @@ class ShardDesc(ctypes.Structure):
         ("dry_run", _i32), ("schedule", _i32),
         ("shp_own", _vp),
         ("dry_run_busbw_GBps", _f32), ("dry_run_latency_us", _f32),
-        ("comm_small", _vp), ("sstream", _vp),
         ("dry_run_footprint_blocks", _i32), ("direct_prefetch", _i32),
         ("direct_pull_grid", _i32), ("direct_gather_gx", _i32),
         ("p2p_region", _vp), ("p2p_acc_offset", _i64), ("p2p_send_offset", _i64),

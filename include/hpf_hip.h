@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 19
+#define HPF_HIP_ABI_VERSION 20
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -418,8 +418,8 @@ typedef struct hpf_shard_desc {
     float *acc_own;                /* [sum of slice lengths][k] reduce-scatter outputs, range after range */
     float *e_own;                  /* [sum of slice lengths][e_own_ld] new E rows of the slices (all-gather input) */
     int32_t e_own_ld, item_sweep_grid;   /* e_own_ld = ld (schedule 0: all-gather straight into eB) or
-                                            hpf_hip_gather_payload_ld(k) (schedules 1-3: [numerators | base] rows) */
-    float *ag_recv;                /* schedules 1-3: [world][sum of slice lengths][e_own_ld] gathered rows */
+                                            hpf_hip_gather_payload_ld(k) (schedules 1 and 3: [numerators | base] rows) */
+    float *ag_recv;                /* schedules 1 and 3: [world][sum of slice lengths][e_own_ld] gathered rows */
     float a, k_shp, add_k_rte, c, t_shp, add_t_rte;
     void *comm;                    /* ncclComm_t (hpf_hip_rccl_comm_init), or NULL */
     hpf_collective_fn coll; void *coll_ctx;   /* used instead of RCCL when coll != NULL */
@@ -427,17 +427,12 @@ typedef struct hpf_shard_desc {
     int32_t dry_run;               /* 1: this rank alone -- every collective is its one-rank form (local copy of the
                                       rank's slice) + a 1-element all-reduce on comm if given: the compute-only
                                       schedule of a rank, for probes and the bench's exposed-exchange figure */
-    int32_t schedule;              /* HPF_SCHEDULE_FINALIZE_THEN_GATHER (0), _GATHER_EARLY (1), _GATHER_CARRIED (2), _DIRECT (3) */
+    int32_t schedule;              /* HPF_SCHEDULE_FINALIZE_THEN_GATHER (0), _GATHER_EARLY (1), _DIRECT (3) */
     float *shp_own;                /* gather-early: [sum of slice lengths][ld] shapes between the finalizer's halves */
     float dry_run_busbw_GBps;      /* dry run only, > 0: every collective additionally occupies its stream for
                                       latency + bytes * (world-1)/world / busbw -- one idle-spinning wavefront (the links
                                       do the work on a real node), so that a one-GPU probe shows what each schedule hides */
     float dry_run_latency_us;
-    void *comm_small;              /* schedule 2: a SECOND communicator for the two k-float all-reduces (RCCL executes the
-                                      operations of one communicator in issue order whatever their streams, so on `comm` they
-                                      would queue behind the bulk collectives they must overtake); NULL: `comm` */
-    void *sstream;                 /* schedule 2: a third stream for colsum(Beta) (reduce + all-reduce under the last item
-                                      sweep); NULL: the compute stream */
     int32_t dry_run_footprint_blocks;  /* dry run with busbw > 0: the stand-in of a bulk collective is this many workgroups
                                       of 256 threads, 128 VGPRs and 64 KB of LDS each (what a collective library's
                                       kernel needs to be RESIDENT beside the sweeps), each holding its slot for the link
@@ -452,7 +447,7 @@ typedef struct hpf_shard_desc {
     int64_t p2p_acc_offset, p2p_send_offset;   /* bytes from the start of the region's data buffer */
 } hpf_shard_desc;
 
-/* Four schedules of the same exchange.
+/* Three schedules of the same exchange.
  * 0, finalize-then-gather: after the user side, all-reduce colsum(Theta), finish this rank's item slices
  *    (hpf_hip_row_finalize_ranges_f32), all-gather the new E rows range by range; the next iteration's sweep of a range waits
  *    for that range's all-gather -- the all-gather hides only under the item sweeps of the other ranges.
@@ -463,14 +458,8 @@ typedef struct hpf_shard_desc {
  *    all-reduce of colsum(Theta) (on the compute stream: no stream hand-over) every rank applies the rates to all items
  *    locally.  csB_part then has the grid of the apply kernel (csB_part_rows blocks over nI rows).  The exchange leaves
  *    the critical path except for two k-float all-reduces.
- * 2, gather-carried: gather-early with the exchange of iteration t running on INTO iteration t+1.  Range by range:
- *    reduce-scatter, shape half, all-gather of that range's [numerators | base rate] rows (ag_recv: range j's block
- *    [world][slice rows of j][payload ld] at row offset world * (slice rows of the ranges before j)); the apply half of
- *    range j is CARRIED to the start of the next iteration, just ahead of that range's item sweep -- the only reader of
- *    its E rows before the user side -- so the all-gather of range j has until then, not until the end of the user side,
- *    and the links can stay busy for the whole iteration.  hpf_hip_shard_join applies what is pending (the state after a
- *    join is the state after schedule 1).  The two k-float all-reduces must not queue behind the bulk collectives:
- *    comm_small.  csB_part_rows (a multiple of world, >= world * nranges) is divided over the ranges' apply launches.
+ * (2 was "gather-carried", rounds 3-4: gather-early with the exchange running on into the next iteration on two RCCL
+ *    communicators; the direct exchange hides more link time without a collective library and replaced it.)
  * 3, direct: gather-early WITHOUT collectives (section "Multi-GPU, direct exchange" below).  acc_i and e_own live in the
  *    rank's peer-mapped region.  Compute stream: item sweeps (the launch after a range's sweep tells every rank, on entry,
  *    that the range is complete -- no stream event ties the two streams), user side, colsum(Theta) summed over the ranks
@@ -482,7 +471,6 @@ typedef struct hpf_shard_desc {
  *    sweeps.  comm / coll are not used; a dry run is a region connected to itself (hpf_hip_p2p_region_connect(region, NULL)). */
 #define HPF_SCHEDULE_FINALIZE_THEN_GATHER 0
 #define HPF_SCHEDULE_GATHER_EARLY 1
-#define HPF_SCHEDULE_GATHER_CARRIED 2
 #define HPF_SCHEDULE_DIRECT 3
 
 /* dry_run == 2, "trace": nothing is issued and no device is needed -- every kernel launch, collective, event record /

@@ -100,8 +100,8 @@ def _run(rank, world, port, out_dir, k, its, case, device="cpu"):
         Y, iu, ii = datagen.triplets(df)
     Theta = np.empty((nU, k), np.float32)
     Beta = np.empty((nI, k), np.float32)
-    # (HPF_TEST_CHECK_EVERY: llk checks in the middle of the fit -- the sharded schedules are joined, and a carried
-    # apply half flushed, between iterations; the model does not depend on it)
+    # (HPF_TEST_CHECK_EVERY: llk checks in the middle of the fit -- the sharded schedules are joined between iterations;
+    # the model does not depend on it)
     check_every = int(os.environ.get("HPF_TEST_CHECK_EVERY", its))
     i, temp, llk = be.fit_hpf(0.3, 0.3, 1.0, 0.3, 0.3, 1.0, Y, iu, ii, Theta, Beta, its, "maxiter", check_every, 1e-3, 0, 0,
                               None, 0, np.zeros(1, np.uint64), "", seed, 1, 1, 0, 0, np.empty(0, np.float32),

@@ -577,7 +577,7 @@ def test_fused_and_split_drivers_agree(hip_backend):
 
 
 @pytest.mark.parametrize("mode", ["direct", "direct-no-prefetch", "direct-one-range", "gather-early", "finalize-then-gather",
-                                  "gather-carried", "py:gather-early", "py:finalize-then-gather"])
+                                  "py:gather-early", "py:finalize-then-gather"])
 def test_sharded_path_single_rank_nccl(mode):
     """The multi-GPU code path on one GPU with a real one-rank RCCL group (HPF_FORCE_SHARDED=1): every schedule of
     HPF_SCHEDULE issued by one C call (hpf_hip_shard_iterate) -- "direct": the peer-mapped exchange, its region connected to
@@ -849,8 +849,7 @@ def test_tiny_shape_priors(hip_backend):
     (2, "gather-early", "cb", 20), (3, "gather-early", "cb", 100), (8, "gather-early", "tiny-cb", 20),
     (2, "gather-early", "checks-cb", 20), (2, "gather-early", "verify-cb", 50),
     (2, "finalize-then-gather", "cb", 20), (3, "finalize-then-gather", "cb", 50),
-    (2, "gather-carried", "cb", 20), (3, "gather-carried", "cb", 50), (3, "gather-carried", "checks-cb", 20),
-    (8, "gather-carried", "tiny-cb", 20),
+    (3, "gather-early", "checks-cb", 50), (3, "finalize-then-gather", "checks-cb", 20),
     # the call-by-call Python forms on the real kernels
     (2, "finalize-then-gather", "py", 20), (3, "finalize-then-gather", "py", 100), (3, "gather-early", "py", 50)])
 def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypatch, world, sched, variant, k):
@@ -866,7 +865,7 @@ def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypat
         case = "c1"
     if "few" in flags:                   # 3 users over 4 ranks
         case = "few"
-    if "checks" in flags:                # llk checks every 2 iterations: joins (and carried applies) mid-fit
+    if "checks" in flags:                # llk checks every 2 iterations: joins mid-fit
         monkeypatch.setenv("HPF_TEST_CHECK_EVERY", "2")
     if "no" in flags:                    # ("no-prefetch") the apply kernel reads the owners' buffers itself
         monkeypatch.setenv("HPF_DIRECT_PREFETCH", "0")
@@ -987,7 +986,7 @@ def test_bench_multi_rank_path_selftest(ranks):
 
 def test_bench_autotune_on_a_one_rank_rccl_group():
     """The exchange autotune of bench.py on REAL RCCL (one rank, HPF_FORCE_SHARDED=1, --autotune-all): every candidate
-    completes, including gather-carried with its second communicator; the `collective` block comes from the chosen one."""
+    completes; the `collective` block comes from the chosen one."""
     import json
     import subprocess
     import sys
@@ -1007,8 +1006,8 @@ def test_bench_autotune_on_a_one_rank_rccl_group():
     d = json.loads(lines[0])
     at = d["config"]["exchange_autotune"]
     assert not at["failed"], at["failed"]
-    assert {"default: direct/2", "direct/1", "gather-early/2", "finalize-then-gather/2", "gather-carried/2",
-            "gather-early/1", "direct/3"} <= set(at["ms_per_iteration"]), at
+    assert {"default: direct/2", "direct/1", "gather-early/2", "finalize-then-gather/2", "gather-early/1",
+            "direct/3"} <= set(at["ms_per_iteration"]), at
     ts = list(at["ms_per_iteration"].values())
     assert max(ts) < 2.0 * min(ts), at          # (nothing to exchange with one rank: all candidates cost about the same)
     co = d["collective"]

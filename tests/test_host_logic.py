@@ -446,7 +446,7 @@ def test_backend_accepts_what_the_reference_class_passes(cpu_ops_backend):
                 assert len(out) == 6 and out[0].shape == named["Theta"].shape
 
 
-def _traced_plan(world, rank, schedule, nranges=2, k=50, nI=1003, small_comm=True):
+def _traced_plan(world, rank, schedule, nranges=2, k=50, nI=1003):
     """A C-issued iteration plan in trace mode (hpf_shard_desc.dry_run = 2): nothing is dereferenced or issued, so the
     table pointers are arbitrary non-null values and no GPU is needed."""
     from hpfrec_amd import shard_native as sn
@@ -474,21 +474,21 @@ def _traced_plan(world, rank, schedule, nranges=2, k=50, nI=1003, small_comm=Tru
     d.csB_part_rows, d.item_sweep_grid = 8 * world, 256
     d.e_own_ld = ld if schedule == 0 else (k + 4) // 4 * 4
     d.a = d.k_shp = d.add_k_rte = d.c = d.t_shp = d.add_t_rte = 0.3
-    d.xstream, d.sstream = 0xE0, 0x50 if schedule == 2 else None
+    d.xstream = 0xE0
     d.dry_run, d.schedule = 2, schedule
     d.direct_prefetch, d.direct_pull_grid, d.direct_gather_gx = 1, 256, 16      # (read by the direct schedule only)
     plan = sn.ShardPlan(d)
     return plan, sn
 
 
-@pytest.mark.parametrize("schedule", [0, 1, 2])
+@pytest.mark.parametrize("schedule", [0, 1])
 @pytest.mark.parametrize("world,nranges", [(8, 2), (3, 2), (2, 1)])
 def test_c_issued_iteration_traces(schedule, world, nranges):
     """What a multi-rank run of the C-issued iteration depends on, checked WITHOUT a GPU on the operations each rank's plan
     issues (trace mode of hpf_hip_shard_iterate / _join): every rank issues the SAME sequence of collectives (kind and
     element count -- a mismatch is a hang on real links), every stream wait names an event recorded before it, each
     range's reduce-scatter follows its sweep and precedes its all-gather, the user side is issued once per iteration,
-    and a join leaves nothing pending (gather-carried: the carried apply halves are issued by the join)."""
+    and a join issues no kernel."""
     CS = 0xC0
     traces = []
     for rank in range(world):
@@ -515,7 +515,7 @@ def test_c_issued_iteration_traces(schedule, world, nranges):
                 elif kind == sn.TRACE_WAIT:
                     assert a in recorded, (schedule, rank, step, hex(a))
             if step == 3:       # the join
-                assert ("item_apply" in names) == (schedule == 2) and "sweep" not in names
+                assert "item_apply" not in names and "sweep" not in names
                 continue
             assert names.count("sweep_finalize") == 1 and names.count("sweep") == nranges
             c = coll(tr)
@@ -523,8 +523,7 @@ def test_c_issued_iteration_traces(schedule, world, nranges):
             n_ag = sum(1 for i, a in c if i == sn.COLL_ALL_GATHER)
             n_small = sum(1 for i, a in c if i == (sn.COLL_ALL_REDUCE | 0x100) or i == sn.COLL_ALL_REDUCE)
             assert n_rs == nranges and n_ag == (1 if schedule == 1 else nranges)
-            # (gather-carried: colsum(Beta) of an iteration is summed at the start of the next one, or by the join)
-            assert n_small == (2 if schedule != 2 or step > 0 else 1)
+            assert n_small == 2
             # a range's reduce-scatter after its sweep, its all-gather after its reduce-scatter
             kinds = [("sweep", None) if (kind == sn.TRACE_KERNEL and KER[i] == "sweep") else
                      ("rs", a) if (kind == sn.TRACE_COLLECTIVE and i == sn.COLL_REDUCE_SCATTER) else
@@ -540,14 +539,11 @@ def test_c_issued_iteration_traces(schedule, world, nranges):
                     assert seen_rs <= seen_sweeps
                 else:
                     assert seen_rs >= 1
-            if schedule == 2 and step > 0:      # the carried apply of a range just ahead of that range's sweep
-                order = [n for n in names if n in ("item_apply", "sweep")]
-                assert order == ["item_apply", "sweep"] * nranges, order
-            elif schedule == 1:                 # apply of all ranges after the user side
+            if schedule == 1:                   # apply of all ranges after the user side
                 assert names.index("item_apply") > names.index("sweep_finalize")
 
 
-@pytest.mark.parametrize("schedule", [0, 1, 2])
+@pytest.mark.parametrize("schedule", [0, 1])
 def test_c_issued_iteration_traces_with_fewer_items_than_ranks(schedule):
     """5 items over 8 ranks: ranks 5-7 own pad rows only -- they launch no item finalizer (or shape half), yet take part in
     every collective with the same element counts as everybody else."""

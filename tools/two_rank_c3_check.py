@@ -4,7 +4,7 @@ host: slow, but it is the real sharded driver on the real kernels at C3 size -- 
 pad rows), a few iterations, every rank's tables against the single-process run.
 
     python tools/two_rank_c3_check.py [world=2] [HPF_SCHEDULE=direct|gather-early|...] [iterations=3] [workload=c3]
-    HPF_TEST_NATIVE_GLOO=1 python tools/two_rank_c3_check.py 8 gather-carried     (C-issued, gloo behind the callback)
+    HPF_TEST_NATIVE_GLOO=1 python tools/two_rank_c3_check.py 8 gather-early       (C-issued, gloo behind the callback)
 """
 import os
 import sys
