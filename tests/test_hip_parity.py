@@ -915,6 +915,33 @@ def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypat
             assert np.array_equal(outs[r][n], outs[0][n]), (r, n)   # replicas agree bit for bit
 
 
+@pytest.mark.parametrize("world", [3, 8])
+def test_direct_exchange_many_iterations_twice_bit_identical(tmp_path, hip_backend, monkeypatch, world):
+    """A soak of the flag protocol: 120 iterations of the direct exchange between `world` processes sharing the GPU, run
+    TWICE -- a pull that ever read a peer's buffer too early or too late would show as a run-to-run difference (the
+    arithmetic itself is deterministic: no atomics, fixed summation orders).  All eight arrays of every rank bit-identical
+    between the two runs and across the ranks, and finite."""
+    import dist_worker
+    from conftest import spawn_ranks
+    monkeypatch.setenv("HPF_SCHEDULE", "direct")
+    monkeypatch.setenv("HPF_DIRECT_TIMEOUT_MS", "60000")
+    its, k = 120, 20
+    names = ("Theta", "Beta", "Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "k_rte", "t_rte")
+    runs = []
+    for rep in range(2):
+        d = tmp_path / ("run%d" % rep)
+        d.mkdir()
+        spawn_ranks(dist_worker.run, lambda port: (world, port, str(d), k, its, "mid", "cuda"), world, str(d))
+        runs.append([np.load(os.path.join(str(d), "rank%d.npz" % r)) for r in range(world)])
+    for r in range(world):
+        assert str(runs[0][r]["schedule"]) == "direct" and int(runs[0][r]["native_plans"]) >= 1
+        for n in names:
+            a = runs[0][r][n]
+            assert np.isfinite(a).all(), (r, n)
+            assert np.array_equal(a, runs[1][r][n]), (r, n, "run to run")
+            assert np.array_equal(a, runs[0][0][n]), (r, n, "rank to rank")
+
+
 def test_rank1_rate_tables_expand_bit_identically(ops):
     """The iteration keeps the rate tables factored (old scalar rate per row + column sums); what fetch() expands
     with torch must be bit-identical to what the kernel stores when it is given an rte pointer (PXI:236, PXI:255)."""
