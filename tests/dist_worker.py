@@ -121,5 +121,6 @@ def _run(rank, world, port, out_dir, k, its, case, device="cpu"):
         return
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), Theta=Theta, Beta=Beta, Gamma_shp=temp[0], Gamma_rte=temp[1],
              Lambda_shp=temp[2], Lambda_rte=temp[3], k_rte=temp[4], t_rte=temp[5], llk=np.float64(llk), niter=i,
-             native_plans=native, schedule=str(shard.LAST_SCHEDULE[0]))
+             native_plans=native, schedule=str(shard.LAST_SCHEDULE[0]),
+             checked_iterations=max(shard._PASSED.values(), default=0))
     dist.destroy_process_group()

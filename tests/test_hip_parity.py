@@ -910,6 +910,8 @@ def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypat
         assert abs(float(outs[r]["llk"]) / float(llk) - 1) < 1e-6
         assert str(outs[r]["schedule"]) == expect_sched + ("" if native else ", call by call"), outs[r]["schedule"]
         assert (int(outs[r]["native_plans"]) >= 1) == native, "the iteration was not issued from C"
+        if "verify" in flags:      # the first three C-issued iterations were each checked against the call-by-call form
+            assert int(outs[r]["checked_iterations"]) == 3
         for n in names:
             assert np.max(np.abs(outs[r][n] - single[n]) / np.abs(single[n])) < 1e-5, (r, n)
             assert np.array_equal(outs[r][n], outs[0][n]), (r, n)   # replicas agree bit for bit
