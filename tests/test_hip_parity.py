@@ -843,6 +843,8 @@ def test_tiny_shape_priors(hip_backend):
     (4, "direct", "few", 20), (4, "gather-early", "few-cb", 20),     # more ranks than users: empty user shards
     # k == ld (the [numerators | base] row is 4 floats longer than a table row), the smallest ld, ld = 256
     (2, "direct", "", 64), (3, "direct", "", 7), (2, "direct", "", 200), (2, "direct", "no-prefetch", 64),
+    # world sizes that are not powers of two, three and four item ranges, k = 33 (ld 64) and k = 128 (= ld)
+    (5, "direct", "", 33), (7, "direct", "three", 20), (6, "direct", "four-no-prefetch", 128), (5, "gather-early", "three-cb", 20),
     (2, "direct", "verify-failinject-cb", 20),      # the first-iteration check of `direct` fails -> every rank on gather-early
     (3, "direct", "regionfail-cb", 20),             # ONE rank cannot create its exchange region -> every rank on gather-early
     # the RCCL-shaped schedules issued from C, gloo standing in for RCCL through the collective callback
@@ -871,6 +873,8 @@ def test_two_and_three_ranks_share_one_gpu_gloo(tmp_path, hip_backend, monkeypat
         monkeypatch.setenv("HPF_DIRECT_PREFETCH", "0")
     if "one" in flags:                   # ("one-range")
         monkeypatch.setenv("HPF_ITEM_RANGES", "1")
+    if "three" in flags or "four" in flags:
+        monkeypatch.setenv("HPF_ITEM_RANGES", "3" if "three" in flags else "4")
     if "verify" in flags:                # the first C-issued iteration checked against the call-by-call form, all ranks voting
         monkeypatch.setenv("HPF_VERIFY_FIRST", "1")
     expect_sched = sched
