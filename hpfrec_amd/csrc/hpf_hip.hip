@@ -876,7 +876,11 @@ __global__ __launch_bounds__(BLOCK) void colsum_kernel(const float *__restrict__
     }
 }
 
-// cs_out[c] = sum_b cs_partial[b][c]; 16 interleaved double chains per column, folded in order
+// cs_out[c] = sum_b cs_partial[b][c] in double, fixed order.  ONE workgroup per FOUR columns: a thread sums its rows
+// (b = t, t + 1024, ...) of the block's float4 column group, the 1024 chains are folded by a butterfly inside each wave and
+// in order across the 16 waves.  A single workgroup per 64 columns read the sweep's 4096 partial rows (1 MB) at the ~40 GB/s
+// one CU can pull -- 26 us, twice per iteration on the critical path, however wide or many its loads; 16 workgroups read
+// 64 KB each (the row's other columns come out of L2 for the others).
 // peers != null (direct exchange): the column sums of ALL ranks -- each rank publishes its value of a column as an
 // {value, epoch} granule in every peer's control block and sums the N granules it receives in rank order, so every rank
 // ends with the same floats (the k-float all-reduce of the iteration without a collective library)
@@ -884,36 +888,45 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float *__rest
                                                              float *__restrict__ cs_out, int ld,
                                                              const hpf_p2p::Peers *__restrict__ peers, int which,
                                                              uint32_t epoch, uint32_t then_wait_kinds, int then_wait_self) {
-    __shared__ double red[16][WAVE];
-    const int cl = threadIdx.x & (WAVE - 1);
-    const int chunk = threadIdx.x >> 6;
-    const int c = blockIdx.x * WAVE + cl;
-    double s = 0.0;
-    if (c < ld) {
-        int b = chunk;
-        // up to ~2k partial rows, 128 per chain: 32 loads in flight (the launch sits on the iteration's critical path)
-        for (; b + 16 * 31 < nblk; b += 16 * 32) {
-            float p[32];
+    __shared__ double red[16][4];
+    const int c0 = blockIdx.x * 4;          // (ld is a multiple of 4: grid = ld / 4)
+    const float *col = cs_partial + c0;
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+    int b = threadIdx.x;
+    for (; b + 1024 * 3 < nblk; b += 1024 * 4) {
+        float4 p[4];
 #pragma unroll
-            for (int u = 0; u < 32; u++) p[u] = cs_partial[(size_t)(b + 16 * u) * ld + c];
+        for (int u = 0; u < 4; u++) p[u] = *reinterpret_cast<const float4 *>(col + (size_t)(b + 1024 * u) * ld);
 #pragma unroll
-            for (int u = 0; u < 32; u++) s += (double)p[u];
+        for (int u = 0; u < 4; u++) {
+            s4[0] += (double)p[u].x;
+            s4[1] += (double)p[u].y;
+            s4[2] += (double)p[u].z;
+            s4[3] += (double)p[u].w;
         }
-        for (; b + 16 * 7 < nblk; b += 16 * 8) {
-            float p[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) p[u] = cs_partial[(size_t)(b + 16 * u) * ld + c];
-#pragma unroll
-            for (int u = 0; u < 8; u++) s += (double)p[u];
-        }
-        for (; b < nblk; b += 16) s += (double)cs_partial[(size_t)b * ld + c];
     }
-    red[chunk][cl] = s;
-    __syncthreads();
-    if (chunk == 0 && c < ld) {
-        double t = red[0][cl];
+    for (; b < nblk; b += 1024) {
+        const float4 p = *reinterpret_cast<const float4 *>(col + (size_t)b * ld);
+        s4[0] += (double)p.x;
+        s4[1] += (double)p.y;
+        s4[2] += (double)p.z;
+        s4[3] += (double)p.w;
+    }
 #pragma unroll
-        for (int q = 1; q < 16; q++) t += red[q][cl];
+    for (int e = 0; e < 4; e++) {
+#pragma unroll
+        for (int m = 1; m < WAVE; m <<= 1) s4[e] += __shfl_xor(s4[e], m);
+    }
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) red[threadIdx.x >> 6][e] = s4[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int c = c0 + threadIdx.x;
+        double t = red[0][threadIdx.x];
+#pragma unroll
+        for (int q = 1; q < 16; q++) t += red[q][threadIdx.x];
         float out = (float)t;
         if (peers) {
             const hpf_p2p::Peers pp = *peers;
@@ -925,7 +938,7 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float *__rest
     // direct exchange: this small launch also does the waiting for the large-grid launch behind it on the stream (flag
     // kinds of the bit mask from every peer, then_wait_self from this rank itself) -- a grid of polling workgroups would
     // sit on the wave slots the flags' producers need
-    if (peers && (then_wait_kinds || then_wait_self >= 0)) {
+    if (peers && blockIdx.x == 0 && (then_wait_kinds || then_wait_self >= 0)) {      // (ONE workgroup waits)
         const hpf_p2p::Peers pp = *peers;
         for (int kind = 0; kind < HPF_P2P_NKINDS; kind++)
             if ((then_wait_kinds >> kind) & 1u) hpf_p2p::block_acquire(pp, kind, epoch, 0xFFFFFFFFu);
@@ -2174,8 +2187,9 @@ int hpf_hip_item_apply_rows_f32(const float *recv, const float *shp_own, float *
 }
 
 int hpf_hip_colsum_reduce_f32(const float *cs_partial, int nblk, float *cs_out, int ld, void *stream) {
-    if (!cs_partial || !cs_out || nblk <= 0 || ld < 32) return HPF_EINVAL;
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((ld + WAVE - 1) / WAVE), dim3(1024), 0, (hipStream_t)stream,
+    if (!cs_partial || !cs_out || nblk <= 0 || ld < 32 || (ld & 3) || (reinterpret_cast<uintptr_t>(cs_partial) & 15))
+        return HPF_EINVAL;
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(ld / 4), dim3(1024), 0, (hipStream_t)stream,
                        cs_partial, nblk, cs_out, ld, (const hpf_p2p::Peers *)nullptr, 0, 0u, 0u, -1);
     return last_error();
 }
@@ -2425,9 +2439,10 @@ int item_apply_blocks(const float *const *blocks, int nblocks, int wait_kind, in
 
 int colsum_reduce_allreduce(const float *cs_partial, int nblk, float *cs_out, int ld, const hpf_p2p::Peers *peers_dev,
                             int which, uint32_t epoch, uint32_t then_wait_kinds, int then_wait_self, hipStream_t st) {
-    if (!cs_partial || !cs_out || nblk <= 0 || ld < 32 || !peers_dev || which < 0 || which >= HPF_P2P_NVEC)
+    if (!cs_partial || !cs_out || nblk <= 0 || ld < 32 || (ld & 3) || (reinterpret_cast<uintptr_t>(cs_partial) & 15) ||
+        !peers_dev || which < 0 || which >= HPF_P2P_NVEC)
         return HPF_EINVAL;
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((ld + WAVE - 1) / WAVE), dim3(1024), 0, st, cs_partial, nblk, cs_out, ld,
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(ld / 4), dim3(1024), 0, st, cs_partial, nblk, cs_out, ld,
                        peers_dev, which, epoch, then_wait_kinds, then_wait_self);
     return last_error();
 }
