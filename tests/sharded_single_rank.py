@@ -51,6 +51,8 @@ if __name__ == "__main__":
         print("DIRECT_RCCL_USED")
     if cavi.NATIVE_PLANS_CREATED[0] > 0:
         print("NATIVE_PLAN_USED")
+    from hpfrec_amd import shard
+    print("CHECKED_ITERATIONS %d" % max(shard._PASSED.values(), default=0))
     dist.destroy_process_group()
     worst = max(float(np.max(np.abs(a - b) / np.abs(b))) for a, b in zip(sharded, plain))
     print("SHARDED_VS_PLAIN max-rel %.3e llk-rel %.3e" % (worst, abs(llk1 / llk0 - 1)))

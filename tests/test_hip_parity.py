@@ -576,8 +576,8 @@ def test_fused_and_split_drivers_agree(hip_backend):
         assert _maxrel(a[n], b[n]) < 2e-6, n
 
 
-@pytest.mark.parametrize("mode", ["direct", "direct-no-prefetch", "direct-one-range", "gather-early", "finalize-then-gather",
-                                  "py:gather-early", "py:finalize-then-gather"])
+@pytest.mark.parametrize("mode", ["direct", "direct-no-prefetch", "direct-one-range", "direct-verify", "gather-early-verify",
+                                  "gather-early", "finalize-then-gather", "py:gather-early", "py:finalize-then-gather"])
 def test_sharded_path_single_rank_nccl(mode):
     """The multi-GPU code path on one GPU with a real one-rank RCCL group (HPF_FORCE_SHARDED=1): every schedule of
     HPF_SCHEDULE issued by one C call (hpf_hip_shard_iterate) -- "direct": the peer-mapped exchange, its region connected to
@@ -596,6 +596,8 @@ def test_sharded_path_single_rank_nccl(mode):
         sched, env["HPF_DIRECT_PREFETCH"] = "direct", "0"
     if sched == "direct-one-range":
         sched, env["HPF_ITEM_RANGES"] = "direct", "1"
+    if sched.endswith("-verify"):         # the first three C-issued iterations checked against RCCL's own collectives, which
+        sched, env["HPF_VERIFY_FIRST"] = sched[:-7], "1"      # then run on the tensors of the peer-mapped region
     env["HPF_SCHEDULE"] = sched
     out = subprocess.run([sys.executable, os.path.join(here, "sharded_single_rank.py")], env=env, capture_output=True,
                          text=True, timeout=600)
@@ -603,6 +605,7 @@ def test_sharded_path_single_rank_nccl(mode):
     assert ("NATIVE_PLAN_USED" in out.stdout) == native, out.stdout[-2000:]
     assert "SCHEDULE %s" % sched in out.stdout, out.stdout[-2000:]
     assert ("DIRECT_RCCL_USED" in out.stdout) == (native and sched != "direct"), out.stdout[-2000:]
+    assert ("CHECKED_ITERATIONS 3" in out.stdout) == mode.endswith("-verify"), out.stdout[-2000:]
 
 
 @pytest.mark.parametrize("k", [30, 50, 200, 1024])
