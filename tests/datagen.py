@@ -87,6 +87,13 @@ def large_counts(nusers=200_000, nitems=50_000, nnz=5_400_000, seed=9):
     return u, i, y, nusers, nitems
 
 
+def svi_large_counts(nusers=60_000, nitems=50_000, nnz=2_400_000, seed=13):
+    """The stochastic golden case above toy size (tests/golden/svi_large.npz): 60k x 50k, >= 2M nonzeros, batches of
+    8192 rows -- the whole-table float32 column sums every batch takes (cython_loops.pxi:300,318,352,370) run over
+    5e4..6e4 rows.  The pair (nusers-1, nitems-1) is appended so that reindex=False sees the full shape."""
+    return large_counts(nusers, nitems, nnz, seed)
+
+
 def boundary_valset(nusers, nitems, n=400, seed=21):
     """A small validation set for the llk / RMSE fixtures of tests/golden/c1_boundary.npz."""
     rs = np.random.RandomState(seed)

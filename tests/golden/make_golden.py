@@ -163,6 +163,29 @@ def c1_svi():
     print("c1_svi", len(out))
 
 
+def svi_large():
+    """60k x 50k, >= 2M nonzeros, k = 50, users_per_batch = items_per_batch = 8192 through the REAL extension at
+    ncores=1: sub-sampled rows (every 125th) and float64 column sums of all eight arrays after 2 epochs (an item epoch
+    then a user epoch, PXI:265-268) and 3 (item, user, item); users-only and items-only runs after 2 epochs.  Pins the
+    stochastic path (PXI:262-377) where its per-batch whole-table float32 column sums (PXI:300,318,352,370) carry
+    visible rounding, with the reference itself."""
+    u, i, y, nU, nI = datagen.svi_large_counts()
+    df = pd.DataFrame({"UserId": u.astype(np.int64), "ItemId": i.astype(np.int64), "Count": y})
+    out = {"nnz": np.int64(df.shape[0])}
+    for tag, its, kw in (("both", 2, dict(users_per_batch=8192, items_per_batch=8192)),
+                         ("both", 3, dict(users_per_batch=8192, items_per_batch=8192)),
+                         ("users", 2, dict(users_per_batch=8192)),
+                         ("items", 2, dict(items_per_batch=8192))):
+        m = fit_ref(df, 50, its, **kw)
+        assert m.Theta.shape == (nU, 50) and m.Beta.shape == (nI, 50)
+        for n, v in grab(m).items():
+            out["%s_ep%d_%s_rows" % (tag, its, n)] = v[::125].copy()
+            out["%s_ep%d_%s_colsum64" % (tag, its, n)] = v.astype(np.float64).sum(axis=0)
+        print("svi_large", tag, its, flush=True)
+    np.savez_compressed(os.path.join(OUT, "svi_large.npz"), **out)
+    print("svi_large", len(out))
+
+
 def c1_predict():
     df, nU, nI = datagen.readme_counts()
     m = fit_ref(df, 30, 20, keep_data=True)
@@ -263,4 +286,5 @@ if __name__ == "__main__":
     large_full()
     c1_partial_fit()
     c1_svi()
+    svi_large()
     c1_predict()

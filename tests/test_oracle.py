@@ -100,6 +100,28 @@ def test_svi_epochs_bit_exact(tag, upb, ipb):
         assert np.array_equal(getattr(st, n), g["%s_%s" % (tag, n)]), (tag, n)
 
 
+SVI_LARGE = (("both", 2, 8192, 8192), ("both", 3, 8192, 8192), ("users", 2, 8192, 0), ("items", 2, 0, 8192))
+
+
+@pytest.mark.parametrize("tag,epochs,upb,ipb", SVI_LARGE)
+def test_svi_large_bit_exact(tag, epochs, upb, ipb):
+    """60k x 50k, 2.4M nonzeros, k = 50, 8192-row batches: O.fit_svi against the REAL reference (tests/golden/
+    svi_large.npz, made by make_golden.py svi_large at ncores=1) at a size where the whole-table float32 column sums
+    every batch takes (PXI:300,318,352,370) round visibly.  Sub-sampled rows bit-exact, float64 column sums of every
+    array bit-exact: item + user epoch, item-user-item, users only, items only."""
+    u, i, y, nU, nI = datagen.svi_large_counts()
+    g = np.load(os.path.join(GOLDEN, "svi_large.npz"))
+    assert int(g["nnz"]) == y.shape[0] >= 2_000_000
+    st_ix_u = np.zeros(1, np.uint64)
+    if upb > 0:
+        y, u, i, st_ix_u = O.svi_inputs_like_reference(y, u, i, nU, nI)
+    st = O.fit_svi(y, u, i, st_ix_u, nU, nI, 50, epochs, 123, upb, ipb, nthreads=O.max_threads())
+    for n in O.State.names:
+        v = getattr(st, n)
+        assert np.array_equal(v[::125], g["%s_ep%d_%s_rows" % (tag, epochs, n)]), (tag, epochs, n)
+        assert np.array_equal(v.astype(np.float64).sum(axis=0), g["%s_ep%d_%s_colsum64" % (tag, epochs, n)]), (tag, n)
+
+
 def test_large_bit_exact():
     """200k x 50k, 5.4M nonzeros, k = 50: the oracle against the REAL reference (tests/golden/large_full.npz, made by
     make_golden.py large_full) where numpy's sequential float32 column sums over 2e5 rows (PXI:236,255) carry visible

@@ -58,6 +58,32 @@ def _svi_fits():
         assert len(m.topN(user=3, n=5)) == 5
 
 
+def _svi_large_fits(cases, bar=1e-4):
+    """tests/golden/svi_large.npz: the REAL reference at 60k x 50k, 2.4M nonzeros, k = 50, 8192-row batches (ncores=1),
+    sub-sampled rows + float64 column sums.  Returns the worst deviation per case."""
+    u, i, y, nU, nI = datagen.svi_large_counts()
+    df = pd.DataFrame({"UserId": u.astype(np.int64), "ItemId": i.astype(np.int64), "Count": y})
+    g = np.load(os.path.join(GOLDEN, "svi_large.npz"))
+    worst = {}
+    for tag, epochs, kw in cases:
+        m = HPF(k=50, maxiter=epochs, random_seed=123, ncores=1, reindex=False, verbose=False, check_every=None, **kw)
+        m.fit(df.copy())
+        assert m.niter == epochs - 1 and m.Theta.shape == (nU, 50) and m.Beta.shape == (nI, 50)
+        for n in NAMES:
+            v = np.asarray(getattr(m, n))
+            dev = _maxrel(v[::125], g["%s_ep%d_%s_rows" % (tag, epochs, n)])
+            cs = g["%s_ep%d_%s_colsum64" % (tag, epochs, n)]
+            dev_cs = float(np.max(np.abs(v.astype(np.float64).sum(axis=0) - cs) / np.abs(cs)))
+            worst[(tag, epochs, n)] = (dev, dev_cs)
+            assert dev < bar and dev_cs < bar, (tag, epochs, n, dev, dev_cs)
+    return worst
+
+
+SVI_LARGE_CASES = (("both", 2, dict(users_per_batch=8192, items_per_batch=8192)),
+                   ("both", 3, dict(users_per_batch=8192, items_per_batch=8192)),
+                   ("users", 2, dict(users_per_batch=8192)), ("items", 2, dict(items_per_batch=8192)))
+
+
 def _fold_in():
     df, nU, nI = datagen.readme_counts()
     gp = np.load(os.path.join(GOLDEN, "c1_predict.npz"))
@@ -103,6 +129,21 @@ def test_svi_on_gpu(hip_backend):
 @pytest.mark.gpu
 def test_fold_in_on_gpu(hip_backend):
     _fold_in()
+
+
+def test_svi_large_on_standin(cpu_ops_backend):
+    _svi_large_fits(SVI_LARGE_CASES[:1])
+
+
+@pytest.mark.gpu
+def test_svi_large_vs_golden_on_gpu(hip_backend):
+    """The stochastic path above toy size against the reference ITSELF (north_star's 1e-4): every eighth-of-a-percent
+    row sample and the float64 column sums of all eight arrays, after item+user, item+user+item, users-only and
+    items-only epochs of 8192-row batches (6-8 batches per epoch, each taking whole-table column sums)."""
+    worst = _svi_large_fits(SVI_LARGE_CASES)
+    w = max(worst.items(), key=lambda kv: kv[1][0])
+    print("svi_large: worst row deviation %.2e (%s), worst column-sum deviation %.2e"
+          % (w[1][0], w[0], max(v[1] for v in worst.values())))
 
 
 def _partial_fit_growing_model():
