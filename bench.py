@@ -230,6 +230,155 @@ def cpu_baseline(nU, nI, k, nnz_full, sample_users=200_000, iters=4, device=None
     return out
 
 
+class HbmActivitySampler:
+    """Memory-controller (UMC) activity of one GPU sampled from the driver while the long confirmation pass runs -- the
+    only HBM-side observable of this platform (rocprofv3 on gfx950 has no MALL / DRAM byte counter:
+    profiles/r04_rocprofv3_memory_counters_available.txt).  Sources, first one that answers: the amdgpu sysfs files
+    `mem_busy_percent` and `gpu_metrics` (average_umc_activity, a uint16 percentage at byte 14 of the v1.x table), then
+    `amd-smi metric --usage --json`.  10 Hz (sysfs) / as fast as the tool answers (amd-smi).  Rank 0 only; never
+    inside the timed region."""
+
+    def __init__(self, index):
+        self.index = index
+        self.samples = {}
+        self.errors = {}
+        self._stop = False
+        self._thread = None
+        self.card = self._find_card(index)
+
+    @staticmethod
+    def _find_card(index):
+        import glob
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        except Exception:   # noqa: BLE001
+            want = None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "gpu_metrics")) or
+                 os.path.exists(os.path.join(c, "mem_busy_percent"))]
+        for c in cards:
+            try:
+                if want and os.path.basename(os.path.realpath(c)).lower().startswith(want):
+                    return c
+            except Exception:   # noqa: BLE001
+                pass
+        return cards[index] if index < len(cards) else (cards[0] if len(cards) == 1 else None)
+
+    def _read_sysfs(self):
+        import struct
+        got = {}
+        if self.card is None:
+            return got
+        try:
+            got["sysfs_mem_busy_percent"] = float(open(os.path.join(self.card, "mem_busy_percent")).read().strip())
+        except Exception as exc:   # noqa: BLE001
+            self.errors.setdefault("sysfs_mem_busy_percent", repr(exc)[:120])
+        try:
+            b = open(os.path.join(self.card, "gpu_metrics"), "rb").read()
+            size, fmt, rev = struct.unpack_from("<HBB", b, 0)
+            if fmt == 1 and rev >= 4 and len(b) >= 16:
+                gfx, umc = struct.unpack_from("<HH", b, 12)
+                if umc <= 100 or umc == 0xFFFF:
+                    if umc != 0xFFFF:
+                        got["gpu_metrics_average_umc_activity"] = float(umc)
+                        got["gpu_metrics_average_gfx_activity"] = float(gfx)
+                    else:
+                        self.errors.setdefault("gpu_metrics", "average_umc_activity reads 0xFFFF (not reported)")
+                else:
+                    self.errors.setdefault("gpu_metrics", "unexpected value %d at the v1.%d umc offset" % (umc, rev))
+            else:
+                self.errors.setdefault("gpu_metrics", "table format %d.%d, %d bytes: layout not known here" % (fmt, rev, len(b)))
+        except Exception as exc:   # noqa: BLE001
+            self.errors.setdefault("gpu_metrics", repr(exc)[:120])
+        return got
+
+    def _read_smi(self):
+        import shutil
+        import subprocess
+        exe = shutil.which("amd-smi")
+        if not exe:
+            self.errors.setdefault("amd-smi", "not on PATH")
+            return {}
+        try:
+            out = subprocess.run([exe, "metric", "-g", str(self.index), "--usage", "--json"], capture_output=True, text=True,
+                                 timeout=20)
+            d = json.loads(out.stdout)
+            while isinstance(d, (list, dict)) and not (isinstance(d, dict) and "usage" in d):
+                d = d[0] if isinstance(d, list) else next(iter(d.values()))
+            u = d["usage"].get("umc_activity")
+            v = u.get("value") if isinstance(u, dict) else u
+            return {"amd_smi_umc_activity": float(v)}
+        except Exception as exc:   # noqa: BLE001
+            self.errors.setdefault("amd-smi", repr(exc)[:160])
+            return {}
+
+    def _loop(self):
+        use_smi = None
+        while not self._stop:
+            got = self._read_sysfs()
+            if not got and use_smi is not False:
+                got = self._read_smi()
+                use_smi = bool(got)
+            for k_, v in got.items():
+                self.samples.setdefault(k_, []).append(v)
+            if not got and use_smi is False:
+                return
+            time.sleep(0.1)
+
+    def start(self):
+        import threading
+        self._thread = threading.Thread(target=self._loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thread:
+            self._thread.join(timeout=30)
+        out = {"card": self.card, "sources": {}, "unavailable": self.errors or None}
+        for k_, v in self.samples.items():
+            v = v[1:] if len(v) > 2 else v        # (the first sample may predate the pass: the driver averages over ~1 s)
+            out["sources"][k_] = {"samples": len(v), "mean": float(np.mean(v)), "max": float(np.max(v)),
+                                  "median": float(np.median(v))}
+        return out
+
+
+def umc_calibration(device, index, seconds=1.2):
+    """What the driver's UMC-activity percentage reads while the GPU moves a KNOWN number of DRAM bytes: device-to-device
+    copies of a 2 GiB buffer (far beyond the 256 MB Infinity Cache: every byte is read from and written to HBM), timed
+    with HIP events, and the same copies over a 32 MiB buffer (Infinity-Cache resident: the stacks should idle).  Gives
+    percent per TB/s, so that the percentage sampled under the benchmark converts into DRAM bytes without assuming that
+    100 % means the 8 TB/s peak."""
+    out = {}
+    for name, nbytes in (("copy_2GiB", 2 << 30), ("copy_32MiB_cache_resident", 32 << 20)):
+        a = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
+        b = torch.empty_like(a)
+        b.copy_(a)
+        torch.cuda.synchronize()
+        per = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        per[0].record()
+        for _ in range(4):
+            b.copy_(a)
+        per[1].record()
+        torch.cuda.synchronize()
+        reps = int(max(8, seconds / (per[0].elapsed_time(per[1]) * 1e-3 / 4)))
+        smp = HbmActivitySampler(index)
+        smp.start()
+        ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev[0].record()
+        for _ in range(reps):
+            b.copy_(a)
+        ev[1].record()
+        torch.cuda.synchronize()
+        got = smp.stop()
+        rate = 2.0 * nbytes * reps / (ev[0].elapsed_time(ev[1]) * 1e-3)
+        out[name] = {"bytes_read_plus_written_per_s": rate, "seconds": ev[0].elapsed_time(ev[1]) * 1e-3,
+                     "umc_activity": {k_: v["mean"] for k_, v in got["sources"].items()}}
+        del a, b
+    torch.cuda.empty_cache()
+    return out
+
+
 watchdog_state = {"done": False, "autotune": None, "meta": None}
 _LINE_FD = [None]
 
@@ -291,6 +440,27 @@ def watchdog_progress():
         watchdog_state["deadline"] = time.monotonic() + watchdog_state["seconds"]
 
 
+def _launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: become `torch.distributed.run --nproc-per-node N bench.py <same
+    arguments>` (one rank per GPU, rendezvous on 127.0.0.1 at a free port).  Rank 0 of the children prints the line on
+    the stdout this process was given."""
+    import socket
+    selftest = os.environ.get("HPF_BENCH_SELFTEST_GLOO") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not selftest:
+        raise SystemExit("bench.py: --gpus %d but this node shows %d GPU(s) (HPF_BENCH_SELFTEST_GLOO=1 runs the N-rank code "
+                         "path with all ranks on one GPU: a self-test, not a benchmark)" % (n, have))
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+                              "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+             + sys.argv[1:])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -310,6 +480,9 @@ def main():
     ap.add_argument("--lean", action="store_true",
                     help="skip the stores of the six [n,k] output tables in the timed iterations")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _launch_ranks(args.gpus)        # (does not return: this process becomes the launcher of N ranks of this script)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -338,7 +511,9 @@ def main():
     else:
         dist = None
         torch.cuda.set_device(0)
-    assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N>1)"
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (run `python bench.py --gpus N` and let it launch its own "
+                         "ranks, or launch N ranks with torch.distributed.run)" % (args.gpus, world))
     device = torch.device("cuda", local_rank if world > 1 else 0)
 
     nU, nI, nnz_target, k, label = WORKLOADS[args.workload]
@@ -545,6 +720,37 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the same iterations once more over a FIXED >= 2 s window (never part of `value`): a --steps 20 timed region lasts
+    # 0.07 s at C3 -- too short for any outside observer (a busy sampler, a wall clock around the process) to corroborate
+    long_ms = long_steps = None
+    sampled = None
+    if not args.no_extras:
+        long_steps = int(min(50_000, max(args.steps, np.ceil(2000.0 / (dt / args.steps * 1e3)))))
+        held = (ops.events, ops.recording)
+        ops.events, ops.recording = {}, (events_in_timed and not args.no_events)
+        sampler = HbmActivitySampler(local_rank if world > 1 else 0) if rank == 0 else None
+        fence()
+        if sampler:
+            sampler.start()
+        t_l = time.perf_counter()
+        if events_in_timed:
+            for _ in range(long_steps):
+                model.iterate(store)
+        else:
+            model.iterate_many(long_steps, store)
+        fence()
+        long_dt = time.perf_counter() - t_l
+        if sampler:
+            sampled = sampler.stop()
+            if world == 1 and sampled["sources"]:
+                sampled["calibration"] = umc_calibration(device, local_rank if world > 1 else 0)
+        ops.events, ops.recording = held
+        if dist:
+            t = torch.tensor([long_dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            long_dt = float(t.item())
+        long_ms = long_dt / long_steps * 1e3
+
     # what fit_hpf actually does between checks: the six [n,k] output tables (shapes, rates, Theta/Beta) are
     # not written.  Reported as an extra field; `value` above is the conservative all-tables-stored figure.
     # per-kernel breakdown of an iteration (every launch bracketed), outside the timed region
@@ -588,6 +794,21 @@ def main():
 
     # N>1: what the exchange costs on its own and how much of it the iteration failed to hide (last: it spoils the state)
     collective = None
+    links = None
+    if sharded and world > 1:
+        # what the links give the primitives of the exchange, measured with this job's ranks -- first, and on its own, so
+        # that a run whose schedule fell back (or whose exchange report fails) still returns link data
+        watchdog_progress()
+        try:
+            from hpfrec_amd import p2p as _p2p
+            links = _p2p.link_probe(device, dist, rank, world)
+        except Exception as exc:   # noqa: BLE001
+            links = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+        try:
+            links["library_collectives"] = library_collective_probe(dist, world, device, nI * k)
+        except Exception as exc:   # noqa: BLE001
+            links["library_collectives"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+        watchdog_progress()
     if sharded:
         try:
             collective = exchange_report(model, dist, world, device, dt / args.steps * 1e3, store, fence)
@@ -595,6 +816,8 @@ def main():
                 collective["ranks_equal_n_gpus"] = bool(collective["ranks"] == world)
         except Exception as exc:   # noqa: BLE001  (the line must survive)
             collective = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+        if links is not None:
+            collective["link_probe"] = links
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -656,6 +879,41 @@ def main():
                                         "fabric_side_over_hbm_peak": traffic / t_k / HBM_PEAK,
                                         "over_algorithmic": traffic / b_launch,
                                         "counts": "L2<->fabric requests (includes Infinity-Cache hits); not HBM-only"}
+            if sampled is not None:
+                pref = [n for n in ("gpu_metrics_average_umc_activity", "amd_smi_umc_activity", "sysfs_mem_busy_percent")
+                        if n in sampled["sources"]]
+                hs = {"window": "the long confirmation pass (%d iterations, %.1f s), sampled on rank 0's GPU"
+                                % (long_steps, long_ms * long_steps * 1e-3), **sampled}
+                cal = (sampled.get("calibration") or {}).get("copy_2GiB")
+                if pref:
+                    pct = sampled["sources"][pref[0]]["mean"]
+                    hs["source"] = pref[0]
+                    hs["umc_activity_percent_mean"] = pct
+                    cal_pct = cal["umc_activity"].get(pref[0]) if cal else None
+                    if cal_pct:
+                        # percent -> bytes through the copy whose DRAM traffic is known (read + written bytes per second)
+                        per_pct = cal["bytes_read_plus_written_per_s"] / cal_pct
+                        hs["dram_bytes_per_s_per_percent"] = per_pct
+                        hs["implied_dram_GBps"] = pct * per_pct / 1e9
+                        hs["implied_dram_over_hbm_peak"] = pct * per_pct / HBM_PEAK
+                        hs["implied_dram_bytes_per_iteration"] = pct * per_pct * long_ms * 1e-3
+                        hs["implied_dram_over_algorithmic_bytes"] = hs["implied_dram_bytes_per_iteration"] / b_iter
+                        if traffic and world == 1:
+                            fabric_iter = 2.0 * traffic         # two sweep launches carry an iteration's traffic
+                            hs["fabric_side_bytes_per_iteration"] = fabric_iter
+                            hs["implied_infinity_cache_hit_share"] = 1.0 - hs["implied_dram_bytes_per_iteration"] / fabric_iter
+                        hs["reading"] = ("UMC activity = the driver's memory-controller busy percentage (gpu_metrics / "
+                                         "mem_busy_percent, 1 % resolution); converted to bytes with the percentage the SAME "
+                                         "counter shows under a 2 GiB device-to-device copy whose DRAM traffic is known "
+                                         "(calibration.copy_2GiB; the 32 MiB copy shows what an Infinity-Cache-resident stream "
+                                         "reads) -- linear in between is an assumption; implied hit share = 1 - DRAM bytes / "
+                                         "fabric-side bytes (FETCH_SIZE + WRITE_SIZE of the committed PMC passes)")
+                    else:
+                        hs["reading"] = "UMC activity sampled, but the calibration copy gave no reading: percentage only"
+                else:
+                    hs["source"] = None
+                    hs["reading"] = "no UMC / HBM activity source answered on this box (see `unavailable`)"
+                roof["hbm_util_sampled"] = hs
             if roof["frac"] > 1.0:
                 roof["note"] = ("algorithmic bytes exceed what HBM delivers: at this size the gathered tables stay in "
                                 "L2 / Infinity Cache (each gather is still counted at face value, SURVEY.md section 8d)")
@@ -676,12 +934,20 @@ def main():
                        "native_plan_error": getattr(model, "native_error", None) if sharded else None,
                        "first_iteration_check": getattr(model, "first_check", None) if sharded else None,
                        "first_iteration_checks_failed": getattr(model, "first_checks_failed", None) if sharded else None,
+                       # per schedule, for the whole process (autotune candidates included): C-issued iterations that were
+                       # compared with the call-by-call form on the same state and agreed / schedules struck by that check
+                       "checked_iterations_passed": _shard_checks()[0] if sharded else None,
+                       "schedules_struck_by_the_check": _shard_checks()[1] if sharded else None,
                        "seg_cap": cavi.layout.SEG_CAP, "fused_finalize": model.fused and world == 1,
                        "stores_all_state_tables": store, "state_finite": finite},
             "roofline": roof,
         }
         if sharded:
             line["collective"] = collective
+        if long_ms is not None:
+            line["ms_per_step_long"] = long_ms
+            line["steps_long"] = long_steps
+            line["ms_per_step_long_over_ms_per_step"] = long_ms / ms
         if lean_ms is not None:
             line["ms_per_step_without_output_table_stores"] = lean_ms
         if llk_ms is not None:
@@ -803,6 +1069,43 @@ def exchange_report(model, dist, world, device, ms_per_step, store, fence, reps=
             "exposed_ms": ms_per_step - comp_ms,
             "note": "exchange alone: back to back, nothing else running (direct: rs = the pulling shape halves, ag = the "
                     "pull of the finished rows); compute only: the exchange emulated locally (state not meaningful afterwards)"}
+
+
+def _shard_checks():
+    from hpfrec_amd import shard
+    return ({k_[0]: n for k_, n in shard._PASSED.items()}, sorted(k_[0] for k_ in shard._FAILED))
+
+
+def library_collective_probe(dist, world, device, floats, reps=5):
+    """torch.distributed's own all-reduce / reduce-scatter / all-gather (RCCL on a GPU job) over a buffer the size of the
+    item statistics (nI*k floats), alone on the GPU: ms and bus GB/s (nccl-tests' convention) -- the yardstick the
+    exchange kernels of this library are to be read against, and link data that does not depend on peer mapping."""
+    n = (floats // (4 * world)) * 4 * world
+    buf = torch.ones(n, dtype=torch.float32, device=device)
+    part = torch.empty(n // world, dtype=torch.float32, device=device)
+    out = {"backend": dist.get_backend(), "bytes": n * 4}
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(reps):
+            fn()
+        ev[1].record()
+        torch.cuda.synchronize()
+        t = torch.tensor([ev[0].elapsed_time(ev[1]) / reps], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    bus = (world - 1) / world
+    for name, fn, factor in (("all_reduce", lambda: dist.all_reduce(buf), 2 * bus),
+                             ("reduce_scatter", lambda: dist.reduce_scatter_tensor(part, buf), bus),
+                             ("all_gather", lambda: dist.all_gather_into_tensor(buf, part), bus)):
+        ms = timed(fn)
+        out[name] = {"ms": ms, "busbw_GBps": n * 4 * factor / ms / 1e6}
+        buf.fill_(1.0)
+    return out
 
 
 def kernel_source_sha16():

@@ -67,6 +67,14 @@ __device__ __forceinline__ T stream_load(const T *p) {
 #endif
 }
 
+// one 16-byte load (global_load_dwordx4).  Written as a vector-typed load on purpose: `cond ? p[i] : zero4` on HIP's float4
+// struct is lowered to four dword loads per lane (svi_side_kernel ran its whole-table passes that way until round 5).
+typedef float hpf_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const float4 *p) {
+    const hpf_v4f t = *reinterpret_cast<const hpf_v4f *>(p);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+
 // ----------------------------------------------------------------------------------------
 // cross-lane helpers
 // ----------------------------------------------------------------------------------------
@@ -1319,6 +1327,124 @@ __global__ __launch_bounds__(BLOCK) void svi_refresh_kernel(int64_t nrows, const
     }
 }
 
+// The batch side of a LAZY epoch step on its own (svi_side_kernel with rate_mode 0, no rate / mean table stored, no E row
+// written -- the same float32 statements in the same order, bit for bit): the pass READS the side's shapes (1 GB at C5's
+// user side) and little else, so it is a streaming kernel -- 8 rows' loads in flight per wave, the acc / e rows of the few
+// flagged rows (one in sixteen of a C5 user batch) fetched on demand, 16-byte loads (the general kernel's `cond ? p[i] : zero4` had
+// been lowered to four dword loads per lane: 137 VGPRs, 3 waves per SIMD, 4 KB in flight per wave, 3.2 TB/s on this pass).
+//   flagged rows:  shp = w_new*(prior + e (*) acc[r]) (+ w_old*shp)                     PXI:304-316, 356-368
+//   every row:     rte = top/rs_rate + cs_other (not stored);  fac = shp/rte (not stored); per-block column sums of fac
+//   rs_mode 2: every row, 1: flagged rows:  rs = step*(add + sum_k fac) + step_prev*rs   PXI:324-325, 376-377
+template <int LD>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void svi_lazy_batch_side_kernel(int64_t nrows, const uint8_t *__restrict__ flag, const float *__restrict__ acc,
+                                const float *__restrict__ e, float *__restrict__ shp, float *__restrict__ rs,
+                                const float *__restrict__ cs_other, float *__restrict__ cs_partial, float prior,
+                                float w_new, float w_old, float top, float add, float step, float step_prev,
+                                int rs_mode, int k, const float *__restrict__ rs_rate,
+                                float *__restrict__ rs_prev_out) {
+    static_assert(LD >= 4 * WAVE, "float4-per-lane rows");
+    constexpr int VPL = LD / (4 * WAVE);
+    constexpr int VR = (VPL == 1) ? 8 : (VPL == 2 ? 4 : 2);
+    __shared__ float red[WPB][LD];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WPB;
+    float4 cs4[VPL], acc4[VPL];
+    bool act[VPL];
+    const int nq4 = ((k + 15) / 16) * 4;      // float4s of a row in sectors that hold columns (the padding is not read)
+#pragma unroll
+    for (int v = 0; v < VPL; v++) {
+        const int c = (v * WAVE + lane) * 4;
+        act[v] = v * WAVE + lane < nq4;
+        cs4[v] = make_float4(c < k ? cs_other[c] : 0.f, c + 1 < k ? cs_other[c + 1] : 0.f, c + 2 < k ? cs_other[c + 2] : 0.f,
+                             c + 3 < k ? cs_other[c + 3] : 0.f);
+        acc4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t g = ((int64_t)blockIdx.x * WPB + wid) * WAVE; g < nrows; g += nwaves * WAVE) {
+        const int64_t rl = g + lane;
+        const bool lv = rl < nrows;
+        const unsigned long long fmask = __ballot(lv && flag && flag[rl] != 0);
+        const float rs_l = lv ? rs[rl] : 1.f;
+        const float rsr_l = (lv && rs_rate) ? rs_rate[rl] : rs_l;
+        float rs_new_l = rs_l;
+        const int cnt = (int)min((int64_t)WAVE, nrows - g);
+        for (int b0 = 0; b0 < cnt; b0 += VR) {
+            float4 sv[VR][VPL];
+            // (wave-uniform row bases + a 32-bit lane offset: the loads take the scalar-base form, a row's address costs
+            // no vector registers)
+            const size_t ob = (size_t)(g + b0) * (LD / 4);
+            const float4 *sp = reinterpret_cast<const float4 *>(shp) + ob;
+#pragma unroll
+            for (int i = 0; i < VR; i++) {
+                const bool live = b0 + i < cnt;
+#pragma unroll
+                for (int v = 0; v < VPL; v++) {
+                    sv[i][v] = zero4;
+                    if (live && act[v]) sv[i][v] = ld4(sp + i * (LD / 4) + (v * WAVE + lane));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < VR; i++) {
+                if (b0 + i >= cnt) break;
+                const bool fl = ((fmask >> (b0 + i)) & 1ull) != 0;      // (wave-uniform)
+                const float rs_old = __shfl(rs_l, b0 + i);
+                const float base = top / __shfl(rsr_l, b0 + i);
+                const size_t ou = ob + (size_t)i * (LD / 4);         // (uniform)
+                float fsum = 0.f;
+#pragma unroll
+                for (int v = 0; v < VPL; v++) {
+                    const int c = (v * WAVE + lane) * 4;
+                    float s4[4] = {sv[i][v].x, sv[i][v].y, sv[i][v].z, sv[i][v].w};
+                    if (fl) {
+                        float4 aq = zero4, eq = zero4;
+                        if (act[v]) {
+                            aq = ld4(reinterpret_cast<const float4 *>(acc) + ou + (v * WAVE + lane));
+                            eq = ld4(reinterpret_cast<const float4 *>(e) + ou + (v * WAVE + lane));
+                        }
+                        const float a4[4] = {aq.x, aq.y, aq.z, aq.w}, e4[4] = {eq.x, eq.y, eq.z, eq.w};
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; e2++) {
+                            const float fresh = fmaf(e4[e2], a4[e2], prior);
+                            const float sx = (w_old == 0.f) ? w_new * fresh : w_new * fresh + w_old * s4[e2];
+                            s4[e2] = (c + e2 < k) ? sx : 0.f;          // (pad columns: what the tables hold there)
+                        }
+                        (reinterpret_cast<float4 *>(shp) + ou)[v * WAVE + lane] = make_float4(s4[0], s4[1], s4[2], s4[3]);
+                    }
+                    const float c4[4] = {cs4[v].x, cs4[v].y, cs4[v].z, cs4[v].w};
+                    float f4[4];
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; e2++) {
+                        f4[e2] = (c + e2 < k) ? s4[e2] / (base + c4[e2]) : 0.f;
+                        fsum += f4[e2];
+                    }
+                    acc4[v].x += f4[0];
+                    acc4[v].y += f4[1];
+                    acc4[v].z += f4[2];
+                    acc4[v].w += f4[3];
+                }
+                if (rs_mode == 2 || (rs_mode == 1 && fl)) {
+                    fsum = wave_sum(fsum);
+                    if (lane == b0 + i) rs_new_l = step * (add + fsum) + step_prev * rs_old;
+                }
+                __builtin_amdgcn_sched_barrier(0);      // (one row's divisions at a time: interleaved they cost 116 VGPRs)
+            }
+        }
+        if (lv && rs_prev_out) rs_prev_out[rl] = rsr_l;
+        if (lv && (rs_mode == 2 || (rs_mode == 1 && ((fmask >> lane) & 1ull) != 0))) rs[rl] = rs_new_l;
+    }
+#pragma unroll
+    for (int v = 0; v < VPL; v++) reinterpret_cast<float4 *>(&red[wid][0])[v * WAVE + lane] = acc4[v];
+    __syncthreads();
+    for (int c = threadIdx.x; c < LD; c += BLOCK) {
+        float t = red[0][c];
+#pragma unroll
+        for (int w2 = 1; w2 < WPB; w2++) t += red[w2][c];
+        cs_partial[(size_t)blockIdx.x * LD + c] = t;
+    }
+}
+
 // One pass over ALL rows of a side that applies everything an SVI step does to that side (the statements of
 // svi_shape_rows + svi_rate_rows + svi_refresh, row-local, same float32 operations in the same order):
 //   flagged rows (flag[r] != 0: the batch's rows / the rows the batch touched):
@@ -1329,7 +1455,7 @@ __global__ __launch_bounds__(BLOCK) void svi_refresh_kernel(int64_t nrows, const
 //   rs_mode 2: every row, 1: flagged rows: rs = step*(add + sum_k fac) + step_prev*rs   PXI:324-325,376-377,472-473
 template <int LD>
 __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const uint8_t *__restrict__ flag,
-                                                         const float *__restrict__ acc, const float *__restrict__ e,
+                                                         const float *__restrict__ acc, const float *e,
                                                          float *__restrict__ shp, float *__restrict__ rte,
                                                          float *__restrict__ fac, float *__restrict__ rs,
                                                          const float *__restrict__ cs_other,
@@ -1338,7 +1464,8 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                                                          float step_prev, int rate_mode, int rs_mode, int k,
                                                          const float *__restrict__ rs_rate,
                                                          float *__restrict__ rs_prev_out, float *e_out) {
-    // e_out (may alias e): the step's rows also get their NEW E row, exp(psi(shp))/rte row-scaled, from the shape and rate
+    // e_out (may alias e -- which is why `e` carries no __restrict__: the row's loads must stay ordered before its stores, and
+    // must not be routed through a read-only path): the step's rows also get their NEW E row, exp(psi(shp))/rte row-scaled, from the shape and rate
     // just formed -- what expect_kernel would compute from the tables at the start of the next step (same function, same
     // inputs, same bits), without reading them back; rows outside the step keep theirs (nothing of theirs changed in a
     // rate_mode 1 pass), so a side whose E table was current for all rows stays current.
@@ -1393,11 +1520,16 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                     const size_t o4 = (size_t)(live[i] ? g + b0 + i : 0) * (LD / 4) + lane;
 #pragma unroll
                     for (int v = 0; v < VPL; v++) {
-                        sv[i][v] = (live[i] && act[v]) ? reinterpret_cast<const float4 *>(shp)[o4 + v * WAVE] : zero4;
-                        rv[i][v] = (live[i] && act[v] && rate_mode != 0) ? reinterpret_cast<const float4 *>(rte)[o4 + v * WAVE]
-                                                                         : one4;
-                        av[i][v] = (fl[i] && act[v]) ? reinterpret_cast<const float4 *>(acc)[o4 + v * WAVE] : zero4;
-                        ev[i][v] = (fl[i] && act[v]) ? reinterpret_cast<const float4 *>(e)[o4 + v * WAVE] : zero4;
+                        sv[i][v] = av[i][v] = ev[i][v] = zero4;
+                        rv[i][v] = one4;
+                        if (live[i] && act[v]) {       // (ld4: ONE 16-byte load each -- see its comment)
+                            sv[i][v] = ld4(reinterpret_cast<const float4 *>(shp) + o4 + v * WAVE);
+                            if (rate_mode != 0) rv[i][v] = ld4(reinterpret_cast<const float4 *>(rte) + o4 + v * WAVE);
+                            if (fl[i]) {
+                                av[i][v] = ld4(reinterpret_cast<const float4 *>(acc) + o4 + v * WAVE);
+                                ev[i][v] = ld4(reinterpret_cast<const float4 *>(e) + o4 + v * WAVE);
+                            }
+                        }
                     }
                 }
 #pragma unroll
@@ -2324,6 +2456,23 @@ int hpf_hip_svi_side_f32(int64_t nrows, const uint8_t *flag, const float *acc, c
         return HPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     // grid not clamped: every block writes its cs_partial row
+    if (ld >= 256 && rate_mode == 0 && !rte && !fac && !e_out) {
+        // the batch side of a lazy epoch step: the streaming kernel of its own (same statements, same floats)
+        switch (ld) {
+#define CALLB(LD)                                                                                                      \
+    case LD:                                                                                                           \
+        hipLaunchKernelGGL((svi_lazy_batch_side_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, nrows, flag, acc, \
+                           e, shp, rs, cs_other, cs_partial, prior, w_new, w_old, top, add, step, step_prev, rs_mode, \
+                           k, rs_rate, rs_prev_out);                                                                   \
+        break;
+            CALLB(256)
+            CALLB(512)
+            CALLB(1024)
+#undef CALLB
+            default: return HPF_EUNSUPPORTED;
+        }
+        return last_error();
+    }
 #define CALL(LD)                                                                                                    \
     hipLaunchKernelGGL((svi_side_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, nrows, flag, acc, e, shp, rte, \
                        fac, rs, cs_other, cs_partial, prior, w_new, w_old, top, add, step, step_prev, rate_mode,    \

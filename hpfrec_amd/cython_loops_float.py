@@ -492,6 +492,8 @@ def fit_hpf(a, a_prime, b_prime, c, c_prime, d_prime, Y, ix_u, ix_i, Theta, Beta
                         [Theta, Beta] + list(temp))
     if not keep_all_objs:
         temp = None
+    if eng.dist:
+        model.release_exchange()      # (peer-mapped memory is freed behind a barrier, never by the garbage collector)
     tick("outputs to the host")
     return i, temp, last_llk
 

@@ -8,6 +8,7 @@ rank of the node.  The 128 handle bytes per rank travel through torch.distribute
 plane), exactly like the ncclUniqueId of rccl.DirectComm.  The reference has no counterpart (single-node OpenMP,
 /root/reference/hpfrec/cython_loops.pxi:4).
 """
+import atexit
 import ctypes
 import os
 
@@ -137,15 +138,139 @@ class PeerRegion:
             raise P2PError("direct exchange: a peer's flag never arrived (error word 0x%x, code %d)" % (err.value, rc))
 
     def close(self):
-        """Frees the region.  No collective in here (it may run from a destructor): the caller closes only after a host-side
-        collective every rank entered with its device synchronised (the end of a fit, the first-iteration vote), so that no
-        peer's pull can still be reading this memory."""
+        """Frees the region.  No collective in here: the caller closes only after a host-side collective every rank
+        entered with its device synchronised (the end of a fit: ShardedMixin.release_exchange; the first-iteration vote; the
+        barrier of link_probe), so that no peer's pull can still be reading this memory."""
         if getattr(self, "handle", None) is not None and self.handle.value:
             self.L.hpf_hip_p2p_region_destroy(self.handle)
             self.handle = None
 
     def __del__(self):
+        # A region that is merely dropped (an exception mid-fit, a model garbage-collected on ONE rank) is not freed here:
+        # a peer may still have a pull of this memory queued, and reading freed memory faults ITS GPU instead of running
+        # into the bounded flag time-out.  The handle is parked and freed when the process ends.
         try:
-            self.close()
+            if getattr(self, "handle", None) is not None and self.handle.value:
+                if getattr(self, "local", True):
+                    self.close()
+                else:
+                    _PARKED.append((self.L, self.handle))
+                    self.handle = None
         except Exception:   # noqa: BLE001
             pass
+
+
+_PARKED = []
+
+
+def _free_parked():
+    while _PARKED:
+        L, h = _PARKED.pop()
+        try:
+            L.hpf_hip_p2p_region_destroy(h)
+        except Exception:   # noqa: BLE001
+            pass
+
+
+atexit.register(_free_parked)
+
+
+
+def link_probe(device, dist, rank, world, mbytes=64, reps=3, timeout_ms=15000.0):
+    """What the links between the ranks of a job deliver to the primitives of the direct exchange, measured with the job's
+    own ranks (bench.py's `collective.link_probe`; tools/p2p_probe.py): every rank maps every peer's region, then
+      * pulls `mbytes` MB of peer (rank + s) % world's buffer for s = 1 .. world-1, all ranks at the same shift at the same
+        time (so every link carries one pull per direction), HIP events around `reps` pulls -> GB/s per (rank, peer);
+      * ranks 0 and 1 bounce a flag (signal kernel -> wait kernel, host-issued) -> microseconds per round trip;
+      * the k-float granule all-reduce -> microseconds per call.
+    Collective: every rank of `dist` must call it.  Returns the same dict on every rank; {"error": ...} when the regions
+    could not be created / mapped (every rank learns that together: PeerRegion votes)."""
+    import time
+    device = torch.device(device)
+    n = int(mbytes) * (1 << 20) // 4
+    ld = 64
+    try:
+        reg = PeerRegion(device, n * 4, ld, dist=dist, rank=rank, world=world, timeout_ms=timeout_ms)
+    except P2PError as exc:
+        return {"error": str(exc)[:300]}
+    out = {"ranks": world, "bytes_per_pull": n * 4, "shared_device": None}
+    try:
+        with torch.cuda.device(device):
+            mine = reg.tensor(0, (n,))
+            mine.fill_(float(rank + 1))
+            dst = torch.empty(n, dtype=torch.float32, device=device)
+            e = reg.next_epoch()
+            reg.signal(FLAG_USER, e)
+            pulls, ok = {}, True
+            for s in range(1, world):
+                peer = (rank + s) % world
+                reg.pull(dst, peer, 0, kind=FLAG_USER, epoch=e, grid_blocks=512)        # warm; waits for the peer's flag
+                torch.cuda.synchronize(device)
+                ok = ok and bool((dst[:: max(1, n // 1024)] == float(peer + 1)).all().item())
+                dist.barrier()
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                ev[0].record()
+                for _ in range(reps):
+                    reg.pull(dst, peer, 0, grid_blocks=512)
+                ev[1].record()
+                torch.cuda.synchronize(device)
+                pulls[peer] = n * 4 * reps / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9
+            reg.status()
+            dist.barrier()
+            # flag round trip 0 <-> 1
+            rounds, rt = 100, None
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(rounds):
+                e = reg.next_epoch()
+                if world >= 2 and rank == 0:
+                    reg.signal(FLAG_USER, e)
+                    reg.wait(FLAG_USER + 1, e, 1 << 1)
+                elif world >= 2 and rank == 1:
+                    reg.wait(FLAG_USER, e, 1 << 0)
+                    reg.signal(FLAG_USER + 1, e)
+            torch.cuda.synchronize(device)
+            if rank < 2 <= world:
+                rt = (time.perf_counter() - t0) / rounds * 1e6
+            reg.status()
+            dist.barrier()
+            vec = torch.ones(ld, dtype=torch.float32, device=device)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for it in range(rounds):
+                e = reg.next_epoch()
+                reg.allreduce_vec(it & 1, e, vec)
+                vec.fill_(1.0)
+            torch.cuda.synchronize(device)
+            ar = (time.perf_counter() - t0) / rounds * 1e6
+            reg.status()
+            try:
+                bus = torch.cuda.get_device_properties(device).pci_bus_id
+            except Exception:   # noqa: BLE001
+                bus = None
+            got = [None] * world
+            dist.all_gather_object(got, {"rank": rank, "device": str(device), "pci_bus_id": bus, "pull_GBps": pulls,
+                                         "values_ok": ok, "flag_round_trip_us": rt, "vec_allreduce_us": ar})
+            out["per_rank"] = got
+            flat = [v for g in got for v in g["pull_GBps"].values()]
+            out["pull_GBps_min"] = min(flat) if flat else None
+            out["pull_GBps_median"] = float(np.median(flat)) if flat else None
+            out["pull_GBps_max"] = max(flat) if flat else None
+            out["flag_round_trip_us_0_1"] = got[0]["flag_round_trip_us"]
+            out["vec_allreduce_us_max"] = max(g["vec_allreduce_us"] for g in got)
+            out["values_ok"] = all(g["values_ok"] for g in got)
+            ids = [(g["device"], g["pci_bus_id"]) for g in got]
+            out["shared_device"] = len(set(ids)) < world
+            out["note"] = ("pull = p2p_pull_kernel (512 workgroups, 16-byte loads, 8 in flight per lane) reading the peer's "
+                           "mapped buffer into local memory, every rank pulling from (rank+s)%world at the same time; flag round "
+                           "trip = two host-issued one-wave kernels per hop (launch latency included)")
+            del mine, dst
+    except P2PError as exc:
+        out["error"] = str(exc)[:300]
+    finally:
+        try:
+            dist.barrier()          # (no peer may still be reading this rank's buffer when it is freed)
+        except Exception:   # noqa: BLE001
+            pass
+        reg.close()
+    return out

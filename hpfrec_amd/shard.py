@@ -40,6 +40,7 @@ CHECKED_ITERATIONS = 3          # the first C-issued iterations of a process tha
 _FAILED = set()                 # the same keys: schedules whose check failed -- not set up again in this process
 NATIVE_PLANS_CREATED = [0]      # how many models of this process run their sharded iteration from C (tests, bench)
 LAST_SCHEDULE = [None]          # "<schedule>" / "<schedule>, call by call" of the last model that set its exchange up
+_STATUS_EVERY = int(os.environ.get("HPF_DIRECT_STATUS_EVERY", "256"))
 _side_stream = _streams.side_stream
 
 
@@ -74,6 +75,7 @@ class ShardedMixin:
         want = requested_schedule()
         cuda = self.device.type == "cuda"
         c_issue = cuda and os.environ.get("HPF_NATIVE_SHARD", "1") == "1"
+        self._want_auto = want == "auto"
         if want == "auto":
             want = "direct" if c_issue else "gather-early"
         if want == "direct" and not c_issue:
@@ -147,12 +149,24 @@ class ShardedMixin:
             return self._chunk_views
         cuda = self.device.type == "cuda"
         native_wanted = cuda and os.environ.get("HPF_NATIVE_SHARD", "1") == "1" and self.fused
+        if self._want == "direct" and not native_wanted and self._want_auto:
+            # the default resolved to the C-issued-only exchange, but this model issues call by call (set_fused(False),
+            # HPF_NATIVE_SHARD=0 set after construction): the in-order split-finalizer form, like a CPU / gloo run
+            self._want = "gather-early"
         order = [self._want]
         if native_wanted:      # what to fall back to when the preferred schedule cannot get a plan on every rank
             order += {"direct": ["gather-early", "finalize-then-gather"],
                       "gather-early": ["finalize-then-gather"]}.get(self._want, [])
         # (a schedule whose first-iteration check failed in this process is not tried again; the verdict was every rank's)
-        order = [s_ for s_ in order if (s_, self.world, str(self.device)) not in _FAILED] or ["finalize-then-gather"]
+        struck = [s_ for s_ in order if (s_, self.world, str(self.device)) in _FAILED]
+        order = [s_ for s_ in order if s_ not in struck]
+        if not order:
+            # every C-issued schedule this model could use has produced wrong results in this process: no plan at all,
+            # the call-by-call form on torch.distributed collectives (the checker itself) carries the fit
+            warnings.warn("hpfrec_amd: every C-issued schedule (%s) failed its first-iteration check in this process; "
+                          "iterating call by call" % ", ".join(struck))
+            order, native_wanted = ["gather-early" if "gather-early" in struck or "direct" in struck
+                                    else "finalize-then-gather"], False
         errors = []
         for idx, sched in enumerate(order):
             self.schedule = sched
@@ -350,6 +364,14 @@ class ShardedMixin:
             self._sync_scatter_streams()      # (switching forms: the other one's exchanges first)
         self._last_native = True
         self._plan.iterate(self.eT, self.eT_next, store, torch.cuda.current_stream(self.device).cuda_stream)
+        if self.schedule == "direct" and _STATUS_EVERY > 0:
+            # a flag wait that ran into HPF_DIRECT_TIMEOUT_MS sets the region's error word and every later wait is skipped:
+            # the iterations after it compute on garbage.  Look at the word now and then (one device synchronisation per
+            # HPF_DIRECT_STATUS_EVERY iterations) so that a long fit without llk checks stops instead of going on
+            self._since_status = getattr(self, "_since_status", 0) + 1
+            if self._since_status >= _STATUS_EVERY:
+                self._since_status = 0
+                self._plan.status()
         self.rte_factored = True         # (the C call keeps colsum(Beta) on storing iterations)
         self._sc_fresh = False
         self._tables_split = True
@@ -371,8 +393,12 @@ class ShardedMixin:
         previous iteration left behind, which the first iteration cannot have.  On for RCCL jobs with more than one rank;
         HPF_VERIFY_FIRST=1/0 forces it on (tests with gloo ranks) or off."""
         key = (self.schedule, self.world, str(self.device))
-        if key in _VERIFIED:
+        if _VERIFIED.get(key) is True:
             return False
+        if key in _FAILED:
+            # struck earlier in this process and still holding a plan (nothing else was left to fall back to): never run it
+            # unchecked -- _scatter_views builds no plan for a struck schedule, so this is a second line of defence
+            raise RuntimeError("hpfrec_amd: the %s schedule failed its first-iteration check in this process" % self.schedule)
         flag = os.environ.get("HPF_VERIFY_FIRST")
         if flag is not None:
             on = flag == "1"
@@ -599,6 +625,29 @@ class ShardedMixin:
                 for tab in (self.Lambda_shp, self.Beta, self.t_rte, self.t_rte_prev):
                     self.dist.all_gather_into_tensor(tab[c["lo"]: c["hi"]], tab[c["o0"]: c["o1"]].clone())
             self._tables_split = False
+
+    def release_exchange(self):
+        """End of a sharded fit (every rank calls it): wait for the exchanges, meet the other ranks on the host, THEN free
+        the peer-mapped region and the plan -- no peer can still have a pull of this rank's memory queued.  The model can
+        go on iterating afterwards (the exchange is set up again on first use)."""
+        if not self.dist or self._chunk_views is None:
+            return
+        self._sync_scatter()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        if self.world > 1 and hasattr(self.dist, "barrier"):
+            self.dist.barrier()
+        if self._plan is not None:
+            self._plan.close()
+        self._plan = None
+        if self._region is not None:
+            self.acc_i = self.e_own_all = None
+            for c in self._chunk_views:
+                c.pop("acc", None), c.pop("e_own", None)
+            self._region.close()
+            self._region = None
+        self._chunk_views = None
+        self._last_native, self._sc_fresh = False, True
 
     def flush_items(self, store=True):
         """Sharded path: make the item tables current on this rank (wait + gather)."""

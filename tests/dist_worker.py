@@ -1,6 +1,8 @@
 """Worker for tests/test_dist_gloo.py: one rank of a world_size-N gloo job running the sharded
 driver on the numpy stand-in ops -- or, with device="cuda", on the real HIP kernels (all ranks share cuda:0;
-gloo moves the CUDA tensors through the host: a correctness run of the N>1 path on a one-GPU box)."""
+gloo moves the CUDA tensors through the host: a correctness run of the N>1 path on a one-GPU box) -- or, with
+device="cuda-per-rank" (tests/test_multi_gpu.py, boxes with >= N GPUs), one process per GPU on the nccl backend
+(RCCL): rank r on cuda:r, the links between the GPUs carrying the exchange."""
 import os
 import sys
 
@@ -66,12 +68,20 @@ def _run(rank, world, port, out_dir, k, its, case, device="cpu"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if device == "cuda-per-rank":
+        import torch
+        assert torch.cuda.device_count() >= world, "one GPU per rank"
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     import cpu_ops
     import datagen
     from hpfrec_amd import cython_loops_float as be
     if device == "cpu":
         be.HipOps = lambda device=None: cpu_ops.CpuOps()   # numpy stand-in for the kernels (host logic test)
+    elif device == "cuda-per-rank":
+        pass                  # (the library's own defaults: RCCL job with more than one rank -> first iterations checked)
     else:
         import torch
         torch.cuda.set_device(0)
@@ -116,7 +126,8 @@ def _run(rank, world, port, out_dir, k, its, case, device="cpu"):
             out[n + "_rows"] = v[::(400 if v.shape[0] == nU else 100)].copy()
             out[n + "_colsum64"] = v.astype(np.float64).sum(axis=0)
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), llk=np.float64(llk), niter=i, native_plans=native,
-                 schedule=str(shard.LAST_SCHEDULE[0]), **out)
+                 schedule=str(shard.LAST_SCHEDULE[0]), checked_iterations=max(shard._PASSED.values(), default=0),
+                 failed_schedules=",".join(sorted(k_[0] for k_ in shard._FAILED)), **out)
         dist.destroy_process_group()
         return
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), Theta=Theta, Beta=Beta, Gamma_shp=temp[0], Gamma_rte=temp[1],

@@ -803,6 +803,47 @@ def test_svi_side_op(ops, k, rate_mode, rs_mode, w):
         assert torch.equal(got["rsc"][untouched], rsc[untouched])
 
 
+@pytest.mark.parametrize("k", [200, 256, 300, 600, 1024])
+@pytest.mark.parametrize("rs_mode,w,flagged", [(1, (1.0, 0.0), 0.07), (2, (1.0, 0.0), 0.5), (1, (0.35, 0.55), 1.0),
+                                               (1, (1.0, 0.0), None)])
+def test_lazy_batch_side_kernel_is_the_general_one_bit_for_bit(ops, k, rs_mode, w, flagged):
+    """hpf_hip_svi_side_f32 with rate_mode 0 and no rate / mean / E table to store (the batch side of a lazy epoch step,
+    ld >= 256) runs a streaming kernel of its own (svi_lazy_batch_side_kernel); the same call with a rate table to store
+    runs the general kernel.  Same float32 statements: shapes, scalar rates, the scalars the rates were formed with and the
+    column sums of the means must be EQUAL -- with few, half, all and no rows flagged, a row count that is not a multiple
+    of 64, rs_rate given or not."""
+    rs = np.random.RandomState(11 * k + rs_mode)
+    ld = _lib.ld_for_k(k)
+    n = 64 * 37 + 13
+    shp = _rand_tables(rs, n, k, ld) + 0.3
+    shp[:, k:] = 0
+    e = _rand_tables(rs, n, k, ld).cuda()
+    acc = torch.from_numpy(rs.gamma(1, 2, size=(n, ld)).astype(np.float32)).cuda()
+    rsc = torch.from_numpy(rs.uniform(0.5, 20, size=n).astype(np.float32))
+    rs_rate = torch.from_numpy(rs.uniform(0.5, 20, size=n).astype(np.float32)).cuda()
+    flag = None if flagged is None else torch.from_numpy((rs.random_sample(n) < flagged).astype(np.uint8)).cuda()
+    cs = torch.zeros(ld)
+    cs[:k] = torch.from_numpy(rs.uniform(3, 30, size=k).astype(np.float32))
+    cs = cs.cuda()
+    for use_rate in (False, True):
+        out = []
+        for general in (False, True):
+            T = dict(shp=shp.clone().cuda(), rsc=rsc.clone().cuda(), prev=torch.zeros(n, device="cuda"))
+            csp = torch.zeros((ops.finalize_grid(n), ld), device="cuda")
+            rte = torch.zeros((n, ld), device="cuda") if general else None
+            ops.svi_side(n, flag, acc, e, T["shp"], rte, None, T["rsc"], cs, csp, 0.3, w[0], w[1], 15.3, 0.3, 0.7, 0.3, 0,
+                         rs_mode, k, ld, rs_rate=rs_rate if use_rate else None, rs_prev_out=T["prev"])
+            torch.cuda.synchronize()
+            out.append((T, csp))
+        (a, ca), (b, cb) = out
+        for name in ("shp", "rsc", "prev"):
+            assert torch.equal(a[name], b[name]), (name, use_rate)
+        assert torch.equal(ca, cb), use_rate
+        if flag is not None and rs_mode == 1:
+            un = flag == 0
+            assert torch.equal(a["rsc"][un], rsc.cuda()[un]) and torch.equal(a["shp"][un], shp.cuda()[un])
+
+
 def test_c2_size_vs_oracle(hip_backend):
     """BASELINE config C2 shape at full size (138k x 27k, ~19.4M unique nonzeros, k=50): every array against the
     CPU oracle after 1 and 2 iterations.  At this size the reference's own arithmetic is the noisier side

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""N processes sharing cuda:0 map one another's exchange regions (hpfrec_amd/p2p.py) and run the primitives of the
+"""N processes sharing cuda:0 (or, P2P_PROBE_DEVICE_PER_RANK=1, one GPU each) map one another's exchange regions (hpfrec_amd/p2p.py) and run the primitives of the
 direct exchange: flag signal / wait, pulls of a peer's buffer, the k-float all-reduce by granules.  Answers, on a one-GPU
 box, what the direct exchange needs from the platform: hipIpc of coarse- and fine-grained memory between processes, kernels
 of several processes running at the same time (a waiting kernel must not starve the kernel it waits for), and what a
@@ -21,8 +21,10 @@ def worker():
     import torch.distributed as dist
     from hpfrec_amd import p2p
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
+    per_rank = os.environ.get("P2P_PROBE_DEVICE_PER_RANK") == "1"      # one GPU per process: the links carry everything
+    idx = rank if per_rank else 0
+    torch.cuda.set_device(idx)
+    dev = torch.device("cuda", idx)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ld = 64
     n = 1 << 20                     # floats per rank in the data buffer (4 MB)
@@ -94,9 +96,14 @@ def worker():
         assert timed_out and dt < 5.0, (timed_out, dt)
     dist.barrier()
     if rank == 0:
-        print("world %d: pulls of every peer's buffer after its flag OK; flag round trip 0<->1 %.1f us; "
+        print("world %d (%s): pulls of every peer's buffer after its flag OK; flag round trip 0<->1 %.1f us; "
               "all-reduce of %d floats by granules %.1f us per call (incl. one copy kernel); time-out path OK"
-              % (world, rt, ld, ar), flush=True)
+              % (world, "one GPU per rank" if per_rank else "ranks share cuda:0", rt, ld, ar), flush=True)
+    # 5. what the links deliver: per-peer pull GB/s (hpfrec_amd.p2p.link_probe, the block bench.py carries)
+    lp = p2p.link_probe(dev, dist, rank, world)
+    if rank == 0:
+        import json
+        print("link_probe " + json.dumps({k_: v for k_, v in lp.items() if k_ != "note"}), flush=True)
     dist.barrier()
     del mine
     reg.close()

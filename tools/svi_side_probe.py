@@ -48,3 +48,11 @@ for name, frac in (("no flag array", None), ("no row flagged", 0.0), ("6.5 %% fl
     print("lazy batch side, %-16s: %.3f ms = %.2f TB/s of shapes" % (name, t, gb / t))
 t = timed(lambda: ops.svi_side(n, None, acc, e, shp, rte, fac, rs, cs, part, 0.3, 1.0, 0.0, 0.3, 0.3, 0.5, 0.5, 0, 1, k, ld))
 print("stored batch side (rate and mean tables written, 3 x %.2f GB): %.3f ms = %.2f TB/s" % (gb, t, 3 * gb / t))
+
+# the OTHER side of a lazy step: rate_mode 1 (rates of the touched rows blended), E rows written, 99 % of the rows touched
+fl = (torch.rand(n, device=dev) < 0.99).to(torch.uint8)
+t = timed(lambda: ops.svi_side(n, fl, acc, e, shp, rte, None, rs, cs, part, 0.3, 0.4, 0.6, 0.3, 0.3, 0.5, 0.5, 1, 1, k, ld,
+                               e_out=e))
+moved = n * 0.99 * 7 * k * 4 / 1e9 + n * 0.01 * 2 * k * 4 / 1e9
+print("lazy other side, 99 %% of the rows touched (reads shp, rte, acc, e; writes shp, rte, e: %.2f GB of columns): %.3f ms = "
+      "%.2f TB/s" % (moved, t, moved / t))
