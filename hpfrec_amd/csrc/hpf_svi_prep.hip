@@ -67,11 +67,11 @@ __device__ __forceinline__ void block_exclusive_scan(const long long (&v)[NC], l
 // sum over tiles before `tile` of the per-tile totals (NC components each) -- every block does its own: TILES is small
 template <int NC>
 __device__ __forceinline__ void tiles_before(const long long *__restrict__ tiles, int tile, long long (&before)[NC],
-                                             long long (&all)[NC]) {
+                                             long long (&all)[NC], int ntile = TILES) {
     long long mine[NC], tot[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) mine[c] = tot[c] = 0;
-    for (int t = threadIdx.x; t < TILES; t += BLOCK) {
+    for (int t = threadIdx.x; t < ntile; t += BLOCK) {
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             const long long x = tiles[(size_t)t * NC + c];
@@ -107,15 +107,20 @@ __global__ __launch_bounds__(BLOCK) void svi_mark_kernel(const int64_t *__restri
 
 // (2a) own side: per tile of the side's global segment list, how many segments belong to flagged rows and how many of
 // those open a split row
+// EPOCH (second half of this file): `flag` holds the BATCH of every row, blockIdx.y is the batch this block compacts for,
+// gridDim.x tiles per batch; every per-batch output is a fixed-capacity slice
+template <bool EPOCH>
 __global__ __launch_bounds__(BLOCK) void svi_own_count_kernel(const hpf_segment *__restrict__ segs, int64_t nseg,
                                                               const uint8_t *__restrict__ flag,
                                                               long long *__restrict__ tiles) {
-    const int64_t per = (nseg + TILES - 1) / TILES;
+    const int ntile = gridDim.x, want = EPOCH ? (int)blockIdx.y : 1;
+    tiles += (size_t)blockIdx.y * ntile * 2;
+    const int64_t per = (nseg + ntile - 1) / ntile;
     const int64_t s0 = (int64_t)blockIdx.x * per, s1 = min(nseg, s0 + per);
     long long v[2] = {0, 0};
     for (int64_t s = s0 + threadIdx.x; s < s1; s += BLOCK) {
         const hpf_segment g = segs[s];
-        if (flag[g.row]) {
+        if (EPOCH ? flag[g.row] == want : flag[g.row] != 0) {
             v[0]++;
             // the first segment of a split row: not flagged whole-row, and the previous segment is another row's
             if (!(g.len & HPF_SEG_WHOLE_ROW) && (s == 0 || segs[s - 1].row != g.row)) v[1]++;
@@ -131,6 +136,7 @@ __global__ __launch_bounds__(BLOCK) void svi_own_count_kernel(const hpf_segment 
 
 // (2b) own side: the stable compaction itself.  b_segs = the flagged rows' descriptors (unchanged: they index the global
 // idx / y); b_multi[m] = {first compacted segment, segments, row} of every split row of the batch
+template <bool EPOCH>
 __global__ __launch_bounds__(BLOCK) void svi_own_write_kernel(const hpf_segment *__restrict__ segs, int64_t nseg,
                                                               const int64_t *__restrict__ row_seg_ptr,
                                                               const uint8_t *__restrict__ flag,
@@ -138,14 +144,19 @@ __global__ __launch_bounds__(BLOCK) void svi_own_write_kernel(const hpf_segment 
                                                               hpf_segment *__restrict__ b_segs, int64_t b_cap,
                                                               int64_t *__restrict__ b_multi, int64_t m_cap,
                                                               int64_t *__restrict__ sizes) {
+    const int ntile = gridDim.x, want = EPOCH ? (int)blockIdx.y : 1;
+    tiles += (size_t)blockIdx.y * ntile * 2;
+    b_segs += (size_t)blockIdx.y * b_cap;
+    b_multi += (size_t)blockIdx.y * m_cap * 3;
+    sizes += (size_t)blockIdx.y * 8;
     long long base[2], all[2];
-    tiles_before<2>(tiles, blockIdx.x, base, all);
+    tiles_before<2>(tiles, blockIdx.x, base, all, ntile);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         sizes[0] = min((long long)b_cap, all[0]);
         sizes[1] = min((long long)m_cap, all[1]);
         if (all[0] > b_cap || all[1] > m_cap) sizes[7] = 1;      // overflow (cannot happen with the caller's bound)
     }
-    const int64_t per = (nseg + TILES - 1) / TILES;
+    const int64_t per = (nseg + ntile - 1) / ntile;
     const int64_t s0 = (int64_t)blockIdx.x * per, s1 = min(nseg, s0 + per);
     for (int64_t c0 = s0; c0 < s1; c0 += BLOCK) {                 // chunks of BLOCK segments, in order
         const int64_t s = c0 + threadIdx.x;
@@ -157,7 +168,7 @@ __global__ __launch_bounds__(BLOCK) void svi_own_write_kernel(const hpf_segment 
         bool keep = false, opens = false;
         if (s < s1) {
             g = segs[s];
-            keep = flag[g.row] != 0;
+            keep = EPOCH ? flag[g.row] == want : flag[g.row] != 0;
             opens = keep && !(g.len & HPF_SEG_WHOLE_ROW) && (s == 0 || segs[s - 1].row != g.row);
             v[0] = keep;
             v[1] = opens;
@@ -471,6 +482,230 @@ __global__ __launch_bounds__(BLOCK) void segsum_desc_kernel(const float *__restr
     }
 }
 
+
+// ============================================================================================================
+// One preparation per EPOCH (hpf_hip_svi_epoch_prepare).  The batches of an epoch partition the rows of its side, so the
+// per-batch filter above -- a pass over all of the other side's ids for every batch, 11-16 of them per C5 epoch, 20 % of
+// the epoch's kernel time -- is one labelled partition of those ids: key, count per {batch, segment}, one scan, one
+// scatter.  What each batch then needs is a slice of the epoch's arrays; the per-batch host call disappears.
+// ============================================================================================================
+constexpr int ETILES = 256;           // scan tiles per batch of the row / segment compactions of an epoch
+
+// (E0) the epoch's order -> batch of every row, the batch's row flags, zeroed accumulator rows of rows without nonzeros
+__global__ __launch_bounds__(BLOCK) void svi_epoch_mark_kernel(const int64_t *__restrict__ order, int64_t nrows, int64_t per,
+                                                               uint8_t *__restrict__ batch_of, uint8_t *__restrict__ flag,
+                                                               const int64_t *__restrict__ indptr, float *__restrict__ acc,
+                                                               int ld) {
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < nrows; t += stride) {
+        const int64_t r = order[t], b = t / per;
+        batch_of[r] = (uint8_t)b;
+        flag[(size_t)b * nrows + r] = 1;
+        if (indptr[r + 1] == indptr[r]) {
+            float4 *row = reinterpret_cast<float4 *>(acc + (size_t)r * ld);
+            for (int c = 0; c < ld / 4; c++) row[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+__device__ __forceinline__ long long readlane64(long long x, int l) {
+    const int lo = __builtin_amdgcn_readlane((int)(x & 0xffffffffll), l);
+    const int hi = __builtin_amdgcn_readlane((int)(x >> 32), l);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// (E1) one wavefront per segment of the other side's global layout: key[e] = batch of the own-side row of nonzero e (a
+// byte gather from a table the L2 holds), cnt[b][s] = nonzeros of segment s that belong to batch b.  Lane j counts
+// bucket j (+64w): the distinct keys of a 64-entry chunk are walked with ballots, no LDS, no atomics.
+template <int NBW>
+__global__ __launch_bounds__(BLOCK) void svi_epoch_key_kernel(const hpf_segment *__restrict__ segs, int64_t nseg,
+                                                              const int32_t *__restrict__ idx,
+                                                              const uint8_t *__restrict__ batch_of,
+                                                              uint8_t *__restrict__ key, int32_t *__restrict__ cnt, int nb) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t nwaves = (int64_t)gridDim.x * WPB;
+    for (int64_t s = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); s < nseg; s += nwaves) {
+        const hpf_segment g = segs[s];
+        const int len = g.len & HPF_SEG_LEN_MASK;
+        int c[NBW];
+#pragma unroll
+        for (int w = 0; w < NBW; w++) c[w] = 0;
+        for (int o = 0; o < len; o += 4 * WAVE) {
+            int32_t id[4];
+            int kb[4];
+            bool in[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                in[u] = o + u * WAVE + lane < len;
+                id[u] = in[u] ? idx[g.begin + o + u * WAVE + lane] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) kb[u] = in[u] ? (int)batch_of[id[u]] : 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (in[u]) key[g.begin + o + u * WAVE + lane] = (uint8_t)kb[u];
+                unsigned long long rem = __ballot(in[u]);
+                while (rem) {
+                    const int v = __builtin_amdgcn_readlane(kb[u], __ffsll((long long)rem) - 1);
+                    const unsigned long long m = __ballot(in[u] && kb[u] == v);
+                    const int n = __popcll(m);
+#pragma unroll
+                    for (int w = 0; w < NBW; w++)
+                        if ((v >> 6) == w && lane == (v & 63)) c[w] += n;
+                    rem &= ~m;
+                }
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < NBW; w++)
+            if (w * WAVE + lane < nb) cnt[(int64_t)(w * WAVE + lane) * nseg + s] = c[w];
+    }
+}
+
+// (E2) the scatter: pos[b][s] (the exclusive scan of cnt in {batch, segment} order) is where segment s's nonzeros of
+// batch b go; inside the segment they keep their order (rank among the same key's lanes of the chunk + the running base)
+template <int NBW>
+__global__ __launch_bounds__(BLOCK) void svi_epoch_scatter_kernel(const hpf_segment *__restrict__ segs, int64_t nseg,
+                                                                  const int32_t *__restrict__ idx, const float *__restrict__ y,
+                                                                  const uint8_t *__restrict__ key,
+                                                                  const int64_t *__restrict__ pos, int nb,
+                                                                  int32_t *__restrict__ e_idx, float *__restrict__ e_y) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const unsigned long long below = (1ull << lane) - 1;
+    const int64_t nwaves = (int64_t)gridDim.x * WPB;
+    for (int64_t s = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); s < nseg; s += nwaves) {
+        const hpf_segment g = segs[s];
+        const int len = g.len & HPF_SEG_LEN_MASK;
+        long long base[NBW];
+#pragma unroll
+        for (int w = 0; w < NBW; w++) base[w] = (w * WAVE + lane < nb) ? pos[(int64_t)(w * WAVE + lane) * nseg + s] : 0;
+        for (int o = 0; o < len; o += 4 * WAVE) {
+            int32_t id[4];
+            float yy[4];
+            int kb[4];
+            bool in[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int64_t e = g.begin + o + u * WAVE + lane;
+                in[u] = o + u * WAVE + lane < len;
+                id[u] = in[u] ? idx[e] : 0;
+                yy[u] = in[u] ? y[e] : 0.f;
+                kb[u] = in[u] ? (int)key[e] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                long long p = 0;
+                unsigned long long rem = __ballot(in[u]);
+                while (rem) {
+                    const int v = __builtin_amdgcn_readlane(kb[u], __ffsll((long long)rem) - 1);
+                    const unsigned long long m = __ballot(in[u] && kb[u] == v);
+                    long long bv = 0;
+#pragma unroll
+                    for (int w = 0; w < NBW; w++)
+                        if ((v >> 6) == w) bv = readlane64(base[w], v & 63);
+                    if (in[u] && kb[u] == v) p = bv + __popcll(m & below);
+#pragma unroll
+                    for (int w = 0; w < NBW; w++)
+                        if ((v >> 6) == w && lane == (v & 63)) base[w] += __popcll(m);
+                    rem &= ~m;
+                }
+                if (in[u]) {
+                    e_idx[p] = id[u];
+                    e_y[p] = yy[u];
+                }
+            }
+        }
+    }
+}
+
+// (E3) per batch (blockIdx.y) and tile of the other side's rows: totals of {rows present, batch segments, split rows}.
+// A row's nonzeros of batch b sit at pos[b][first segment of the row] .. pos[b][first segment of the next row]
+__global__ __launch_bounds__(BLOCK) void svi_epoch_oth_count_kernel(const int64_t *__restrict__ row_seg_ptr, int64_t nrows,
+                                                                    int64_t nseg, const int64_t *__restrict__ pos, int cap,
+                                                                    long long *__restrict__ tiles) {
+    const int ntile = gridDim.x;
+    const int64_t *pb = pos + (int64_t)blockIdx.y * nseg;
+    const int64_t per = (nrows + ntile - 1) / ntile;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(nrows, r0 + per);
+    long long v[3] = {0, 0, 0};
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += BLOCK) {
+        const long long c = pb[row_seg_ptr[r + 1]] - pb[row_seg_ptr[r]];
+        if (c > 0) {
+            const long long ns = (c + cap - 1) / cap;
+            v[0]++;
+            v[1] += ns;
+            v[2] += ns > 1;
+        }
+    }
+    long long e[3], tot[3];
+    block_exclusive_scan<3>(v, e, tot);
+    if (threadIdx.x == 0)
+        for (int c = 0; c < 3; c++) tiles[((size_t)blockIdx.y * ntile + blockIdx.x) * 3 + c] = tot[c];
+}
+
+// (E4) the layout of every batch's other side: flags of the rows present, segments cut at `cap`, split-row descriptors,
+// sizes -- svi_oth_layout_kernel with a batch dimension
+__global__ __launch_bounds__(BLOCK) void svi_epoch_oth_layout_kernel(const int64_t *__restrict__ row_seg_ptr, int64_t nrows,
+                                                                     int64_t nseg, const int64_t *__restrict__ pos, int cap,
+                                                                     const long long *__restrict__ tiles,
+                                                                     uint8_t *__restrict__ flag_oth,
+                                                                     hpf_segment *__restrict__ o_segs, int64_t o_segs_cap,
+                                                                     int64_t *__restrict__ o_multi, int64_t m_cap,
+                                                                     int64_t *__restrict__ sizes) {
+    const int ntile = gridDim.x;
+    const int64_t *pb = pos + (int64_t)blockIdx.y * nseg;
+    tiles += (size_t)blockIdx.y * ntile * 3;
+    flag_oth += (size_t)blockIdx.y * nrows;
+    o_segs += (size_t)blockIdx.y * o_segs_cap;
+    o_multi += (size_t)blockIdx.y * m_cap * 3;
+    sizes += (size_t)blockIdx.y * 8;
+    long long base[3], all[3];
+    tiles_before<3>(tiles, blockIdx.x, base, all, ntile);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sizes[5] = all[0];
+        sizes[4] = pb[nseg] - pb[0];
+        sizes[2] = min((long long)o_segs_cap, all[1]);
+        sizes[3] = min((long long)m_cap, all[2]);
+        if (all[1] > o_segs_cap || all[2] > m_cap) sizes[7] = 1;
+    }
+    const int64_t per = (nrows + ntile - 1) / ntile;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(nrows, r0 + per);
+    for (int64_t c0 = r0; c0 < r1; c0 += BLOCK) {
+        const int64_t r = c0 + threadIdx.x;
+        long long v[3] = {0, 0, 0};
+        long long c = 0, ns = 0, start = 0;
+        if (r < r1) {
+            start = pb[row_seg_ptr[r]];
+            c = pb[row_seg_ptr[r + 1]] - start;
+            ns = (c + cap - 1) / cap;
+            flag_oth[r] = c > 0;
+            v[0] = c > 0;
+            v[1] = ns;
+            v[2] = ns > 1;
+        }
+        long long e[3], tot[3];
+        block_exclusive_scan<3>(v, e, tot);
+        if (c > 0) {
+            const long long sg0 = base[1] + e[1], m0 = base[2] + e[2];
+            for (long long q = 0; q < ns; q++) {
+                if (sg0 + q >= o_segs_cap) break;
+                hpf_segment g;
+                g.begin = start + q * cap;
+                const long long left = c - q * cap;
+                g.len = (int32_t)(left < cap ? left : cap) | (ns == 1 ? HPF_SEG_WHOLE_ROW : 0);
+                g.row = (int32_t)r;
+                o_segs[sg0 + q] = g;
+            }
+            if (ns > 1 && m0 < m_cap) {
+                o_multi[m0 * 3 + 0] = sg0;
+                o_multi[m0 * 3 + 1] = ns;
+                o_multi[m0 * 3 + 2] = r;
+            }
+        }
+        for (int q = 0; q < 3; q++) base[q] += tot[q];
+    }
+}
+
 inline int last_error() { return (int)hipGetLastError(); }
 
 }  // namespace
@@ -499,9 +734,9 @@ int hpf_hip_svi_batch_prepare(const hpf_svi_batch *b, void *stream) {
         hipLaunchKernelGGL(svi_mark_kernel, dim3(grid_for(b->nids, BLOCK)), dim3(BLOCK), 0, st, b->prev_ids, b->nprev,
                            b->ids, b->nids, b->flag_own, b->own_indptr, b->acc_own, b->ld, 1);
     long long *tiles_own = (long long *)b->tiles, *tiles_oth = (long long *)b->tiles + TILES * 4;   // [2 | 3 | 1 per tile]
-    hipLaunchKernelGGL(svi_own_count_kernel, dim3(TILES), dim3(BLOCK), 0, st, b->own_segs, b->own_nseg, b->flag_own,
+    hipLaunchKernelGGL(svi_own_count_kernel<false>, dim3(TILES), dim3(BLOCK), 0, st, b->own_segs, b->own_nseg, b->flag_own,
                        tiles_own);
-    hipLaunchKernelGGL(svi_own_write_kernel, dim3(TILES), dim3(BLOCK), 0, st, b->own_segs, b->own_nseg,
+    hipLaunchKernelGGL(svi_own_write_kernel<false>, dim3(TILES), dim3(BLOCK), 0, st, b->own_segs, b->own_nseg,
                        b->own_row_seg_ptr, b->flag_own, (const long long *)tiles_own, b->b_segs, b->b_segs_cap, b->b_multi,
                        b->multi_cap, b->sizes);
     const int64_t nnz = b->oth_nnz;
@@ -549,6 +784,60 @@ int hpf_hip_svi_batch_prepare(const hpf_svi_batch *b, void *stream) {
         hipLaunchKernelGGL(svi_oth_write_kernel, dim3(tgrid), dim3(BLOCK), 0, st, b->oth_idx, b->oth_y, nnz,
                            (const unsigned long long *)mask, (const uint16_t *)chunk_pre, (const int64_t *)b->tile_off,
                            b->o_idx, b->o_y, b->o_cap);
+    return last_error();
+}
+
+int64_t hpf_hip_svi_epoch_sizeof(void) { return (int64_t)sizeof(hpf_svi_epoch); }
+int64_t hpf_hip_svi_epoch_scratch_words(int nb) { return (int64_t)(nb < 1 ? 1 : nb) * ETILES * 5 + TILES; }
+
+int hpf_hip_svi_epoch_prepare(const hpf_svi_epoch *b, void *stream) {
+    if (!b || !b->own_segs || !b->own_row_seg_ptr || !b->own_indptr || !b->oth_segs || !b->oth_row_seg_ptr || !b->oth_idx ||
+        !b->oth_y || !b->order || !b->acc_own || !b->batch_of || !b->flag_own || !b->flag_oth || !b->b_segs || !b->b_multi ||
+        !b->e_idx || !b->e_y || !b->o_segs || !b->o_multi || !b->sizes || !b->key || !b->seg_cnt || !b->seg_pos || !b->tiles ||
+        b->own_nrows <= 0 || b->oth_nrows <= 0 || b->own_nseg < 0 || b->oth_nseg < 0 || b->oth_nnz < 0 || b->per <= 0 ||
+        b->nb < 1 || b->nb > 255 || (int64_t)b->nb * b->per < b->own_nrows || b->seg_cap <= 0 ||
+        b->seg_cap > HPF_SEG_LEN_MASK || b->ld <= 0)
+        return HPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    auto grid_for = [](int64_t n, int per) { int64_t g = (n + per - 1) / per; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); };
+    const int nb = b->nb;
+    hipError_t e = hipMemsetAsync(b->flag_own, 0, (size_t)nb * b->own_nrows, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(svi_epoch_mark_kernel, dim3(grid_for(b->own_nrows, BLOCK)), dim3(BLOCK), 0, st, b->order, b->own_nrows,
+                       b->per, b->batch_of, b->flag_own, b->own_indptr, b->acc_own, b->ld);
+    long long *tiles_own = (long long *)b->tiles, *tiles_oth = tiles_own + (size_t)nb * ETILES * 2,
+              *groups = tiles_oth + (size_t)nb * ETILES * 3;
+    hipLaunchKernelGGL(svi_own_count_kernel<true>, dim3(ETILES, nb), dim3(BLOCK), 0, st, b->own_segs, b->own_nseg,
+                       (const uint8_t *)b->batch_of, tiles_own);
+    hipLaunchKernelGGL(svi_own_write_kernel<true>, dim3(ETILES, nb), dim3(BLOCK), 0, st, b->own_segs, b->own_nseg,
+                       b->own_row_seg_ptr, (const uint8_t *)b->batch_of, (const long long *)tiles_own, b->b_segs,
+                       b->b_segs_cap, b->b_multi, b->multi_cap, b->sizes);
+    const int64_t nseg = b->oth_nseg, n_pairs = (int64_t)nb * nseg;
+    const int sgrid = grid_for(nseg, WPB);
+    if (nseg > 0) {
+        if (nb <= 64)
+            hipLaunchKernelGGL((svi_epoch_key_kernel<1>), dim3(sgrid), dim3(BLOCK), 0, st, b->oth_segs, nseg, b->oth_idx,
+                               (const uint8_t *)b->batch_of, b->key, b->seg_cnt, nb);
+        else
+            hipLaunchKernelGGL((svi_epoch_key_kernel<4>), dim3(sgrid), dim3(BLOCK), 0, st, b->oth_segs, nseg, b->oth_idx,
+                               (const uint8_t *)b->batch_of, b->key, b->seg_cnt, nb);
+    }
+    hipLaunchKernelGGL(svi_tile_sums_kernel, dim3(TILES), dim3(BLOCK), 0, st, (const int32_t *)b->seg_cnt, n_pairs, groups);
+    hipLaunchKernelGGL(svi_tile_offsets_kernel, dim3(TILES), dim3(BLOCK), 0, st, (const int32_t *)b->seg_cnt, n_pairs,
+                       (const long long *)groups, b->seg_pos);
+    if (nseg > 0) {
+        if (nb <= 64)
+            hipLaunchKernelGGL((svi_epoch_scatter_kernel<1>), dim3(sgrid), dim3(BLOCK), 0, st, b->oth_segs, nseg, b->oth_idx,
+                               b->oth_y, (const uint8_t *)b->key, (const int64_t *)b->seg_pos, nb, b->e_idx, b->e_y);
+        else
+            hipLaunchKernelGGL((svi_epoch_scatter_kernel<4>), dim3(sgrid), dim3(BLOCK), 0, st, b->oth_segs, nseg, b->oth_idx,
+                               b->oth_y, (const uint8_t *)b->key, (const int64_t *)b->seg_pos, nb, b->e_idx, b->e_y);
+    }
+    hipLaunchKernelGGL(svi_epoch_oth_count_kernel, dim3(ETILES, nb), dim3(BLOCK), 0, st, b->oth_row_seg_ptr, b->oth_nrows,
+                       nseg, (const int64_t *)b->seg_pos, b->seg_cap, tiles_oth);
+    hipLaunchKernelGGL(svi_epoch_oth_layout_kernel, dim3(ETILES, nb), dim3(BLOCK), 0, st, b->oth_row_seg_ptr, b->oth_nrows,
+                       nseg, (const int64_t *)b->seg_pos, b->seg_cap, (const long long *)tiles_oth, b->flag_oth, b->o_segs,
+                       b->o_segs_cap, b->o_multi, b->multi_cap, b->sizes);
     return last_error();
 }
 

@@ -36,6 +36,26 @@ def _svi_batch_struct():
 SviBatchDesc = _svi_batch_struct()
 
 
+def _svi_epoch_struct():
+    import ctypes
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+
+    class SviEpochDesc(ctypes.Structure):
+        """hpf_svi_epoch (include/hpf_hip.h), field for field."""
+        _fields_ = [("own_segs", vp), ("own_nseg", i64), ("own_row_seg_ptr", vp), ("own_indptr", vp), ("own_nrows", i64),
+                    ("oth_segs", vp), ("oth_nseg", i64), ("oth_row_seg_ptr", vp),
+                    ("oth_idx", vp), ("oth_y", vp), ("oth_nrows", i64), ("oth_nnz", i64),
+                    ("order", vp), ("per", i64), ("nb", i32), ("ld", i32), ("seg_cap", i32), ("reserved", i32),
+                    ("acc_own", vp), ("batch_of", vp), ("flag_own", vp), ("flag_oth", vp),
+                    ("b_segs", vp), ("b_segs_cap", i64), ("b_multi", vp), ("multi_cap", i64),
+                    ("e_idx", vp), ("e_y", vp), ("o_segs", vp), ("o_segs_cap", i64), ("o_multi", vp),
+                    ("sizes", vp), ("key", vp), ("seg_cnt", vp), ("seg_pos", vp), ("tiles", vp)]
+    return SviEpochDesc
+
+
+SviEpochDesc = _svi_epoch_struct()
+
+
 class HipOps:
     name = "hip"
 
@@ -228,6 +248,33 @@ class HipOps:
 
     def svi_prep_scratch_words(self):
         return int(self.L.hpf_hip_svi_prep_scratch_words())
+
+    def svi_epoch_scratch_words(self, nb):
+        return int(self.L.hpf_hip_svi_epoch_scratch_words(int(nb)))
+
+    def svi_epoch_prepare(self, ws):
+        """The index structures of EVERY batch of an epoch (svi.EpochWorkspace; ws.order = the epoch's shuffled rows), by
+        one call (hpf_hip_svi_epoch_prepare): the other side's nonzeros partitioned by batch in one labelled pass instead
+        of one filter pass per batch; nothing is read back."""
+        import ctypes
+        d = ws.__dict__.get("_hip_desc")
+        if d is None:
+            d = ws._hip_desc = SviEpochDesc()
+            assert ctypes.sizeof(d) == int(self.L.hpf_hip_svi_epoch_sizeof())
+            own, oth = ws.own, ws.oth
+            d.own_segs, d.own_nseg, d.own_row_seg_ptr = _ptr(own.segs), own.nseg, _ptr(own.row_seg_ptr)
+            d.own_indptr, d.own_nrows = _ptr(own.indptr), own.nrows
+            d.oth_segs, d.oth_nseg, d.oth_row_seg_ptr = _ptr(oth.segs), oth.nseg, _ptr(oth.row_seg_ptr)
+            d.oth_idx, d.oth_y, d.oth_nrows, d.oth_nnz = _ptr(oth.idx), _ptr(oth.y), oth.nrows, oth.nnz
+            d.per, d.nb, d.ld, d.seg_cap = int(ws.per), int(ws.nb), int(ws.ld), int(ws.seg_cap)
+            d.acc_own, d.batch_of, d.flag_own, d.flag_oth = _ptr(ws.acc_own), _ptr(ws.batch_of), _ptr(ws.flag_own), _ptr(ws.flag_oth)
+            d.b_segs, d.b_segs_cap, d.b_multi, d.multi_cap = _ptr(ws.b_segs), ws.b_cap, _ptr(ws.b_multi), ws.multi_cap
+            d.e_idx, d.e_y = _ptr(ws.e_idx), _ptr(ws.e_y)
+            d.o_segs, d.o_segs_cap, d.o_multi = _ptr(ws.o_segs), ws.o_segs_cap, _ptr(ws.o_multi)
+            d.sizes, d.key, d.seg_cnt, d.seg_pos, d.tiles = _ptr(ws.sizes), _ptr(ws.key), _ptr(ws.seg_cnt), _ptr(ws.seg_pos), _ptr(ws.tiles)
+        assert int(ws.order.shape[0]) == ws.own.nrows and ws.order.dtype == torch.int64
+        d.order = _ptr(ws.order)
+        _lib.check(self.L.hpf_hip_svi_epoch_prepare(ctypes.byref(d), self._stream()), "hpf_hip_svi_epoch_prepare")
 
     def segsum_desc(self, part, desc, ndesc_dev, ndesc_max, acc, ld):
         """acc[row] = sum of a split row's part[] rows for the {first, n, row} descriptors of a device-built batch."""

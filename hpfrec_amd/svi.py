@@ -135,6 +135,84 @@ class BatchWorkspace:
         return bool(int(self.sizes[7].item()) != 0)
 
 
+class EpochWorkspace:
+    """Device buffers for the index structures of EVERY batch of an epoch over the rows of `own`, filled once per epoch
+    by ops.svi_epoch_prepare (hpf_hip_svi_epoch_prepare) from the epoch's shuffled order: an epoch's batches partition the
+    side's rows, so the other side's nonzeros are partitioned by batch in one pass (e_idx / e_y) instead of being filtered
+    once per batch, and a batch is a set of fixed-capacity slices -- `batch(j)` hands them out, no device work.  Capacities
+    per batch come from the same bound as BatchWorkspace's (the nonzeros of the `batch_rows` largest rows)."""
+
+    MAX_BATCHES = 255                       # (a batch id is a byte)
+
+    @staticmethod
+    def plan(own, oth, batch_rows, seg_cap=layout.SEG_CAP):
+        """(nb, per, bound, bytes of the per-batch slices) of an epoch over `own` in batches of `batch_rows` rows."""
+        per = int(min(batch_rows, own.nrows))
+        nb = -(-own.nrows // per)
+        deg = own.indptr[1:] - own.indptr[:-1]
+        bound = int(torch.topk(deg, per).values.sum().item()) if per > 0 else 0       # (once per fit)
+        o_segs_cap = min(oth.nrows, bound) + bound // seg_cap + 1
+        b_cap = per + bound // seg_cap + 1
+        nbytes = nb * (16 * (o_segs_cap + b_cap) + own.nrows + oth.nrows + 12 * oth.nseg) + 9 * oth.nnz
+        return nb, per, bound, nbytes
+
+    @classmethod
+    def fits(cls, own, oth, batch_rows, seg_cap=layout.SEG_CAP):
+        """An epoch-level preparation is used when a batch id fits a byte and the per-batch slices stay a modest share of
+        the device (HPF_SVI_EPOCH_BYTES, default 16 GiB); otherwise the batches are prepared one by one (BatchWorkspace)."""
+        if os.environ.get("HPF_SVI_EPOCH_PREP", "1") != "1" or batch_rows <= 0:
+            return False
+        nb, _, _, nbytes = cls.plan(own, oth, batch_rows, seg_cap)
+        return nb <= cls.MAX_BATCHES and nbytes <= int(os.environ.get("HPF_SVI_EPOCH_BYTES", str(16 << 30)))
+
+    def __init__(self, ops, own, oth, acc_own, ld, batch_rows, seg_cap=layout.SEG_CAP):
+        dev = own.idx.device
+        i64 = dict(dtype=torch.int64, device=dev)
+        u8 = dict(dtype=torch.uint8, device=dev)
+        self.own, self.oth, self.acc_own, self.ld, self.seg_cap = own, oth, acc_own, int(ld), int(seg_cap)
+        self.nb, self.per, bound, _ = self.plan(own, oth, batch_rows, seg_cap)
+        assert 1 <= self.nb <= self.MAX_BATCHES
+        nb = self.nb
+        self.nnz_bound = bound
+        self.b_cap = self.per + bound // seg_cap + 1
+        self.multi_cap = bound // seg_cap + 2
+        self.o_segs_cap = min(oth.nrows, bound) + bound // seg_cap + 1
+        self.batch_of = torch.zeros(own.nrows, **u8)
+        self.flag_own = torch.zeros((nb, own.nrows), **u8)
+        self.flag_oth = torch.zeros((nb, oth.nrows), **u8)
+        self.b_segs = torch.zeros((nb, self.b_cap, 2), **i64)
+        self.b_multi = torch.zeros((nb, self.multi_cap, 3), **i64)
+        self.o_multi = torch.zeros((nb, self.multi_cap, 3), **i64)
+        self.o_segs = torch.zeros((nb, self.o_segs_cap, 2), **i64)
+        self.e_idx = torch.zeros(max(oth.nnz, 1), dtype=torch.int32, device=dev)
+        self.e_y = torch.zeros(max(oth.nnz, 1), dtype=torch.float32, device=dev)
+        self.sizes = torch.zeros((nb, 8), **i64)
+        self.key = torch.zeros(max(oth.nnz, 1), **u8)
+        self.seg_cnt = torch.zeros(nb * oth.nseg + 1, dtype=torch.int32, device=dev)
+        self.seg_pos = torch.zeros(nb * oth.nseg + 1, **i64)
+        self.tiles = torch.zeros(ops.svi_epoch_scratch_words(nb), **i64)
+        self.order = None
+        self.ready = self.free = None         # events: structures built (preparation stream) / consumed (compute stream)
+        # own side: descriptors index the side's GLOBAL idx / y (no hint); other side: a handful of nonzeros per row
+        self._sides = [(DevSide(self.b_segs[j], self.b_cap, own.idx, own.y, self.sizes[j, 0:1], self.b_multi[j],
+                                self.sizes[j, 1:2], self.multi_cap, 0),
+                        DevSide(self.o_segs[j], self.o_segs_cap, self.e_idx, self.e_y, self.sizes[j, 2:3], self.o_multi[j],
+                                self.sizes[j, 3:4], self.multi_cap, 1)) for j in range(nb)]
+
+    def prepare(self, ops, order):
+        """Builds the structures of all batches of the epoch whose shuffled rows are `order` (device int64, a permutation
+        of the side's rows) on the current stream."""
+        self.order = order
+        ops.svi_epoch_prepare(self)
+
+    def batch(self, j):
+        """(own side, other side, flags of the batch's rows, flags of the other side's rows it touches) of batch j."""
+        return self._sides[j][0], self._sides[j][1], self.flag_own[j], self.flag_oth[j]
+
+    def overflowed(self):
+        return bool(int(self.sizes[:, 7].sum().item()) != 0)
+
+
 class DeviceModel:
     """The variational state as padded device tables; `v(name)` is the [:, :k] view used by the dense algebra."""
 
@@ -459,10 +537,12 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
     rng = np.random.default_rng(seed=random_seed if random_seed > 0 else None)   # PXI:207
 
     # A batch's index structures (its rows' segment list, the same nonzeros grouped by the other side, the flags of the
-    # rows both touch) are built ON THE DEVICE by one call per batch (BatchWorkspace / hpf_hip_svi_batch_prepare) on a
-    # second stream, one batch ahead of the batch whose kernels run: two workspaces per epoch type, alternating.  The
-    # host's share of a batch is that call, the shuffle (numpy's, as in the reference) once per epoch and one 8-byte-per-
-    # row upload of the epoch's order -- nothing data-dependent comes back.
+    # rows both touch) are built ON THE DEVICE, on a second stream, ahead of the kernels that use them; nothing data-
+    # dependent comes back.  The batches of an epoch partition its side's rows, so they are built per EPOCH
+    # (EpochWorkspace / hpf_hip_svi_epoch_prepare: one labelled partition of the other side's nonzeros, queued while the
+    # PREVIOUS epoch's batches run); when an epoch has more batches than a byte counts, or its slices would not fit, per
+    # batch (BatchWorkspace / hpf_hip_svi_batch_prepare: one filter pass per batch, one batch ahead, two workspaces
+    # alternating).  The host's share is the shuffle (numpy's, as in the reference) and one 8-byte-per-row upload per epoch.
     # (HPF_SVI_LAZY=0: every batch stores the rate and mean tables the reference rewrites -- 2-3 GB per C5 batch that nothing
     # reads before the next check; kept as a switch so that a test can hold the lazy form against it bit for bit)
     lazy = os.environ.get("HPF_SVI_LAZY", "1") == "1"
@@ -472,19 +552,25 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
     if prep_stream is not None:
         prep_stream.wait_stream(torch.cuda.current_stream(dev))      # the CSR / CSC built above
     workspaces = {}
+    per_epoch = {}       # epoch type -> whether its batches are prepared per epoch
 
-    def workspace(user_epoch, slot):
-        key = (bool(user_epoch), slot)
+    def sides_of(user_epoch):
+        return (users, items, m.acc_u, users_per_batch) if user_epoch else (items, users, m.acc_i, items_per_batch)
+
+    def workspace(user_epoch, slot, epoch_level=False):
+        key = (bool(user_epoch), slot, epoch_level)
         if key not in workspaces:
-            own, oth = (users, items) if user_epoch else (items, users)
-            workspaces[key] = BatchWorkspace(ops, own, oth, m.acc_u if user_epoch else m.acc_i, m.ld,
-                                             users_per_batch if user_epoch else items_per_batch)
+            own, oth, acc, per = sides_of(user_epoch)
+            workspaces[key] = (EpochWorkspace if epoch_level else BatchWorkspace)(ops, own, oth, acc, m.ld, per)
+            if prep_stream is not None:      # (its buffers were zero-filled on the compute stream)
+                prep_stream.wait_stream(torch.cuda.current_stream(dev))
         return workspaces[key]
 
     order_host = {}      # page-locked staging for an epoch's order, per epoch type (re-used once its copy has completed)
 
     def upload_order(numeration, user_epoch):
-        """The epoch's shuffled row order -> device int64 (one asynchronous copy from page-locked memory)."""
+        """The epoch's shuffled row order -> device int64: one asynchronous copy from page-locked memory, queued on the
+        preparation stream (its only consumer), so that the compute stream never waits for PCIe."""
         n = numeration.shape[0]
         if dev.type != "cuda":
             return torch.from_numpy(numeration.astype(np.int64))
@@ -494,22 +580,46 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
         if slot[1] is not None:
             slot[1].synchronize()
         slot[0].numpy()[:] = numeration.view(np.int64)
-        out = slot[0].to(dev, non_blocking=True)
-        slot[1] = torch.cuda.Event()
-        slot[1].record()
+        with torch.cuda.stream(prep_stream):
+            out = slot[0].to(dev, non_blocking=True)
+            slot[1] = torch.cuda.Event()
+            slot[1].record(prep_stream)
         return out
 
-    def prepare(ws, ids):
-        """Queue the preparation of a batch on the preparation stream (after the step that last used `ws`)."""
+    def prepare(ws, arg):
+        """Queue a preparation (a batch's: arg = its rows; an epoch's: arg = its order) on the preparation stream, after
+        the step that last read `ws`."""
         if prep_stream is None:
-            ws.prepare(ops, ids)
+            ws.prepare(ops, arg)
             return
         if ws.free is not None:
             prep_stream.wait_event(ws.free)
         with torch.cuda.stream(prep_stream):
-            ws.prepare(ops, ids)
+            ws.prepare(ops, arg)
             ws.ready = torch.cuda.Event()
             ws.ready.record(prep_stream)
+
+    def plan_epoch(i):
+        """Epoch i's shuffle (PXI:277 / 329; called in epoch order: one generator), the upload of its order and, for an
+        epoch prepared as a whole, the preparation itself -- queued while the epoch before it runs."""
+        if users_per_batch > 0 and items_per_batch > 0:
+            user_epoch = ((i + 1) % 2) == 0        # PXI:265-269: epoch 0 is an item epoch
+        else:
+            user_epoch = users_per_batch > 0
+        numeration = users_numeration if user_epoch else items_numeration
+        rng.shuffle(numeration)
+        own, oth, _, per = sides_of(user_epoch)
+        per = int(per)
+        if user_epoch not in per_epoch:
+            per_epoch[user_epoch] = EpochWorkspace.fits(own, oth, per)
+        order = upload_order(numeration, user_epoch)
+        ews = None
+        if per_epoch[user_epoch]:
+            # (epochs alternate sides: one workspace per side; an SVI over one side only alternates two of them)
+            ews = workspace(user_epoch, i % 2, epoch_level=True)
+            prepare(ews, order)
+        return dict(user_epoch=user_epoch, order=order, per=per, n_side=own.nrows, ews=ews,
+                    nb=nbatches_u if user_epoch else nbatches_i)
 
     errs = np.zeros(2, dtype=np.longdouble)
     last_crit = -np.inf
@@ -542,51 +652,61 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
     t_loop = time.perf_counter()
     host_s = [0.0, 0.0]       # host time spent preparing batches / issuing their kernels
     i = -1
+    planned = None
     for i in range(maxiter):
         step = float(np.float32(step_size(i)))
-        if users_per_batch > 0 and items_per_batch > 0:
-            user_epoch = ((i + 1) % 2) == 0        # PXI:265-269: epoch 0 is an item epoch
-        else:
-            user_epoch = users_per_batch > 0
-        if user_epoch:
-            rng.shuffle(users_numeration)
-            numeration, per, n_side = users_numeration, int(users_per_batch), nU
-        else:
-            rng.shuffle(items_numeration)
-            numeration, per, n_side = items_numeration, int(items_per_batch), nI
         t_h = time.perf_counter()
-        order = upload_order(numeration, user_epoch)
-        if prep_stream is not None:
-            prep_stream.wait_stream(torch.cuda.current_stream(dev))      # (the order's copy is queued on this stream)
-            order.record_stream(prep_stream)
-        nb = nbatches_u if user_epoch else nbatches_i
-        chunks = [order[bt * per: min(n_side, (bt + 1) * per)] for bt in range(nb)]
-        prepare(workspace(user_epoch, 0), chunks[0])
+        cur = planned if planned is not None else plan_epoch(i)
+        # the next epoch's order and (epoch-level) preparation are queued BEFORE this epoch's kernels: they run beside
+        # them.  (A stop at this epoch's check leaves one unused shuffle behind: the generator is the fit's own.)
+        planned = plan_epoch(i + 1) if i + 1 < maxiter else None
+        user_epoch, per, n_side, nb, order = cur["user_epoch"], cur["per"], cur["n_side"], cur["nb"], cur["order"]
         host_s[0] += time.perf_counter() - t_h
-        for j in range(nb):
+        if cur["ews"] is not None:
+            ews = cur["ews"]
             t_h = time.perf_counter()
-            ws = workspace(user_epoch, j % 2)
-            if ws.ready is not None:
-                torch.cuda.current_stream(dev).wait_event(ws.ready)
-            su, si = (ws.side_own, ws.side_oth) if user_epoch else (ws.side_oth, ws.side_own)
-            flag_u, flag_i = (ws.flag_own, ws.flag_oth) if user_epoch else (ws.flag_oth, ws.flag_own)
-            _svi_step(m, hyd, su, si, flag_u, flag_i, step, float(n_side) / float(chunks[j].shape[0]), user_epoch,
-                      all_scalar_rows=False, lazy=lazy)
+            if ews.ready is not None:
+                torch.cuda.current_stream(dev).wait_event(ews.ready)
+            for j in range(nb):
+                own_side, oth_side, f_own, f_oth = ews.batch(j)
+                su, si = (own_side, oth_side) if user_epoch else (oth_side, own_side)
+                flag_u, flag_i = (f_own, f_oth) if user_epoch else (f_oth, f_own)
+                rows_j = min(n_side, (j + 1) * per) - j * per
+                _svi_step(m, hyd, su, si, flag_u, flag_i, step, float(n_side) / float(rows_j), user_epoch,
+                          all_scalar_rows=False, lazy=lazy)
             if prep_stream is not None:
-                ws.free = torch.cuda.Event()
-                ws.free.record(torch.cuda.current_stream(dev))
+                ews.free = torch.cuda.Event()
+                ews.free.record(torch.cuda.current_stream(dev))
             host_s[1] += time.perf_counter() - t_h
-            if j + 1 < nb:
-                # the next batch's structures are built while this batch's kernels run.  Its workspace was last used by
-                # batch j-1: the host waits for that step here (not a bubble -- batch j is queued already), which also
-                # keeps it at most a batch ahead of the device, so the two clocks below time host WORK, not a full
-                # launch queue
-                nxt = workspace(user_epoch, (j + 1) % 2)
-                if nxt.free is not None:
-                    nxt.free.synchronize()
+        else:
+            t_h = time.perf_counter()
+            chunks = [order[bt * per: min(n_side, (bt + 1) * per)] for bt in range(nb)]
+            prepare(workspace(user_epoch, 0), chunks[0])
+            host_s[0] += time.perf_counter() - t_h
+            for j in range(nb):
                 t_h = time.perf_counter()
-                prepare(nxt, chunks[j + 1])
-                host_s[0] += time.perf_counter() - t_h
+                ws = workspace(user_epoch, j % 2)
+                if ws.ready is not None:
+                    torch.cuda.current_stream(dev).wait_event(ws.ready)
+                su, si = (ws.side_own, ws.side_oth) if user_epoch else (ws.side_oth, ws.side_own)
+                flag_u, flag_i = (ws.flag_own, ws.flag_oth) if user_epoch else (ws.flag_oth, ws.flag_own)
+                _svi_step(m, hyd, su, si, flag_u, flag_i, step, float(n_side) / float(chunks[j].shape[0]), user_epoch,
+                          all_scalar_rows=False, lazy=lazy)
+                if prep_stream is not None:
+                    ws.free = torch.cuda.Event()
+                    ws.free.record(torch.cuda.current_stream(dev))
+                host_s[1] += time.perf_counter() - t_h
+                if j + 1 < nb:
+                    # the next batch's structures are built while this batch's kernels run.  Its workspace was last used
+                    # by batch j-1: the host waits for that step here (not a bubble -- batch j is queued already), which
+                    # also keeps it at most a batch ahead of the device, so the two clocks time host WORK, not a full
+                    # launch queue
+                    nxt = workspace(user_epoch, (j + 1) % 2)
+                    if nxt.free is not None:
+                        nxt.free.synchronize()
+                    t_h = time.perf_counter()
+                    prepare(nxt, chunks[j + 1])
+                    host_s[0] += time.perf_counter() - t_h
 
         if check_every > 0 and ((i + 1) % check_every) == 0:
             if stop_crit == "diff-norm":

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 20
+#define HPF_HIP_ABI_VERSION 21
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -313,6 +313,36 @@ typedef struct hpf_svi_batch {
 int64_t hpf_hip_svi_batch_sizeof(void);   /* sizeof(hpf_svi_batch), for a binding's layout check */
 int64_t hpf_hip_svi_prep_scratch_words(void);
 int hpf_hip_svi_batch_prepare(const hpf_svi_batch *batch, void *stream);
+/*
+ * The same structures for ALL batches of one epoch, built once (hpfrec_amd/csrc/hpf_svi_prep.hip, second half).  An
+ * epoch's batches partition the rows of its side (`order` is the epoch's shuffle, PXI:277 / 329; batch b = rows
+ * order[b*per .. min(own_nrows, (b+1)*per))), so every nonzero belongs to exactly one batch: instead of filtering the
+ * other side's 48M ids once per batch (11-16 passes per C5 epoch), one pass labels every nonzero with its batch
+ * (key[e] = batch_of[idx[e]]), a scan over {batch, segment of the other side} counts gives every segment's place in
+ * every batch, and one scatter writes e_idx / e_y = the other side's layout PARTITIONED by batch (stable: inside a batch
+ * the order of hpf_hip_svi_batch_prepare's o_idx / o_y).  Each batch then owns fixed-capacity slices:
+ *   flag_own [nb][own_nrows], flag_oth [nb][oth_nrows], b_segs [nb][b_segs_cap], b_multi [nb][multi_cap][3],
+ *   o_segs [nb][o_segs_cap] (their `begin` indexes e_idx / e_y as a whole), o_multi [nb][multi_cap][3], sizes [nb][8]
+ * with the meaning hpf_hip_svi_batch_prepare gives them for that batch (the per-batch call and this one produce the
+ * same segment lists, flags and nonzero order -- tests/test_svi_paths.py).  acc_own rows of rows without nonzeros are zeroed.
+ * nb <= 255.  Scratch: batch_of [own_nrows] u8, key [oth_nnz] u8, seg_cnt [nb*oth_nseg + 1] i32,
+ * seg_pos [nb*oth_nseg + 1] i64, tiles [hpf_hip_svi_epoch_scratch_words(nb)] i64.  sizes[b][7] is sticky as above.
+ */
+typedef struct hpf_svi_epoch {
+    const hpf_segment *own_segs; int64_t own_nseg; const int64_t *own_row_seg_ptr; const int64_t *own_indptr;
+    int64_t own_nrows;
+    const hpf_segment *oth_segs; int64_t oth_nseg; const int64_t *oth_row_seg_ptr;
+    const int32_t *oth_idx; const float *oth_y; int64_t oth_nrows; int64_t oth_nnz;
+    const int64_t *order; int64_t per; int32_t nb, ld, seg_cap, reserved;
+    float *acc_own; uint8_t *batch_of; uint8_t *flag_own; uint8_t *flag_oth;
+    hpf_segment *b_segs; int64_t b_segs_cap; int64_t *b_multi; int64_t multi_cap;
+    int32_t *e_idx; float *e_y; hpf_segment *o_segs; int64_t o_segs_cap; int64_t *o_multi;
+    int64_t *sizes;
+    uint8_t *key; int32_t *seg_cnt; int64_t *seg_pos; int64_t *tiles;
+} hpf_svi_epoch;
+int64_t hpf_hip_svi_epoch_sizeof(void);
+int64_t hpf_hip_svi_epoch_scratch_words(int nb);
+int hpf_hip_svi_epoch_prepare(const hpf_svi_epoch *epoch, void *stream);
 /* acc[row][0:ld] = sum of part[first .. first+n) for the descriptors {first, n, row} (b_multi / o_multi above), the
  * first min(ndesc_max, *ndesc_dev) of them: the split rows of a batch sweep (hpf_hip_segsum_f32 with device-side lists). */
 int hpf_hip_segsum_desc_f32(const float *part, const int64_t *desc, const int64_t *ndesc_dev, int64_t ndesc_max,

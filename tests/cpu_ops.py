@@ -310,6 +310,38 @@ class CpuOps:
     def svi_prep_scratch_words(self):
         return 8
 
+    @staticmethod
+    def _batch_structures(own, oth, cap, flag):
+        """The structures of the batch made of the rows with flag != 0 (numpy): own side's kept descriptors + split-row
+        list, other side's filtered nonzeros, present rows, segments cut at cap, split-row list."""
+        segs = _np(own.segs)
+        row = (segs[:, 1] >> 32).astype(np.int64)
+        keep = flag[row] != 0
+        kept = segs[keep]
+        krow = row[keep]
+        rsp = _np(own.row_seg_ptr)
+        opens = np.nonzero(((kept[:, 1] & 0x40000000) == 0) & (np.concatenate([[True], krow[1:] != krow[:-1]])))[0]
+        bm = np.stack([opens, rsp[krow[opens] + 1] - rsp[krow[opens]], krow[opens]], axis=1).astype(np.int64)
+        optr = _np(oth.indptr)
+        mask = flag[_np(oth.idx).astype(np.int64)] != 0
+        row_of = np.repeat(np.arange(oth.nrows), optr[1:] - optr[:-1])
+        o_idx, o_y = _np(oth.idx)[mask], _np(oth.y)[mask]
+        cnt = np.bincount(row_of[mask], minlength=oth.nrows).astype(np.int64)
+        rows = np.nonzero(cnt > 0)[0]
+        c = cnt[rows]
+        start = np.cumsum(c) - c
+        ns = (c + cap - 1) // cap
+        sg0 = np.cumsum(ns) - ns
+        nseg = int(ns.sum())
+        local = np.repeat(np.arange(rows.shape[0]), ns)
+        within = np.arange(nseg) - sg0[local]
+        begin = start[local] + within * cap
+        length = np.minimum(c[local] - within * cap, cap) | np.where(ns[local] == 1, 0x40000000, 0)
+        osegs = np.stack([begin, length | (rows[local] << 32)], axis=1).astype(np.int64)
+        multi = np.nonzero(ns > 1)[0]
+        om = np.stack([sg0[multi], ns[multi], rows[multi]], axis=1).astype(np.int64)
+        return kept, bm, o_idx, o_y, cnt > 0, osegs, om, rows.shape[0]
+
     def svi_batch_prepare(self, ws):
         """hpf_hip_svi_batch_prepare in numpy: same outputs in the same layout (tests compare them with the kernels')."""
         own, oth, cap = ws.own, ws.oth, int(ws.seg_cap)
@@ -323,52 +355,48 @@ class CpuOps:
         _np(ws.acc_own)[empty] = 0
         sizes = _np(ws.sizes)
         sizes[:] = 0
-        # own side: stable compaction of the global segment list
-        segs = _np(own.segs)
-        row = (segs[:, 1] >> 32).astype(np.int64)
-        keep = flag[row] != 0
-        kept = segs[keep]
-        nb = kept.shape[0]
-        assert nb <= ws.b_cap
-        _np(ws.b_segs)[:nb] = kept
-        krow = row[keep]
-        rsp = _np(own.row_seg_ptr)
-        opens = np.nonzero(((kept[:, 1] & 0x40000000) == 0) & (np.concatenate([[True], krow[1:] != krow[:-1]])))[0]
-        bm = _np(ws.b_multi)
-        bm[: opens.shape[0], 0] = opens
-        bm[: opens.shape[0], 1] = rsp[krow[opens] + 1] - rsp[krow[opens]]
-        bm[: opens.shape[0], 2] = krow[opens]
-        sizes[0], sizes[1] = nb, opens.shape[0]
-        # other side: its global layout filtered by the flag
-        optr = _np(oth.indptr)
-        mask = flag[_np(oth.idx).astype(np.int64)] != 0
-        row_of = np.repeat(np.arange(oth.nrows), optr[1:] - optr[:-1])
-        n = int(mask.sum())
-        assert n <= ws.o_cap
-        _np(ws.o_idx)[:n] = _np(oth.idx)[mask]
-        _np(ws.o_y)[:n] = _np(oth.y)[mask]
-        cnt = np.bincount(row_of[mask], minlength=oth.nrows).astype(np.int64)
-        _np(ws.flag_oth)[:] = cnt > 0
-        rows = np.nonzero(cnt > 0)[0]
-        c = cnt[rows]
-        start = np.cumsum(c) - c
-        ns = (c + cap - 1) // cap
-        sg0 = np.cumsum(ns) - ns
-        nseg = int(ns.sum())
-        assert nseg <= ws.o_segs_cap
-        local = np.repeat(np.arange(rows.shape[0]), ns)
-        within = np.arange(nseg) - sg0[local]
-        begin = start[local] + within * cap
-        length = np.minimum(c[local] - within * cap, cap) | np.where(ns[local] == 1, 0x40000000, 0)
-        osegs = _np(ws.o_segs)
-        osegs[:nseg, 0] = begin
-        osegs[:nseg, 1] = length | (rows[local] << 32)
-        multi = np.nonzero(ns > 1)[0]
-        om = _np(ws.o_multi)
-        om[: multi.shape[0], 0] = sg0[multi]
-        om[: multi.shape[0], 1] = ns[multi]
-        om[: multi.shape[0], 2] = rows[multi]
-        sizes[2], sizes[3], sizes[4], sizes[5] = nseg, multi.shape[0], n, rows.shape[0]
+        kept, bm, o_idx, o_y, present, osegs, om, nrows_present = self._batch_structures(own, oth, cap, flag)
+        assert kept.shape[0] <= ws.b_cap and o_idx.shape[0] <= ws.o_cap and osegs.shape[0] <= ws.o_segs_cap
+        _np(ws.b_segs)[: kept.shape[0]] = kept
+        _np(ws.b_multi)[: bm.shape[0]] = bm
+        _np(ws.o_idx)[: o_idx.shape[0]] = o_idx
+        _np(ws.o_y)[: o_idx.shape[0]] = o_y
+        _np(ws.flag_oth)[:] = present
+        _np(ws.o_segs)[: osegs.shape[0]] = osegs
+        _np(ws.o_multi)[: om.shape[0]] = om
+        sizes[:6] = kept.shape[0], bm.shape[0], osegs.shape[0], om.shape[0], o_idx.shape[0], nrows_present
+
+    def svi_epoch_scratch_words(self, nb):
+        return 8
+
+    def svi_epoch_prepare(self, ws):
+        """hpf_hip_svi_epoch_prepare in numpy: every batch of the epoch through the per-batch construction, the batches'
+        nonzeros laid end to end in e_idx / e_y (the other side's segments index them as a whole)."""
+        own, oth, cap, nb, per = ws.own, ws.oth, int(ws.seg_cap), int(ws.nb), int(ws.per)
+        order = _np(ws.order)
+        ptr = _np(own.indptr)
+        _np(ws.acc_own)[order[ptr[order + 1] == ptr[order]]] = 0
+        _np(ws.flag_own)[:] = 0
+        sizes = _np(ws.sizes)
+        base = 0
+        for b in range(nb):
+            ids = order[b * per: min(own.nrows, (b + 1) * per)]
+            flag = _np(ws.flag_own)[b]
+            flag[ids] = 1
+            _np(ws.batch_of)[ids] = b
+            kept, bm, o_idx, o_y, present, osegs, om, nrows_present = self._batch_structures(own, oth, cap, flag)
+            assert kept.shape[0] <= ws.b_cap and osegs.shape[0] <= ws.o_segs_cap
+            osegs = osegs.copy()
+            osegs[:, 0] += base
+            _np(ws.b_segs)[b, : kept.shape[0]] = kept
+            _np(ws.b_multi)[b, : bm.shape[0]] = bm
+            _np(ws.e_idx)[base: base + o_idx.shape[0]] = o_idx
+            _np(ws.e_y)[base: base + o_idx.shape[0]] = o_y
+            _np(ws.flag_oth)[b] = present
+            _np(ws.o_segs)[b, : osegs.shape[0]] = osegs
+            _np(ws.o_multi)[b, : om.shape[0]] = om
+            sizes[b, :6] = kept.shape[0], bm.shape[0], osegs.shape[0], om.shape[0], o_idx.shape[0], nrows_present
+            base += o_idx.shape[0]
 
     def segsum_desc(self, part, desc, ndesc_dev, ndesc_max, acc, ld):
         nd = min(int(ndesc_max), int(_np(ndesc_dev)[0]))

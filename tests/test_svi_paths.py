@@ -321,3 +321,83 @@ def test_lazy_epochs_equal_the_stored_form_bit_for_bit(any_backend, monkeypatch,
         out[lazy]["llk"] = np.float64(m.train_llk)
     for n in out["1"]:
         assert np.array_equal(out["1"][n], out["0"][n]), n
+
+
+@pytest.mark.parametrize("case,batch_frac", [("ragged", 3), ("hubs", 4), ("empty-rows", 2), ("ragged", 70), ("hubs", 1)])
+def test_epoch_workspace_equals_the_batch_workspaces(any_backend, case, batch_frac):
+    """svi.EpochWorkspace (hpf_hip_svi_epoch_prepare: ONE labelled partition of the other side's nonzeros per epoch) hands
+    every batch of an epoch the structures svi.BatchWorkspace (one filter pass per batch) builds for the same rows: same
+    sizes, flags, own-side descriptors and split rows, the same nonzeros in the same order behind the other side's
+    segments (their `begin` shifted by the batch's place in the epoch's arrays), accumulator rows of rows without
+    nonzeros zeroed -- user and item epochs, batches of a third / a quarter / half / 1/70th of the rows (more batches
+    than one 64-lane word of counters holds) and one batch holding every row; a workspace re-used for a second epoch."""
+    import torch
+    from hpfrec_amd import layout, svi
+    ops = any_backend._make_ops()
+    dev = ops.device
+    rs = np.random.RandomState({"ragged": 11, "hubs": 12, "empty-rows": 13}[case] + batch_frac)
+    nU, nI, cap, ld = 700, 300, 16, 32
+    nnz = 9000 if case != "empty-rows" else 900
+    iu = (nU * rs.random_sample(nnz) ** (3 if case == "hubs" else 1.3)).astype(np.int64)
+    ii = (nI * rs.random_sample(nnz) ** (4 if case == "hubs" else 1.5)).astype(np.int64)
+    y = (1 + rs.poisson(1.0, size=nnz)).astype(np.float32)
+    users, items, _ = layout.build_sides(torch.from_numpy(iu).to(dev), torch.from_numpy(ii).to(dev),
+                                         torch.from_numpy(y).to(dev), nU, nI, seg_cap=cap)
+    for side, other, n_rows in ((users, items, nU), (items, users, nI)):
+        per = max(1, -(-n_rows // batch_frac))
+        acc = torch.ones((n_rows, ld), dtype=torch.float32, device=dev)
+        acc_b = torch.ones((n_rows, ld), dtype=torch.float32, device=dev)
+        ews = svi.EpochWorkspace(ops, side, other, acc, ld, per, seg_cap=cap)
+        assert ews.nb == -(-n_rows // per) and ews.per == per
+        deg = (side.indptr[1:] - side.indptr[:-1]).cpu().numpy()
+        for rep in range(2):                                      # the second epoch re-uses the workspace
+            order = rs.permutation(n_rows).astype(np.int64)
+            acc.fill_(1.0)
+            ews.prepare(ops, torch.from_numpy(order).to(dev))
+            a = acc.cpu().numpy()
+            assert np.all(a[deg == 0] == 0) and np.all(a[deg > 0] == 1)
+            assert not ews.overflowed()
+            assert np.array_equal(ews.batch_of.cpu().numpy()[order], np.arange(n_rows) // per)
+            base = 0
+            for j in range(ews.nb):
+                ids = order[j * per: min(n_rows, (j + 1) * per)]
+                bws = svi.BatchWorkspace(ops, side, other, acc_b, ld, per, seg_cap=cap)
+                bws.prepare(ops, torch.from_numpy(ids).to(dev))
+                own_e, oth_e, f_own, f_oth = ews.batch(j)
+                se, sb = ews.sizes[j].cpu().numpy(), bws.sizes.cpu().numpy()
+                assert np.array_equal(se[:6], sb[:6]) and se[7] == 0, (case, j, se, sb)
+                assert torch.equal(f_own, bws.flag_own) and torch.equal(f_oth, bws.flag_oth)
+                assert torch.equal(own_e.segs[: se[0]], bws.b_segs[: sb[0]])
+                assert torch.equal(own_e.multi[: se[1]], bws.b_multi[: sb[1]])
+                assert own_e.idx is side.idx and own_e.y is side.y
+                got = oth_e.segs[: se[2]].clone()
+                got[:, 0] -= base
+                assert torch.equal(got, bws.o_segs[: sb[2]])
+                assert torch.equal(oth_e.multi[: se[3]], bws.o_multi[: sb[3]])
+                assert torch.equal(oth_e.idx[base: base + se[4]], bws.o_idx[: sb[4]])
+                assert torch.equal(oth_e.y[base: base + se[4]], bws.o_y[: sb[4]])
+                assert int(own_e.nseg_dev[0]) == se[0] and int(oth_e.nseg_dev[0]) == se[2]
+                base += int(se[4])
+            assert base == side.nnz
+
+
+@pytest.mark.parametrize("kw", [dict(users_per_batch=20, items_per_batch=25), dict(users_per_batch=30),
+                                dict(items_per_batch=40), dict(users_per_batch=100, items_per_batch=34)])
+def test_epochs_prepared_as_a_whole_equal_the_batch_by_batch_form_bit_for_bit(any_backend, monkeypatch, kw):
+    """fit_hpf's stochastic epochs with their batches prepared per epoch (the default) and one by one
+    (HPF_SVI_EPOCH_PREP=0; also what an epoch of more than 255 batches falls back to): all eight arrays and the llk EQUAL
+    -- alternating epoch types (one workspace per side), user-only and item-only epochs (two workspaces alternating), one
+    batch per user epoch beside item epochs whose last batch is short."""
+    df, nU, nI = datagen.readme_counts()
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HPF_SVI_EPOCH_PREP", mode)
+        m = HPF(k=12, maxiter=5, random_seed=7, ncores=1, reindex=False, verbose=True, check_every=2,
+                stop_crit="maxiter", **kw)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m.fit(df.copy())
+        out[mode] = {n: np.array(getattr(m, n)) for n in NAMES}
+        out[mode]["llk"] = np.float64(m.train_llk)
+    for n in out["1"]:
+        assert np.array_equal(out["1"][n], out["0"][n]), n
