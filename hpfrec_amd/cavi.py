@@ -100,7 +100,7 @@ def draw_init_words(ops, mt_state, nU, nI, k):
 class FullBatchCavi(ShardedMixin):
     """Device-resident state + one-iteration step for (a shard of) the HPF model."""
 
-    def __init__(self, ops, device, ix_u, ix_i, y, nU, nI, hyper, seg_cap=layout.SEG_CAP):
+    def __init__(self, ops, device, ix_u, ix_i, y, nU, nI, hyper, seg_cap=None):
         """ix_u/ix_i/y: COO triplets of THIS rank (user ids local to the shard), torch tensors."""
         self.ops = ops
         self.device = torch.device(device)

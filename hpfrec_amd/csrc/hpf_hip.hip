@@ -137,6 +137,22 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b) {
 // one shared reciprocal for 1/s, the recurrence sum and 1/rte, Newton steps instead of an IEEE divide,
 // and a short exp (fdlibm-style ln2 split + degree-9 Taylor, rel. error < 1e-11) instead of ocml's.
 // ----------------------------------------------------------------------------------------
+// The blends of a stochastic step, a*x + b*y, with each product and the sum rounded on its own -- numpy's float32 statements
+// (PXI:316-325, 368-377) -- and NOT contracted into an fma: a contraction is the compiler's choice per kernel, and the same
+// statement is formed by several kernels (the whole-table passes, the row-list kernels, the sweep's fused epilogue) whose
+// results must agree bit for bit.
+__device__ __forceinline__ float blend2(float a, float x, float b, float y) {
+    return __fadd_rn(__fmul_rn(a, x), __fmul_rn(b, y));
+}
+// shp = w_new*(prior + e*acc) [+ w_old*shp]: `fresh` = fmaf(e, acc, prior) at every site
+__device__ __forceinline__ float blend_shape(float w_new, float fresh, float w_old, float old) {
+    return (w_old == 0.f) ? __fmul_rn(w_new, fresh) : blend2(w_new, fresh, w_old, old);
+}
+// step*(base + c) + step_prev*old (rates: base = top/rs, c = a column sum; row scalars: base = add, c = sum_k fac)
+__device__ __forceinline__ float blend_rate(float step, float base, float c, float step_prev, float old) {
+    return blend2(step, __fadd_rn(base, c), step_prev, old);
+}
+
 __device__ __forceinline__ double fast_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);  // v_rcp_f64: ~24 good bits
     r = fma(fma(-x, r, 1.0), r, r);
@@ -207,9 +223,14 @@ struct FinalizeArgs {  // the row-finalize operands when it is fused into the sw
     uint32_t sig_epoch;
     float *cs_other_copy;     // optional: block 0 keeps a copy of cs_other (the column sums this launch used)
     int nq4;                  // SKIP: float4s of a gathered row that hold columns < k, rounded up to whole 64-byte sectors
+    float w_new, w_old, step, step_prev;   // MODE 2: the blend weights of a stochastic step (shapes; rates and row scalars)
 };
 
-// MODE: 0 = plain sweep; 1 = row finalize fused as EPILOGUE of whole-row segments.
+// MODE: 0 = plain sweep; 1 = row finalize fused as EPILOGUE of whole-row segments; 2 = the OTHER side of a stochastic step
+// fused the same way (svi_side_kernel's rate_mode 1 statements for the rows the batch touches: shapes and rates blended
+// towards the step's estimate, means, the row scalar, the new E row): the rows a batch touches on its other side are short
+// (8-12 nonzeros at BASELINE config C5), so writing their phi-sums to memory, reading them back next to the E row the sweep
+// already holds, and only then updating the row was as much traffic as the gathers themselves.
 // SKIP: the zero padding of the gathered rows is not fetched -- lanes whose float4 lies in a 64-byte sector past column k
 // issue no load (k = 200 in ld = 256: 13 of a row's 16 sectors; k = 100 in ld = 128: 7 of 8).  Only instantiated for those k:
 // with k = 50 in ld = 64 every sector holds columns and the kernel is the unmasked one.
@@ -292,6 +313,67 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
         }
     };
 
+    // MODE 2: the same for a row of the OTHER side of a stochastic step (svi_side_kernel, rate_mode 1, rs_mode 1, a flagged
+    // row -- the same statements through the same helpers): so / ro = the row's old shape and rate entries
+    auto finish_row_svi = [&](const float (&a)[NC], const float (&eo)[NC], const float (&so)[NC], const float (&ro)[NC],
+                              int row) {
+        const float rs_old = fa.rs[row];
+        const float base_rte = fa.top_shp / rs_old;
+        float sh[NC], rt[NC], fc[NC], en[NC];
+        float fsum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NC; t++) {
+            const bool valid = colq[t] < fa.k;
+            const float fresh = fmaf(eo[t], a[t], fa.prior_shp);
+            sh[t] = valid ? blend_shape(fa.w_new, fresh, fa.w_old, so[t]) : 0.f;
+            rt[t] = valid ? blend_rate(fa.step, base_rte, csl[t], fa.step_prev, ro[t]) : 0.f;
+            fc[t] = valid ? sh[t] / rt[t] : 0.f;
+            en[t] = 0.f;
+            fsum += fc[t];
+            csacc[t] += fc[t];
+        }
+        if (fa.e_new) {
+            double ev[NC];
+            int ehi = 0;
+#pragma unroll
+            for (int t = 0; t < NC; t++) {
+                ev[t] = (colq[t] < fa.k) ? expect_ratio(sh[t], rt[t]) : 0.0;
+                ehi = max(ehi, __double2hiint(ev[t]));
+            }
+            const double inv = row_pow2_scale(ehi);
+#pragma unroll
+            for (int t = 0; t < NC; t++) en[t] = (colq[t] < fa.k) ? (float)(ev[t] * inv) : 0.f;
+        }
+        if constexpr (NG == 1) {
+            // lane j owns whole float4s (columns (v*LPR + j)*4 .. +3 = entries 4v .. 4v+3): 16-byte stores
+#pragma unroll
+            for (int v = 0; v < VPL; v++) {
+                if (v * LPR + j < fa.nq4 || !SKIP) {
+                    const size_t o4 = (size_t)row * (LD / 4) + v * LPR + j;
+                    reinterpret_cast<float4 *>(fa.shp)[o4] = make_float4(sh[4 * v], sh[4 * v + 1], sh[4 * v + 2], sh[4 * v + 3]);
+                    reinterpret_cast<float4 *>(fa.rte)[o4] = make_float4(rt[4 * v], rt[4 * v + 1], rt[4 * v + 2], rt[4 * v + 3]);
+                    if (fa.fac)
+                        reinterpret_cast<float4 *>(fa.fac)[o4] = make_float4(fc[4 * v], fc[4 * v + 1], fc[4 * v + 2], fc[4 * v + 3]);
+                    if (fa.e_new)
+                        reinterpret_cast<float4 *>(fa.e_new)[o4] = make_float4(en[4 * v], en[4 * v + 1], en[4 * v + 2], en[4 * v + 3]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NC; t++) {
+                if (colq[t] < LD) {
+                    const size_t o = (size_t)row * LD + colq[t];
+                    fa.shp[o] = sh[t];
+                    fa.rte[o] = rt[t];
+                    if (fa.fac) fa.fac[o] = fc[t];
+                    if (fa.e_new) fa.e_new[o] = en[t];
+                }
+            }
+        }
+        fsum = wave_sum(fsum);
+        if (lane == 0) fa.rs[row] = blend_rate(fa.step, fa.add_rte, fsum, fa.step_prev, rs_old);
+    };
+
     for (int64_t sg = (int64_t)blockIdx.x * WPB + wid; sg < nseg; sg += nwaves) {
         const hpf_segment sgm = segs[sg];
         const int len = sgm.len & HPF_SEG_LEN_MASK;
@@ -301,6 +383,21 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
         for (int v = 0; v < VPL; v++) {
             rv[v] = selfp[v * LPR + j];
             acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // MODE 2: the row's old shapes and rates are requested with its E row, ahead of the gathers (in-order returns: by
+        // the time the last gather has landed they are there)
+        float4 sold[MODE == 2 ? VPL : 1], rold[MODE == 2 ? VPL : 1];
+        if constexpr (MODE == 2) {
+            if ((sgm.len & HPF_SEG_WHOLE_ROW) != 0) {
+                const float4 *sp4 = reinterpret_cast<const float4 *>(fa.shp + (size_t)sgm.row * LD);
+                const float4 *rp4 = reinterpret_cast<const float4 *>(fa.rte + (size_t)sgm.row * LD);
+#pragma unroll
+                for (int v = 0; v < VPL; v++) {
+                    const bool in = !SKIP || v * LPR + j < fa.nq4;
+                    sold[v] = in ? sp4[v * LPR + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    rold[v] = in ? rp4[v * LPR + j] : make_float4(1.f, 1.f, 1.f, 1.f);
+                }
+            }
         }
         const int32_t *ip = idx + sgm.begin;
         const float *yp = y + sgm.begin;
@@ -375,7 +472,7 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
                     if (c + 3 < fa.acc_ld) ar[c + 3] = acc[v].w;
                 }
             }
-        } else if (MODE != 1 || !whole_row) {
+        } else if (MODE == 0 || !whole_row) {
             if (g == 0) {
                 float4 *pp = reinterpret_cast<float4 *>(part + (size_t)sg * LD);
 #pragma unroll
@@ -401,6 +498,30 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
                 eo[t] = ov_;
             }
             finish_row(a, eo, en, sgm.row);
+        } else if constexpr (MODE == 2) {
+            float a[NC], eo[NC], so[NC], ro[NC];
+#pragma unroll
+            for (int t = 0; t < NC; t++) {
+                const int q = g + t * NG;
+                float av_ = 0.f, ov_ = 0.f, sv_ = 0.f, rv_ = 1.f;
+#pragma unroll
+                for (int qq = 0; qq < NQ; qq++) {  // pick float4 component q (q is lane-dependent unless NG == 1)
+                    const int v = qq >> 2, e = qq & 3;
+                    const float av = (e == 0) ? acc[v].x : (e == 1) ? acc[v].y : (e == 2) ? acc[v].z : acc[v].w;
+                    const float ov = (e == 0) ? rv[v].x : (e == 1) ? rv[v].y : (e == 2) ? rv[v].z : rv[v].w;
+                    const float sv = (e == 0) ? sold[v].x : (e == 1) ? sold[v].y : (e == 2) ? sold[v].z : sold[v].w;
+                    const float rr = (e == 0) ? rold[v].x : (e == 1) ? rold[v].y : (e == 2) ? rold[v].z : rold[v].w;
+                    av_ = (qq == q) ? av : av_;
+                    ov_ = (qq == q) ? ov : ov_;
+                    sv_ = (qq == q) ? sv : sv_;
+                    rv_ = (qq == q) ? rr : rv_;
+                }
+                a[t] = av_;
+                eo[t] = ov_;
+                so[t] = sv_;
+                ro[t] = rv_;
+            }
+            finish_row_svi(a, eo, so, ro, sgm.row);
         }
     }
 
@@ -1236,7 +1357,7 @@ __global__ __launch_bounds__(BLOCK) void svi_shape_rows_kernel(const int64_t *__
                 const size_t o = (size_t)r * LD + c;
                 const float a = acc ? acc[(size_t)ar * LD + c] : 0.f;
                 const float fresh = fmaf(e[o], a, prior);
-                shp[o] = (w_old == 0.f) ? w_new * fresh : w_new * fresh + w_old * shp[o];
+                shp[o] = blend_shape(w_new, fresh, w_old, shp[o]);
             }
         }
     }
@@ -1309,7 +1430,7 @@ __global__ __launch_bounds__(BLOCK) void svi_refresh_kernel(int64_t nrows, const
             }
             if (blend_rs) {
                 fsum = wave_sum(fsum);
-                if (lane == 0) rs[r] = step * (add + fsum) + step_prev * rs_old[i];
+                if (lane == 0) rs[r] = blend_rate(step, add, fsum, step_prev, rs_old[i]);
             }
         }
     }
@@ -1407,7 +1528,7 @@ void svi_lazy_batch_side_kernel(int64_t nrows, const uint8_t *__restrict__ flag,
 #pragma unroll
                         for (int e2 = 0; e2 < 4; e2++) {
                             const float fresh = fmaf(e4[e2], a4[e2], prior);
-                            const float sx = (w_old == 0.f) ? w_new * fresh : w_new * fresh + w_old * s4[e2];
+                            const float sx = blend_shape(w_new, fresh, w_old, s4[e2]);
                             s4[e2] = (c + e2 < k) ? sx : 0.f;          // (pad columns: what the tables hold there)
                         }
                         (reinterpret_cast<float4 *>(shp) + ou)[v * WAVE + lane] = make_float4(s4[0], s4[1], s4[2], s4[3]);
@@ -1426,7 +1547,7 @@ void svi_lazy_batch_side_kernel(int64_t nrows, const uint8_t *__restrict__ flag,
                 }
                 if (rs_mode == 2 || (rs_mode == 1 && fl)) {
                     fsum = wave_sum(fsum);
-                    if (lane == b0 + i) rs_new_l = step * (add + fsum) + step_prev * rs_old;
+                    if (lane == b0 + i) rs_new_l = blend_rate(step, add, fsum, step_prev, rs_old);
                 }
                 __builtin_amdgcn_sched_barrier(0);      // (one row's divisions at a time: interleaved they cost 116 VGPRs)
             }
@@ -1463,7 +1584,10 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                                                          float w_old, float top, float add, float step,
                                                          float step_prev, int rate_mode, int rs_mode, int k,
                                                          const float *__restrict__ rs_rate,
-                                                         float *__restrict__ rs_prev_out, float *e_out) {
+                                                         float *__restrict__ rs_prev_out, float *e_out, int done_flag) {
+    // done_flag != 0: rows whose flag EQUALS it were finished elsewhere (the sweep's fused epilogue, sweep_kernel MODE 2) --
+    // nothing of theirs is read, written or summed here; the other flagged rows (a split row's flag differs) and the
+    // unflagged rows are treated as ever.
     // e_out (may alias e -- which is why `e` carries no __restrict__: the row's loads must stay ordered before its stores, and
     // must not be routed through a read-only path): the step's rows also get their NEW E row, exp(psi(shp))/rte row-scaled, from the shape and rate
     // just formed -- what expect_kernel would compute from the tables at the start of the next step (same function, same
@@ -1505,17 +1629,20 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
         for (int64_t g = ((int64_t)blockIdx.x * WPB + wid) * WAVE; g < nrows; g += nwaves * WAVE) {
             const int64_t rl = g + lane;
             const bool lv = rl < nrows;
-            const unsigned long long fmask = __ballot(lv && flag && flag[rl] != 0);
+            const int fv = (lv && flag) ? (int)flag[rl] : 0;
+            const unsigned long long dmask = __ballot(done_flag != 0 && fv == done_flag);
+            const unsigned long long fmask = __ballot(fv != 0) & ~dmask;
             const float rs_l = lv ? rs[rl] : 1.f;
             const float rsr_l = (lv && rs_rate) ? rs_rate[rl] : rs_l;
             float rs_new_l = rs_l;
             const int cnt = (int)min((int64_t)WAVE, nrows - g);
             for (int b0 = 0; b0 < cnt; b0 += VR) {
+                if (((dmask >> b0) & ((1ull << VR) - 1)) == ((1ull << VR) - 1)) continue;     // (all of them finished elsewhere)
                 float4 sv[VR][VPL], rv[VR][VPL], av[VR][VPL], ev[VR][VPL];
                 bool fl[VR], live[VR];
 #pragma unroll
                 for (int i = 0; i < VR; i++) {
-                    live[i] = b0 + i < cnt;
+                    live[i] = b0 + i < cnt && ((dmask >> (b0 + i)) & 1ull) == 0;
                     fl[i] = live[i] && ((fmask >> (b0 + i)) & 1ull) != 0;
                     const size_t o4 = (size_t)(live[i] ? g + b0 + i : 0) * (LD / 4) + lane;
 #pragma unroll
@@ -1534,7 +1661,8 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                 }
 #pragma unroll
                 for (int i = 0; i < VR; i++) {
-                    if (!live[i]) break;
+                    if (b0 + i >= cnt) break;
+                    if (!live[i]) continue;
                     const int64_t r = g + b0 + i;
                     const float rs_old = __shfl(rs_l, b0 + i);
                     const float base = top / __shfl(rsr_l, b0 + i);
@@ -1555,13 +1683,13 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                                 float sx = s4[e2];
                                 if (fl[i]) {
                                     const float fresh = fmaf(e4[e2], a4[e2], prior);
-                                    sx = (w_old == 0.f) ? w_new * fresh : w_new * fresh + w_old * sx;
+                                    sx = blend_shape(w_new, fresh, w_old, sx);
                                 }
                                 float rt = r4[e2];
                                 if (rate_mode == 0)
                                     rt = base + c4[e2];
                                 else if (fl[i])
-                                    rt = step * (base + c4[e2]) + step_prev * rt;
+                                    rt = blend_rate(step, base, c4[e2], step_prev, rt);
                                 f = sx / rt;
                                 s4[e2] = sx;
                                 r4[e2] = rt;
@@ -1607,7 +1735,7 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                     }
                     if (rs_mode == 2 || (rs_mode == 1 && fl[i])) {
                         fsum = wave_sum(fsum);
-                        if (lane == b0 + i) rs_new_l = step * (add + fsum) + step_prev * rs_old;
+                        if (lane == b0 + i) rs_new_l = blend_rate(step, add, fsum, step_prev, rs_old);
                     }
                 }
             }
@@ -1636,19 +1764,21 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
     constexpr int R = (CPL <= 4) ? 2 : 1;   // rows in flight per wavefront
     for (int64_t r0 = (int64_t)blockIdx.x * WPB + wid; r0 < nrows; r0 += R * nwaves) {
         float sv[R][CPL], rv[R][CPL], av[R][CPL], ev[R][CPL], rs_old[R], rs_rt[R];
-        bool fl[R];
+        bool fl[R], dn[R];
 #pragma unroll
         for (int i = 0; i < R; i++) {       // (flags and scalars of all rows first: see the float4 path)
             const int64_t r = r0 + i * nwaves;
             const bool live = r < nrows;
-            fl[i] = live && flag && flag[r] != 0;
+            const int fv = (live && flag) ? (int)flag[r] : 0;
+            dn[i] = done_flag != 0 && fv == done_flag;
+            fl[i] = fv != 0 && !dn[i];
             rs_old[i] = live ? rs[r] : 1.f;
             rs_rt[i] = (live && rs_rate) ? rs_rate[r] : rs_old[i];
         }
 #pragma unroll
         for (int i = 0; i < R; i++) {
             const int64_t r = r0 + i * nwaves;
-            const bool live = r < nrows;
+            const bool live = r < nrows && !dn[i];
 #pragma unroll
             for (int q = 0; q < CPL; q++) {
                 const int c = lane + WAVE * q;
@@ -1664,6 +1794,7 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
         for (int i = 0; i < R; i++) {
             const int64_t r = r0 + i * nwaves;
             if (r >= nrows) break;
+            if (dn[i]) continue;
             const float base = top / rs_rt[i];
             float fsum = 0.f;
 #pragma unroll
@@ -1676,7 +1807,7 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                         float s = sv[i][q];
                         if (fl[i]) {
                             const float fresh = fmaf(ev[i][q], av[i][q], prior);
-                            s = (w_old == 0.f) ? w_new * fresh : w_new * fresh + w_old * s;
+                            s = blend_shape(w_new, fresh, w_old, s);
                             shp[o] = s;
                         }
                         float rt = rv[i][q];
@@ -1684,7 +1815,7 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                             rt = base + csl[q];
                             if (rte) rte[o] = rt;
                         } else if (fl[i]) {
-                            rt = step * (base + csl[q]) + step_prev * rt;
+                            rt = blend_rate(step, base, csl[q], step_prev, rt);
                             rte[o] = rt;
                         }
                         f = s / rt;
@@ -1719,7 +1850,7 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
             if (rs_prev_out && lane == 0) rs_prev_out[r] = rs_rt[i];
             if (rs_mode == 2 || (rs_mode == 1 && fl[i])) {
                 fsum = wave_sum(fsum);
-                if (lane == 0) rs[r] = step * (add + fsum) + step_prev * rs_old[i];
+                if (lane == 0) rs[r] = blend_rate(step, add, fsum, step_prev, rs_old[i]);
             }
         }
     }
@@ -1759,7 +1890,7 @@ __global__ __launch_bounds__(BLOCK) void svi_rate_rows_kernel(const int64_t *__r
                 const int c = lane + WAVE * q;
                 if (c < k) {
                     const size_t o = (size_t)r * LD + c;
-                    rte[o] = step * (base + cs_other[c]) + step_prev * rte[o];
+                    rte[o] = blend_rate(step, base, cs_other[c], step_prev, rte[o]);
                 }
             }
         } else {
@@ -1770,7 +1901,7 @@ __global__ __launch_bounds__(BLOCK) void svi_rate_rows_kernel(const int64_t *__r
                 if (c < k) fsum += fac[(size_t)r * LD + c];
             }
             fsum = wave_sum(fsum);
-            if (lane == 0) rs[r] = step * (add + fsum) + step_prev * rs[r];
+            if (lane == 0) rs[r] = blend_rate(step, add, fsum, step_prev, rs[r]);
         }
     }
 }
@@ -2188,6 +2319,51 @@ int hpf_hip_sweep_finalize_f32(const hpf_segment *segs, int64_t nseg, const int3
                                hpf_direct::Signal{nullptr, 0, 0}, (hipStream_t)stream);
 }
 
+int hpf_hip_sweep_svi_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y, const float *tab_self,
+                          const float *tab_other, float *part, float *e_new, float *shp, float *rte, float *fac, float *rs,
+                          const float *cs_other, float *cs_partial, float prior, float w_new, float w_old, float top,
+                          float add, float step, float step_prev, int k, int ld, int short_rows, int grid_blocks,
+                          const int64_t *nseg_dev, void *stream) {
+    if (!segs || !idx || !y || !tab_self || !tab_other || !part || !shp || !rte || !rs || !cs_other || !cs_partial ||
+        nseg <= 0 || k <= 0 || ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0 || (e_new && e_new != tab_self))
+        return HPF_EINVAL;
+    // grid NOT clamped: every block writes its cs_partial row (zeros when it had no segment)
+    FinalizeArgs fa = {};
+    fa.cs_other = cs_other;
+    fa.cs_partial = cs_partial;
+    fa.e_new = e_new;
+    fa.shp = shp;
+    fa.rte = rte;
+    fa.fac = fac;
+    fa.rs = rs;
+    fa.prior_shp = prior;
+    fa.top_shp = top;
+    fa.add_rte = add;
+    fa.k = k;
+    fa.nseg_dev = nseg_dev;
+    fa.nq4 = sector_float4s(k);
+    fa.w_new = w_new;
+    fa.w_old = w_old;
+    fa.step = step;
+    fa.step_prev = step_prev;
+    const bool skip = fa.nq4 < ld / 4;
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int US = (HPF_U >= 8) ? HPF_U / 2 : HPF_U;
+#define LAUNCH(LPR, VPL, UU_, SKIP_)                                                                                      \
+    hipLaunchKernelGGL((sweep_kernel<LPR, VPL, 2, UU_, SKIP_>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg, idx, y, \
+                       tab_self, tab_other, part, fa)
+#define CALL(LPR, VPL)                                                                                              \
+    if (short_rows) {                                                                                               \
+        if (skip) LAUNCH(LPR, VPL, US, true); else LAUNCH(LPR, VPL, US, false);                                     \
+    } else {                                                                                                        \
+        if (skip) LAUNCH(LPR, VPL, HPF_U, true); else LAUNCH(LPR, VPL, HPF_U, false);                               \
+    }
+    HPF_DISPATCH_LD(ld, CALL)
+#undef CALL
+#undef LAUNCH
+    return last_error();
+}
+
 int hpf_hip_row_finalize_f32(const float *part, const int64_t *row_seg_ptr, const int64_t *row_list, int64_t nrows,
                              const float *e_old, float *e_new, float *shp, float *rte, float *fac, float *rs,
                              float *rs_prev, const float *cs_other, float *cs_partial, float prior_shp, float top_shp,
@@ -2449,14 +2625,15 @@ int hpf_hip_svi_side_f32(int64_t nrows, const uint8_t *flag, const float *acc, c
                          float *fac, float *rs, const float *cs_other, float *cs_partial, float prior, float w_new,
                          float w_old, float top, float add, float step, float step_prev, int rate_mode, int rs_mode,
                          int k, int ld, int grid_blocks, const float *rs_rate, float *rs_prev_out, float *e_out,
-                         void *stream) {
+                         int done_flag, void *stream) {
     if (!shp || !rs || !cs_other || !cs_partial || (flag && (!acc || !e)) || nrows <= 0 || k <= 0 ||
         ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0 || (rate_mode != 0 && rate_mode != 1) || rs_mode < 0 ||
-        rs_mode > 2 || (rate_mode == 1 && !rte) || (e_out && !flag))
+        rs_mode > 2 || (rate_mode == 1 && !rte) || (e_out && !flag) || done_flag < 0 || done_flag > 255 ||
+        (done_flag != 0 && (!flag || rs_mode == 2 || rs_rate || rs_prev_out)))
         return HPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     // grid not clamped: every block writes its cs_partial row
-    if (ld >= 256 && rate_mode == 0 && !rte && !fac && !e_out) {
+    if (ld >= 256 && rate_mode == 0 && !rte && !fac && !e_out && done_flag == 0) {
         // the batch side of a lazy epoch step: the streaming kernel of its own (same statements, same floats)
         switch (ld) {
 #define CALLB(LD)                                                                                                      \
@@ -2476,7 +2653,7 @@ int hpf_hip_svi_side_f32(int64_t nrows, const uint8_t *flag, const float *acc, c
 #define CALL(LD)                                                                                                    \
     hipLaunchKernelGGL((svi_side_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, nrows, flag, acc, e, shp, rte, \
                        fac, rs, cs_other, cs_partial, prior, w_new, w_old, top, add, step, step_prev, rate_mode,    \
-                       rs_mode, k, rs_rate, rs_prev_out, e_out);
+                       rs_mode, k, rs_rate, rs_prev_out, e_out, done_flag);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
     return last_error();

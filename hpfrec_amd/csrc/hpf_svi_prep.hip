@@ -381,7 +381,7 @@ __global__ __launch_bounds__(BLOCK) void svi_oth_layout_kernel(int64_t nrows, co
         if (r < r1) {
             c = row_cnt[r];
             ns = (c + cap - 1) / cap;
-            flag_oth[r] = c > 0;
+            flag_oth[r] = c > 0 ? (ns > 1 ? 2 : 1) : 0;      // (a split row is told apart: hpf_hip_sweep_svi_f32)
             v[0] = c > 0;
             v[1] = ns;
             v[2] = ns > 1;
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(BLOCK) void svi_epoch_oth_layout_kernel(const int64
             start = pb[row_seg_ptr[r]];
             c = pb[row_seg_ptr[r + 1]] - start;
             ns = (c + cap - 1) / cap;
-            flag_oth[r] = c > 0;
+            flag_oth[r] = c > 0 ? (ns > 1 ? 2 : 1) : 0;      // (a split row is told apart: hpf_hip_sweep_svi_f32)
             v[0] = c > 0;
             v[1] = ns;
             v[2] = ns > 1;

@@ -25,7 +25,7 @@ SEG_WHOLE_ROW = 0x40000000   # include/hpf_hip.h: HPF_SEG_WHOLE_ROW
 class SparseSide:
     """Nonzeros grouped by the rows of one side (users -> CSR, items -> CSC)."""
 
-    def __init__(self, nrows, indptr, idx, y, seg_cap=SEG_CAP):
+    def __init__(self, nrows, indptr, idx, y, seg_cap=None):
         self.nrows = int(nrows)
         self.indptr = indptr            # int64 [nrows+1]
         self.idx = idx                  # int32 [nnz] row ids of the *other* side
@@ -39,13 +39,14 @@ class SparseSide:
         self.nmulti = int(self.multi_rows.shape[0])
 
 
-def build_segments(indptr, seg_cap=SEG_CAP):
+def build_segments(indptr, seg_cap=None):
     """Cut rows into segments of at most seg_cap nonzeros.
 
     Returns (segs, row_seg_ptr): segs is an int64 [nseg,2] tensor whose memory image is an array
     of hpf_segment {int64 begin; int32 len|flags; int32 row} (little endian: len | flags | row<<32), and
     row_seg_ptr [nrows+1] lists each row's segment range (empty rows have no segment).
     """
+    seg_cap = SEG_CAP if seg_cap is None else int(seg_cap)     # (the module's value at CALL time)
     dev = indptr.device
     deg = indptr[1:] - indptr[:-1]
     nseg_row = (deg + (seg_cap - 1)) // seg_cap
@@ -82,7 +83,7 @@ def ids_to_device(a, dev):
     return torch.from_numpy(a).to(dev)
 
 
-def build_sides(ix_u, ix_i, y, nU, nI, seg_cap=SEG_CAP):
+def build_sides(ix_u, ix_i, y, nU, nI, seg_cap=None):
     """(user side, item side, ix_u sorted) from COO triplets (int64 ids, float32 counts).
 
     User side: sorted by (user, item).  Item side: a stable re-sort of that order by item, so users

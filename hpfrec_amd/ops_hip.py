@@ -317,16 +317,31 @@ class HipOps:
                                                   ld, cs_partial.shape[0], self._stream()), "hpf_hip_svi_refresh_f32")
 
     def svi_side(self, nrows, flag, acc, e, shp, rte, fac, rs, cs_other, cs_partial, prior, w_new, w_old, top, add, step,
-                 step_prev, rate_mode, rs_mode, k, ld, rs_rate=None, rs_prev_out=None, e_out=None):
+                 step_prev, rate_mode, rs_mode, k, ld, rs_rate=None, rs_prev_out=None, e_out=None, done_flag=0):
         """rte / fac None: not stored (rte: rate_mode 0 only); rs_prev_out: the scalar each row's rate was formed with;
         rs_rate: form the rate from these scalars instead of rs (expanding a factored rate); e_out: the flagged rows' new
-        E rows (what `expect` would compute from the tables afterwards)."""
+        E rows (what `expect` would compute from the tables afterwards); done_flag: rows whose flag equals it were finished
+        by sweep_svi and are skipped."""
         _lib.check(self.L.hpf_hip_svi_side_f32(nrows, _ptr(flag), _ptr(acc), _ptr(e), _ptr(shp), _ptr(rte), _ptr(fac),
                                                _ptr(rs), _ptr(cs_other), _ptr(cs_partial), float(prior), float(w_new),
                                                float(w_old), float(top), float(add), float(step), float(step_prev),
                                                int(rate_mode), int(rs_mode), k, ld, cs_partial.shape[0], _ptr(rs_rate),
-                                               _ptr(rs_prev_out), _ptr(e_out), self._stream()),
+                                               _ptr(rs_prev_out), _ptr(e_out), int(done_flag), self._stream()),
                    "hpf_hip_svi_side_f32")
+
+    def sweep_svi(self, side, tab_self, tab_other, part, e_new, shp, rte, fac, rs, cs_other, cs_partial, prior, w_new,
+                  w_old, top, add, step, step_prev, k, ld):
+        """The sweep over a batch grouped by its OTHER side's rows with that side's step fused in (hpf_hip_sweep_svi_f32):
+        rows present in one segment are finished by the wavefront that swept them; cs_partial: one row per block."""
+        # (8 gathers in flight even for short rows: the epilogue caps the occupancy at 4 waves per SIMD either way, and
+        #  the plain sweep's short-row launch buys its occupancy with half the gathers -- 25.7 -> 25.1 ms per C5 epoch)
+        short = int(os.environ.get("HPF_SVI_FUSED_SHORT", "0"))
+        _lib.check(self.L.hpf_hip_sweep_svi_f32(_ptr(side.segs), side.nseg, _ptr(side.idx), _ptr(side.y), _ptr(tab_self),
+                                                _ptr(tab_other), _ptr(part), _ptr(e_new), _ptr(shp), _ptr(rte), _ptr(fac),
+                                                _ptr(rs), _ptr(cs_other), _ptr(cs_partial), float(prior), float(w_new),
+                                                float(w_old), float(top), float(add), float(step), float(step_prev), k, ld,
+                                                short, cs_partial.shape[0], _ptr(getattr(side, "nseg_dev", None)),
+                                                self._stream()), "hpf_hip_sweep_svi_f32")
 
     def svi_rate_rows(self, row_list, rte, fac, rs, cs_other, top, add, step, step_prev, mode, k, ld):
         _lib.check(self.L.hpf_hip_svi_rate_rows_f32(_ptr(row_list), int(row_list.shape[0]), _ptr(rte), _ptr(fac),

@@ -27,10 +27,11 @@ SVI_TIMINGS = {}      # HPF_TIMING=1: {"epochs": n, "seconds": wall time of the 
 class BatchSide:
     """Segments over the rows touched by a batch (same fields the sweep launcher reads from SparseSide)."""
 
-    def __init__(self, rows, cols, y, seg_cap=layout.SEG_CAP, grouped=False):
+    def __init__(self, rows, cols, y, seg_cap=None, grouped=False):
         """rows/cols: int64 device tensors of a COO batch.  grouped=True: the triplets already come grouped by
         ascending `rows` (a sorted row list's nonzeros gathered out of a CSR) -- no sort needed; otherwise they are
         grouped here with a stable sort."""
+        seg_cap = layout.SEG_CAP if seg_cap is None else int(seg_cap)
         if grouped:
             r_s, c_s, y_s = rows, cols, y
         else:
@@ -86,9 +87,10 @@ class BatchWorkspace:
     side -- so that no batch can overflow it.  The reference slices the same things on the host per batch
     (PXI:280-290, 332-342, 27-42)."""
 
-    def __init__(self, ops, own, oth, acc_own, ld, batch_rows, seg_cap=layout.SEG_CAP):
+    def __init__(self, ops, own, oth, acc_own, ld, batch_rows, seg_cap=None):
         dev = own.idx.device
         i64 = dict(dtype=torch.int64, device=dev)
+        seg_cap = layout.SEG_CAP if seg_cap is None else int(seg_cap)
         self.own, self.oth, self.acc_own, self.ld, self.seg_cap = own, oth, acc_own, int(ld), int(seg_cap)
         B = int(min(batch_rows, own.nrows))
         deg = own.indptr[1:] - own.indptr[:-1]
@@ -145,8 +147,9 @@ class EpochWorkspace:
     MAX_BATCHES = 255                       # (a batch id is a byte)
 
     @staticmethod
-    def plan(own, oth, batch_rows, seg_cap=layout.SEG_CAP):
+    def plan(own, oth, batch_rows, seg_cap=None):
         """(nb, per, bound, bytes of the per-batch slices) of an epoch over `own` in batches of `batch_rows` rows."""
+        seg_cap = layout.SEG_CAP if seg_cap is None else int(seg_cap)
         per = int(min(batch_rows, own.nrows))
         nb = -(-own.nrows // per)
         deg = own.indptr[1:] - own.indptr[:-1]
@@ -157,7 +160,7 @@ class EpochWorkspace:
         return nb, per, bound, nbytes
 
     @classmethod
-    def fits(cls, own, oth, batch_rows, seg_cap=layout.SEG_CAP):
+    def fits(cls, own, oth, batch_rows, seg_cap=None):
         """An epoch-level preparation is used when a batch id fits a byte and the per-batch slices stay a modest share of
         the device (HPF_SVI_EPOCH_BYTES, default 16 GiB); otherwise the batches are prepared one by one (BatchWorkspace)."""
         if os.environ.get("HPF_SVI_EPOCH_PREP", "1") != "1" or batch_rows <= 0:
@@ -165,10 +168,11 @@ class EpochWorkspace:
         nb, _, _, nbytes = cls.plan(own, oth, batch_rows, seg_cap)
         return nb <= cls.MAX_BATCHES and nbytes <= int(os.environ.get("HPF_SVI_EPOCH_BYTES", str(16 << 30)))
 
-    def __init__(self, ops, own, oth, acc_own, ld, batch_rows, seg_cap=layout.SEG_CAP):
+    def __init__(self, ops, own, oth, acc_own, ld, batch_rows, seg_cap=None):
         dev = own.idx.device
         i64 = dict(dtype=torch.int64, device=dev)
         u8 = dict(dtype=torch.uint8, device=dev)
+        seg_cap = layout.SEG_CAP if seg_cap is None else int(seg_cap)
         self.own, self.oth, self.acc_own, self.ld, self.seg_cap = own, oth, acc_own, int(ld), int(seg_cap)
         self.nb, self.per, bound, _ = self.plan(own, oth, batch_rows, seg_cap)
         assert 1 <= self.nb <= self.MAX_BATCHES
@@ -242,6 +246,7 @@ class DeviceModel:
         self.flag_u = torch.zeros(self.nU, dtype=torch.uint8, device=dev)   # rows of the current step, per side
         self.flag_i = torch.zeros(self.nI, dtype=torch.uint8, device=dev)     # (partial_fit; epochs use the workspace's)
         self._part = None                    # scratch for the split rows' partial sums of a device-built batch
+        self._cs_fused = None
         # Lazy epochs (fit_hpf_svi): the rate of a BATCH side is rank-1 -- Gamma_rte = k_shp/k_rte + colsum(Beta) for every
         # row, recomputed every batch (PXI:300 / 352) -- and the means are read only through their column sums until a
         # check or the end of the fit.  A side in "factored" form keeps rs_prev (the scalar each row's rate was formed
@@ -358,19 +363,20 @@ class DeviceModel:
             self._part = torch.empty((rows, self.ld), dtype=torch.float32, device=self.ops.device)
         return self._part
 
-    def batch_phi_sums(self, su, si, flag_u, flag_i, e_current=()):
+    def batch_phi_sums(self, su, si, flag_u, flag_i, e_current=(), sides=("u", "i")):
         """Per touched row, sum_n w_n * (other side's E row) over the batch's nonzeros (update_phi[_csr] +
         update_G_n_L_sh[_csr] restricted to the batch; sum phi = E_row (*) this), from the CURRENT shapes/rates,
         left in acc_u[user] / acc_i[item] for the rows present in the batch.  su / si: the batch grouped by user / by
         item -- BatchSides (partial_fit: sizes known on the host) or DevSides (epochs: sizes on the device); flag_u /
-        flag_i: one byte per row, the rows of the step."""
+        flag_i: one byte per row, the rows of the step.  sides: which groupings are swept here (the E rows of both are
+        brought up to date either way: each sweep gathers the other side's)."""
         ops, k, ld = self.ops, self.k, self.ld
         if "u" not in e_current:         # (e_current: sides whose E table is up to date for every row already)
             ops.expect(self.Gamma_shp, self.Gamma_rte, self.eT, self.nU, k, ld, flag=flag_u, factored=self.factored["u"])
         if "i" not in e_current:
             ops.expect(self.Lambda_shp, self.Lambda_rte, self.eB, self.nI, k, ld, flag=flag_i, factored=self.factored["i"])
-        for side, e_self, e_other, acc in ((su, self.eT, self.eB, self.acc_u), (si, self.eB, self.eT, self.acc_i)):
-            if side.nseg == 0:
+        for w, side, e_self, e_other, acc in (("u", su, self.eT, self.eB, self.acc_u), ("i", si, self.eB, self.eT, self.acc_i)):
+            if side.nseg == 0 or w not in sides:
                 continue
             # a row that is one segment long writes its sums straight to acc[row]; split rows go through part[]
             if isinstance(side, DevSide):
@@ -384,6 +390,12 @@ class DeviceModel:
                 tmp = torch.zeros((side.nmulti, ld), dtype=torch.float32, device=ops.device)
                 ops.segsum(part, side.row_seg_ptr, side.nmulti, tmp, ld, row_list=side.multi_local)
                 acc.index_copy_(0, side.rows[side.multi_local], tmp)
+
+    def fused_cs_part(self, blocks, tail):
+        """[blocks + tail, ld] partial column sums: the fused sweep's blocks, then the whole-table pass's."""
+        if self._cs_fused is None or self._cs_fused.shape[0] != blocks + tail:
+            self._cs_fused = torch.zeros((blocks + tail, self.ld), dtype=torch.float32, device=self.ops.device)
+        return self._cs_fused
 
 
 def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_rows, lazy=False):
@@ -415,12 +427,20 @@ def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_
     m.e_valid[bw] = False                                          # (its rates change for every row below)
     if not lazy:
         m.e_valid[ow] = False
-    m.batch_phi_sums(su, si, flag_u, flag_i, e_current)            # phi from the OLD parameters
     U = dict(n=m.nU, flag=flag_u, shp=m.Gamma_shp, rte=m.Gamma_rte, fac=m.Theta, rs=m.k_rte, e=m.eT, acc=m.acc_u,
              prior=hy["a"], top=hy["k_shp"], add=hy["add_k_rte"], cs="csT")
     I = dict(n=m.nI, flag=flag_i, shp=m.Lambda_shp, rte=m.Lambda_rte, fac=m.Beta, rs=m.t_rte, e=m.eB, acc=m.acc_i,
              prior=hy["c"], top=hy["t_shp"], add=hy["add_t_rte"], cs="csB")
     B, O = (U, I) if user_batch else (I, U)     # batch side, other side
+    s_oth = si if user_batch else su             # the batch grouped by the other side's rows
+    # The other side's pass FUSED into its sweep (hpf_hip_sweep_svi_f32): the rows a batch touches there are short, the
+    # wavefront that forms a row's phi-sum finishes the row.  Epochs only (device-built batches: their flags tell split
+    # rows apart, and only the step's rows blend their scalar rates); needs the batch side's NEW column sums, so that
+    # sweep runs after the batch side's pass -- phi still comes from the OLD parameters: the batch side's pass writes
+    # neither E table, and the other side's rows are rewritten by the very wavefront that has just used them.
+    fused = (isinstance(s_oth, DevSide) and not all_scalar_rows and s_oth.nseg > 0
+             and os.environ.get("HPF_SVI_FUSED", "1") == "1")
+    m.batch_phi_sums(su, si, flag_u, flag_i, e_current, sides=(bw,) if fused else ("u", "i"))   # phi from the OLD parameters
     # SVI epochs blend the scalar rates of the step's rows only (PXI:324-325, 376-377), partial_fit of all (PXI:472-473)
     rs_mode = 2 if all_scalar_rows else 1
     # One pass per side (hpf_hip_svi_side_f32).  Batch side: shapes of its rows reset to prior + phi, the rate of
@@ -440,11 +460,25 @@ def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_
     setattr(m, B["cs"], cs_batch)
     # ... other side: shapes and rates of the touched rows blended towards the step's estimate (the rates with the
     # batch side's NEW column sums), means of every row, scalar rates, column sums
-    ops.svi_side(O["n"], O["flag"], O["acc"], O["e"], O["shp"], O["rte"], None if lazy else O["fac"], O["rs"], cs_batch,
-                 m._cs_part, O["prior"], w_other, step_prev, O["top"], O["add"], step, step_prev, 1, rs_mode, k, ld,
-                 e_out=O["e"] if e_current else None)
+    e_out = O["e"] if e_current else None
+    if fused:
+        blocks, tail = ops.sweep_blocks, m._cs_part.shape[0]
+        cs_part = m.fused_cs_part(blocks, tail)
+        part = m._part_scratch(s_oth.nseg)
+        ops.sweep_svi(s_oth, O["e"], B["e"], part, e_out, O["shp"], O["rte"], None if lazy else O["fac"], O["rs"], cs_batch,
+                      cs_part[:blocks], O["prior"], w_other, step_prev, O["top"], O["add"], step, step_prev, k, ld)
+        ops.segsum_desc(part, s_oth.multi, s_oth.nmulti_dev, s_oth.multi_cap, O["acc"], ld)
+        # split rows and the rows the batch does not touch (their means still count in the column sums)
+        ops.svi_side(O["n"], O["flag"], O["acc"], O["e"], O["shp"], O["rte"], None if lazy else O["fac"], O["rs"], cs_batch,
+                     cs_part[blocks:], O["prior"], w_other, step_prev, O["top"], O["add"], step, step_prev, 1, rs_mode, k, ld,
+                     e_out=e_out, done_flag=1)
+    else:
+        cs_part = m._cs_part
+        ops.svi_side(O["n"], O["flag"], O["acc"], O["e"], O["shp"], O["rte"], None if lazy else O["fac"], O["rs"], cs_batch,
+                     cs_part, O["prior"], w_other, step_prev, O["top"], O["add"], step, step_prev, 1, rs_mode, k, ld,
+                     e_out=e_out)
     cs_o = torch.zeros(ld, dtype=torch.float32, device=ops.device)
-    ops.colsum_reduce(m._cs_part, cs_o, ld)
+    ops.colsum_reduce(cs_part, cs_o, ld)
     setattr(m, O["cs"], cs_o)
 
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 21
+#define HPF_HIP_ABI_VERSION 22
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -255,7 +255,25 @@ int hpf_hip_svi_side_f32(int64_t nrows, const uint8_t *flag, const float *acc, c
                          float *fac, float *rs, const float *cs_other, float *cs_partial, float prior, float w_new,
                          float w_old, float top, float add, float step, float step_prev, int rate_mode, int rs_mode,
                          int k, int ld, int grid_blocks, const float *rs_rate, float *rs_prev_out, float *e_out,
-                         void *stream);
+                         int done_flag, void *stream);
+/*
+ * done_flag (0: none): rows whose flag EQUALS done_flag were finished elsewhere and are skipped entirely -- no load, no
+ * store, no share of the column sums.  That elsewhere is the next entry: the OTHER side's pass of a stochastic step fused
+ * into the sweep that forms its phi-sums.  hpf_hip_sweep_svi_f32 = hpf_hip_sweep_f32 over the batch grouped by the other
+ * side's rows + for every HPF_SEG_WHOLE_ROW segment the flagged-row statements of hpf_hip_svi_side_f32 with rate_mode 1,
+ * rs_mode 1, applied by the wavefront that swept the row while it still holds the row's phi-sum and E row: shp and rte
+ * are read and rewritten, fac (optional) written, rs blended, e_new (optional; must be tab_self) = the row's new E row,
+ * cs_partial[grid_blocks][ld] = per-block column sums of fac over the rows finished here (all blocks write theirs).
+ * Split rows write part[] as in hpf_hip_sweep_f32 and are finished, with the rows the batch does not touch, by a
+ * hpf_hip_svi_side_f32 call with done_flag = the flag value of whole rows (the preparations above write 1 for a row
+ * present in one segment, 2 for a split row); the two calls' partial column sums add up to the side's (PXI:370-374).
+ * Same float32 statements through the same device functions: a row finished here and one finished there agree bit for bit.
+ */
+int hpf_hip_sweep_svi_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y, const float *tab_self,
+                          const float *tab_other, float *part, float *e_new, float *shp, float *rte, float *fac, float *rs,
+                          const float *cs_other, float *cs_partial, float prior, float w_new, float w_old, float top,
+                          float add, float step, float step_prev, int k, int ld, int short_rows, int grid_blocks,
+                          const int64_t *nseg_dev, void *stream);
 int hpf_hip_svi_rate_rows_f32(const int64_t *row_list, int64_t nrows, float *rte, const float *fac, float *rs,
                               const float *cs_other, float top, float add, float step, float step_prev, int mode,
                               int k, int ld, void *stream);
@@ -285,7 +303,8 @@ int hpf_hip_fold_in_f32(const int32_t *idx, const float *y, int64_t n, const flo
  *               prev_ids, is unmarked first); acc_own[row] is zeroed for batch rows without nonzeros;
  *   other side: the batch's nonzeros grouped by the other side's rows, in the order the other side's global layout holds
  *               them (ascending own-side ids: stable, no sort): o_idx = own-side row id, o_y = count, o_segs / o_multi as
- *               above with `begin` indexing o_idx / o_y; flag_oth[row] = 1 for rows present, 0 for all others.
+ *               above with `begin` indexing o_idx / o_y; flag_oth[row] = 1 for rows present in one segment, 2 for split
+ *               rows, 0 for all others.
  * sizes[0..8) (device int64): segments own, split rows own, segments other, split rows other, nonzeros, rows other, -,
  * overflow (a capacity was too small; never with capacities from the side's largest rows; STICKY: entries 0..6 are reset
  * by every call, the overflow flag only by the caller, so one read after many batches sees any of them).  Nothing is read back: the

@@ -340,7 +340,9 @@ class CpuOps:
         osegs = np.stack([begin, length | (rows[local] << 32)], axis=1).astype(np.int64)
         multi = np.nonzero(ns > 1)[0]
         om = np.stack([sg0[multi], ns[multi], rows[multi]], axis=1).astype(np.int64)
-        return kept, bm, o_idx, o_y, cnt > 0, osegs, om, rows.shape[0]
+        present = np.zeros(oth.nrows, np.uint8)            # 1: present in one segment, 2: a split row
+        present[rows] = np.where(ns > 1, 2, 1)
+        return kept, bm, o_idx, o_y, present, osegs, om, rows.shape[0]
 
     def svi_batch_prepare(self, ws):
         """hpf_hip_svi_batch_prepare in numpy: same outputs in the same layout (tests compare them with the kernels')."""
@@ -471,11 +473,59 @@ class CpuOps:
         cp[:] = 0
         cp[0] = F.astype(np.float64).sum(axis=0).astype(np.float32)
 
+    sweep_blocks = 1          # (rows of partial column sums the fused sweep writes)
+
+    def sweep_svi(self, side, tab_self, tab_other, part, e_new, shp, rte, fac, rs, cs_other, cs_partial, prior, w_new,
+                  w_old, top, add, step, step_prev, k, ld):
+        """hpf_hip_sweep_svi_f32: the plain sweep, then the flagged-row statements of svi_side (rate_mode 1, rs_mode 1)
+        for the rows present in ONE segment, on a compacted copy of their rows (so that only they enter the column sums)."""
+        nseg = _live_nseg(side)
+        _np(cs_partial)[:] = 0
+        if nseg == 0:
+            return
+        acc = torch.zeros_like(shp)
+        self.sweep(side, tab_self, tab_other, part, k, ld, acc_rows=acc, acc_ld=ld)
+        begin, length, row = _decode_segs(side)
+        whole = (_np(side.segs)[:nseg, 1] & 0x40000000) != 0
+        rows = torch.from_numpy(np.sort(row[whole]).astype(np.int64))
+        if rows.shape[0] == 0:
+            return
+        sub = {n: t[rows].clone() for n, t in (("acc", acc), ("e", tab_self), ("shp", shp), ("rte", rte), ("rs", rs))}
+        fac_s = torch.zeros_like(sub["shp"])
+        ones = torch.ones(rows.shape[0], dtype=torch.uint8)
+        e_s = sub["e"].clone() if e_new is not None else None
+        self.svi_side(rows.shape[0], ones, sub["acc"], sub["e"], sub["shp"], sub["rte"], fac_s, sub["rs"], cs_other,
+                      cs_partial, prior, w_new, w_old, top, add, step, step_prev, 1, 1, k, ld, e_out=e_s)
+        shp[rows], rte[rows], rs[rows] = sub["shp"], sub["rte"], sub["rs"]
+        if fac is not None:
+            fac[rows] = fac_s
+        if e_new is not None:
+            e_new[rows] = e_s
+
     def svi_side(self, nrows, flag, acc, e, shp, rte, fac, rs, cs_other, cs_partial, prior, w_new, w_old, top, add, step,
-                 step_prev, rate_mode, rs_mode, k, ld, rs_rate=None, rs_prev_out=None, e_out=None):
+                 step_prev, rate_mode, rs_mode, k, ld, rs_rate=None, rs_prev_out=None, e_out=None, done_flag=0):
         """hpf_hip_svi_side_f32 = the separate stand-in statements in the reference's order.  rte / fac None: computed
         into scratch tables and dropped; rs_rate / rs_prev_out: the factored-rate plumbing of the lazy epochs; e_out: the
-        flagged rows' new E rows (= expect over them afterwards)."""
+        flagged rows' new E rows (= expect over them afterwards); done_flag: rows whose flag equals it are left out
+        altogether (the pass runs on a compacted copy of the others)."""
+        if done_flag:
+            assert flag is not None and rs_mode != 2 and rs_rate is None and rs_prev_out is None and rate_mode == 1
+            rows = torch.nonzero(flag[:nrows] != done_flag).reshape(-1)
+            _np(cs_partial)[:] = 0
+            if rows.shape[0] == 0:
+                return
+            sub = {n: t[rows].clone() for n, t in (("acc", acc), ("e", e), ("shp", shp), ("rte", rte), ("rs", rs))}
+            fac_s = torch.zeros_like(sub["shp"])
+            e_s = sub["e"].clone() if e_out is not None else None
+            self.svi_side(rows.shape[0], (flag[rows] != 0).to(torch.uint8), sub["acc"], sub["e"], sub["shp"], sub["rte"],
+                          fac_s, sub["rs"], cs_other, cs_partial, prior, w_new, w_old, top, add, step, step_prev, rate_mode,
+                          rs_mode, k, ld, e_out=e_s)
+            shp[rows], rte[rows], rs[rows] = sub["shp"], sub["rte"], sub["rs"]
+            if fac is not None:
+                fac[rows] = fac_s
+            if e_out is not None:
+                e_out[rows] = e_s
+            return
         rows = torch.nonzero(flag[:nrows] != 0).reshape(-1) if flag is not None else torch.empty(0, dtype=torch.int64)
         self.svi_shape_rows(rows, acc, e, shp, prior, w_new, w_old, k, ld, acc_by_row=True)
         rte_t = rte if rte is not None else torch.zeros_like(shp)

@@ -205,7 +205,7 @@ def test_partial_fit_growing_model_on_gpu(hip_backend):
 def test_batch_workspace_equals_the_tensor_library_structures(any_backend, case):
     """svi.BatchWorkspace (hpf_hip_svi_batch_prepare: everything on the device, one call, nothing read back) builds
     the structures BatchSide(gather_rows(...)) builds with tensor-library sorts: same rows, same nonzeros in the same
-    order, same segment descriptors and split-row lists, same flags, for both sides of user and item batches -- incl.
+    order, same segment descriptors and split-row lists, same flags (1: a row present in one segment, 2: a split row), for both sides of user and item batches -- incl.
     rows longer than a segment, listed rows without nonzeros (their accumulator rows zeroed), a batch without any
     nonzero, and a workspace re-used for a second batch (the first one's marks removed)."""
     import torch
@@ -246,7 +246,8 @@ def test_batch_workspace_equals_the_tensor_library_structures(any_backend, case)
             f[ids] = 1
             assert np.array_equal(ws.flag_own.cpu().numpy(), f)
             fo = np.zeros(other.nrows, np.uint8)
-            fo[want_oth.rows.cpu().numpy()] = 1
+            wrsp = want_oth.row_seg_ptr.cpu().numpy()
+            fo[want_oth.rows.cpu().numpy()] = np.where(wrsp[1:] - wrsp[:-1] > 1, 2, 1)      # (2: a split row)
             assert np.array_equal(ws.flag_oth.cpu().numpy(), fo)
             # accumulator rows of batch rows without nonzeros are zeroed, nothing else is touched
             a = acc.cpu().numpy()
@@ -401,3 +402,30 @@ def test_epochs_prepared_as_a_whole_equal_the_batch_by_batch_form_bit_for_bit(an
         out[mode]["llk"] = np.float64(m.train_llk)
     for n in out["1"]:
         assert np.array_equal(out["1"][n], out["0"][n]), n
+
+
+@pytest.mark.parametrize("kw", [dict(users_per_batch=20, items_per_batch=25), dict(users_per_batch=30),
+                                dict(items_per_batch=40)])
+@pytest.mark.parametrize("lazy", ["1", "0"])
+def test_other_side_fused_into_its_sweep_equals_the_separate_pass(any_backend, monkeypatch, kw, lazy):
+    """The other side's statements of an epoch step run in the epilogue of its sweep (hpf_hip_sweep_svi_f32: rows present in
+    one segment) + a whole-table pass that skips those rows (split rows, untouched rows); HPF_SVI_FUSED=0 runs the plain
+    sweep and the whole-table pass over everything.  Same statements row by row; only the order in which the rows' means
+    enter the column sums differs, so the fits agree to float32 summation noise -- lazy and stored forms, all epoch kinds."""
+    df, nU, nI = datagen.readme_counts()
+    monkeypatch.setenv("HPF_SVI_LAZY", lazy)
+    from hpfrec_amd import layout
+    monkeypatch.setattr(layout, "SEG_CAP", 8)       # (rows cut into several segments on both sides)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HPF_SVI_FUSED", mode)
+        m = HPF(k=12, maxiter=5, random_seed=7, ncores=1, reindex=False, verbose=True, check_every=2,
+                stop_crit="maxiter", **kw)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m.fit(df.copy())
+        out[mode] = {n: np.array(getattr(m, n)) for n in NAMES}
+        out[mode]["llk"] = np.float64(m.train_llk)
+    for n in out["1"]:
+        assert np.isfinite(out["1"][n]).all()
+        assert _maxrel(out["1"][n], out["0"][n]) < 2e-5, (n, _maxrel(out["1"][n], out["0"][n]))
