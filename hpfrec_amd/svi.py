@@ -247,7 +247,6 @@ class DeviceModel:
         self.flag_i = torch.zeros(self.nI, dtype=torch.uint8, device=dev)     # (partial_fit; epochs use the workspace's)
         self._part = None                    # scratch for the split rows' partial sums of a device-built batch
         self._cs_fused = None
-        self.e_ahead = None                  # (side, event): E rows of the next batch's rows being formed on a side stream
         # Lazy epochs (fit_hpf_svi): the rate of a BATCH side is rank-1 -- Gamma_rte = k_shp/k_rte + colsum(Beta) for every
         # row, recomputed every batch (PXI:300 / 352) -- and the means are read only through their column sums until a
         # check or the end of the fit.  A side in "factored" form keeps rs_prev (the scalar each row's rate was formed
@@ -399,15 +398,13 @@ class DeviceModel:
         return self._cs_fused
 
 
-def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_rows, lazy=False, next_flag=None):
+def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_rows, lazy=False):
     """One stochastic update in the reference's statement order (user batch: PXI:292-325 / 438-473;
     item batch: PXI:344-377).  su / si: the batch grouped by user / by item; flag_u / flag_i (uint8 per row): the rows
     the updates run over -- supersets of the rows present in the batch; a listed row without a nonzero must hold a zero
     phi-sum in acc_u / acc_i (the callers see to that).  `hy` carries a, c, k_shp, t_shp, add_k_rte, add_t_rte as
     python floats.  lazy (the epochs of fit_hpf_svi): the batch side's rate stays factored and no mean table is
-    stored -- DeviceModel.materialize() brings the tables up to date when somebody reads them.  next_flag (lazy epochs):
-    the row flags of the NEXT batch of the same epoch -- its rows' E rows are formed on a side stream while this step's
-    other side is swept (see below)."""
+    stored -- DeviceModel.materialize() brings the tables up to date when somebody reads them."""
     ops, k, ld = m.ops, m.k, m.ld
     step_prev = float(np.float32(1) - np.float32(step))
     step = float(np.float32(step))
@@ -430,11 +427,6 @@ def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_
     m.e_valid[bw] = False                                          # (its rates change for every row below)
     if not lazy:
         m.e_valid[ow] = False
-    ahead, m.e_ahead = m.e_ahead, None
-    if ahead is not None:             # the batch's own E rows were formed beside the previous step's other-side sweep
-        assert ahead[0] == bw and lazy
-        torch.cuda.current_stream(ops.device).wait_event(ahead[1])
-        e_current = e_current + (bw,)
     U = dict(n=m.nU, flag=flag_u, shp=m.Gamma_shp, rte=m.Gamma_rte, fac=m.Theta, rs=m.k_rte, e=m.eT, acc=m.acc_u,
              prior=hy["a"], top=hy["k_shp"], add=hy["add_k_rte"], cs="csT")
     I = dict(n=m.nI, flag=flag_i, shp=m.Lambda_shp, rte=m.Lambda_rte, fac=m.Beta, rs=m.t_rte, e=m.eB, acc=m.acc_i,
@@ -463,23 +455,9 @@ def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_
     else:
         ops.svi_side(B["n"], B["flag"], B["acc"], B["e"], B["shp"], B["rte"], B["fac"], B["rs"], cs_for_batch,
                      m._cs_part, B["prior"], 1.0, 0.0, B["top"], B["add"], step, step_prev, 0, rs_mode, k, ld)
-    cs_batch = torch.zeros(ld, dtype=torch.float32, device=ops.device)
+    cs_batch = torch.empty(ld, dtype=torch.float32, device=ops.device)      # (the reduction writes every column)
     ops.colsum_reduce(m._cs_part, cs_batch, ld)
     setattr(m, B["cs"], cs_batch)
-    if (next_flag is not None and lazy and ops.device.type == "cuda" and os.environ.get("HPF_SVI_E_AHEAD", "1") == "1"):
-        # The NEXT batch's rows need their E rows from the rates just formed (this side's shapes, row scalars and the
-        # column sums they were formed with do not change before that step; the rows are not this batch's, whose E rows
-        # the sweep below still gathers): 90 us of float64 work per C5 batch that has nothing to do with the other
-        # side's sweep -- it runs beside it, on a stream of its own.
-        side_stream = _streams.side_stream(ops.device, "svi-expect")
-        here = torch.cuda.Event()
-        here.record(torch.cuda.current_stream(ops.device))
-        with torch.cuda.stream(side_stream):
-            side_stream.wait_event(here)
-            ops.expect(B["shp"], B["rte"], B["e"], B["n"], k, ld, flag=next_flag, factored=m.factored[bw])
-            done = torch.cuda.Event()
-            done.record(side_stream)
-        m.e_ahead = (bw, done)
     # ... other side: shapes and rates of the touched rows blended towards the step's estimate (the rates with the
     # batch side's NEW column sums), means of every row, scalar rates, column sums
     e_out = O["e"] if e_current else None
@@ -499,7 +477,7 @@ def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_
         ops.svi_side(O["n"], O["flag"], O["acc"], O["e"], O["shp"], O["rte"], None if lazy else O["fac"], O["rs"], cs_batch,
                      cs_part, O["prior"], w_other, step_prev, O["top"], O["add"], step, step_prev, 1, rs_mode, k, ld,
                      e_out=e_out)
-    cs_o = torch.zeros(ld, dtype=torch.float32, device=ops.device)
+    cs_o = torch.empty(ld, dtype=torch.float32, device=ops.device)
     ops.colsum_reduce(cs_part, cs_o, ld)
     setattr(m, O["cs"], cs_o)
 
@@ -729,7 +707,7 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
                 flag_u, flag_i = (f_own, f_oth) if user_epoch else (f_oth, f_own)
                 rows_j = min(n_side, (j + 1) * per) - j * per
                 _svi_step(m, hyd, su, si, flag_u, flag_i, step, float(n_side) / float(rows_j), user_epoch,
-                          all_scalar_rows=False, lazy=lazy, next_flag=ews.batch(j + 1)[2] if j + 1 < nb else None)
+                          all_scalar_rows=False, lazy=lazy)
             if prep_stream is not None:
                 ews.free = torch.cuda.Event()
                 ews.free.record(torch.cuda.current_stream(dev))

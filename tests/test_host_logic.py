@@ -58,6 +58,24 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     assert L.hpf_hip_colsum_reduce_f32(None, 4, None, 64, None) == EINVAL
     assert L.hpf_hip_pair_dot_f32(p, p, p, p, -1, p, 50, 64, None) == EINVAL
     assert L.hpf_hip_ld_for_k(2000) == EUNSUPPORTED
+    # round 5 entries: the epoch-level batch preparation, the sweep with the other side's stochastic step fused in, the
+    # whole-table pass's done_flag
+    L.hpf_hip_svi_epoch_prepare.argtypes = [vp, vp]
+    L.hpf_hip_sweep_svi_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp] + [cf] * 7 + [ci] * 4 + [vp, vp]
+    L.hpf_hip_svi_side_f32.argtypes = [i64] + [vp] * 9 + [cf] * 7 + [ci] * 5 + [vp, vp, vp, ci, vp]
+    assert L.hpf_hip_svi_epoch_prepare(None, None) == EINVAL
+    desc = ctypes.create_string_buffer(512)
+    assert L.hpf_hip_svi_epoch_prepare(ctypes.cast(desc, vp), None) == EINVAL                    # all-null descriptor
+    w = (0.3, 1.0, 0.0, 15.3, 0.3, 0.5, 0.5)
+    assert L.hpf_hip_sweep_svi_f32(None, 5, p, p, p, p, p, None, p, p, None, p, p, p, *w, 50, 64, 0, 8, None, None) == EINVAL
+    assert L.hpf_hip_sweep_svi_f32(p, 5, p, p, p, p, p, None, p, p, None, p, p, p, *w, 50, 128, 0, 8, None, None) == EINVAL   # ld
+    q = ctypes.cast(ctypes.create_string_buffer(64), vp)
+    assert L.hpf_hip_sweep_svi_f32(p, 5, p, p, p, p, p, q, p, p, None, p, p, p, *w, 50, 64, 0, 8, None, None) == EINVAL   # e_new must be tab_self
+    side = lambda flag, rs_mode, done: L.hpf_hip_svi_side_f32(4, flag, p, p, p, p, None, p, p, p, *w, 1, rs_mode, 50, 64, 2, None,  # noqa: E731
+                                                              None, None, done, None)
+    assert side(None, 1, 1) == EINVAL            # done_flag without flags
+    assert side(p, 2, 1) == EINVAL               # done_flag with every row's scalar rate blended
+    assert side(p, 1, 300) == EINVAL
 
 
 def test_integration_doc_stub_matches_the_abi():
