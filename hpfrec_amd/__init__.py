@@ -682,10 +682,12 @@ class HPF:
         Y_batch = np.require(counts_df["Count"], dtype=be.c_real_t, requirements=req)
         ix_u_batch = np.require(counts_df["UserId"], dtype=be.obj_ind_type, requirements=req)
         ix_i_batch = np.require(counts_df["ItemId"], dtype=be.obj_ind_type, requirements=req)
-        users_in_batch = (np.unique(ix_u_batch) if users_in_batch is None
-                          else np.require(users_in_batch, dtype=be.obj_ind_type, requirements=req))
-        items_in_batch = (np.unique(ix_i_batch) if items_in_batch is None
-                          else np.require(items_in_batch, dtype=be.obj_ind_type, requirements=req))
+        # (INIT:864-871 takes np.unique of the batch's ids when the lists are not given: here they fall out of the
+        #  grouping the step builds on the device anyway -- svi.partial_fit_device)
+        if users_in_batch is not None:
+            users_in_batch = np.require(users_in_batch, dtype=be.obj_ind_type, requirements=req)
+        if items_in_batch is not None:
+            items_in_batch = np.require(items_in_batch, dtype=be.obj_ind_type, requirements=req)
 
         if self._state.host.get("Theta") is None or self._state.host.get("Beta") is None:
             self._cast_before_fit()
@@ -714,16 +716,16 @@ class HPF:
         t_shp = be.cast_real_t(self.c_prime + self.k * self.c)
         add_k_rte = be.cast_real_t(self.a_prime / self.b_prime)
         add_t_rte = be.cast_real_t(self.c_prime / self.d_prime)
-        # sic (INIT:912): the multiplier uses the user counts for item batches too
-        multiplier_batch = float(nusers) / users_in_batch.shape[0]
+        # sic (INIT:912): the multiplier uses the user counts for item batches too (None: the device counts the users)
+        multiplier_batch = None if users_in_batch is None else be.cast_real_t(float(nusers) / users_in_batch.shape[0])
 
         # the same step as the extension's partial_fit (be.partial_fit, PXI:423-473), on the state that stays on the
         # device between calls: only the batch crosses PCIe; host copies are refreshed when somebody reads them
         from . import svi
         m = self._state.ensure_model(be._make_ops())
         svi.partial_fit_device(m, Y_batch, ix_u_batch, ix_i_batch, add_k_rte, add_t_rte, self.a, self.c, k_shp, t_shp,
-                               users_in_batch, items_in_batch, be.cast_real_t(step_size),
-                               be.cast_real_t(multiplier_batch), user_batch)
+                               users_in_batch, items_in_batch, be.cast_real_t(step_size), multiplier_batch, user_batch,
+                               nusers_total=nusers)
         self._state.touched()
         self.niter += 1
         self.is_fitted = True

@@ -488,22 +488,32 @@ def _dev_ids(a, dev):
 
 # -- PXI:423-473 ------------------------------------------------------------------------------------
 def partial_fit_device(m, Y_batch, ix_u_batch, ix_i_batch, add_k_rte, add_t_rte, a, c, k_shp, t_shp,
-                       users_this_batch, items_this_batch, step_size_batch, multiplier_batch, user_batch):
+                       users_this_batch, items_this_batch, step_size_batch, multiplier_batch, user_batch,
+                       nusers_total=None):
     """One partial_fit step on a DeviceModel that already holds the current state: only the batch's triplets and
-    row lists cross PCIe.  Mutates all eight state tables of `m` (as the reference mutates its arrays, PXI:443-473)."""
+    row lists cross PCIe.  Mutates all eight state tables of `m` (as the reference mutates its arrays, PXI:443-473).
+    users_this_batch / items_this_batch None: the users / items that occur in the batch (what the class computes with
+    np.unique, INIT:864-871) -- they fall out of the grouping the step needs anyway, on the device (np.unique over the
+    3-8M ids of a C5 batch was 60 % of a call); multiplier_batch None: nusers_total / (number of those users), INIT:912."""
     ops = m.ops
-    if ix_u_batch.size and (int(ix_u_batch.max()) >= m.nU or int(ix_i_batch.max()) >= m.nI):
-        raise ValueError("partial_fit: user/item id out of range")
     dev = ops.device
     hy = {"a": float(np.float32(a)), "c": float(np.float32(c)), "k_shp": float(np.float32(k_shp)),
           "t_shp": float(np.float32(t_shp)), "add_k_rte": float(np.float32(add_k_rte)),
           "add_t_rte": float(np.float32(add_t_rte))}
     bu, bi = _dev_ids(ix_u_batch, dev), _dev_ids(ix_i_batch, dev)
+    if bu.numel() > 0:      # (ids >= 2^63 of the reference's size_t arrive negative)
+        lim = torch.stack([bu.max(), bi.max(), -bu.min(), -bi.min()]).cpu().numpy()
+        if lim[0] >= m.nU or lim[1] >= m.nI or lim[2] > 0 or lim[3] > 0:
+            raise ValueError("partial_fit: user/item id out of range")
     by = torch.from_numpy(np.ascontiguousarray(Y_batch, dtype=np.float32)).to(dev)
     su, si = BatchSide(bu, bi, by), BatchSide(bi, bu, by)
-    users_tb, items_tb = _dev_ids(users_this_batch, dev), _dev_ids(items_this_batch, dev)
-    if not (bool(torch.isin(su.rows, users_tb).all()) and bool(torch.isin(si.rows, items_tb).all())):
+    users_tb = su.rows if users_this_batch is None else _dev_ids(users_this_batch, dev)
+    items_tb = si.rows if items_this_batch is None else _dev_ids(items_this_batch, dev)
+    if not ((users_this_batch is None or bool(torch.isin(su.rows, users_tb).all()))
+            and (items_this_batch is None or bool(torch.isin(si.rows, items_tb).all()))):
         raise ValueError("the batch contains users/items that are not in users_in_batch/items_in_batch")
+    if multiplier_batch is None:
+        multiplier_batch = np.float32(float(nusers_total) / float(users_tb.shape[0]))
     for tb, side, acc, flag in ((users_tb, su, m.acc_u, m.flag_u), (items_tb, si, m.acc_i, m.flag_i)):
         if tb.shape[0] != side.nrows:        # listed rows without any nonzero in the batch: a zero phi-sum
             acc.index_fill_(0, tb, 0.0)
