@@ -429,3 +429,38 @@ def test_other_side_fused_into_its_sweep_equals_the_separate_pass(any_backend, m
     for n in out["1"]:
         assert np.isfinite(out["1"][n]).all()
         assert _maxrel(out["1"][n], out["0"][n]) < 2e-5, (n, _maxrel(out["1"][n], out["0"][n]))
+
+
+def test_epoch_level_preparation_is_chosen_only_where_it_fits(cpu_ops_backend, monkeypatch):
+    """svi.EpochWorkspace.fits: a batch id is a byte (more than 255 batches per epoch -> one batch at a time), the slices
+    must stay under HPF_SVI_EPOCH_BYTES, HPF_SVI_EPOCH_PREP=0 switches the epoch form off; and a fit whose user epochs
+    have 300 one-row batches (per-batch form) beside item epochs of 3 batches (epoch form) runs both forms side by side."""
+    import torch
+    from hpfrec_amd import layout, svi
+    rs = np.random.RandomState(5)
+    nU, nI, nnz = 300, 90, 2500
+    iu, ii = rs.randint(0, nU, nnz), rs.randint(0, nI, nnz)
+    y = (1 + rs.poisson(1.0, size=nnz)).astype(np.float32)
+    users, items, _ = layout.build_sides(torch.from_numpy(iu), torch.from_numpy(ii), torch.from_numpy(y), nU, nI)
+    assert svi.EpochWorkspace.fits(users, items, 2) and svi.EpochWorkspace.plan(users, items, 2)[0] == 150
+    assert not svi.EpochWorkspace.fits(users, items, 1)               # 300 batches
+    assert svi.EpochWorkspace.fits(items, users, 1)                   # 90 batches
+    monkeypatch.setenv("HPF_SVI_EPOCH_BYTES", "1000")
+    assert not svi.EpochWorkspace.fits(users, items, 100)
+    monkeypatch.delenv("HPF_SVI_EPOCH_BYTES")
+    monkeypatch.setenv("HPF_SVI_EPOCH_PREP", "0")
+    assert not svi.EpochWorkspace.fits(users, items, 100)
+    monkeypatch.delenv("HPF_SVI_EPOCH_PREP")
+    import pandas as pd
+    df = pd.DataFrame({"UserId": iu, "ItemId": ii, "Count": y}).drop_duplicates(["UserId", "ItemId"])
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HPF_SVI_EPOCH_PREP", mode)
+        m = HPF(k=8, maxiter=4, random_seed=3, ncores=1, reindex=False, verbose=False, users_per_batch=1,
+                items_per_batch=30, stop_crit="maxiter", check_every=None)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m.fit(df.copy())
+        out[mode] = {n: np.array(getattr(m, n)) for n in NAMES}
+    for n in out["1"]:
+        assert np.isfinite(out["1"][n]).all() and np.array_equal(out["1"][n], out["0"][n]), n
