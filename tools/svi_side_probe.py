@@ -46,6 +46,13 @@ for name, frac in (("no flag array", None), ("no row flagged", 0.0), ("6.5 %% fl
     t = timed(lambda: ops.svi_side(n, flag, acc, e, shp, None, None, rs, cs, part, 0.3, 1.0, 0.0, 0.3, 0.3, 0.5, 0.5, 0, 1,
                                    k, ld, rs_prev_out=rsp))
     print("lazy batch side, %-16s: %.3f ms = %.2f TB/s of shapes" % (name, t, gb / t))
+for g in [int(x) for x in os.environ.get("PROBE_GRIDS", "").split(",") if x]:
+    pg = torch.zeros((g, ld), **f32)
+    fl65 = (torch.rand(n, device=dev) < 0.065).to(torch.uint8)
+    t = timed(lambda: ops.svi_side(n, fl65, acc, e, shp, None, None, rs, cs, pg, 0.3, 1.0, 0.0, 0.3, 0.3, 0.5, 0.5, 0, 1, k, ld,
+                                   rs_prev_out=rsp), reps=20)
+    print("lazy batch side, 6.5 %% flagged, grid %5d workgroups: %.3f ms = %.2f TB/s of shapes (%.2f TB/s of the sectors read)"
+          % (g, t, gb / t, gb * 13 / 16 / t))
 t = timed(lambda: ops.svi_side(n, None, acc, e, shp, rte, fac, rs, cs, part, 0.3, 1.0, 0.0, 0.3, 0.3, 0.5, 0.5, 0, 1, k, ld))
 print("stored batch side (rate and mean tables written, 3 x %.2f GB): %.3f ms = %.2f TB/s" % (gb, t, 3 * gb / t))
 
