@@ -791,8 +791,9 @@ int64_t hpf_hip_svi_epoch_sizeof(void) { return (int64_t)sizeof(hpf_svi_epoch); 
 int64_t hpf_hip_svi_epoch_scratch_words(int nb) { return (int64_t)(nb < 1 ? 1 : nb) * ETILES * 5 + TILES; }
 
 int hpf_hip_svi_epoch_prepare(const hpf_svi_epoch *b, void *stream) {
-    if (!b || !b->own_segs || !b->own_row_seg_ptr || !b->own_indptr || !b->oth_segs || !b->oth_row_seg_ptr || !b->oth_idx ||
-        !b->oth_y || !b->order || !b->acc_own || !b->batch_of || !b->flag_own || !b->flag_oth || !b->b_segs || !b->b_multi ||
+    // (a side without any nonzero has no segment list and no nonzero arrays: null pointers with zero counts are fine)
+    if (!b || (!b->own_segs && b->own_nseg != 0) || !b->own_row_seg_ptr || !b->own_indptr || (!b->oth_segs && b->oth_nseg != 0) ||
+        !b->oth_row_seg_ptr || ((!b->oth_idx || !b->oth_y) && b->oth_nnz != 0) || !b->order || !b->acc_own || !b->batch_of || !b->flag_own || !b->flag_oth || !b->b_segs || !b->b_multi ||
         !b->e_idx || !b->e_y || !b->o_segs || !b->o_multi || !b->sizes || !b->key || !b->seg_cnt || !b->seg_pos || !b->tiles ||
         b->own_nrows <= 0 || b->oth_nrows <= 0 || b->own_nseg < 0 || b->oth_nseg < 0 || b->oth_nnz < 0 || b->per <= 0 ||
         b->nb < 1 || b->nb > 255 || (int64_t)b->nb * b->per < b->own_nrows || b->seg_cap <= 0 ||

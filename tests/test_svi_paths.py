@@ -464,3 +464,31 @@ def test_epoch_level_preparation_is_chosen_only_where_it_fits(cpu_ops_backend, m
         out[mode] = {n: np.array(getattr(m, n)) for n in NAMES}
     for n in out["1"]:
         assert np.isfinite(out["1"][n]).all() and np.array_equal(out["1"][n], out["0"][n]), n
+
+
+@pytest.mark.parametrize("k", [7, 50, 100, 200, 300, 600])
+def test_fused_other_side_for_every_row_width(any_backend, monkeypatch, k):
+    """hpf_hip_sweep_svi_f32 is instantiated per leading dimension (ld = 32 ... 1024: lanes per row, float4s per lane, the
+    16-byte-store form of its epilogue from ld = 256 on); for a k in each of them, epochs with the other side fused into its
+    sweep agree with the separate whole-table pass -- hub rows cut into several segments and rows without data included."""
+    from hpfrec_amd import layout
+    monkeypatch.setattr(layout, "SEG_CAP", 32)
+    rs = np.random.RandomState(k)
+    nU, nI, nnz = 260, 170, 5000
+    iu = np.minimum((nU * rs.random_sample(nnz) ** 2.5).astype(np.int64), nU - 2)       # (the last user has no data)
+    ii = np.minimum((nI * rs.random_sample(nnz) ** 3.0).astype(np.int64), nI - 1)
+    import pandas as pd
+    df = pd.DataFrame({"UserId": iu, "ItemId": ii, "Count": (1 + rs.poisson(1.0, size=nnz)).astype(np.float32)})
+    df = df.drop_duplicates(["UserId", "ItemId"]).reset_index(drop=True)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HPF_SVI_FUSED", mode)
+        m = HPF(k=k, maxiter=4, random_seed=11, ncores=1, reindex=False, verbose=False, users_per_batch=70,
+                items_per_batch=60, stop_crit="maxiter", check_every=None)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m.fit(df.copy())
+        out[mode] = {n: np.array(getattr(m, n)) for n in NAMES}
+    for n in out["1"]:
+        assert np.isfinite(out["1"][n]).all() and (out["1"][n] > 0).all()
+        assert _maxrel(out["1"][n], out["0"][n]) < 3e-5, (k, n, _maxrel(out["1"][n], out["0"][n]))
