@@ -27,13 +27,13 @@ SOURCES = (SRC_PATH, SHARD_SRC_PATH, MT_SRC_PATH, SVI_SRC_PATH, P2P_SRC_PATH)
 HEADERS = (os.path.join(_PKG, "csrc", "hpf_p2p_dev.h"),)
 INC_PATH = os.path.join(_ROOT, "include")
 
-HPF_HIP_ABI_VERSION = 22
+HPF_HIP_ABI_VERSION = 23
 
 #: every symbol include/hpf_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = (
     "hpf_hip_abi_version", "hpf_hip_ld_for_k", "hpf_hip_device_info", "hpf_hip_sweep_f32",
     "hpf_hip_sweep_finalize_f32",
-    "hpf_hip_row_finalize_f32", "hpf_hip_row_finalize_ranges_f32", "hpf_hip_colsum_reduce_f32", "hpf_hip_colsum_f32", "hpf_hip_expect_f32",
+    "hpf_hip_row_finalize_f32", "hpf_hip_row_finalize_ranges_f32", "hpf_hip_colsum_reduce_f32", "hpf_hip_colsum_f32", "hpf_hip_colsum_sequential_f32", "hpf_hip_expect_f32",
     "hpf_hip_segsum_f32", "hpf_hip_pair_llk_f32", "hpf_hip_llk_sweep_f32", "hpf_hip_pair_dot_f32", "hpf_hip_score_rows_f32", "hpf_hip_gather_probe_f32",
     "hpf_hip_svi_shape_rows_f32", "hpf_hip_svi_refresh_f32", "hpf_hip_svi_rate_rows_f32", "hpf_hip_svi_side_f32", "hpf_hip_sweep_svi_f32", "hpf_hip_mt19937_words", "hpf_hip_uniform_rows_f32", "hpf_hip_svi_batch_prepare", "hpf_hip_svi_prep_scratch_words", "hpf_hip_svi_batch_sizeof", "hpf_hip_svi_epoch_prepare", "hpf_hip_svi_epoch_scratch_words", "hpf_hip_svi_epoch_sizeof", "hpf_hip_segsum_desc_f32", "hpf_hip_fold_in_f32",
     "hpf_hip_item_shape_rows_f32", "hpf_hip_item_apply_rows_f32", "hpf_hip_gather_payload_ld", "hpf_hip_rccl_open", "hpf_hip_rccl_unique_id", "hpf_hip_rccl_comm_init", "hpf_hip_rccl_comm_count",
@@ -112,6 +112,7 @@ def lib():
     L.hpf_hip_colsum_reduce_f32.argtypes = [vp, ci, vp, ci, vp]
     L.hpf_hip_colsum_f32.argtypes = [vp, i64, ci, vp, ci, vp]
     L.hpf_hip_expect_f32.argtypes = [vp, vp, vp, vp, vp, i64, ci, ci, vp, vp, cf, vp]
+    L.hpf_hip_colsum_sequential_f32.argtypes = [vp, i64, ci, vp, vp]
     L.hpf_hip_segsum_f32.argtypes = [vp, vp, vp, i64, vp, ci, ci, ci, vp]
     L.hpf_hip_pair_llk_f32.argtypes = [vp, vp, vp, vp, vp, i64, vp, ci, ci, ci, ci, vp]
     L.hpf_hip_llk_sweep_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]

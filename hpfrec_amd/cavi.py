@@ -160,6 +160,12 @@ class FullBatchCavi(ShardedMixin):
         self.csB = torch.zeros(ld, **f32)
         self.csT = torch.zeros(ld, **f32)
         self.niter_done = 0
+        # HPF_COLSUM_ORDER=reference (a diagnostic, single GPU): Theta.sum(axis=0) / Beta.sum(axis=0) in numpy's own order --
+        # float32, row after row (PXI:236,255) -- instead of the sweeps' per-block partials summed in double: the reference's
+        # sums bit for bit, at the price of a chain of nrows dependent adds per iteration and side
+        self.ref_sums = os.environ.get("HPF_COLSUM_ORDER", "tree") == "reference"
+        if self.ref_sums and self.dist:
+            raise ValueError("HPF_COLSUM_ORDER=reference is a single-GPU diagnostic mode")
 
     # ------------------------------------------------------------------------------------
     def _pad(self, host_arr, out):
@@ -217,6 +223,9 @@ class FullBatchCavi(ShardedMixin):
         if self.nU > 0:
             ops.expect(self.Gamma_shp, self.Gamma_rte, self.eT, self.nU, k, ld)
         ops.expect(self.Lambda_shp, self.Lambda_rte, self.eB, self.nI, k, ld)
+        if self.ref_sums:
+            ops.colsum_sequential(self.Beta, self.nI, ld, self.csB)
+            return
         ops.colsum(self.Beta, self.nI, ld, self.cs_scratch)
         ops.colsum_reduce(self.cs_scratch, self.csB, ld)
 
@@ -257,17 +266,24 @@ class FullBatchCavi(ShardedMixin):
         if self.dist:
             return self._iterate_scatter(store)          # (shard.py)
         ops, hy, ld = self.ops, self.hy, self.ld
+        store = store or self.ref_sums       # (the reference-order sums walk the stored mean tables)
         # user side: phi-weighted gather over CSR rows, then the closed-form user updates
         self._side_update(self.users, self.nU, self.eT, self.eB, self.eT_next, self.part_u, self.Gamma_shp,
                           self.k_rte_prev, self.Theta, self.k_rte, self.csB, self.csT_part, self.gsu, self.gu,
                           hy.a, hy.k_shp, hy.add_k_rte, store)
-        ops.colsum_reduce(self.csT_part, self.csT, ld)
+        if self.ref_sums:
+            ops.colsum_sequential(self.Theta, self.nU, ld, self.csT)
+        else:
+            ops.colsum_reduce(self.csT_part, self.csT, ld)
         # item side: same kernel over CSC rows; still reads the OLD eT (double-buffered)
         self._keep_csB(store)
         self._side_update(self.items, self.nI, self.eB, self.eT, self.eB, self.part_i, self.Lambda_shp,
                           self.t_rte_prev, self.Beta, self.t_rte, self.csT, self.csB_part, self.gsi, self.gi,
                           hy.c, hy.t_shp, hy.add_t_rte, store)
-        ops.colsum_reduce(self.csB_part, self.csB, ld)
+        if self.ref_sums:
+            ops.colsum_sequential(self.Beta, self.nI, ld, self.csB)
+        else:
+            ops.colsum_reduce(self.csB_part, self.csB, ld)
         self.eT, self.eT_next = self.eT_next, self.eT
         self.niter_done += 1
 
@@ -304,7 +320,9 @@ class FullBatchCavi(ShardedMixin):
         """(sum_u Theta) . (sum_i Beta) in float32, the subtrahend of the train llk (PXI:78)."""
         self.flush_items()
         if self.niter_done == 0:
-            if self.nU > 0:
+            if self.nU > 0 and self.ref_sums:
+                self.ops.colsum_sequential(self.Theta, self.nU, self.ld, self.csT)
+            elif self.nU > 0:
                 self.ops.colsum(self.Theta, self.nU, self.ld, self.cs_scratch)
                 self.ops.colsum_reduce(self.cs_scratch, self.csT, self.ld)
             else:

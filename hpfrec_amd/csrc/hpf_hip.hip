@@ -1005,6 +1005,32 @@ __global__ __launch_bounds__(BLOCK) void colsum_kernel(const float *__restrict__
     }
 }
 
+// tab.sum(axis=0) in numpy's OWN order (PXI:236,255: Beta.sum(axis=0), Theta.sum(axis=0) of float32 arrays): numpy adds the
+// rows one after the other in float32 -- out[c] = fl(... fl(fl(a[0][c] + a[1][c]) + a[2][c]) ...), verified against a
+// row-by-row loop -- so one lane per column walking the rows in sequence reproduces the reference's sums BIT FOR BIT.  A chain
+// of nrows dependent adds cannot be spread over the chip: this is the diagnostic mode HPF_COLSUM_ORDER=reference (7 ms per
+// 2e5-row table), which shows that what separates the default path from the reference at 1e5..1e6 rows is this order and
+// nothing else (tests/test_hip_parity.py::test_large_vs_golden); the product sums per-block partials in double, fixed order.
+__global__ __launch_bounds__(WAVE) void colsum_sequential_kernel(const float *__restrict__ tab, int64_t nrows, int ld,
+                                                                 float *__restrict__ cs_out) {
+    constexpr int UNR = 64;            // rows in flight per lane
+    const int c = blockIdx.x * WAVE + threadIdx.x;
+    if (c >= ld) return;
+    const float *col = tab + c;
+    float s = 0.f;                     // (0 + a[0] is a[0]: the same chain as starting from the first row)
+    int64_t r = 0;
+    for (; r + UNR <= nrows; r += UNR) {
+        float v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) v[u] = col[(size_t)(r + u) * ld];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) s = __fadd_rn(s, v[u]);
+    }
+    for (; r < nrows; r++) s = __fadd_rn(s, col[(size_t)r * ld]);
+    cs_out[c] = s;
+}
+
+
 // cs_out[c] = sum_b cs_partial[b][c] in double, fixed order.  ONE workgroup per FOUR columns: a thread sums its rows
 // (b = t, t + 1024, ...) of the block's float4 column group, the 1024 chains are folded by a butterfly inside each wave and
 // in order across the 16 waves.  A single workgroup per 64 columns read the sweep's 4096 partial rows (1 MB) at the ~40 GB/s
@@ -2509,6 +2535,13 @@ int hpf_hip_colsum_f32(const float *tab, int64_t nrows, int ld, float *cs_partia
     hipLaunchKernelGGL((colsum_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, tab, nrows, cs_partial);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
+    return last_error();
+}
+
+int hpf_hip_colsum_sequential_f32(const float *tab, int64_t nrows, int ld, float *cs_out, void *stream) {
+    if (!tab || !cs_out || nrows < 0 || ld < 32 || (ld & 31)) return HPF_EINVAL;
+    hipLaunchKernelGGL(colsum_sequential_kernel, dim3((ld + WAVE - 1) / WAVE), dim3(WAVE), 0, (hipStream_t)stream, tab, nrows,
+                       ld, cs_out);
     return last_error();
 }
 

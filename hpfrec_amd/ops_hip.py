@@ -170,6 +170,11 @@ class HipOps:
         _lib.check(self.L.hpf_hip_colsum_f32(_ptr(tab), nrows, ld, _ptr(cs_partial), cs_partial.shape[0],
                                              self._stream()), "hpf_hip_colsum_f32")
 
+    def colsum_sequential(self, tab, nrows, ld, cs_out):
+        """cs_out = tab[:nrows].sum(axis=0) in numpy's order (float32, row after row): the reference's sums, bit for bit."""
+        _lib.check(self.L.hpf_hip_colsum_sequential_f32(_ptr(tab), int(nrows), ld, _ptr(cs_out), self._stream()),
+                   "hpf_hip_colsum_sequential_f32")
+
     def expect(self, shp, rte, e, nrows, k, ld, row_list=None, flag=None, factored=None):
         """flag (uint8 per table row): only rows with a non-zero flag.  factored = (rs, cs, top): the rate is
         top / rs[r] + cs[c] instead of a table (rte may be None)."""

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 22
+#define HPF_HIP_ABI_VERSION 23
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -176,6 +176,13 @@ int hpf_hip_colsum_reduce_f32(const float *cs_partial, int nblk, float *cs_out, 
 
 /* Per-block column sums of a table (first iteration / partial_fit: Beta.sum(axis=0) from host-initialised Beta). */
 int hpf_hip_colsum_f32(const float *tab, int64_t nrows, int ld, float *cs_partial, int grid_blocks, void *stream);
+
+/* cs_out[c] = tab[0][c] + tab[1][c] + ... in float32, the rows IN SEQUENCE: numpy's own order for Beta.sum(axis=0) /
+ * Theta.sum(axis=0) (PXI:236,255), reproduced bit for bit -- one lane per column, a chain of nrows dependent adds.  The
+ * diagnostic mode HPF_COLSUM_ORDER=reference of the full-batch driver uses it instead of the partial sums of the sweeps +
+ * hpf_hip_colsum_reduce_f32: it shows that this order is what separates the default path from the reference at 1e5..1e6
+ * rows (tests/test_hip_parity.py::test_large_vs_golden).  Not for production: 7 ms per 2e5-row table. */
+int hpf_hip_colsum_sequential_f32(const float *tab, int64_t nrows, int ld, float *cs_out, void *stream);
 
 /* e[r] = exp(psi(shp[r]) - log(rte[r])) / rowmax, pads zeroed: the hoisted transcendental part of
  * update_phi (PXI:570,588,685) for rows whose shape/rate did not come out of hpf_hip_row_finalize_f32

@@ -218,6 +218,9 @@ class CpuOps:
     def colsum_reduce(self, cs_partial, cs_out, ld):
         _np(cs_out)[:] = _np(cs_partial).astype(np.float64).sum(axis=0).astype(np.float32)
 
+    def colsum_sequential(self, tab, nrows, ld, cs_out):
+        _np(cs_out)[:] = _np(tab)[:nrows].sum(axis=0)        # (numpy's own float32 row-after-row order: the reference's)
+
     def colsum(self, tab, nrows, ld, cs_partial):
         cp = _np(cs_partial)
         cp[:] = 0

@@ -88,7 +88,7 @@ def test_mid_vs_golden(hip_backend):
     assert abs(float(llk) / g["train_llk_it10"] - 1) < 1e-4
 
 
-def test_large_vs_golden(hip_backend):
+def test_large_vs_golden(hip_backend, monkeypatch):
     """200k x 50k, 5.4M nonzeros, k=50 against the REAL reference (tests/golden/large_full.npz, made by make_golden.py
     large_full; the oracle reproduces it bit for bit, tests/test_oracle.py): the size class where numpy's sequential
     float32 column sums over 2e5 rows (PXI:236,255) are the noisy side.  north_star's bar, 1e-4 relative, holds against the
@@ -96,7 +96,9 @@ def test_large_vs_golden(hip_backend):
     on the train llk after 5.  After 5 iterations (rounding noise grows ~x1.2 per iteration) the worst element sits AT the
     bar (measured 1.03e-4, Beta), and the test shows whose noise that is: the same iterations with the column sums
     accumulated in float64 (the oracle's diagnostic variant; everything else the reference's arithmetic) are as far from
-    the reference as the GPU is -- and the GPU is within 3e-5 of THAT."""
+    the reference as the GPU is -- and the GPU is within 3e-5 of THAT.  And directly: with the two column sums formed in
+    numpy's own order on the device (HPF_COLSUM_ORDER=reference: float32, row after row -- hpf_hip_colsum_sequential_f32, a
+    diagnostic mode) and nothing else changed, the HIP path is within 1e-4 of the REFERENCE ITSELF after 5 iterations too."""
     u, i, y, nU, nI = datagen.large_counts()
     g = np.load(os.path.join(GOLDEN, "large_full.npz"))
     assert int(g["nnz"]) == y.shape[0]
@@ -129,6 +131,33 @@ def test_large_vs_golden(hip_backend):
     assert gpu_vs_f64 < 3e-5 and ref_vs_f64 > 2 * gpu_vs_f64
     _, arrs, llk = _fit(hip_backend, y, u, i, nU, nI, 50, 5, verbose=1, check_every=5)
     assert abs(float(llk) / g["train_llk_it5"] - 1) < 1e-5
+    # the reference's summation order on the device: the bar holds against the reference itself at every horizon
+    monkeypatch.setenv("HPF_COLSUM_ORDER", "reference")
+    ref_order = {}
+    for its in (1, 3, 5):
+        _, arrs_r, _ = _fit(hip_backend, y, u, i, nU, nI, 50, its)
+        ref_order[its] = max(worst_vs_golden(arrs_r, its).values())
+    print("large golden, column sums in the reference's order on the device: worst deviation from the reference per horizon %s"
+          % ref_order)
+    assert max(ref_order.values()) < 1e-4 and ref_order[5] < 0.5 * worst[5], ref_order
+
+
+@pytest.mark.parametrize("n,k", [(100003, 30), (50000, 200), (37, 50), (1, 7), (0, 50)])
+def test_colsum_sequential_is_numpys_sum_bit_for_bit(hip_backend, n, k):
+    """hpf_hip_colsum_sequential_f32 == numpy's float32 a.sum(axis=0) (the statement of PXI:236,255), every bit: one lane
+    per column adds the rows in sequence, which is the order numpy uses for an axis-0 sum."""
+    import torch
+    from hpfrec_amd import _lib
+    ops = hip_backend._make_ops()
+    ld = _lib.ld_for_k(k)
+    a = np.random.RandomState(n + k).gamma(0.3, 1.0, size=(n, k)).astype(np.float32)
+    tab = torch.zeros((max(n, 1), ld), dtype=torch.float32, device=ops.device)
+    tab[:n, :k] = torch.from_numpy(a).to(ops.device)
+    out = torch.full((ld,), -1.0, dtype=torch.float32, device=ops.device)
+    ops.colsum_sequential(tab, n, ld, out)
+    want = np.zeros(ld, np.float32)
+    want[:k] = a.sum(axis=0) if n > 0 else 0
+    assert np.array_equal(out.cpu().numpy(), want)
 
 
 # ---------------------------------------------------------------------------------------------

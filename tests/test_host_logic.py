@@ -653,3 +653,18 @@ def test_direct_schedule_traces_have_no_collective(world, nranges, prefetch):
             per_rank.append(seq)
     # what every rank waits for / publishes is the same sequence on every rank (a mismatch is a time-out on real links)
     assert all(s == per_rank[0] for s in per_rank)
+
+
+def test_reference_order_column_sums_mode_on_standin(cpu_ops_backend, monkeypatch):
+    """HPF_COLSUM_ORDER=reference (cavi.FullBatchCavi: the two column sums of an iteration in numpy's float32 row-after-row
+    order, as PXI:236,255 form them) runs the same fit as the default -- at 100 rows the orders differ in the last bits only
+    -- and is refused for a sharded model."""
+    df, nU, nI = datagen.readme_counts()
+    Y, iu, ii = datagen.triplets(df)
+    out = {}
+    for mode in ("tree", "reference"):
+        monkeypatch.setenv("HPF_COLSUM_ORDER", mode)
+        _, arrs, llk = _fit(cpu_ops_backend, Y, iu, ii, nU, nI, 30, 5, verbose=1, check_every=5)
+        out[mode] = dict(arrs, llk=np.float64(llk))
+    for n in out["tree"]:
+        assert _maxrel(np.asarray(out["reference"][n]), np.asarray(out["tree"][n])) < 5e-6, n
