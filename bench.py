@@ -205,6 +205,17 @@ def cpu_baseline(nU, nI, k, nnz_full, sample_users=200_000, iters=4, device=None
             m.iterate(True)
             if i + 1 in snaps:
                 got[i + 1] = {n: m.fetch(n) for n in ("Theta", "Beta")}
+        # the same iterations with the two column sums in the reference's (numpy's) own order on the device -- a
+        # diagnostic mode of the driver (HPF_COLSUM_ORDER=reference, hpf_hip_colsum_sequential_f32): what is left then
+        # is everything BUT the summation order of Theta.sum(axis=0) / Beta.sum(axis=0)
+        m.ref_sums = True
+        m.load_state(init["Gamma_shp"], init["Gamma_rte"], init["Lambda_shp"], init["Lambda_rte"], init["k_rte"],
+                     init["t_rte"], init["Theta"], init["Beta"])
+        got_ref = {}
+        for i in range(total_its):
+            m.iterate(True)
+            if i + 1 in snaps:
+                got_ref[i + 1] = {n: m.fetch(n) for n in ("Theta", "Beta")}
         del m
         torch.cuda.empty_cache()
 
@@ -222,6 +233,7 @@ def cpu_baseline(nU, nI, k, nnz_full, sample_users=200_000, iters=4, device=None
         out["parity_vs_gpu_on_sample"] = {
             "max_rel_dev_Theta_Beta": {"after_%d_iterations" % n: dict(
                 vs_port=worst(got[n], snaps[n]),
+                vs_port_with_the_column_sums_in_numpys_order_on_the_device=worst(got_ref[n], snaps[n]),
                 **({"vs_port_with_float64_column_sums": worst(got[n], snaps64[n])} if n in snaps64 else {}))
                 for n in sorted(snaps)},
             "pinned_by": "tests/golden/large_full.npz (the real reference at 200k x 50k, 5.4M nnz; oracle bit-exact, GPU "
