@@ -81,12 +81,15 @@ class CpuOps:
         pos = np.repeat(begin, length) + (np.arange(length.sum()) - np.repeat(offs, length))
         idx = _np(side.idx).astype(np.int64)[pos]
         y = _np(side.y).astype(np.float64)[pos]
-        S = _np(tab_self).astype(np.float64)[row[seg_of_nnz]]
-        O = _np(tab_other).astype(np.float64)[idx]
-        s = (S * O).sum(axis=1)
+        # (columns < k only: the pad columns are zero in both tables; float64 products summed row by row without the
+        #  nnz x ld temporary)
+        S = _np(tab_self)[:, :k].astype(np.float64)[row[seg_of_nnz]]
+        O = _np(tab_other)[:, :k].astype(np.float64)[idx]
+        s = np.einsum("ij,ij->i", S, O)
         w = np.where(y > 0, y / s, 0.0)
-        contrib = w[:, None] * O
-        out = np.add.reduceat(contrib, offs, axis=0)
+        O *= w[:, None]
+        out = np.zeros((nseg, ld))
+        out[:, :k] = np.add.reduceat(O, offs, axis=0)
         if acc_rows is not None:
             whole = (_np(side.segs)[:nseg, 1] & 0x40000000) != 0
             _np(acc_rows)[row[whole], :acc_ld] = out[whole][:, :acc_ld].astype(np.float32)
