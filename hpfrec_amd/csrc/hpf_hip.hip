@@ -140,17 +140,25 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b) {
 // The blends of a stochastic step, a*x + b*y, with each product and the sum rounded on its own -- numpy's float32 statements
 // (PXI:316-325, 368-377) -- and NOT contracted into an fma: a contraction is the compiler's choice per kernel, and the same
 // statement is formed by several kernels (the whole-table passes, the row-list kernels, the sweep's fused epilogue) whose
-// results must agree bit for bit.
+// results must agree bit for bit.  (`#pragma clang fp contract(off)`: HIP's __fmul_rn / __fadd_rn are plain operators, which
+// -ffp-contract=fast still fuses -- the whole-table pass did, the sweep's epilogue did not: one ulp apart in 3 rows of 4.)
 __device__ __forceinline__ float blend2(float a, float x, float b, float y) {
-    return __fadd_rn(__fmul_rn(a, x), __fmul_rn(b, y));
+#pragma clang fp contract(off)
+    const float p = a * x;
+    const float q = b * y;
+    return p + q;
 }
 // shp = w_new*(prior + e*acc) [+ w_old*shp]: `fresh` = fmaf(e, acc, prior) at every site
 __device__ __forceinline__ float blend_shape(float w_new, float fresh, float w_old, float old) {
-    return (w_old == 0.f) ? __fmul_rn(w_new, fresh) : blend2(w_new, fresh, w_old, old);
+#pragma clang fp contract(off)
+    if (w_old == 0.f) return w_new * fresh;
+    return blend2(w_new, fresh, w_old, old);
 }
 // step*(base + c) + step_prev*old (rates: base = top/rs, c = a column sum; row scalars: base = add, c = sum_k fac)
 __device__ __forceinline__ float blend_rate(float step, float base, float c, float step_prev, float old) {
-    return blend2(step, __fadd_rn(base, c), step_prev, old);
+#pragma clang fp contract(off)
+    const float t = base + c;
+    return blend2(step, t, step_prev, old);
 }
 
 __device__ __forceinline__ double fast_rcp(double x) {

@@ -274,7 +274,9 @@ int hpf_hip_svi_side_f32(int64_t nrows, const uint8_t *flag, const float *acc, c
  * Split rows write part[] as in hpf_hip_sweep_f32 and are finished, with the rows the batch does not touch, by a
  * hpf_hip_svi_side_f32 call with done_flag = the flag value of whole rows (the preparations above write 1 for a row
  * present in one segment, 2 for a split row); the two calls' partial column sums add up to the side's (PXI:370-374).
- * Same float32 statements through the same device functions: a row finished here and one finished there agree bit for bit.
+ * Same float32 statements through the same device functions: a row finished here and one finished there get the same
+ * shapes, rates, means and E row bit for bit (tests/test_hip_parity.py::test_sweep_svi_op_row_for_row); its scalar rate holds
+ * a k-term sum that the two kernels fold in different orders (1e-7).
  */
 int hpf_hip_sweep_svi_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y, const float *tab_self,
                           const float *tab_other, float *part, float *e_new, float *shp, float *rte, float *fac, float *rs,

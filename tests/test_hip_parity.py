@@ -832,6 +832,77 @@ def test_svi_side_op(ops, k, rate_mode, rs_mode, w):
         assert torch.equal(got["rsc"][untouched], rsc[untouched])
 
 
+@pytest.mark.parametrize("k", [7, 50, 100, 200, 256, 300, 600, 1024])
+@pytest.mark.parametrize("with_e,with_fac", [(True, False), (False, True)])
+def test_sweep_svi_op_row_for_row(ops, k, with_e, with_fac):
+    """hpf_hip_sweep_svi_f32 (the other side's stochastic step in the epilogue of its sweep) + the whole-table pass that
+    skips the rows it finished (done_flag) against the plain sweep + the whole-table pass over everything: every row's
+    shapes, rates, means and new E row EQUAL -- both forms make the same float32 statements through the same device
+    functions, whichever kernel finishes the row -- its scalar rate (a k-term sum folded over differently dealt lanes) and
+    the column sums equal to summation order.  Rows present in
+    one segment, hub rows cut into several, rows the batch does not touch; every row width (ld = 32 ... 1024)."""
+    from hpfrec_amd import svi
+    rs = np.random.RandomState(11 * k + with_e)
+    ld = _lib.ld_for_k(k)
+    n_self, n_oth, nnz, cap = 500, 300, 6000, 24
+    r_ix = np.minimum((n_self * rs.random_sample(nnz) ** 3.0).astype(np.int64), n_self - 40)      # hubs; the last rows untouched
+    c_ix = rs.randint(0, n_oth, nnz).astype(np.int64)
+    yv = (1 + rs.poisson(1.0, size=nnz)).astype(np.float32)
+    dev = "cuda"
+    side = svi.BatchSide(torch.from_numpy(r_ix).to(dev), torch.from_numpy(c_ix).to(dev), torch.from_numpy(yv).to(dev),
+                         seg_cap=cap)
+    assert side.nmulti > 0 and side.nrows < n_self
+    side.short_rows = 1
+    flag = torch.zeros(n_self, dtype=torch.uint8, device=dev)
+    flag[side.rows] = 1
+    flag[side.rows[side.multi_local]] = 2
+    shp0 = _rand_tables(rs, n_self, k, ld) + 0.3
+    rte0 = _rand_tables(rs, n_self, k, ld) + 0.5
+    shp0[:, k:] = 0
+    rte0[:, k:] = 0
+    e_self0 = _rand_tables(rs, n_self, k, ld)
+    e_oth = (_rand_tables(rs, n_oth, k, ld)).to(dev)
+    rs0 = torch.from_numpy(rs.uniform(0.5, 20, size=n_self).astype(np.float32))
+    cs = torch.zeros(ld)
+    cs[:k] = torch.from_numpy(rs.uniform(3, 30, size=k).astype(np.float32))
+    cs = cs.to(dev)
+    hyper = (0.3, 0.35, 0.55, 15.3, 0.3, 0.45, 0.55)      # prior, w_new, w_old, top, add, step, step_prev
+
+    def run(fused):
+        T = dict(shp=shp0.clone().to(dev), rte=rte0.clone().to(dev), e=e_self0.clone().to(dev), rsc=rs0.clone().to(dev),
+                 fac=torch.zeros((n_self, ld), device=dev))
+        acc = torch.zeros((n_self, ld), device=dev)
+        part = torch.zeros((side.nseg, ld), device=dev)
+        fac = T["fac"] if with_fac else None
+        e_out = T["e"] if with_e else None
+        blocks, tail = 64, ops.refresh_grid(n_self)
+        csp = torch.zeros((blocks + tail, ld), device=dev)
+        if fused:
+            ops.sweep_svi(side, T["e"], e_oth, part, e_out, T["shp"], T["rte"], fac, T["rsc"], cs, csp[:blocks], *hyper, k, ld)
+        else:
+            ops.sweep(side, T["e"], e_oth, part, k, ld, acc_rows=acc, acc_ld=ld)
+        tmp = torch.zeros((side.nmulti, ld), device=dev)
+        ops.segsum(part, side.row_seg_ptr, side.nmulti, tmp, ld, row_list=side.multi_local)
+        acc.index_copy_(0, side.rows[side.multi_local], tmp)
+        ops.svi_side(n_self, flag, acc, T["e"], T["shp"], T["rte"], fac, T["rsc"], cs, csp[blocks:], *hyper, 1, 1, k, ld,
+                     e_out=e_out, done_flag=1 if fused else 0)
+        cso = torch.zeros(ld, device=dev)
+        ops.colsum_reduce(csp, cso, ld)
+        torch.cuda.synchronize()
+        return {a: v.cpu() for a, v in T.items()}, cso.cpu()
+
+    (got, g), (want, w) = run(True), run(False)
+    for name in ("shp", "rte") + (("e",) if with_e else ()) + (("fac",) if with_fac else ()):
+        assert torch.equal(got[name], want[name]), (k, name, float((got[name] - want[name]).abs().max()))
+    # (the row's scalar rate holds sum_k fac: the two kernels deal a row's columns to their lanes differently, so that
+    #  k-term float32 sum is folded in a different order)
+    assert float(((got["rsc"] - want["rsc"]).abs() / want["rsc"].abs()).max()) < 1e-6
+    assert float(((g - w).abs() / w.abs().clamp_min(1e-30))[:k].max()) < 2e-6
+    untouched = (flag == 0).cpu()
+    assert torch.equal(got["shp"][untouched], shp0[untouched]) and torch.equal(got["rsc"][untouched], rs0[untouched])
+    assert float((got["shp"][~untouched][:, :k] - shp0[~untouched][:, :k]).abs().max()) > 0
+
+
 @pytest.mark.parametrize("k", [200, 256, 300, 600, 1024])
 @pytest.mark.parametrize("rs_mode,w,flagged", [(1, (1.0, 0.0), 0.07), (2, (1.0, 0.0), 0.5), (1, (0.35, 0.55), 1.0),
                                                (1, (1.0, 0.0), None)])
