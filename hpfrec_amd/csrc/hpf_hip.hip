@@ -231,7 +231,11 @@ struct FinalizeArgs {  // the row-finalize operands when it is fused into the sw
     uint32_t sig_epoch;
     float *cs_other_copy;     // optional: block 0 keeps a copy of cs_other (the column sums this launch used)
     int nq4;                  // SKIP: float4s of a gathered row that hold columns < k, rounded up to whole 64-byte sectors
-    float w_new, w_old, step, step_prev;   // MODE 2: the blend weights of a stochastic step (shapes; rates and row scalars)
+    float w_new, w_old, step, step_prev;   // MODE 2 / 3: the blend weights of a stochastic step (shapes; rates and row scalars)
+    // MODE 3: the rate a batch row's E row is formed with in the PROLOGUE -- factored (rate_rs != null):
+    // rate_top / rate_rs[row] + rate_cs[c], else the stored table rte_in[row][c] (may be the table `rte` points at)
+    const float *rate_rs, *rate_cs, *rte_in;
+    float rate_top;
 };
 
 // MODE: 0 = plain sweep; 1 = row finalize fused as EPILOGUE of whole-row segments; 2 = the OTHER side of a stochastic step
@@ -239,6 +243,14 @@ struct FinalizeArgs {  // the row-finalize operands when it is fused into the sw
 // towards the step's estimate, means, the row scalar, the new E row): the rows a batch touches on its other side are short
 // (8-12 nonzeros at BASELINE config C5), so writing their phi-sums to memory, reading them back next to the E row the sweep
 // already holds, and only then updating the row was as much traffic as the gathers themselves.
+// MODE 3 = the BATCH side of a stochastic step, both ends of the row's life in the wavefront that sweeps it.  PROLOGUE: the
+// row's E row exp(psi(shp))/rte is formed from its CURRENT shape and rate (expect_kernel's statements: the psi/log/exp hoisted
+// out of update_phi_csr, PXI:683-692) in registers and stored for the other side's sweep of the same step -- the loads of a
+// wave's NEXT segment are requested one segment ahead, the fp64 work runs under the other waves' gathers (as a launch of its
+// own it ran at the latency of one dependent load chain per row: 1.85 TB/s, 7 % of a C5 epoch).  EPILOGUE (a row present in
+// one segment): shape = prior + E (*) phi-sum (PXI:304-314 / 356-366), rate = top/rs + cs_other (PXI:300 / 352), mean, the
+// row's share of the column sums, its scalar rate (PXI:324 / 377) -- svi_side_kernel's rate_mode 0 statements through the
+// same helpers -- so the phi-sum never goes through memory.  Split rows write part[] and are finished by the whole-table pass.
 // SKIP: the zero padding of the gathered rows is not fetched -- lanes whose float4 lies in a 64-byte sector past column k
 // issue no load (k = 200 in ld = 256: 13 of a row's 16 sectors; k = 100 in ld = 128: 7 of 8).  Only instantiated for those k:
 // with k = 50 in ld = 64 every sector holds columns and the kernel is the unmasked one.
@@ -382,15 +394,156 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
         if (lane == 0) fa.rs[row] = blend_rate(fa.step, fa.add_rte, fsum, fa.step_prev, rs_old);
     };
 
+    // MODE 3: a row of the BATCH side of a stochastic step (svi_side_kernel, rate_mode 0, a flagged row -- the same statements
+    // through the same helpers): a = the row's phi-sum entries, eo = its E entries (formed in the prologue below)
+    auto finish_row_batch = [&](const float (&a)[NC], const float (&eo)[NC], int row) {
+        const float rs_old = fa.rs[row];
+        const float base_rte = fa.top_shp / rs_old;
+        float sh[NC], rt[NC], fc[NC];
+        float fsum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NC; t++) {
+            const bool valid = colq[t] < fa.k;
+            const float fresh = fmaf(eo[t], a[t], fa.prior_shp);
+            sh[t] = valid ? blend_shape(fa.w_new, fresh, fa.w_old, 0.f) : 0.f;
+            rt[t] = valid ? base_rte + csl[t] : 0.f;
+            fc[t] = valid ? sh[t] / rt[t] : 0.f;
+            fsum += fc[t];
+            csacc[t] += fc[t];
+        }
+        if constexpr (NG == 1) {
+#pragma unroll
+            for (int v = 0; v < VPL; v++) {
+                if (v * LPR + j < fa.nq4 || !SKIP) {
+                    const size_t o4 = (size_t)row * (LD / 4) + v * LPR + j;
+                    reinterpret_cast<float4 *>(fa.shp)[o4] = make_float4(sh[4 * v], sh[4 * v + 1], sh[4 * v + 2], sh[4 * v + 3]);
+                    if (fa.rte)
+                        reinterpret_cast<float4 *>(fa.rte)[o4] = make_float4(rt[4 * v], rt[4 * v + 1], rt[4 * v + 2], rt[4 * v + 3]);
+                    if (fa.fac)
+                        reinterpret_cast<float4 *>(fa.fac)[o4] = make_float4(fc[4 * v], fc[4 * v + 1], fc[4 * v + 2], fc[4 * v + 3]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NC; t++) {
+                if (colq[t] < LD) {
+                    const size_t o = (size_t)row * LD + colq[t];
+                    fa.shp[o] = sh[t];
+                    if (fa.rte) fa.rte[o] = rt[t];
+                    if (fa.fac) fa.fac[o] = fc[t];
+                }
+            }
+        }
+        fsum = wave_sum(fsum);
+        if (lane == 0) {
+            fa.rs[row] = blend_rate(fa.step, fa.add_rte, fsum, fa.step_prev, rs_old);
+            if (fa.rs_prev) fa.rs_prev[row] = rs_old;
+        }
+    };
+
+    // MODE 3 prologue operands, requested ONE SEGMENT AHEAD: the shape entries (and, when the rate is a stored table, the rate
+    // entries) of the row in this lane's dealt columns colq[t], and the scalar a factored rate is formed with
+    struct RowRequest {
+        float sh[NC], rt[NC], rsr;
+    };
+    float cs_rate[(MODE == 3) ? NC : 1];
+    if constexpr (MODE == 3) {
+#pragma unroll
+        for (int t = 0; t < NC; t++) cs_rate[t] = (fa.rate_rs && colq[t] < fa.k) ? fa.rate_cs[colq[t]] : 0.f;
+    }
+    auto request_row = [&](int row, RowRequest &rq) {
+        rq.rsr = fa.rate_rs ? fa.rate_rs[row] : 1.f;
+        if constexpr (NG == 1) {
+            const float4 *sp4 = reinterpret_cast<const float4 *>(fa.shp + (size_t)row * LD);
+            const float4 *rp4 = reinterpret_cast<const float4 *>(fa.rte_in + (size_t)row * LD);
+#pragma unroll
+            for (int v = 0; v < VPL; v++) {
+                float4 sq = make_float4(1.f, 1.f, 1.f, 1.f), rq4 = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (!SKIP || v * LPR + j < fa.nq4) {
+                    sq = ld4(sp4 + v * LPR + j);
+                    if (!fa.rate_rs) rq4 = ld4(rp4 + v * LPR + j);
+                }
+                rq.sh[4 * v] = sq.x, rq.sh[4 * v + 1] = sq.y, rq.sh[4 * v + 2] = sq.z, rq.sh[4 * v + 3] = sq.w;
+                rq.rt[4 * v] = rq4.x, rq.rt[4 * v + 1] = rq4.y, rq.rt[4 * v + 2] = rq4.z, rq.rt[4 * v + 3] = rq4.w;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NC; t++) {
+                const bool valid = colq[t] < fa.k;
+                rq.sh[t] = valid ? fa.shp[(size_t)row * LD + colq[t]] : 1.f;
+                rq.rt[t] = (valid && !fa.rate_rs) ? fa.rte_in[(size_t)row * LD + colq[t]] : 1.f;
+            }
+        }
+    };
+    RowRequest rq_next;
+    hpf_segment sg_cur, sg_next;
+    sg_cur.begin = 0, sg_cur.len = 0, sg_cur.row = 0;
+    sg_next = sg_cur;
+    if constexpr (MODE == 3) {
+        const int64_t sg0 = (int64_t)blockIdx.x * WPB + wid;
+        if (sg0 < nseg) {
+            sg_cur = segs[sg0];
+            request_row(sg_cur.row, rq_next);
+            if (sg0 + nwaves < nseg) sg_next = segs[sg0 + nwaves];
+        }
+    }
+
     for (int64_t sg = (int64_t)blockIdx.x * WPB + wid; sg < nseg; sg += nwaves) {
-        const hpf_segment sgm = segs[sg];
+        const hpf_segment sgm = (MODE == 3) ? sg_cur : segs[sg];
         const int len = sgm.len & HPF_SEG_LEN_MASK;
         const float4 *selfp = reinterpret_cast<const float4 *>(tab_self + (size_t)sgm.row * LD);
         float4 rv[VPL], acc[VPL];
+        float en3[(MODE == 3) ? NC : 1];
+        if constexpr (MODE == 3) {
+            // PROLOGUE: this row's E row from the operands requested one segment ago; then the next segment's are requested
+            const RowRequest rq = rq_next;
+            if (sg + nwaves < nseg) {
+                sg_cur = sg_next;
+                request_row(sg_cur.row, rq_next);
+                if (sg + 2 * nwaves < nseg) sg_next = segs[sg + 2 * nwaves];
+            }
+            const float base_old = fa.rate_rs ? fa.rate_top / rq.rsr : 0.f;
+            double ev[NC];
+            int ehi = 0;
 #pragma unroll
-        for (int v = 0; v < VPL; v++) {
-            rv[v] = selfp[v * LPR + j];
-            acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t = 0; t < NC; t++) {
+                const bool valid = colq[t] < fa.k;
+                const float rt = valid ? (fa.rate_rs ? base_old + cs_rate[t] : rq.rt[t]) : 1.f;
+                ev[t] = valid ? expect_ratio(valid ? rq.sh[t] : 1.f, rt) : 0.0;
+                ehi = max(ehi, __double2hiint(ev[t]));
+            }
+            const double inv = row_pow2_scale(ehi);
+#pragma unroll
+            for (int t = 0; t < NC; t++) en3[t] = (colq[t] < fa.k) ? (float)(ev[t] * inv) : 0.f;
+            // the row of the E table: the other side's sweep of this step gathers it (every segment of a split row writes
+            // the same values)
+            if constexpr (NG == 1) {
+#pragma unroll
+                for (int v = 0; v < VPL; v++) {
+                    rv[v] = make_float4(en3[4 * v], en3[4 * v + 1], en3[4 * v + 2], en3[4 * v + 3]);
+                    if (!SKIP || v * LPR + j < fa.nq4)
+                        reinterpret_cast<float4 *>(fa.e_new)[(size_t)sgm.row * (LD / 4) + v * LPR + j] = rv[v];
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NC; t++)
+                    if (colq[t] < LD) fa.e_new[(size_t)sgm.row * LD + colq[t]] = en3[t];
+                // every lane group needs the whole row as float4s: component q of lane (g', j)'s float4 is held, in the
+                // dealt layout, by lane (q % NG, j) in slot q / NG
+                float comp[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) comp[q] = __shfl(en3[(q / NG < NC) ? q / NG : 0], (q % NG) * LPR + j);
+#pragma unroll
+                for (int v = 0; v < VPL; v++) rv[v] = make_float4(comp[4 * v], comp[4 * v + 1], comp[4 * v + 2], comp[4 * v + 3]);
+            }
+#pragma unroll
+            for (int v = 0; v < VPL; v++) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+#pragma unroll
+            for (int v = 0; v < VPL; v++) {
+                rv[v] = selfp[v * LPR + j];
+                acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         // MODE 2: the row's old shapes and rates are requested with its E row, ahead of the gathers (in-order returns: by
         // the time the last gather has landed they are there)
@@ -467,7 +620,7 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
                 acc[v].w += __shfl_xor(acc[v].w, m);
             }
         }
-        if (MODE != 1 && whole_row && fa.acc_rows) {
+        if (MODE != 1 && MODE != 3 && whole_row && fa.acc_rows) {
             // the row's complete accumulator goes straight into the packed exchange buffer
             if (g == 0) {
                 float *ar = fa.acc_rows + (size_t)sgm.row * fa.acc_ld;
@@ -530,6 +683,21 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
                 ro[t] = rv_;
             }
             finish_row_svi(a, eo, so, ro, sgm.row);
+        } else if constexpr (MODE == 3) {
+            float a[NC];
+#pragma unroll
+            for (int t = 0; t < NC; t++) {
+                const int q = g + t * NG;
+                float av_ = 0.f;
+#pragma unroll
+                for (int qq = 0; qq < NQ; qq++) {  // pick float4 component q (q is lane-dependent unless NG == 1)
+                    const int v = qq >> 2, e = qq & 3;
+                    const float av = (e == 0) ? acc[v].x : (e == 1) ? acc[v].y : (e == 2) ? acc[v].z : acc[v].w;
+                    av_ = (qq == q) ? av : av_;
+                }
+                a[t] = av_;
+            }
+            finish_row_batch(a, en3, sgm.row);
         }
     }
 
@@ -1497,7 +1665,9 @@ void svi_lazy_batch_side_kernel(int64_t nrows, const uint8_t *__restrict__ flag,
                                 const float *__restrict__ cs_other, float *__restrict__ cs_partial, float prior,
                                 float w_new, float w_old, float top, float add, float step, float step_prev,
                                 int rs_mode, int k, const float *__restrict__ rs_rate,
-                                float *__restrict__ rs_prev_out) {
+                                float *__restrict__ rs_prev_out, int done_flag) {
+    // done_flag != 0: rows whose flag EQUALS it were finished by the sweep that formed their phi-sums (sweep_kernel MODE 3):
+    // nothing of theirs is read, written or summed here
     static_assert(LD >= 4 * WAVE, "float4-per-lane rows");
     constexpr int VPL = LD / (4 * WAVE);
     constexpr int VR = (VPL == 1) ? 8 : (VPL == 2 ? 4 : 2);
@@ -1520,12 +1690,15 @@ void svi_lazy_batch_side_kernel(int64_t nrows, const uint8_t *__restrict__ flag,
     for (int64_t g = ((int64_t)blockIdx.x * WPB + wid) * WAVE; g < nrows; g += nwaves * WAVE) {
         const int64_t rl = g + lane;
         const bool lv = rl < nrows;
-        const unsigned long long fmask = __ballot(lv && flag && flag[rl] != 0);
+        const int fv = (lv && flag) ? (int)flag[rl] : 0;
+        const unsigned long long dmask = __ballot(done_flag != 0 && fv == done_flag);
+        const unsigned long long fmask = __ballot(fv != 0) & ~dmask;
         const float rs_l = lv ? rs[rl] : 1.f;
         const float rsr_l = (lv && rs_rate) ? rs_rate[rl] : rs_l;
         float rs_new_l = rs_l;
         const int cnt = (int)min((int64_t)WAVE, nrows - g);
         for (int b0 = 0; b0 < cnt; b0 += VR) {
+            if (((dmask >> b0) & ((1ull << VR) - 1)) == ((1ull << VR) - 1)) continue;     // (all of them finished elsewhere)
             float4 sv[VR][VPL];
             // (wave-uniform row bases + a 32-bit lane offset: the loads take the scalar-base form, a row's address costs
             // no vector registers)
@@ -1533,7 +1706,7 @@ void svi_lazy_batch_side_kernel(int64_t nrows, const uint8_t *__restrict__ flag,
             const float4 *sp = reinterpret_cast<const float4 *>(shp) + ob;
 #pragma unroll
             for (int i = 0; i < VR; i++) {
-                const bool live = b0 + i < cnt;
+                const bool live = b0 + i < cnt && ((dmask >> (b0 + i)) & 1ull) == 0;
 #pragma unroll
                 for (int v = 0; v < VPL; v++) {
                     sv[i][v] = zero4;
@@ -1543,6 +1716,7 @@ void svi_lazy_batch_side_kernel(int64_t nrows, const uint8_t *__restrict__ flag,
 #pragma unroll
             for (int i = 0; i < VR; i++) {
                 if (b0 + i >= cnt) break;
+                if (((dmask >> (b0 + i)) & 1ull) != 0) continue;          // (wave-uniform)
                 const bool fl = ((fmask >> (b0 + i)) & 1ull) != 0;      // (wave-uniform)
                 const float rs_old = __shfl(rs_l, b0 + i);
                 const float base = top / __shfl(rsr_l, b0 + i);
@@ -1586,8 +1760,9 @@ void svi_lazy_batch_side_kernel(int64_t nrows, const uint8_t *__restrict__ flag,
                 __builtin_amdgcn_sched_barrier(0);      // (one row's divisions at a time: interleaved they cost 116 VGPRs)
             }
         }
-        if (lv && rs_prev_out) rs_prev_out[rl] = rsr_l;
-        if (lv && (rs_mode == 2 || (rs_mode == 1 && ((fmask >> lane) & 1ull) != 0))) rs[rl] = rs_new_l;
+        const bool mine = lv && ((dmask >> lane) & 1ull) == 0;      // (a finished row's scalars were written by its sweep)
+        if (mine && rs_prev_out) rs_prev_out[rl] = rsr_l;
+        if (mine && (rs_mode == 2 || (rs_mode == 1 && ((fmask >> lane) & 1ull) != 0))) rs[rl] = rs_new_l;
     }
 #pragma unroll
     for (int v = 0; v < VPL; v++) reinterpret_cast<float4 *>(&red[wid][0])[v * WAVE + lane] = acc4[v];
@@ -1773,8 +1948,9 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                     }
                 }
             }
-            if (lv && rs_prev_out) rs_prev_out[rl] = rsr_l;
-            if (lv && (rs_mode == 2 || (rs_mode == 1 && ((fmask >> lane) & 1ull) != 0))) rs[rl] = rs_new_l;
+            const bool mine = lv && ((dmask >> lane) & 1ull) == 0;  // (a finished row's scalars were written by its sweep)
+            if (mine && rs_prev_out) rs_prev_out[rl] = rsr_l;
+            if (mine && (rs_mode == 2 || (rs_mode == 1 && ((fmask >> lane) & 1ull) != 0))) rs[rl] = rs_new_l;
         }
 #pragma unroll
         for (int v = 0; v < VPL; v++)
@@ -2398,6 +2574,58 @@ int hpf_hip_sweep_svi_f32(const hpf_segment *segs, int64_t nseg, const int32_t *
     return last_error();
 }
 
+int hpf_hip_sweep_svi_batch_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y, float *e_self,
+                                const float *tab_other, float *part, float *shp, const float *rte_in, float *rte_out,
+                                float *fac, float *rs, float *rs_prev_out, const float *rate_rs, const float *rate_cs,
+                                float rate_top, const float *cs_other, float *cs_partial, float prior, float w_new,
+                                float w_old, float top, float add, float step, float step_prev, int k, int ld,
+                                int short_rows, int grid_blocks, const int64_t *nseg_dev, void *stream) {
+    if (!segs || !idx || !y || !e_self || !tab_other || !part || !shp || !rs || !cs_other || !cs_partial ||
+        (!rate_rs && !rte_in) || (rate_rs && !rate_cs) || nseg <= 0 || k <= 0 || ld != hpf_hip_ld_for_k(k) ||
+        grid_blocks <= 0)
+        return HPF_EINVAL;
+    // grid NOT clamped: every block writes its cs_partial row (zeros when it had no segment)
+    FinalizeArgs fa = {};
+    fa.cs_other = cs_other;
+    fa.cs_partial = cs_partial;
+    fa.e_new = e_self;
+    fa.shp = shp;
+    fa.rte = rte_out;
+    fa.fac = fac;
+    fa.rs = rs;
+    fa.rs_prev = rs_prev_out;
+    fa.prior_shp = prior;
+    fa.top_shp = top;
+    fa.add_rte = add;
+    fa.k = k;
+    fa.nseg_dev = nseg_dev;
+    fa.nq4 = sector_float4s(k);
+    fa.w_new = w_new;
+    fa.w_old = w_old;
+    fa.step = step;
+    fa.step_prev = step_prev;
+    fa.rate_rs = rate_rs;
+    fa.rate_cs = rate_cs;
+    fa.rte_in = rte_in;
+    fa.rate_top = rate_top;
+    const bool skip = fa.nq4 < ld / 4;
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int US = (HPF_U >= 8) ? HPF_U / 2 : HPF_U;
+#define LAUNCH(LPR, VPL, UU_, SKIP_)                                                                                      \
+    hipLaunchKernelGGL((sweep_kernel<LPR, VPL, 3, UU_, SKIP_>), dim3(grid_blocks), dim3(BLOCK), 0, st, segs, nseg, idx, y, \
+                       (const float *)e_self, tab_other, part, fa)
+#define CALL(LPR, VPL)                                                                                              \
+    if (short_rows) {                                                                                               \
+        if (skip) LAUNCH(LPR, VPL, US, true); else LAUNCH(LPR, VPL, US, false);                                     \
+    } else {                                                                                                        \
+        if (skip) LAUNCH(LPR, VPL, HPF_U, true); else LAUNCH(LPR, VPL, HPF_U, false);                               \
+    }
+    HPF_DISPATCH_LD(ld, CALL)
+#undef CALL
+#undef LAUNCH
+    return last_error();
+}
+
 int hpf_hip_row_finalize_f32(const float *part, const int64_t *row_seg_ptr, const int64_t *row_list, int64_t nrows,
                              const float *e_old, float *e_new, float *shp, float *rte, float *fac, float *rs,
                              float *rs_prev, const float *cs_other, float *cs_partial, float prior_shp, float top_shp,
@@ -2670,18 +2898,18 @@ int hpf_hip_svi_side_f32(int64_t nrows, const uint8_t *flag, const float *acc, c
     if (!shp || !rs || !cs_other || !cs_partial || (flag && (!acc || !e)) || nrows <= 0 || k <= 0 ||
         ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0 || (rate_mode != 0 && rate_mode != 1) || rs_mode < 0 ||
         rs_mode > 2 || (rate_mode == 1 && !rte) || (e_out && !flag) || done_flag < 0 || done_flag > 255 ||
-        (done_flag != 0 && (!flag || rs_mode == 2 || rs_rate || rs_prev_out)))
+        (done_flag != 0 && (!flag || rs_rate)))
         return HPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     // grid not clamped: every block writes its cs_partial row
-    if (ld >= 256 && rate_mode == 0 && !rte && !fac && !e_out && done_flag == 0) {
+    if (ld >= 256 && rate_mode == 0 && !rte && !fac && !e_out) {
         // the batch side of a lazy epoch step: the streaming kernel of its own (same statements, same floats)
         switch (ld) {
 #define CALLB(LD)                                                                                                      \
     case LD:                                                                                                           \
         hipLaunchKernelGGL((svi_lazy_batch_side_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, nrows, flag, acc, \
                            e, shp, rs, cs_other, cs_partial, prior, w_new, w_old, top, add, step, step_prev, rs_mode, \
-                           k, rs_rate, rs_prev_out);                                                                   \
+                           k, rs_rate, rs_prev_out, done_flag);                                                        \
         break;
             CALLB(256)
             CALLB(512)

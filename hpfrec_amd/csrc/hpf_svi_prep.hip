@@ -86,9 +86,13 @@ __device__ __forceinline__ void tiles_before(const long long *__restrict__ tiles
 
 // (1) flags of the batch's rows: the previous batch that used this workspace is unmarked, the new one marked; a batch row
 // without any nonzero gets its accumulator row zeroed (the dense step reads acc[row] of every flagged row)
+// (flag values: 1 = the row is present in exactly one segment -- the batch-side sweep finishes it itself, hpf_hip_sweep_svi_batch_f32;
+//  2 = a split row or a row without nonzeros: finished by the whole-table pass; every consumer that only asks "is the row in
+//  the batch" tests flag != 0)
 __global__ __launch_bounds__(BLOCK) void svi_mark_kernel(const int64_t *__restrict__ prev_ids, int64_t nprev,
                                                          const int64_t *__restrict__ ids, int64_t nids,
                                                          uint8_t *__restrict__ flag, const int64_t *__restrict__ indptr,
+                                                         const int64_t *__restrict__ row_seg_ptr,
                                                          float *__restrict__ acc, int ld, int phase) {
     const int64_t stride = (int64_t)gridDim.x * BLOCK;
     if (phase == 0) {
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(BLOCK) void svi_mark_kernel(const int64_t *__restri
     }
     for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < nids; t += stride) {
         const int64_t r = ids[t];
-        flag[r] = 1;
+        flag[r] = (row_seg_ptr[r + 1] - row_seg_ptr[r] == 1) ? 1 : 2;
         if (indptr[r + 1] == indptr[r]) {           // (ld is a multiple of 32 and rows are 128-byte aligned)
             float4 *row = reinterpret_cast<float4 *>(acc + (size_t)r * ld);
             for (int c = 0; c < ld / 4; c++) row[c] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -494,13 +498,14 @@ constexpr int ETILES = 256;           // scan tiles per batch of the row / segme
 // (E0) the epoch's order -> batch of every row, the batch's row flags, zeroed accumulator rows of rows without nonzeros
 __global__ __launch_bounds__(BLOCK) void svi_epoch_mark_kernel(const int64_t *__restrict__ order, int64_t nrows, int64_t per,
                                                                uint8_t *__restrict__ batch_of, uint8_t *__restrict__ flag,
-                                                               const int64_t *__restrict__ indptr, float *__restrict__ acc,
+                                                               const int64_t *__restrict__ indptr,
+                                                               const int64_t *__restrict__ row_seg_ptr, float *__restrict__ acc,
                                                                int ld) {
     const int64_t stride = (int64_t)gridDim.x * BLOCK;
     for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < nrows; t += stride) {
         const int64_t r = order[t], b = t / per;
         batch_of[r] = (uint8_t)b;
-        flag[(size_t)b * nrows + r] = 1;
+        flag[(size_t)b * nrows + r] = (row_seg_ptr[r + 1] - row_seg_ptr[r] == 1) ? 1 : 2;      // (see svi_mark_kernel)
         if (indptr[r + 1] == indptr[r]) {
             float4 *row = reinterpret_cast<float4 *>(acc + (size_t)r * ld);
             for (int c = 0; c < ld / 4; c++) row[c] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -729,10 +734,10 @@ int hpf_hip_svi_batch_prepare(const hpf_svi_batch *b, void *stream) {
     if (e != hipSuccess) return (int)e;
     if (b->nprev > 0)
         hipLaunchKernelGGL(svi_mark_kernel, dim3(grid_for(b->nprev, BLOCK)), dim3(BLOCK), 0, st, b->prev_ids, b->nprev,
-                           b->ids, b->nids, b->flag_own, b->own_indptr, b->acc_own, b->ld, 0);
+                           b->ids, b->nids, b->flag_own, b->own_indptr, b->own_row_seg_ptr, b->acc_own, b->ld, 0);
     if (b->nids > 0)
         hipLaunchKernelGGL(svi_mark_kernel, dim3(grid_for(b->nids, BLOCK)), dim3(BLOCK), 0, st, b->prev_ids, b->nprev,
-                           b->ids, b->nids, b->flag_own, b->own_indptr, b->acc_own, b->ld, 1);
+                           b->ids, b->nids, b->flag_own, b->own_indptr, b->own_row_seg_ptr, b->acc_own, b->ld, 1);
     long long *tiles_own = (long long *)b->tiles, *tiles_oth = (long long *)b->tiles + TILES * 4;   // [2 | 3 | 1 per tile]
     hipLaunchKernelGGL(svi_own_count_kernel<false>, dim3(TILES), dim3(BLOCK), 0, st, b->own_segs, b->own_nseg, b->flag_own,
                        tiles_own);
@@ -805,7 +810,7 @@ int hpf_hip_svi_epoch_prepare(const hpf_svi_epoch *b, void *stream) {
     hipError_t e = hipMemsetAsync(b->flag_own, 0, (size_t)nb * b->own_nrows, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(svi_epoch_mark_kernel, dim3(grid_for(b->own_nrows, BLOCK)), dim3(BLOCK), 0, st, b->order, b->own_nrows,
-                       b->per, b->batch_of, b->flag_own, b->own_indptr, b->acc_own, b->ld);
+                       b->per, b->batch_of, b->flag_own, b->own_indptr, b->own_row_seg_ptr, b->acc_own, b->ld);
     long long *tiles_own = (long long *)b->tiles, *tiles_oth = tiles_own + (size_t)nb * ETILES * 2,
               *groups = tiles_oth + (size_t)nb * ETILES * 3;
     hipLaunchKernelGGL(svi_own_count_kernel<true>, dim3(ETILES, nb), dim3(BLOCK), 0, st, b->own_segs, b->own_nseg,

@@ -348,6 +348,19 @@ class HipOps:
                                                 short, cs_partial.shape[0], _ptr(getattr(side, "nseg_dev", None)),
                                                 self._stream()), "hpf_hip_sweep_svi_f32")
 
+    def sweep_svi_batch(self, side, e_self, tab_other, part, shp, rte_in, rte_out, fac, rs, rs_prev_out, factored, cs_other,
+                        cs_partial, prior, w_new, w_old, top, add, step, step_prev, k, ld):
+        """The sweep over a batch's OWN rows with both ends of a row's step fused in (hpf_hip_sweep_svi_batch_f32): the E
+        row is formed in the prologue (factored = (rs, cs, top) of a rank-1 rate, or None: the table rte_in) and written to
+        e_self; rows present in one segment are finished in the epilogue; cs_partial: one row per block."""
+        r_rs, r_cs, r_top = factored if factored is not None else (None, None, 0.0)
+        _lib.check(self.L.hpf_hip_sweep_svi_batch_f32(
+            _ptr(side.segs), side.nseg, _ptr(side.idx), _ptr(side.y), _ptr(e_self), _ptr(tab_other), _ptr(part), _ptr(shp),
+            _ptr(rte_in), _ptr(rte_out), _ptr(fac), _ptr(rs), _ptr(rs_prev_out), _ptr(r_rs), _ptr(r_cs), float(r_top),
+            _ptr(cs_other), _ptr(cs_partial), float(prior), float(w_new), float(w_old), float(top), float(add), float(step),
+            float(step_prev), k, ld, int(getattr(side, "short_rows", 0)), cs_partial.shape[0],
+            _ptr(getattr(side, "nseg_dev", None)), self._stream()), "hpf_hip_sweep_svi_batch_f32")
+
     def svi_rate_rows(self, row_list, rte, fac, rs, cs_other, top, add, step, step_prev, mode, k, ld):
         _lib.check(self.L.hpf_hip_svi_rate_rows_f32(_ptr(row_list), int(row_list.shape[0]), _ptr(rte), _ptr(fac),
                                                     _ptr(rs), _ptr(cs_other), float(top), float(add), float(step),

@@ -440,23 +440,46 @@ def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_
     # neither E table, and the other side's rows are rewritten by the very wavefront that has just used them.
     fused = (isinstance(s_oth, DevSide) and not all_scalar_rows and s_oth.nseg > 0
              and os.environ.get("HPF_SVI_FUSED", "1") == "1")
-    m.batch_phi_sums(su, si, flag_u, flag_i, e_current, sides=(bw,) if fused else ("u", "i"))   # phi from the OLD parameters
+    # The batch side's step FUSED into ITS sweep as well (hpf_hip_sweep_svi_batch_f32): the wavefront that sweeps a batch row
+    # forms the row's E row first (from its current shape and rate: no expectation launch, no read-back of the E row) and,
+    # for a row present in one segment, finishes the row -- shape, rate, mean, scalar rate, column-sum share -- while it holds
+    # the phi-sum.  Its rate uses the OTHER side's column sums from before the step (PXI:300 / 352): nothing it needs is
+    # produced by the step itself.  The whole-table pass then covers split rows, rows without nonzeros and every row outside
+    # the batch (the reference recomputes the batch side's rates and means for ALL rows, PXI:300,318 / 352,370).
+    s_bat = su if user_batch else si             # the batch grouped by its own side's rows
+    fused_b = (isinstance(s_bat, DevSide) and s_bat.nseg > 0 and os.environ.get("HPF_SVI_FUSED_BATCH", "1") == "1")
+    if fused_b:       # (only the other side's E rows are brought up to date here: the batch side's come out of its sweep)
+        m.batch_phi_sums(su, si, flag_u, flag_i, tuple(e_current) + (bw,), sides=())
+    else:
+        m.batch_phi_sums(su, si, flag_u, flag_i, e_current, sides=(bw,) if fused else ("u", "i"))   # phi from the OLD parameters
     # SVI epochs blend the scalar rates of the step's rows only (PXI:324-325, 376-377), partial_fit of all (PXI:472-473)
     rs_mode = 2 if all_scalar_rows else 1
     # One pass per side (hpf_hip_svi_side_f32).  Batch side: shapes of its rows reset to prior + phi, the rate of
     # EVERY row from the other side's current column sums, means, scalar rates, column sums ...
     cs_for_batch = getattr(m, O["cs"])
+    cs_part_b, done_b = m._cs_part, 0
+    if fused_b:
+        blocks, tail = ops.sweep_blocks, m._cs_part.shape[0]
+        cs_fused = m.fused_cs_part(blocks, tail)
+        part = m._part_scratch(s_bat.nseg)
+        ops.sweep_svi_batch(s_bat, B["e"], O["e"], part, B["shp"], B["rte"], None if lazy else B["rte"],
+                            None if lazy else B["fac"], B["rs"], m._rs_prev[bw] if lazy else None, m.factored[bw],
+                            cs_for_batch, cs_fused[:blocks], B["prior"], 1.0, 0.0, B["top"], B["add"], step, step_prev, k, ld)
+        ops.segsum_desc(part, s_bat.multi, s_bat.nmulti_dev, s_bat.multi_cap, B["acc"], ld)
+        if not fused:         # the other side's phi-sums, from the E rows the sweep above has just written (OLD parameters)
+            m.batch_phi_sums(su, si, flag_u, flag_i, ("u", "i"), sides=(ow,))
+        cs_part_b, done_b = cs_fused[blocks:], 1
     if lazy:
         ops.svi_side(B["n"], B["flag"], B["acc"], B["e"], B["shp"], None, None, B["rs"], cs_for_batch,
-                     m._cs_part, B["prior"], 1.0, 0.0, B["top"], B["add"], step, step_prev, 0, rs_mode, k, ld,
-                     rs_prev_out=m._rs_prev[bw])
+                     cs_part_b, B["prior"], 1.0, 0.0, B["top"], B["add"], step, step_prev, 0, rs_mode, k, ld,
+                     rs_prev_out=m._rs_prev[bw], done_flag=done_b)
         m.factored[bw] = (m._rs_prev[bw], cs_for_batch, B["top"])
         m.means_stale[bw] = m.means_stale[ow] = True
     else:
         ops.svi_side(B["n"], B["flag"], B["acc"], B["e"], B["shp"], B["rte"], B["fac"], B["rs"], cs_for_batch,
-                     m._cs_part, B["prior"], 1.0, 0.0, B["top"], B["add"], step, step_prev, 0, rs_mode, k, ld)
+                     cs_part_b, B["prior"], 1.0, 0.0, B["top"], B["add"], step, step_prev, 0, rs_mode, k, ld, done_flag=done_b)
     cs_batch = torch.empty(ld, dtype=torch.float32, device=ops.device)      # (the reduction writes every column)
-    ops.colsum_reduce(m._cs_part, cs_batch, ld)
+    ops.colsum_reduce(cs_fused if fused_b else m._cs_part, cs_batch, ld)
     setattr(m, B["cs"], cs_batch)
     # ... other side: shapes and rates of the touched rows blended towards the step's estimate (the rates with the
     # batch side's NEW column sums), means of every row, scalar rates, column sums
@@ -774,6 +797,11 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
                             break
                         last_crit = errs[0]
 
+    if prep_stream is not None:
+        # an epoch planned ahead of a stop at this epoch's check (its order upload and hpf_hip_svi_epoch_prepare) may still be
+        # running on the preparation stream: the compute stream joins it before anything below reads the workspaces' sizes
+        # or the caching allocator can hand their buffers (allocated on the compute stream's pool) to somebody else
+        torch.cuda.current_stream(dev).wait_stream(prep_stream)
     if any(ws.overflowed() for ws in workspaces.values()):        # (cannot happen: capacities come from the largest rows)
         raise _lib.HpfHipError("hpfrec_amd: a stochastic batch outgrew its workspace")
     tick("epochs and checks")

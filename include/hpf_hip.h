@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HPF_HIP_ABI_VERSION 23
+#define HPF_HIP_ABI_VERSION 24
 
 #define HPF_EINVAL (-1)  /* bad argument (null pointer, k<=0, ld mismatch ...) */
 #define HPF_EUNSUPPORTED (-2) /* k larger than the kernels are instantiated for */
@@ -286,6 +286,32 @@ int hpf_hip_sweep_svi_f32(const hpf_segment *segs, int64_t nseg, const int32_t *
 int hpf_hip_svi_rate_rows_f32(const int64_t *row_list, int64_t nrows, float *rte, const float *fac, float *rs,
                               const float *cs_other, float top, float add, float step, float step_prev, int mode,
                               int k, int ld, void *stream);
+
+/*
+ * The BATCH side of a stochastic step in the sweep that forms its phi-sums (PXI:292-314,324 for a user batch, 344-366,377 for
+ * an item batch; partial_fit PXI:438-457,472-473).  hpf_hip_sweep_svi_batch_f32 = for every segment of the batch's rows
+ *   prologue:  the row's E row exp(psi(shp[row]))/rate[row], row-scaled (hpf_hip_expect_f32's statements: the psi/log/exp
+ *              of update_phi_csr, PXI:683-692, hoisted to the row), from the row's CURRENT shape and rate -- the rate either
+ *              factored, rate_top / rate_rs[row] + rate_cs[c] (rate_rs != NULL), or the stored table rte_in -- written to
+ *              e_self[row] (the other side's sweep of the same step gathers it) and kept in registers;
+ *   sweep:     hpf_hip_sweep_f32's loop over the segment's nonzeros (gathers from tab_other);
+ *   epilogue (HPF_SEG_WHOLE_ROW segments): the flagged-row statements of hpf_hip_svi_side_f32 with rate_mode 0 --
+ *              shp = w_new*(prior + E (*) phi-sum), rate = top/rs[row] + cs_other (stored to rte_out / the mean to fac
+ *              when those are given), rs[row] = step*(add + sum_k mean) + step_prev*rs[row], rs_prev_out[row] (optional) =
+ *              the scalar the rate was formed with, cs_partial[grid_blocks][ld] = per-block column sums of the means of
+ *              the rows finished here (all blocks write theirs).
+ * Split rows write part[] as in hpf_hip_sweep_f32 and are finished, with every row outside the batch, by a
+ * hpf_hip_svi_side_f32 call with done_flag = the flag value of whole rows (the batch preparations write 1 for a batch row
+ * present in one segment, 2 for a split row or a row without nonzeros); the two calls' partial column sums add up to the
+ * side's (PXI:318 / 370).  Same float32 statements through the same device functions as the separate passes.
+ * rate_rs may alias rs_prev_out and rte_in may alias rte_out (a row is read in its prologue, written in its epilogue).
+ */
+int hpf_hip_sweep_svi_batch_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y, float *e_self,
+                                const float *tab_other, float *part, float *shp, const float *rte_in, float *rte_out,
+                                float *fac, float *rs, float *rs_prev_out, const float *rate_rs, const float *rate_cs,
+                                float rate_top, const float *cs_other, float *cs_partial, float prior, float w_new,
+                                float w_old, float top, float add, float step, float step_prev, int k, int ld,
+                                int short_rows, int grid_blocks, const int64_t *nseg_dev, void *stream);
 
 /*
  * calc_user_factors (PXI:476-520): the local coordinate ascent of ONE user against fixed item parameters, looping on

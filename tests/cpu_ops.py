@@ -357,7 +357,8 @@ class CpuOps:
         if ws.prev_ids is not None:
             flag[_np(ws.prev_ids)] = 0
         ids = _np(ws.ids)
-        flag[ids] = 1
+        rsp_own = _np(own.row_seg_ptr)
+        flag[ids] = np.where(rsp_own[ids + 1] - rsp_own[ids] == 1, 1, 2)      # 2: a split row or a row without nonzeros
         ptr = _np(own.indptr)
         empty = ids[ptr[ids + 1] == ptr[ids]]
         _np(ws.acc_own)[empty] = 0
@@ -390,7 +391,8 @@ class CpuOps:
         for b in range(nb):
             ids = order[b * per: min(own.nrows, (b + 1) * per)]
             flag = _np(ws.flag_own)[b]
-            flag[ids] = 1
+            rsp_own = _np(own.row_seg_ptr)
+            flag[ids] = np.where(rsp_own[ids + 1] - rsp_own[ids] == 1, 1, 2)
             _np(ws.batch_of)[ids] = b
             kept, bm, o_idx, o_y, present, osegs, om, nrows_present = self._batch_structures(own, oth, cap, flag)
             assert kept.shape[0] <= ws.b_cap and osegs.shape[0] <= ws.o_segs_cap
@@ -508,6 +510,38 @@ class CpuOps:
         if e_new is not None:
             e_new[rows] = e_s
 
+    def sweep_svi_batch(self, side, e_self, tab_other, part, shp, rte_in, rte_out, fac, rs, rs_prev_out, factored, cs_other,
+                        cs_partial, prior, w_new, w_old, top, add, step, step_prev, k, ld):
+        """hpf_hip_sweep_svi_batch_f32: expect over the rows that have a segment (prologue), the plain sweep, then the
+        flagged-row statements of svi_side (rate_mode 0, rs_mode 1) for the rows present in ONE segment, on a compacted
+        copy of their rows (so that only they enter the column sums)."""
+        nseg = _live_nseg(side)
+        _np(cs_partial)[:] = 0
+        if nseg == 0:
+            return
+        begin, length, row = _decode_segs(side)
+        rows_all = torch.from_numpy(np.unique(row).astype(np.int64))
+        self.expect(shp, rte_in, e_self, int(rows_all.shape[0]), k, ld, row_list=rows_all, factored=factored)
+        acc = torch.zeros_like(shp)
+        self.sweep(side, e_self, tab_other, part, k, ld, acc_rows=acc, acc_ld=ld)
+        whole = (_np(side.segs)[:nseg, 1] & 0x40000000) != 0
+        rows = torch.from_numpy(np.sort(row[whole]).astype(np.int64))
+        if rows.shape[0] == 0:
+            return
+        sub = {n: t[rows].clone() for n, t in (("acc", acc), ("e", e_self), ("shp", shp), ("rs", rs))}
+        rte_s, fac_s = torch.zeros_like(sub["shp"]), torch.zeros_like(sub["shp"])
+        rsp_s = torch.zeros(rows.shape[0], dtype=torch.float32)
+        ones = torch.ones(rows.shape[0], dtype=torch.uint8)
+        self.svi_side(rows.shape[0], ones, sub["acc"], sub["e"], sub["shp"], rte_s, fac_s, sub["rs"], cs_other, cs_partial,
+                      prior, w_new, w_old, top, add, step, step_prev, 0, 1, k, ld, rs_prev_out=rsp_s)
+        shp[rows], rs[rows] = sub["shp"], sub["rs"]
+        if rte_out is not None:
+            rte_out[rows] = rte_s
+        if fac is not None:
+            fac[rows] = fac_s
+        if rs_prev_out is not None:
+            rs_prev_out[rows] = rsp_s
+
     def svi_side(self, nrows, flag, acc, e, shp, rte, fac, rs, cs_other, cs_partial, prior, w_new, w_old, top, add, step,
                  step_prev, rate_mode, rs_mode, k, ld, rs_rate=None, rs_prev_out=None, e_out=None, done_flag=0):
         """hpf_hip_svi_side_f32 = the separate stand-in statements in the reference's order.  rte / fac None: computed
@@ -515,22 +549,28 @@ class CpuOps:
         flagged rows' new E rows (= expect over them afterwards); done_flag: rows whose flag equals it are left out
         altogether (the pass runs on a compacted copy of the others)."""
         if done_flag:
-            assert flag is not None and rs_mode != 2 and rs_rate is None and rs_prev_out is None and rate_mode == 1
+            assert flag is not None and rs_rate is None
             rows = torch.nonzero(flag[:nrows] != done_flag).reshape(-1)
             _np(cs_partial)[:] = 0
             if rows.shape[0] == 0:
                 return
-            sub = {n: t[rows].clone() for n, t in (("acc", acc), ("e", e), ("shp", shp), ("rte", rte), ("rs", rs))}
+            sub = {n: t[rows].clone() for n, t in (("acc", acc), ("e", e), ("shp", shp), ("rs", rs))}
+            rte_s = rte[rows].clone() if rte is not None else None
             fac_s = torch.zeros_like(sub["shp"])
             e_s = sub["e"].clone() if e_out is not None else None
-            self.svi_side(rows.shape[0], (flag[rows] != 0).to(torch.uint8), sub["acc"], sub["e"], sub["shp"], sub["rte"],
+            rsp_s = torch.zeros(rows.shape[0], dtype=torch.float32) if rs_prev_out is not None else None
+            self.svi_side(rows.shape[0], (flag[rows] != 0).to(torch.uint8), sub["acc"], sub["e"], sub["shp"], rte_s,
                           fac_s, sub["rs"], cs_other, cs_partial, prior, w_new, w_old, top, add, step, step_prev, rate_mode,
-                          rs_mode, k, ld, e_out=e_s)
-            shp[rows], rte[rows], rs[rows] = sub["shp"], sub["rte"], sub["rs"]
+                          rs_mode, k, ld, rs_prev_out=rsp_s, e_out=e_s)
+            shp[rows], rs[rows] = sub["shp"], sub["rs"]
+            if rte is not None:
+                rte[rows] = rte_s
             if fac is not None:
                 fac[rows] = fac_s
             if e_out is not None:
                 e_out[rows] = e_s
+            if rs_prev_out is not None:
+                rs_prev_out[rows] = rsp_s
             return
         rows = torch.nonzero(flag[:nrows] != 0).reshape(-1) if flag is not None else torch.empty(0, dtype=torch.int64)
         self.svi_shape_rows(rows, acc, e, shp, prior, w_new, w_old, k, ld, acc_by_row=True)

@@ -903,6 +903,87 @@ def test_sweep_svi_op_row_for_row(ops, k, with_e, with_fac):
     assert float((got["shp"][~untouched][:, :k] - shp0[~untouched][:, :k]).abs().max()) > 0
 
 
+@pytest.mark.parametrize("k", [7, 50, 100, 200, 256, 300, 600, 1024])
+@pytest.mark.parametrize("factored,stored,rs_mode", [(True, False, 1), (False, True, 1), (False, False, 2), (True, True, 2)])
+def test_sweep_svi_batch_op_row_for_row(ops, k, factored, stored, rs_mode):
+    """hpf_hip_sweep_svi_batch_f32 (the BATCH side's stochastic step at both ends of its sweep: the E row formed in the
+    prologue, rows present in one segment finished in the epilogue) + the whole-table pass that skips the rows it finished
+    (done_flag) against the separate form -- expectation pass over the batch's rows, plain sweep, whole-table pass over
+    everything: shapes, E rows, the stored rates and means, the scalars the rates were formed with EQUAL; a row's scalar
+    rate and the column sums equal to summation order.  Factored and stored rates in the prologue, stored and lazy tables,
+    scalar rates of the batch's rows / of all rows blended, rows present in one segment, hub rows cut into several, batch
+    rows without nonzeros, rows outside the batch; every row width (ld = 32 ... 1024)."""
+    from hpfrec_amd import svi
+    rs = np.random.RandomState(13 * k + 2 * factored + stored)
+    ld = _lib.ld_for_k(k)
+    n_self, n_oth, nnz, cap = 500, 300, 6000, 24
+    r_ix = np.minimum((n_self * rs.random_sample(nnz) ** 3.0).astype(np.int64), n_self - 40)      # hubs; the last rows untouched
+    c_ix = rs.randint(0, n_oth, nnz).astype(np.int64)
+    yv = (1 + rs.poisson(1.0, size=nnz)).astype(np.float32)
+    dev = "cuda"
+    side = svi.BatchSide(torch.from_numpy(r_ix).to(dev), torch.from_numpy(c_ix).to(dev), torch.from_numpy(yv).to(dev),
+                         seg_cap=cap)
+    assert side.nmulti > 0 and side.nrows < n_self
+    flag = torch.zeros(n_self, dtype=torch.uint8, device=dev)
+    flag[side.rows] = 1
+    flag[side.rows[side.multi_local]] = 2
+    flag[n_self - 30: n_self - 20] = 2           # batch rows without any nonzero
+    shp0 = _rand_tables(rs, n_self, k, ld) + 0.3
+    rte0 = _rand_tables(rs, n_self, k, ld) + 0.5
+    shp0[:, k:] = 0
+    rte0[:, k:] = 0
+    e_oth = (_rand_tables(rs, n_oth, k, ld)).to(dev)
+    rs0 = torch.from_numpy(rs.uniform(0.5, 20, size=n_self).astype(np.float32))
+    rs_rate0 = torch.from_numpy(rs.uniform(0.5, 20, size=n_self).astype(np.float32))
+    cs = torch.zeros(ld)
+    cs[:k] = torch.from_numpy(rs.uniform(3, 30, size=k).astype(np.float32))
+    cs = cs.to(dev)
+    cs_used = torch.zeros(ld)
+    cs_used[:k] = torch.from_numpy(rs.uniform(3, 30, size=k).astype(np.float32))
+    cs_used = cs_used.to(dev)
+    top = 15.3
+    hyper = (0.3, 1.0, 0.0, top, 0.3, 0.45, 0.55)      # prior, w_new, w_old, top, add, step, step_prev
+
+    def run(fused):
+        T = dict(shp=shp0.clone().to(dev), rte=rte0.clone().to(dev), e=torch.zeros((n_self, ld), device=dev),
+                 rsc=rs0.clone().to(dev), fac=torch.zeros((n_self, ld), device=dev), prev=rs_rate0.clone().to(dev))
+        fr = (T["prev"], cs_used, top) if factored else None
+        acc = torch.zeros((n_self, ld), device=dev)
+        part = torch.zeros((side.nseg, ld), device=dev)
+        rte_out, fac = (T["rte"], T["fac"]) if stored else (None, None)
+        blocks, tail = 64, ops.refresh_grid(n_self)
+        csp = torch.zeros((blocks + tail, ld), device=dev)
+        if fused:
+            ops.sweep_svi_batch(side, T["e"], e_oth, part, T["shp"], T["rte"], rte_out, fac, T["rsc"], T["prev"], fr, cs,
+                                csp[:blocks], *hyper, k, ld)
+        else:
+            ops.expect(T["shp"], T["rte"], T["e"], n_self, k, ld, flag=flag, factored=fr)
+            ops.sweep(side, T["e"], e_oth, part, k, ld, acc_rows=acc, acc_ld=ld)
+        tmp = torch.zeros((side.nmulti, ld), device=dev)
+        ops.segsum(part, side.row_seg_ptr, side.nmulti, tmp, ld, row_list=side.multi_local)
+        acc.index_copy_(0, side.rows[side.multi_local], tmp)
+        ops.svi_side(n_self, flag, acc, T["e"], T["shp"], rte_out, fac, T["rsc"], cs, csp[blocks:], *hyper, 0, rs_mode, k, ld,
+                     rs_prev_out=T["prev"], done_flag=1 if fused else 0)
+        cso = torch.zeros(ld, device=dev)
+        ops.colsum_reduce(csp, cso, ld)
+        torch.cuda.synchronize()
+        return {a: v.cpu() for a, v in T.items()}, cso.cpu()
+
+    (got, g), (want, w) = run(True), run(False)
+    swept = torch.zeros(n_self, dtype=torch.bool)
+    swept[side.rows.cpu()] = True
+    assert torch.equal(got["e"][swept], want["e"][swept]), (k, float((got["e"] - want["e"])[swept].abs().max()))
+    for name in ("shp", "prev") + (("rte", "fac") if stored else ()):
+        assert torch.equal(got[name], want[name]), (k, name, float((got[name] - want[name]).abs().max()))
+    assert float(((got["rsc"] - want["rsc"]).abs() / want["rsc"].abs()).max()) < 1e-6
+    assert float(((g - w).abs() / w.abs().clamp_min(1e-30))[:k].max()) < 2e-6
+    untouched = (flag == 0).cpu()
+    assert torch.equal(got["shp"][untouched], shp0[untouched])
+    if rs_mode == 1:
+        assert torch.equal(got["rsc"][untouched], rs0[untouched])
+    assert float((got["shp"][~untouched][:, :k] - shp0[~untouched][:, :k]).abs().max()) > 0
+
+
 @pytest.mark.parametrize("k", [200, 256, 300, 600, 1024])
 @pytest.mark.parametrize("rs_mode,w,flagged", [(1, (1.0, 0.0), 0.07), (2, (1.0, 0.0), 0.5), (1, (0.35, 0.55), 1.0),
                                                (1, (1.0, 0.0), None)])

@@ -74,8 +74,16 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     side = lambda flag, rs_mode, done: L.hpf_hip_svi_side_f32(4, flag, p, p, p, p, None, p, p, p, *w, 1, rs_mode, 50, 64, 2, None,  # noqa: E731
                                                               None, None, done, None)
     assert side(None, 1, 1) == EINVAL            # done_flag without flags
-    assert side(p, 2, 1) == EINVAL               # done_flag with every row's scalar rate blended
     assert side(p, 1, 300) == EINVAL
+    assert L.hpf_hip_svi_side_f32(4, p, p, p, p, p, None, p, p, p, *w, 1, 1, 50, 64, 2, p, None, None, 1, None) == EINVAL  # done_flag + rs_rate
+    # round 6: the sweep with the BATCH side's stochastic step fused in
+    L.hpf_hip_sweep_svi_batch_f32.argtypes = [vp, i64] + [vp] * 13 + [cf, vp, vp] + [cf] * 7 + [ci] * 4 + [vp, vp]
+    bat = lambda segs, rte_in, rate_rs, rate_cs, ld: L.hpf_hip_sweep_svi_batch_f32(      # noqa: E731
+        segs, 5, p, p, p, p, p, p, rte_in, None, None, p, None, rate_rs, rate_cs, 15.3, p, p, *w, 50, ld, 0, 8, None, None)
+    assert bat(None, p, None, None, 64) == EINVAL         # no segments
+    assert bat(p, None, None, None, 64) == EINVAL         # neither a factored rate nor a rate table for the prologue
+    assert bat(p, None, p, None, 64) == EINVAL            # factored rate without its column sums
+    assert bat(p, p, None, None, 128) == EINVAL           # ld is not ld(k)
 
 
 def test_integration_doc_stub_matches_the_abi():

@@ -243,7 +243,7 @@ def test_batch_workspace_equals_the_tensor_library_structures(any_backend, case)
             assert (sz[1], sz[3]) == (want_own.nmulti, want_oth.nmulti)
             # flags
             f = np.zeros(n_rows, np.uint8)
-            f[ids] = 1
+            f[ids] = np.where((deg[ids] > 0) & (deg[ids] <= cap), 1, 2)      # (2: a split row or a row without nonzeros)
             assert np.array_equal(ws.flag_own.cpu().numpy(), f)
             fo = np.zeros(other.nrows, np.uint8)
             wrsp = want_oth.row_seg_ptr.cpu().numpy()
@@ -419,6 +419,36 @@ def test_other_side_fused_into_its_sweep_equals_the_separate_pass(any_backend, m
     out = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("HPF_SVI_FUSED", mode)
+        m = HPF(k=12, maxiter=5, random_seed=7, ncores=1, reindex=False, verbose=True, check_every=2,
+                stop_crit="maxiter", **kw)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m.fit(df.copy())
+        out[mode] = {n: np.array(getattr(m, n)) for n in NAMES}
+        out[mode]["llk"] = np.float64(m.train_llk)
+    for n in out["1"]:
+        assert np.isfinite(out["1"][n]).all()
+        assert _maxrel(out["1"][n], out["0"][n]) < 2e-5, (n, _maxrel(out["1"][n], out["0"][n]))
+
+
+@pytest.mark.parametrize("kw", [dict(users_per_batch=20, items_per_batch=25), dict(users_per_batch=30),
+                                dict(items_per_batch=40)])
+@pytest.mark.parametrize("lazy,fused_other", [("1", "1"), ("0", "1"), ("1", "0")])
+def test_batch_side_fused_into_its_sweep_equals_the_separate_passes(any_backend, monkeypatch, kw, lazy, fused_other):
+    """The batch side's statements of an epoch step run at both ends of ITS sweep (hpf_hip_sweep_svi_batch_f32: the E row in
+    the prologue, rows present in one segment finished in the epilogue) + a whole-table pass that skips those rows;
+    HPF_SVI_FUSED_BATCH=0 runs the expectation pass, the plain sweep and the whole-table pass over everything.  Same
+    statements row by row; only the order in which the rows' means enter the column sums differs, so the fits agree to
+    float32 summation noise -- lazy and stored forms, with the other side fused or not, all epoch kinds, rows cut into
+    several segments on both sides."""
+    df, nU, nI = datagen.readme_counts()
+    monkeypatch.setenv("HPF_SVI_LAZY", lazy)
+    monkeypatch.setenv("HPF_SVI_FUSED", fused_other)
+    from hpfrec_amd import layout
+    monkeypatch.setattr(layout, "SEG_CAP", 8)       # (rows cut into several segments on both sides)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HPF_SVI_FUSED_BATCH", mode)
         m = HPF(k=12, maxiter=5, random_seed=7, ncores=1, reindex=False, verbose=True, check_every=2,
                 stop_crit="maxiter", **kw)
         with warnings.catch_warnings():
