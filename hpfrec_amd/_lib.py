@@ -111,7 +111,7 @@ def lib():
     L.hpf_hip_shard_trace.argtypes = [vp, vp, i64, ctypes.POINTER(i64)]
     L.hpf_hip_colsum_reduce_f32.argtypes = [vp, ci, vp, ci, vp]
     L.hpf_hip_colsum_f32.argtypes = [vp, i64, ci, vp, ci, vp]
-    L.hpf_hip_expect_f32.argtypes = [vp, vp, vp, vp, vp, i64, ci, ci, vp, vp, cf, vp]
+    L.hpf_hip_expect_f32.argtypes = [vp, vp, vp, vp, vp, i64, ci, ci, vp, vp, cf, vp, vp]
     L.hpf_hip_colsum_sequential_f32.argtypes = [vp, i64, ci, vp, vp]
     L.hpf_hip_segsum_f32.argtypes = [vp, vp, vp, i64, vp, ci, ci, ci, vp]
     L.hpf_hip_pair_llk_f32.argtypes = [vp, vp, vp, vp, vp, i64, vp, ci, ci, ci, ci, vp]

@@ -161,6 +161,51 @@ __device__ __forceinline__ float blend_rate(float step, float base, float c, flo
     return blend2(step, t, step_prev, old);
 }
 
+// a / b for TWO independent pairs, correctly rounded, for operands and quotients in the normal range: the compiler's IEEE
+// expansion of a float32 division (v_div_scale x2, v_rcp, the Newton / residual FMAs, v_div_fmas, v_div_fixup) minus its range
+// handling -- the scale factors are 1 and the fix-up returns the quotient unchanged unless an operand or the quotient is
+// denormal, infinite or NaN -- with the seven FMA-type steps of the two divisions issued as packed instructions
+// (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth per issue).  The same roundings, so the same bits as `a / b`
+// (tests/test_hip_parity.py::test_lazy_batch_side_kernel_is_the_general_one_bit_for_bit holds the two against each other);
+// a streaming pass over a [rows][256] table does 200 divisions per 832-byte row and was bound by their issue rate, not by
+// memory.  Shapes are >= the prior (0.3) and rates >= a column sum: normal range by construction.
+typedef float hpf_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ hpf_v2f div2_normal(hpf_v2f a, hpf_v2f b) {
+    hpf_v2f r;
+    r.x = __builtin_amdgcn_rcpf(b.x);
+    r.y = __builtin_amdgcn_rcpf(b.y);
+    const hpf_v2f one = {1.f, 1.f};
+    hpf_v2f e = __builtin_elementwise_fma(-b, r, one);
+    r = __builtin_elementwise_fma(e, r, r);
+    hpf_v2f q;
+    {
+#pragma clang fp contract(off)
+        q = a * r;
+    }
+    e = __builtin_elementwise_fma(-b, q, a);
+    q = __builtin_elementwise_fma(e, r, q);
+    e = __builtin_elementwise_fma(-b, q, a);
+    q = __builtin_elementwise_fma(e, r, q);
+    return q;
+}
+
+// fc[t] = valid ? sh[t] / rt[t] : 0 for a lane's NC columns, in pairs through div2_normal where NC is even
+template <int NC>
+__device__ __forceinline__ void div_columns(const float (&sh)[NC], const float (&rt)[NC], const bool (&valid)[NC],
+                                            float (&fc)[NC]) {
+    if constexpr (NC % 2 == 0) {
+#pragma unroll
+        for (int t = 0; t < NC; t += 2) {
+            const hpf_v2f q = div2_normal(hpf_v2f{sh[t], sh[t + 1]}, hpf_v2f{rt[t], rt[t + 1]});
+            fc[t] = valid[t] ? q.x : 0.f;
+            fc[t + 1] = valid[t + 1] ? q.y : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NC; t++) fc[t] = valid[t] ? sh[t] / rt[t] : 0.f;
+    }
+}
+
 __device__ __forceinline__ double fast_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);  // v_rcp_f64: ~24 good bits
     r = fma(fma(-x, r, 1.0), r, r);
@@ -340,6 +385,7 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
         const float rs_old = fa.rs[row];
         const float base_rte = fa.top_shp / rs_old;
         float sh[NC], rt[NC], fc[NC], en[NC];
+        bool vld[NC];
         float fsum = 0.f;
 #pragma unroll
         for (int t = 0; t < NC; t++) {
@@ -347,8 +393,12 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
             const float fresh = fmaf(eo[t], a[t], fa.prior_shp);
             sh[t] = valid ? blend_shape(fa.w_new, fresh, fa.w_old, so[t]) : 0.f;
             rt[t] = valid ? blend_rate(fa.step, base_rte, csl[t], fa.step_prev, ro[t]) : 0.f;
-            fc[t] = valid ? sh[t] / rt[t] : 0.f;
+            vld[t] = valid;
             en[t] = 0.f;
+        }
+        div_columns<NC>(sh, rt, vld, fc);
+#pragma unroll
+        for (int t = 0; t < NC; t++) {
             fsum += fc[t];
             csacc[t] += fc[t];
         }
@@ -400,6 +450,7 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
         const float rs_old = fa.rs[row];
         const float base_rte = fa.top_shp / rs_old;
         float sh[NC], rt[NC], fc[NC];
+        bool vld[NC];
         float fsum = 0.f;
 #pragma unroll
         for (int t = 0; t < NC; t++) {
@@ -407,7 +458,11 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
             const float fresh = fmaf(eo[t], a[t], fa.prior_shp);
             sh[t] = valid ? blend_shape(fa.w_new, fresh, fa.w_old, 0.f) : 0.f;
             rt[t] = valid ? base_rte + csl[t] : 0.f;
-            fc[t] = valid ? sh[t] / rt[t] : 0.f;
+            vld[t] = valid;
+        }
+        div_columns<NC>(sh, rt, vld, fc);
+#pragma unroll
+        for (int t = 0; t < NC; t++) {
             fsum += fc[t];
             csacc[t] += fc[t];
         }
@@ -1309,8 +1364,16 @@ __device__ __forceinline__ void expect_load(const float *__restrict__ shp, const
 }
 
 template <int LD>
-__device__ __forceinline__ void expect_finish(float *__restrict__ e, int64_t r, int k, int lane, const ExpectIn<LD> &in) {
+__device__ __forceinline__ void expect_finish(float *__restrict__ e, int64_t r, int k, int lane, const ExpectIn<LD> &in,
+                                              float *__restrict__ rte_out = nullptr) {
     constexpr int CPL = ExpectIn<LD>::CPL;
+    if (rte_out) {       // (the factored rate just formed, kept as the table row: pads zero, as every table holds them)
+#pragma unroll
+        for (int q = 0; q < CPL; q++) {
+            const int c = lane + WAVE * q;
+            if (c < LD) rte_out[(size_t)r * LD + c] = (c < k) ? in.rt[q] : 0.f;
+        }
+    }
     double ev[CPL];
     int ehi = 0;
 #pragma unroll
@@ -1331,7 +1394,7 @@ template <int LD>
 __global__ __launch_bounds__(BLOCK) void expect_kernel(const float *__restrict__ shp, const float *__restrict__ rte,
                                                        float *__restrict__ e, const int64_t *__restrict__ row_list,
                                                        const uint8_t *__restrict__ flag, int64_t nrows, int k,
-                                                       const FactoredRate fr) {
+                                                       const FactoredRate fr, float *__restrict__ rte_out) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * WPB;
@@ -1354,7 +1417,7 @@ __global__ __launch_bounds__(BLOCK) void expect_kernel(const float *__restrict__
                     m &= m - 1;
                     expect_load<LD>(shp, rte, g + b2, k, lane, fr, __shfl(rs_l, b2), nxt);
                 }
-                expect_finish<LD>(e, g + b, k, lane, cur);
+                expect_finish<LD>(e, g + b, k, lane, cur, rte_out);
                 if (!more) break;
                 cur = nxt;
                 b = b2;
@@ -1379,7 +1442,7 @@ __global__ __launch_bounds__(BLOCK) void expect_kernel(const float *__restrict__
     while (true) {
         const int64_t r2 = next_row(t);
         if (r2 >= 0) expect_load<LD>(shp, rte, r2, k, lane, fr, fr.rs ? fr.rs[r2] : 1.f, nxt);
-        expect_finish<LD>(e, r, k, lane, cur);
+        expect_finish<LD>(e, r, k, lane, cur, rte_out);
         if (r2 < 0) break;
         cur = nxt;
         r = r2;
@@ -1658,19 +1721,22 @@ __global__ __launch_bounds__(BLOCK) void svi_refresh_kernel(int64_t nrows, const
 //   flagged rows:  shp = w_new*(prior + e (*) acc[r]) (+ w_old*shp)                     PXI:304-316, 356-368
 //   every row:     rte = top/rs_rate + cs_other (not stored);  fac = shp/rte (not stored); per-block column sums of fac
 //   rs_mode 2: every row, 1: flagged rows:  rs = step*(add + sum_k fac) + step_prev*rs   PXI:324-325, 376-377
+// The next group of VR rows is requested BEFORE the current group's divisions are issued (two groups alternate in registers)
+// and the divisions go through div2_normal: 0.267 -> 0.227 ms on a 1M-row table, where a plain read of the table (torch.sum)
+// takes 0.263 ms for 16/13 of the bytes -- the pass runs at the box's streaming rate (profiles/r06_svi_side_probe.txt).
+// done_flag != 0: rows whose flag EQUALS it were finished by the sweep that formed their phi-sums (sweep_kernel MODE 3):
+// nothing of theirs is read, written or summed here.
 template <int LD>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void svi_lazy_batch_side_kernel(int64_t nrows, const uint8_t *__restrict__ flag, const float *__restrict__ acc,
-                                const float *__restrict__ e, float *__restrict__ shp, float *__restrict__ rs,
-                                const float *__restrict__ cs_other, float *__restrict__ cs_partial, float prior,
-                                float w_new, float w_old, float top, float add, float step, float step_prev,
-                                int rs_mode, int k, const float *__restrict__ rs_rate,
-                                float *__restrict__ rs_prev_out, int done_flag) {
-    // done_flag != 0: rows whose flag EQUALS it were finished by the sweep that formed their phi-sums (sweep_kernel MODE 3):
-    // nothing of theirs is read, written or summed here
+                                   const float *__restrict__ e, float *__restrict__ shp, float *__restrict__ rs,
+                                   const float *__restrict__ cs_other, float *__restrict__ cs_partial, float prior,
+                                   float w_new, float w_old, float top, float add, float step, float step_prev,
+                                   int rs_mode, int k, const float *__restrict__ rs_rate,
+                                   float *__restrict__ rs_prev_out, int done_flag) {
     static_assert(LD >= 4 * WAVE, "float4-per-lane rows");
     constexpr int VPL = LD / (4 * WAVE);
-    constexpr int VR = (VPL == 1) ? 8 : (VPL == 2 ? 4 : 2);
+    constexpr int VR = (VPL == 1) ? 4 : (VPL == 2 ? 2 : 1);
     __shared__ float red[WPB][LD];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1697,22 +1763,19 @@ void svi_lazy_batch_side_kernel(int64_t nrows, const uint8_t *__restrict__ flag,
         const float rsr_l = (lv && rs_rate) ? rs_rate[rl] : rs_l;
         float rs_new_l = rs_l;
         const int cnt = (int)min((int64_t)WAVE, nrows - g);
-        for (int b0 = 0; b0 < cnt; b0 += VR) {
-            if (((dmask >> b0) & ((1ull << VR) - 1)) == ((1ull << VR) - 1)) continue;     // (all of them finished elsewhere)
-            float4 sv[VR][VPL];
-            // (wave-uniform row bases + a 32-bit lane offset: the loads take the scalar-base form, a row's address costs
-            // no vector registers)
-            const size_t ob = (size_t)(g + b0) * (LD / 4);
-            const float4 *sp = reinterpret_cast<const float4 *>(shp) + ob;
+        const float4 *gp = reinterpret_cast<const float4 *>(shp) + (size_t)g * (LD / 4);
+        auto request = [&](int b0, float4 (&sv)[VR][VPL]) {      // rows g + b0 .. g + b0 + VR - 1 (wave-uniform bases)
 #pragma unroll
             for (int i = 0; i < VR; i++) {
                 const bool live = b0 + i < cnt && ((dmask >> (b0 + i)) & 1ull) == 0;
 #pragma unroll
                 for (int v = 0; v < VPL; v++) {
                     sv[i][v] = zero4;
-                    if (live && act[v]) sv[i][v] = ld4(sp + i * (LD / 4) + (v * WAVE + lane));
+                    if (live && act[v]) sv[i][v] = ld4(gp + (size_t)(b0 + i) * (LD / 4) + (v * WAVE + lane));
                 }
             }
+        };
+        auto process = [&](int b0, const float4 (&sv)[VR][VPL]) {
 #pragma unroll
             for (int i = 0; i < VR; i++) {
                 if (b0 + i >= cnt) break;
@@ -1720,7 +1783,7 @@ void svi_lazy_batch_side_kernel(int64_t nrows, const uint8_t *__restrict__ flag,
                 const bool fl = ((fmask >> (b0 + i)) & 1ull) != 0;      // (wave-uniform)
                 const float rs_old = __shfl(rs_l, b0 + i);
                 const float base = top / __shfl(rsr_l, b0 + i);
-                const size_t ou = ob + (size_t)i * (LD / 4);         // (uniform)
+                const size_t ou = (size_t)(g + b0 + i) * (LD / 4);      // (uniform)
                 float fsum = 0.f;
 #pragma unroll
                 for (int v = 0; v < VPL; v++) {
@@ -1741,13 +1804,12 @@ void svi_lazy_batch_side_kernel(int64_t nrows, const uint8_t *__restrict__ flag,
                         }
                         (reinterpret_cast<float4 *>(shp) + ou)[v * WAVE + lane] = make_float4(s4[0], s4[1], s4[2], s4[3]);
                     }
-                    const float c4[4] = {cs4[v].x, cs4[v].y, cs4[v].z, cs4[v].w};
-                    float f4[4];
+                    const hpf_v2f r01 = {base + cs4[v].x, base + cs4[v].y}, r23 = {base + cs4[v].z, base + cs4[v].w};
+                    const hpf_v2f q01 = div2_normal(hpf_v2f{s4[0], s4[1]}, r01), q23 = div2_normal(hpf_v2f{s4[2], s4[3]}, r23);
+                    const float f4[4] = {(c + 0 < k) ? q01.x : 0.f, (c + 1 < k) ? q01.y : 0.f, (c + 2 < k) ? q23.x : 0.f,
+                                         (c + 3 < k) ? q23.y : 0.f};
 #pragma unroll
-                    for (int e2 = 0; e2 < 4; e2++) {
-                        f4[e2] = (c + e2 < k) ? s4[e2] / (base + c4[e2]) : 0.f;
-                        fsum += f4[e2];
-                    }
+                    for (int e2 = 0; e2 < 4; e2++) fsum += f4[e2];
                     acc4[v].x += f4[0];
                     acc4[v].y += f4[1];
                     acc4[v].z += f4[2];
@@ -1757,8 +1819,15 @@ void svi_lazy_batch_side_kernel(int64_t nrows, const uint8_t *__restrict__ flag,
                     fsum = wave_sum(fsum);
                     if (lane == b0 + i) rs_new_l = blend_rate(step, add, fsum, step_prev, rs_old);
                 }
-                __builtin_amdgcn_sched_barrier(0);      // (one row's divisions at a time: interleaved they cost 116 VGPRs)
             }
+        };
+        float4 bufA[VR][VPL], bufB[VR][VPL];
+        request(0, bufA);
+        for (int b0 = 0; b0 < cnt; b0 += 2 * VR) {
+            if (b0 + VR < cnt) request(b0 + VR, bufB);
+            process(b0, bufA);
+            if (b0 + 2 * VR < cnt) request(b0 + 2 * VR, bufA);
+            if (b0 + VR < cnt) process(b0 + VR, bufB);
         }
         const bool mine = lv && ((dmask >> lane) & 1ull) == 0;      // (a finished row's scalars were written by its sweep)
         if (mine && rs_prev_out) rs_prev_out[rl] = rsr_l;
@@ -2783,16 +2852,17 @@ int hpf_hip_colsum_sequential_f32(const float *tab, int64_t nrows, int ld, float
 
 int hpf_hip_expect_f32(const float *shp, const float *rte, float *e, const int64_t *row_list, const uint8_t *flag,
                        int64_t nrows, int k, int ld, const float *rate_rs, const float *rate_cs, float rate_top,
-                       void *stream) {
+                       float *rte_out, void *stream) {
     if (nrows == 0) return 0;
-    if (!shp || (!rte && !rate_rs) || (rate_rs && !rate_cs) || !e || nrows < 0 || k <= 0 || ld != hpf_hip_ld_for_k(k))
+    if (!shp || (!rte && !rate_rs) || (rate_rs && !rate_cs) || !e || nrows < 0 || k <= 0 || ld != hpf_hip_ld_for_k(k) ||
+        (rte_out && !rate_rs))
         return HPF_EINVAL;
     const FactoredRate fr = {rate_rs, rate_cs, rate_top};
     hipStream_t st = (hipStream_t)stream;
     const int grid = (flag && !row_list) ? clamp_grid((nrows + WPB * WAVE - 1) / (WPB * WAVE), 2048)
                                          : clamp_grid((nrows + WPB - 1) / WPB, 2048);
 #define CALL(LD) \
-    hipLaunchKernelGGL((expect_kernel<LD>), dim3(grid), dim3(BLOCK), 0, st, shp, rte, e, row_list, flag, nrows, k, fr);
+    hipLaunchKernelGGL((expect_kernel<LD>), dim3(grid), dim3(BLOCK), 0, st, shp, rte, e, row_list, flag, nrows, k, fr, rte_out);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
     return last_error();

@@ -175,12 +175,13 @@ class HipOps:
         _lib.check(self.L.hpf_hip_colsum_sequential_f32(_ptr(tab), int(nrows), ld, _ptr(cs_out), self._stream()),
                    "hpf_hip_colsum_sequential_f32")
 
-    def expect(self, shp, rte, e, nrows, k, ld, row_list=None, flag=None, factored=None):
+    def expect(self, shp, rte, e, nrows, k, ld, row_list=None, flag=None, factored=None, rte_out=None):
         """flag (uint8 per table row): only rows with a non-zero flag.  factored = (rs, cs, top): the rate is
-        top / rs[r] + cs[c] instead of a table (rte may be None)."""
+        top / rs[r] + cs[c] instead of a table (rte may be None); rte_out: that rate is also stored as table rows."""
         rs, cs, top = factored if factored is not None else (None, None, 0.0)
         _lib.check(self.L.hpf_hip_expect_f32(_ptr(shp), _ptr(rte), _ptr(e), _ptr(row_list), _ptr(flag), nrows, k, ld,
-                                             _ptr(rs), _ptr(cs), float(top), self._stream()), "hpf_hip_expect_f32")
+                                             _ptr(rs), _ptr(cs), float(top), _ptr(rte_out), self._stream()),
+                   "hpf_hip_expect_f32")
 
     def segsum(self, part, row_seg_ptr, nrows, acc, ld, row_list=None, acc_ld=None, acc_by_row=False):
         _lib.check(self.L.hpf_hip_segsum_f32(_ptr(part), _ptr(row_seg_ptr), _ptr(row_list), nrows, _ptr(acc), ld,

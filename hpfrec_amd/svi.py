@@ -410,12 +410,22 @@ def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_
     step = float(np.float32(step))
     w_other = float(np.float32(step * float(np.float32(mult))))   # step*multiplier as one float32 scalar (PXI:316)
     bw, ow = ("u", "i") if user_batch else ("i", "u")
+    e_fold = lazy and os.environ.get("HPF_SVI_E_FOLD", "1") == "1"
     if not lazy:
         m.materialize(means=False)            # (stored form: both rate tables are read and written in place)
     elif m.factored[ow] is not None:
-        m.materialize((ow,), means=False)     # the other side's rate is BLENDED row by row (PXI:320 / 372): it needs the table
+        # the other side's rate is BLENDED row by row (PXI:320 / 372): it needs the table.  At an epoch boundary the side's E
+        # table is refreshed for all rows as well: ONE pass reads the shapes, forms the rank-1 rate, stores it and the E row
+        if e_fold and not m.e_valid[ow]:
+            So = m._side(ow)
+            ops.expect(So["shp"], None, m.eB if ow == "i" else m.eT, So["n"], k, ld, factored=m.factored[ow],
+                       rte_out=So["rte"])
+            m.factored[ow] = None
+            m.e_valid[ow] = True
+        else:
+            m.materialize((ow,), means=False)
     e_current = ()
-    if lazy and os.environ.get("HPF_SVI_E_FOLD", "1") == "1":
+    if e_fold:
         # The other side's E rows change only where a step changes its shapes and rates -- the step's own rows, whose new E
         # rows the whole-table pass below writes while it has them in registers.  So its E table only has to be made current
         # once per epoch (the sides swap roles), not re-read for the touched rows (most of the side) every batch.

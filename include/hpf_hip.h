@@ -189,10 +189,13 @@ int hpf_hip_colsum_sequential_f32(const float *tab, int64_t nrows, int ld, float
  * (initialisation PXI:134-138; the rows of an SVI batch).  r = row_list ? row_list[t] : t, t < nrows; with `flag`
  * (optional, one byte per table row) only rows with flag[r] != 0 are touched.  rate_rs (optional): the rate is not read
  * from a table but formed as rate_top / rate_rs[r] + rate_cs[c] -- the factored (rank-1) form a stochastic epoch keeps for
- * its batch side (hpf_hip_svi_side_f32: rs_prev_out); rte may then be NULL. */
+ * its batch side (hpf_hip_svi_side_f32: rs_prev_out); rte may then be NULL.  rte_out (optional, with rate_rs): the rate
+ * rows formed that way are also STORED there -- the expansion of a factored rate into its table (what the other side's
+ * blend of a stochastic step needs, PXI:320 / 372) rides on the pass that refreshes the side's E table at an epoch
+ * boundary instead of being a second pass over the shapes. */
 int hpf_hip_expect_f32(const float *shp, const float *rte, float *e, const int64_t *row_list, const uint8_t *flag,
                        int64_t nrows, int k, int ld, const float *rate_rs, const float *rate_cs, float rate_top,
-                       void *stream);
+                       float *rte_out, void *stream);
 
 /* acc[t][0:acc_ld] (or acc[r][0:acc_ld] when acc_by_row) = sum of the part[] segments of row
  * r = row_list ? row_list[t] : t, t < nrows (multi-GPU item side before the all-reduce -- acc_ld = k packs the

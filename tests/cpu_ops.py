@@ -229,7 +229,7 @@ class CpuOps:
         cp[:] = 0
         cp[0] = _np(tab)[:nrows].astype(np.float64).sum(axis=0).astype(np.float32)
 
-    def expect(self, shp, rte, e, nrows, k, ld, row_list=None, flag=None, factored=None):
+    def expect(self, shp, rte, e, nrows, k, ld, row_list=None, flag=None, factored=None, rte_out=None):
         rows = np.arange(nrows) if row_list is None else _np(row_list)[:nrows].astype(np.int64)
         if flag is not None:
             rows = rows[_np(flag)[rows] != 0]
@@ -240,6 +240,9 @@ class CpuOps:
             rs, cs, top = factored
             R = (np.float32(top) / _np(rs)[rows][:, None] + _np(cs)[None, :]).astype(np.float32)
             R[:, k:] = 1.0
+            if rte_out is not None:
+                _np(rte_out)[rows, :k] = R[:, :k]
+                _np(rte_out)[rows, k:] = 0
         else:
             R = _np(rte)[rows]
         with np.errstate(divide="ignore", invalid="ignore"):

@@ -44,7 +44,7 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     L = ctypes.CDLL(_lib.build())
     vp, i64, ci, cf = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
     L.hpf_hip_sweep_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp]
-    L.hpf_hip_expect_f32.argtypes = [vp, vp, vp, vp, vp, i64, ci, ci, vp, vp, cf, vp]
+    L.hpf_hip_expect_f32.argtypes = [vp, vp, vp, vp, vp, i64, ci, ci, vp, vp, cf, vp, vp]
     L.hpf_hip_colsum_reduce_f32.argtypes = [vp, ci, vp, ci, vp]
     L.hpf_hip_pair_dot_f32.argtypes = [vp, vp, vp, vp, i64, vp, ci, ci, vp]
     EINVAL, EUNSUPPORTED = -1, -2
@@ -53,8 +53,9 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     buf = ctypes.create_string_buffer(64)
     p = ctypes.cast(buf, vp)
     assert L.hpf_hip_sweep_f32(p, 1, p, p, p, p, p, None, 0, 50, 128, 0, 8, None, None) == EINVAL      # ld is not ld(k)
-    assert L.hpf_hip_expect_f32(None, None, None, None, None, 3, 50, 64, None, None, 0.0, None) == EINVAL
-    assert L.hpf_hip_expect_f32(p, p, p, None, None, 0, 50, 64, None, None, 0.0, None) == 0                                    # no rows
+    assert L.hpf_hip_expect_f32(None, None, None, None, None, 3, 50, 64, None, None, 0.0, None, None) == EINVAL
+    assert L.hpf_hip_expect_f32(p, p, p, None, None, 0, 50, 64, None, None, 0.0, None, None) == 0                                    # no rows
+    assert L.hpf_hip_expect_f32(p, p, p, None, None, 3, 50, 64, None, None, 0.0, p, None) == EINVAL      # rte_out without a factored rate
     assert L.hpf_hip_colsum_reduce_f32(None, 4, None, 64, None) == EINVAL
     assert L.hpf_hip_pair_dot_f32(p, p, p, p, -1, p, 50, 64, None) == EINVAL
     assert L.hpf_hip_ld_for_k(2000) == EUNSUPPORTED
