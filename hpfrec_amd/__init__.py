@@ -680,8 +680,15 @@ class HPF:
         be = self._backend()
         req = ["ENSUREARRAY", "C_CONTIGUOUS"]
         Y_batch = np.require(counts_df["Count"], dtype=be.c_real_t, requirements=req)
-        ix_u_batch = np.require(counts_df["UserId"], dtype=be.obj_ind_type, requirements=req)
-        ix_i_batch = np.require(counts_df["ItemId"], dtype=be.obj_ind_type, requirements=req)
+
+        def ids_of(col):
+            # (a signed 64-bit id column IS the reference's size_t column bit for bit for every valid id: no conversion
+            #  pass over the batch -- a negative id fails the device's range check instead of wrapping around)
+            v = counts_df[col].to_numpy(copy=False)
+            if v.dtype == np.int64 and v.flags.c_contiguous:
+                return v.view(np.uint64)
+            return np.require(counts_df[col], dtype=be.obj_ind_type, requirements=req)
+        ix_u_batch, ix_i_batch = ids_of("UserId"), ids_of("ItemId")
         # (INIT:864-871 takes np.unique of the batch's ids when the lists are not given: here they fall out of the
         #  grouping the step builds on the device anyway -- svi.partial_fit_device)
         if users_in_batch is not None:
@@ -722,7 +729,7 @@ class HPF:
         # the same step as the extension's partial_fit (be.partial_fit, PXI:423-473), on the state that stays on the
         # device between calls: only the batch crosses PCIe; host copies are refreshed when somebody reads them
         from . import svi
-        m = self._state.ensure_model(be._make_ops())
+        m = self._state.ensure_model(be._make_ops(), lazy_ok=True)
         svi.partial_fit_device(m, Y_batch, ix_u_batch, ix_i_batch, add_k_rte, add_t_rte, self.a, self.c, k_shp, t_shp,
                                users_in_batch, items_in_batch, be.cast_real_t(step_size), multiplier_batch, user_batch,
                                nusers_total=nusers)

@@ -711,6 +711,64 @@ __global__ __launch_bounds__(BLOCK) void svi_epoch_oth_layout_kernel(const int64
     }
 }
 
+// ============================================================================================================
+// One batch handed over as COO triplets (partial_fit, PXI:423-434: Y_batch, ix_u_batch, ix_i_batch in the caller's order):
+// there is no resident CSR to slice, so each grouping is a stable sort of the batch by that side's row id (the caller's:
+// a device radix sort) + the layout below -- heads and tails of the sorted runs, then the other-side layout of the batch
+// preparations above (svi_oth_layout_kernel: flags, segments cut at `cap`, split-row descriptors, sizes).
+// ============================================================================================================
+// (C0) reference ids (size_t, arriving as int64: an id >= 2^63 is negative) -> int32 row ids, with the range check the
+// reference does not make (bounds checks off, PXI:547-550: an id past the table is undefined behaviour there)
+__global__ __launch_bounds__(BLOCK) void svi_coo_narrow_kernel(const int64_t *__restrict__ ids, int64_t n, int64_t limit,
+                                                               int32_t *__restrict__ out, int64_t *__restrict__ err) {
+    bool bad = false;
+    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (int64_t)gridDim.x * BLOCK) {
+        const int64_t v = ids[t];
+        const bool ok = v >= 0 && v < limit;
+        bad |= !ok;
+        out[t] = ok ? (int32_t)v : 0;
+    }
+    if (__ballot(bad) != 0 && (threadIdx.x & (WAVE - 1)) == 0) err[0] = 1;      // (every writer writes the same value)
+}
+
+// (C1) sorted keys -> where each row's run starts and ends (row_cnt holds the END until C2 turns it into the count; it is
+// zero-filled beforehand, and a run's end is >= 1: zero = the row is absent)
+__global__ __launch_bounds__(BLOCK) void svi_coo_heads_kernel(const int32_t *__restrict__ key, int64_t n,
+                                                              int64_t *__restrict__ row_start, int32_t *__restrict__ row_end) {
+    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (int64_t)gridDim.x * BLOCK) {
+        const int32_t r = key[t];
+        if (t == 0 || key[t - 1] != r) row_start[r] = t;
+        if (t == n - 1 || key[t + 1] != r) row_end[r] = (int32_t)(t + 1);
+    }
+}
+
+// (C2) per row its count; per tile of rows the totals of {rows present, batch segments, split rows} (svi_oth_rows_kernel's
+// outputs from the runs instead of from a keep-mask)
+__global__ __launch_bounds__(BLOCK) void svi_coo_rows_kernel(int64_t nrows, const int64_t *__restrict__ row_start,
+                                                             int32_t *__restrict__ row_cnt, int cap,
+                                                             long long *__restrict__ tiles, int64_t n,
+                                                             int64_t *__restrict__ entries) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) entries[0] = n;      // (where the layout kernel reads the number of nonzeros)
+    const int64_t per = (nrows + TILES - 1) / TILES;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(nrows, r0 + per);
+    long long v[3] = {0, 0, 0};
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += BLOCK) {
+        const int end = row_cnt[r];
+        const int c = end > 0 ? (int)(end - row_start[r]) : 0;
+        row_cnt[r] = c;
+        if (c > 0) {
+            const int ns = (c + cap - 1) / cap;
+            v[0]++;
+            v[1] += ns;
+            v[2] += ns > 1;
+        }
+    }
+    long long e[3], tot[3];
+    block_exclusive_scan<3>(v, e, tot);
+    if (threadIdx.x == 0)
+        for (int c = 0; c < 3; c++) tiles[(size_t)blockIdx.x * 3 + c] = tot[c];
+}
+
 inline int last_error() { return (int)hipGetLastError(); }
 
 }  // namespace
@@ -844,6 +902,41 @@ int hpf_hip_svi_epoch_prepare(const hpf_svi_epoch *b, void *stream) {
     hipLaunchKernelGGL(svi_epoch_oth_layout_kernel, dim3(ETILES, nb), dim3(BLOCK), 0, st, b->oth_row_seg_ptr, b->oth_nrows,
                        nseg, (const int64_t *)b->seg_pos, b->seg_cap, (const long long *)tiles_oth, b->flag_oth, b->o_segs,
                        b->o_segs_cap, b->o_multi, b->multi_cap, b->sizes);
+    return last_error();
+}
+
+int hpf_hip_svi_coo_narrow(const int64_t *ids, int64_t n, int64_t limit, int32_t *out, int64_t *err, void *stream) {
+    if (n == 0) return 0;
+    if (!ids || !out || !err || n < 0 || limit <= 0 || limit > 0x7fffffffll) return HPF_EINVAL;
+    int64_t g = (n + BLOCK - 1) / BLOCK;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(svi_coo_narrow_kernel, dim3((unsigned)g), dim3(BLOCK), 0, (hipStream_t)stream, ids, n, limit, out, err);
+    return last_error();
+}
+
+int64_t hpf_hip_svi_coo_sizeof(void) { return (int64_t)sizeof(hpf_svi_coo); }
+
+int hpf_hip_svi_coo_prepare(const hpf_svi_coo *b, void *stream) {
+    if (!b || b->n < 0 || b->n > 0x7fffffffll || (b->n > 0 && !b->key) || b->nrows <= 0 || b->seg_cap <= 0 ||
+        b->seg_cap > HPF_SEG_LEN_MASK || !b->flag || !b->row_start || !b->row_cnt || !b->segs || !b->multi || !b->sizes ||
+        !b->tiles || b->segs_cap <= 0 || b->multi_cap <= 0)
+        return HPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    auto grid_for = [](int64_t n, int per) { int64_t g = (n + per - 1) / per; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); };
+    hipError_t e = hipMemsetAsync(b->sizes, 0, 7 * sizeof(int64_t), st);      // (sizes[7], the error word, is sticky)
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(b->row_cnt, 0, (size_t)b->nrows * sizeof(int32_t), st);
+    if (e != hipSuccess) return (int)e;
+    long long *tiles = (long long *)b->tiles;
+    int64_t *entries = b->tiles + (size_t)TILES * 3;          // one word: the number of nonzeros (the layout kernel's tile_off[0])
+    if (b->n > 0)
+        hipLaunchKernelGGL(svi_coo_heads_kernel, dim3(grid_for(b->n, BLOCK)), dim3(BLOCK), 0, st, b->key, b->n, b->row_start,
+                           b->row_cnt);
+    hipLaunchKernelGGL(svi_coo_rows_kernel, dim3(TILES), dim3(BLOCK), 0, st, b->nrows, (const int64_t *)b->row_start,
+                       b->row_cnt, b->seg_cap, tiles, b->n, entries);
+    hipLaunchKernelGGL(svi_oth_layout_kernel, dim3(TILES), dim3(BLOCK), 0, st, b->nrows, (const int64_t *)b->row_start,
+                       (const int32_t *)b->row_cnt, b->seg_cap, (const long long *)tiles, (const int64_t *)entries, (int64_t)0,
+                       b->flag, b->segs, b->segs_cap, b->multi, b->multi_cap, b->n > 0 ? b->n : 1, b->sizes);
     return last_error();
 }
 

@@ -56,6 +56,21 @@ def _svi_epoch_struct():
 SviEpochDesc = _svi_epoch_struct()
 
 
+def _svi_coo_struct():
+    import ctypes
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+
+    class SviCooDesc(ctypes.Structure):
+        """hpf_svi_coo (include/hpf_hip.h), field for field."""
+        _fields_ = [("key", vp), ("n", i64), ("nrows", i64), ("seg_cap", i32), ("reserved", i32),
+                    ("flag", vp), ("row_start", vp), ("row_cnt", vp),
+                    ("segs", vp), ("segs_cap", i64), ("multi", vp), ("multi_cap", i64), ("sizes", vp), ("tiles", vp)]
+    return SviCooDesc
+
+
+SviCooDesc = _svi_coo_struct()
+
+
 class HipOps:
     name = "hip"
 
@@ -281,6 +296,23 @@ class HipOps:
         assert int(ws.order.shape[0]) == ws.own.nrows and ws.order.dtype == torch.int64
         d.order = _ptr(ws.order)
         _lib.check(self.L.hpf_hip_svi_epoch_prepare(ctypes.byref(d), self._stream()), "hpf_hip_svi_epoch_prepare")
+
+    def svi_coo_narrow(self, ids, limit, out, err):
+        """out = ids as int32 row ids; err[0] = 1 when an id lies outside [0, limit) (hpf_hip_svi_coo_narrow)."""
+        _lib.check(self.L.hpf_hip_svi_coo_narrow(_ptr(ids), int(ids.shape[0]), int(limit), _ptr(out), _ptr(err),
+                                                 self._stream()), "hpf_hip_svi_coo_narrow")
+
+    def svi_coo_prepare(self, key, nrows, seg_cap, flag, row_start, row_cnt, segs, multi, sizes, tiles):
+        """One grouping of a COO batch from its stably sorted row ids `key` (hpf_hip_svi_coo_prepare): flags, segments,
+        split-row descriptors, sizes -- nothing read back."""
+        import ctypes
+        d = SviCooDesc()
+        assert ctypes.sizeof(d) == int(self.L.hpf_hip_svi_coo_sizeof())
+        d.key, d.n, d.nrows, d.seg_cap = _ptr(key), int(key.shape[0]), int(nrows), int(seg_cap)
+        d.flag, d.row_start, d.row_cnt = _ptr(flag), _ptr(row_start), _ptr(row_cnt)
+        d.segs, d.segs_cap, d.multi, d.multi_cap = _ptr(segs), int(segs.shape[0]), _ptr(multi), int(multi.shape[0])
+        d.sizes, d.tiles = _ptr(sizes), _ptr(tiles)
+        _lib.check(self.L.hpf_hip_svi_coo_prepare(ctypes.byref(d), self._stream()), "hpf_hip_svi_coo_prepare")
 
     def segsum_desc(self, part, desc, ndesc_dev, ndesc_max, acc, ld):
         """acc[row] = sum of a split row's part[] rows for the {first, n, row} descriptors of a device-built batch."""

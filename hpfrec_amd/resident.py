@@ -91,8 +91,10 @@ class ResidentState:
             raise ValueError("the model has no Theta/Beta yet")
         return int(th.shape[0]), int(be.shape[0]), int(th.shape[1])
 
-    def ensure_model(self, ops, names=NAMES):
-        """The DeviceModel with the listed tables current (uploads the stale ones)."""
+    def ensure_model(self, ops, names=NAMES, lazy_ok=False):
+        """The DeviceModel with the listed tables current (uploads the stale ones).  lazy_ok: the caller is a stochastic
+        step, which works on the factored / stale forms its predecessor left (svi.DeviceModel.materialize); everybody
+        else gets the tables themselves."""
         from . import svi
         nU, nI, k = self._shapes()
         m = self.model
@@ -111,6 +113,8 @@ class ResidentState:
                 m.put(n, a)
                 self.stats["h2d_bytes"] += int(a.nbytes)
                 self.dev_ok[n] = True
+        if not lazy_ok:
+            m.materialize()
         return m
 
     def adopt(self, model, names=NAMES):
@@ -144,6 +148,7 @@ class ResidentState:
         """Padded device row [ld] of a table whose device copy is current, else None (never uploads)."""
         if not self.on_device(name) or idx < 0:
             return None
+        self.model.materialize()
         return getattr(self.model, name)[int(idx)]
 
     def rows(self, name, idx):
@@ -152,6 +157,7 @@ class ResidentState:
         if self.host_ok.get(name, False):
             return self.host[name][idx]
         m = self.model
+        m.materialize()
         n = getattr(m, name).shape[0]
         t = torch.from_numpy(np.where(idx < 0, idx + n, idx)).to(m.ops.device)
         if name in ("k_rte", "t_rte"):

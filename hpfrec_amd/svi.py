@@ -21,6 +21,7 @@ import torch
 from . import _lib, _streams, layout
 
 _NAMES = ("Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "Theta", "Beta")
+PF_TIMINGS = {}       # HPF_TIMING=1: {phase: [seconds per partial_fit_device call]}, device-synchronised
 SVI_TIMINGS = {}      # HPF_TIMING=1: {"epochs": n, "seconds": wall time of the last fit's epoch loop}
 
 
@@ -156,7 +157,11 @@ class EpochWorkspace:
         bound = int(torch.topk(deg, per).values.sum().item()) if per > 0 else 0       # (once per fit)
         o_segs_cap = min(oth.nrows, bound) + bound // seg_cap + 1
         b_cap = per + bound // seg_cap + 1
-        nbytes = nb * (16 * (o_segs_cap + b_cap) + own.nrows + oth.nrows + 12 * oth.nseg) + 9 * oth.nnz
+        multi_cap = bound // seg_cap + 2
+        # per batch: the two segment lists, the two flag rows, the split-row lists, the {batch, segment} counts and offsets;
+        # per epoch: e_idx / e_y / key; + the sweeps' part[] scratch of the other side's segment list ([o_segs_cap][ld]: the
+        # caller's, counted by fits())
+        nbytes = nb * (16 * (o_segs_cap + b_cap) + own.nrows + oth.nrows + 12 * oth.nseg + 48 * multi_cap) + 9 * oth.nnz
         return nb, per, bound, nbytes
 
     @classmethod
@@ -166,7 +171,13 @@ class EpochWorkspace:
         if os.environ.get("HPF_SVI_EPOCH_PREP", "1") != "1" or batch_rows <= 0:
             return False
         nb, _, _, nbytes = cls.plan(own, oth, batch_rows, seg_cap)
-        return nb <= cls.MAX_BATCHES and nbytes <= int(os.environ.get("HPF_SVI_EPOCH_BYTES", str(16 << 30)))
+        budget = int(os.environ.get("HPF_SVI_EPOCH_BYTES", str(16 << 30)))
+        dev = own.idx.device
+        if dev.type == "cuda" and "HPF_SVI_EPOCH_BYTES" not in os.environ:
+            # (a smaller device: at most a quarter of what is free now -- an SVI over one side alternates TWO workspaces --
+            #  otherwise the batches are prepared one by one)
+            budget = min(budget, torch.cuda.mem_get_info(dev)[0] // 4)
+        return nb <= cls.MAX_BATCHES and nbytes <= budget
 
     def __init__(self, ops, own, oth, acc_own, ld, batch_rows, seg_cap=None):
         dev = own.idx.device
@@ -268,8 +279,18 @@ class DeviceModel:
     def v(self, name):
         return getattr(self, name)[:, : self.k]
 
+    def coo_scratch(self):
+        """Per-side scratch of CooBatch (row starts / counts of a grouping) + the scan tiles, allocated on first use."""
+        if getattr(self, "_coo", None) is None:
+            dev = self.ops.device
+            self._coo = {w: (torch.empty(n, dtype=torch.int64, device=dev), torch.empty(n, dtype=torch.int32, device=dev))
+                         for w, n in (("u", self.nU), ("i", self.nI))}
+            self._coo["tiles"] = torch.zeros(self.ops.svi_prep_scratch_words(), dtype=torch.int64, device=dev)
+        return self._coo
+
     def put(self, name, host):
         """Upload one state array ([n,k] table or [n,1] scalar-rate vector) from the host."""
+        self.materialize()      # (a table a lazy step left factored / stale is brought up to date before any is replaced)
         dev = self.ops.device
         a = torch.from_numpy(np.ascontiguousarray(host, dtype=np.float32))
         self.e_valid = {"u": False, "i": False}       # (whatever is uploaded, the E tables no longer describe it)
@@ -444,12 +465,12 @@ def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_
     B, O = (U, I) if user_batch else (I, U)     # batch side, other side
     s_oth = si if user_batch else su             # the batch grouped by the other side's rows
     # The other side's pass FUSED into its sweep (hpf_hip_sweep_svi_f32): the rows a batch touches there are short, the
-    # wavefront that forms a row's phi-sum finishes the row.  Epochs only (device-built batches: their flags tell split
-    # rows apart, and only the step's rows blend their scalar rates); needs the batch side's NEW column sums, so that
+    # wavefront that forms a row's phi-sum finishes the row.  Device-built batches only (their flags tell split rows apart;
+    # partial_fit's blend of ALL scalar rates, PXI:472-473, is the whole-table pass's rs_mode 2 over the rows the sweep
+    # did not finish); needs the batch side's NEW column sums, so that
     # sweep runs after the batch side's pass -- phi still comes from the OLD parameters: the batch side's pass writes
     # neither E table, and the other side's rows are rewritten by the very wavefront that has just used them.
-    fused = (isinstance(s_oth, DevSide) and not all_scalar_rows and s_oth.nseg > 0
-             and os.environ.get("HPF_SVI_FUSED", "1") == "1")
+    fused = (isinstance(s_oth, DevSide) and s_oth.nseg > 0 and os.environ.get("HPF_SVI_FUSED", "1") == "1")
     # The batch side's step FUSED into ITS sweep as well (hpf_hip_sweep_svi_batch_f32): the wavefront that sweeps a batch row
     # forms the row's E row first (from its current shape and rate: no expectation launch, no read-back of the E row) and,
     # for a row present in one segment, finishes the row -- shape, rate, mean, scalar rate, column-sum share -- while it holds
@@ -519,40 +540,132 @@ def _dev_ids(a, dev):
     return layout.ids_to_device(a, dev)
 
 
+def _host_ids(a):
+    """The reference's size_t ids as an int64 view (no conversion pass; an id >= 2^63 comes out negative and fails the
+    device's range check)."""
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.uint64:
+        a = a.view(np.int64)
+    elif a.dtype != np.int64:
+        a = a.astype(np.int64)
+    if not a.flags.writeable:
+        a = a.copy()            # (torch.from_numpy wants a writable buffer; never written here)
+    return a
+
+
+class CooBatch:
+    """Both groupings of a batch that arrives as COO triplets (partial_fit), built ON THE DEVICE without a read-back:
+    range check + narrowing of the ids (hpf_hip_svi_coo_narrow), one stable device sort per grouping, the segment layout of
+    each (hpf_hip_svi_coo_prepare: flags 0 / 1 / 2 of every row of the side, segments, split-row descriptors, sizes).  The
+    sides come out as DevSides -- what the fused sweeps of an epoch step take -- and the row lists the reference derives
+    with np.unique (INIT:864-871) are the rows whose flag is set."""
+
+    def __init__(self, m, bu, bi, by, seg_cap=None):
+        ops, dev = m.ops, m.ops.device
+        self.seg_cap = seg_cap = layout.SEG_CAP if seg_cap is None else int(seg_cap)
+        self.n = n = int(by.shape[0])
+        i32 = dict(dtype=torch.int32, device=dev)
+        i64 = dict(dtype=torch.int64, device=dev)
+        self.err = torch.zeros(1, **i64)
+        u32, it32 = torch.empty(n, **i32), torch.empty(n, **i32)
+        ops.svi_coo_narrow(bu, m.nU, u32, self.err)
+        ops.svi_coo_narrow(bi, m.nI, it32, self.err)
+        self.sizes = torch.zeros((2, 8), **i64)
+        scratch = m.coo_scratch()
+        self.parts = {}
+        for w, key, other, nrows, flag in (("u", u32, it32, m.nU, m.flag_u), ("i", it32, u32, m.nI, m.flag_i)):
+            ks, perm = torch.sort(key, stable=True)
+            idx, y = other[perm], by[perm]
+            segs = torch.empty((min(nrows, n) + n // seg_cap + 1, 2), **i64)
+            multi = torch.empty((n // seg_cap + 2, 3), **i64)
+            sz = self.sizes[0 if w == "u" else 1]
+            ops.svi_coo_prepare(ks, nrows, seg_cap, flag, scratch[w][0], scratch[w][1], segs, multi, sz, scratch["tiles"])
+            self.parts[w] = (segs, idx, y, multi, sz)
+
+    def read_sizes(self):
+        """The ONE synchronisation of a partial_fit call: (range error, {side: (segments, split rows, rows present)})."""
+        h = torch.cat([self.err, self.sizes.reshape(-1)]).cpu().numpy()
+        self.host = {"u": (int(h[1 + 2]), int(h[1 + 3]), int(h[1 + 5])), "i": (int(h[9 + 2]), int(h[9 + 3]), int(h[9 + 5]))}
+        return bool(h[0] != 0), bool(h[1 + 7] != 0 or h[9 + 7] != 0)
+
+    def side(self, w):
+        segs, idx, y, multi, sz = self.parts[w]
+        nseg = self.host[w][0]
+        short = 1 if (nseg > 0 and self.n / nseg < layout.SHORT_ROW_NNZ) else 0
+        return DevSide(segs, segs.shape[0], idx, y, sz[2:3], multi, sz[3:4], multi.shape[0], short)
+
+
 # -- PXI:423-473 ------------------------------------------------------------------------------------
 def partial_fit_device(m, Y_batch, ix_u_batch, ix_i_batch, add_k_rte, add_t_rte, a, c, k_shp, t_shp,
                        users_this_batch, items_this_batch, step_size_batch, multiplier_batch, user_batch,
                        nusers_total=None):
     """One partial_fit step on a DeviceModel that already holds the current state: only the batch's triplets and
-    row lists cross PCIe.  Mutates all eight state tables of `m` (as the reference mutates its arrays, PXI:443-473).
+    row lists cross PCIe.  Mutates the state of `m` (as the reference mutates its eight arrays, PXI:443-473; rate and mean
+    tables the step leaves factored / stale are brought up to date when somebody reads them: DeviceModel.materialize).
     users_this_batch / items_this_batch None: the users / items that occur in the batch (what the class computes with
-    np.unique, INIT:864-871) -- they fall out of the grouping the step needs anyway, on the device (np.unique over the
-    3-8M ids of a C5 batch was 60 % of a call); multiplier_batch None: nusers_total / (number of those users), INIT:912."""
+    np.unique, INIT:864-871) -- they fall out of the grouping the step needs anyway, on the device; multiplier_batch None:
+    nusers_total / (number of those users), INIT:912.
+    The step is the epoch step of fit_hpf_svi: both groupings built on the device (CooBatch), both sides' statements fused
+    into their sweeps; only k_rte / t_rte differ -- blended for ALL rows (PXI:472-473)."""
     ops = m.ops
     dev = ops.device
+    if multiplier_batch is None and nusers_total is None:
+        raise ValueError("partial_fit: either multiplier_batch or nusers_total must be given")
     hy = {"a": float(np.float32(a)), "c": float(np.float32(c)), "k_shp": float(np.float32(k_shp)),
           "t_shp": float(np.float32(t_shp)), "add_k_rte": float(np.float32(add_k_rte)),
           "add_t_rte": float(np.float32(add_t_rte))}
-    bu, bi = _dev_ids(ix_u_batch, dev), _dev_ids(ix_i_batch, dev)
-    if bu.numel() > 0:      # (ids >= 2^63 of the reference's size_t arrive negative)
-        lim = torch.stack([bu.max(), bi.max(), -bu.min(), -bi.min()]).cpu().numpy()
-        if lim[0] >= m.nU or lim[1] >= m.nI or lim[2] > 0 or lim[3] > 0:
+    timing = os.environ.get("HPF_TIMING") == "1" and dev.type == "cuda"      # PF_TIMINGS: device-synchronised phases of a call
+    if timing:
+        import time
+        torch.cuda.synchronize(dev)
+        t_ph = [time.perf_counter()]
+
+        def phase(name):
+            torch.cuda.synchronize(dev)
+            t_ph.append(time.perf_counter())
+            PF_TIMINGS.setdefault(name, []).append(t_ph[-1] - t_ph[-2])
+    else:
+        def phase(name):
+            pass
+    # (plain pageable copies: 62 MB of C5 triplets go up in 1.1-1.6 ms here; staging them through a page-locked buffer of
+    #  our own was no faster and its host-side copy stalled for 90 ms every few calls: profiles/r06_partial_fit_upload.txt)
+    bu, bi, by = (torch.from_numpy(x).to(dev) for x in (_host_ids(ix_u_batch), _host_ids(ix_i_batch),
+                                                       np.ascontiguousarray(Y_batch, dtype=np.float32)))
+    phase("upload")
+    batch = CooBatch(m, bu, bi, by)
+    phase("groupings")
+    lists = {}
+    for w, given in (("u", users_this_batch), ("i", items_this_batch)):
+        lists[w] = None if given is None else _dev_ids(given, dev)
+    bad_id, overflow = batch.read_sizes()
+    if bad_id:
+        raise ValueError("partial_fit: user/item id out of range")
+    if overflow:
+        raise _lib.HpfHipError("hpfrec_amd: a partial_fit batch outgrew its workspace")
+    su, si = batch.side("u"), batch.side("i")
+    count = {}
+    for w, flag, acc, nrows in (("u", m.flag_u, m.acc_u, m.nU), ("i", m.flag_i, m.acc_i, m.nI)):
+        tb = lists[w]
+        if tb is None:
+            count[w] = batch.host[w][2]
+            continue
+        if tb.numel() > 0 and (int(tb.min()) < 0 or int(tb.max()) >= nrows):
             raise ValueError("partial_fit: user/item id out of range")
-    by = torch.from_numpy(np.ascontiguousarray(Y_batch, dtype=np.float32)).to(dev)
-    su, si = BatchSide(bu, bi, by), BatchSide(bi, bu, by)
-    users_tb = su.rows if users_this_batch is None else _dev_ids(users_this_batch, dev)
-    items_tb = si.rows if items_this_batch is None else _dev_ids(items_this_batch, dev)
-    if not ((users_this_batch is None or bool(torch.isin(su.rows, users_tb).all()))
-            and (items_this_batch is None or bool(torch.isin(si.rows, items_tb).all()))):
-        raise ValueError("the batch contains users/items that are not in users_in_batch/items_in_batch")
+        listed = torch.zeros(nrows, dtype=torch.bool, device=dev)
+        listed[tb] = True
+        if bool(((flag != 0) & ~listed).any()):
+            raise ValueError("the batch contains users/items that are not in users_in_batch/items_in_batch")
+        absent = tb[flag[tb] == 0]           # listed rows without any nonzero in the batch: a zero phi-sum, finished by the
+        if absent.numel() > 0:                # whole-table pass (flag 2, as a split row)
+            flag[absent] = 2
+            acc.index_fill_(0, absent, 0.0)
+        count[w] = int(tb.shape[0])
     if multiplier_batch is None:
-        multiplier_batch = np.float32(float(nusers_total) / float(users_tb.shape[0]))
-    for tb, side, acc, flag in ((users_tb, su, m.acc_u, m.flag_u), (items_tb, si, m.acc_i, m.flag_i)):
-        if tb.shape[0] != side.nrows:        # listed rows without any nonzero in the batch: a zero phi-sum
-            acc.index_fill_(0, tb, 0.0)
-        flag.zero_()
-        flag.index_fill_(0, tb, 1)
-    _svi_step(m, hy, su, si, m.flag_u, m.flag_i, step_size_batch, multiplier_batch, user_batch, all_scalar_rows=True)
+        multiplier_batch = np.float32(float(nusers_total) / float(max(count["u"], 1)))
+    phase("sizes, lists")
+    _svi_step(m, hy, su, si, m.flag_u, m.flag_i, step_size_batch, multiplier_batch, user_batch, all_scalar_rows=True,
+              lazy=os.environ.get("HPF_SVI_LAZY", "1") == "1")
+    phase("step")
 
 
 def partial_fit_step(ops, Y_batch, ix_u_batch, ix_i_batch, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp,

@@ -400,6 +400,26 @@ typedef struct hpf_svi_epoch {
 int64_t hpf_hip_svi_epoch_sizeof(void);
 int64_t hpf_hip_svi_epoch_scratch_words(int nb);
 int hpf_hip_svi_epoch_prepare(const hpf_svi_epoch *epoch, void *stream);
+/*
+ * A batch handed over as COO triplets in the caller's order (the extension's partial_fit, PXI:423-434): no resident CSR to
+ * slice.  hpf_hip_svi_coo_narrow: the reference's size_t ids (as int64) -> int32 row ids + the range check the reference
+ * does not make (err[0] = 1 when an id is < 0 or >= limit; the id is replaced by 0 so that nothing reads out of bounds).
+ * hpf_hip_svi_coo_prepare: ONE grouping of the batch from its row ids STABLY SORTED (key[n], ascending; the nonzeros'
+ * other-side ids and counts permuted alike by the caller): flag[nrows] (0: row absent, 1: present in one segment, 2: a
+ * split row), segs (their `begin` indexes the sorted arrays), multi = {first segment, segments, row} per split row, sizes
+ * as hpf_hip_svi_batch_prepare gives them for the OTHER side ([2] segments, [3] split rows, [4] nonzeros, [5] rows present,
+ * [7] sticky overflow flag).  Scratch: row_start [nrows] int64, row_cnt [nrows] int32, tiles
+ * [hpf_hip_svi_prep_scratch_words()] int64.  Nothing is read back.
+ */
+typedef struct hpf_svi_coo {
+    const int32_t *key; int64_t n; int64_t nrows; int32_t seg_cap, reserved;
+    uint8_t *flag; int64_t *row_start; int32_t *row_cnt;
+    hpf_segment *segs; int64_t segs_cap; int64_t *multi; int64_t multi_cap;
+    int64_t *sizes; int64_t *tiles;
+} hpf_svi_coo;
+int64_t hpf_hip_svi_coo_sizeof(void);
+int hpf_hip_svi_coo_narrow(const int64_t *ids, int64_t n, int64_t limit, int32_t *out, int64_t *err, void *stream);
+int hpf_hip_svi_coo_prepare(const hpf_svi_coo *coo, void *stream);
 /* acc[row][0:ld] = sum of part[first .. first+n) for the descriptors {first, n, row} (b_multi / o_multi above), the
  * first min(ndesc_max, *ndesc_dev) of them: the split rows of a batch sweep (hpf_hip_segsum_f32 with device-side lists). */
 int hpf_hip_segsum_desc_f32(const float *part, const int64_t *desc, const int64_t *ndesc_dev, int64_t ndesc_max,

@@ -411,6 +411,42 @@ class CpuOps:
             sizes[b, :6] = kept.shape[0], bm.shape[0], osegs.shape[0], om.shape[0], o_idx.shape[0], nrows_present
             base += o_idx.shape[0]
 
+    def svi_coo_narrow(self, ids, limit, out, err):
+        a = _np(ids)
+        bad = (a < 0) | (a >= limit)
+        _np(out)[:] = np.where(bad, 0, a).astype(np.int32)
+        if bad.any():
+            _np(err)[0] = 1
+
+    def svi_coo_prepare(self, key, nrows, seg_cap, flag, row_start, row_cnt, segs, multi, sizes, tiles):
+        """hpf_hip_svi_coo_prepare in numpy: the layout of one grouping of a COO batch from its sorted row ids."""
+        kk, cap = _np(key).astype(np.int64), int(seg_cap)
+        n = kk.shape[0]
+        cnt = np.bincount(kk, minlength=nrows).astype(np.int64)
+        rows = np.nonzero(cnt > 0)[0]
+        c = cnt[rows]
+        start = np.cumsum(c) - c
+        ns = (c + cap - 1) // cap
+        sg0 = np.cumsum(ns) - ns
+        nseg = int(ns.sum())
+        local = np.repeat(np.arange(rows.shape[0]), ns)
+        within = np.arange(nseg) - sg0[local]
+        begin = start[local] + within * cap
+        length = np.minimum(c[local] - within * cap, cap) | np.where(ns[local] == 1, 0x40000000, 0)
+        sg = np.stack([begin, length | (rows[local] << 32)], axis=1).astype(np.int64)
+        mi = np.nonzero(ns > 1)[0]
+        om = np.stack([sg0[mi], ns[mi], rows[mi]], axis=1).astype(np.int64)
+        f = _np(flag)
+        f[:nrows] = 0
+        f[rows] = np.where(ns > 1, 2, 1)
+        sz = _np(sizes)
+        sz[:7] = 0
+        if nseg > segs.shape[0] or om.shape[0] > multi.shape[0]:
+            sz[7] = 1
+        _np(segs)[: min(nseg, segs.shape[0])] = sg[: segs.shape[0]]
+        _np(multi)[: min(om.shape[0], multi.shape[0])] = om[: multi.shape[0]]
+        sz[2], sz[3], sz[4], sz[5] = min(nseg, segs.shape[0]), min(om.shape[0], multi.shape[0]), n, rows.shape[0]
+
     def segsum_desc(self, part, desc, ndesc_dev, ndesc_max, acc, ld):
         nd = min(int(ndesc_max), int(_np(ndesc_dev)[0]))
         P, D = _np(part).astype(np.float64), _np(desc)

@@ -201,6 +201,59 @@ def test_partial_fit_growing_model_on_gpu(hip_backend):
     _partial_fit_growing_model()
 
 
+@pytest.mark.parametrize("case", ["ragged", "hubs", "one-row", "empty"])
+def test_coo_batch_equals_the_tensor_library_structures(any_backend, case):
+    """svi.CooBatch (partial_fit's batch, handed over as COO triplets in any order: range check + narrowing, one stable
+    device sort per grouping, hpf_hip_svi_coo_prepare -- nothing read back but the sizes) builds what BatchSide builds with
+    tensor-library sorts and host-side sizes: the same nonzeros in the same order, the same segment descriptors and
+    split-row lists for both groupings, flags 1 / 2 / 0 for rows present in one segment / split rows / absent rows; an id
+    out of range raises the error flag instead of being gathered."""
+    import torch
+    from hpfrec_amd import svi
+    ops = any_backend._make_ops()
+    dev = ops.device
+    rs = np.random.RandomState({"ragged": 1, "hubs": 2, "one-row": 3, "empty": 4}[case])
+    nU, nI, cap, k = 700, 300, 16, 5
+    nnz = {"ragged": 9000, "hubs": 9000, "one-row": 40, "empty": 0}[case]
+    iu = (nU * rs.random_sample(nnz) ** (3 if case == "hubs" else 1.3)).astype(np.int64)
+    ii = (nI * rs.random_sample(nnz) ** (4 if case == "hubs" else 1.5)).astype(np.int64)
+    if case == "one-row":
+        iu[:] = 17
+    y = (1 + rs.poisson(1.0, size=nnz)).astype(np.float32)
+    m = svi.DeviceModel(ops, k, nU, nI)
+    m.flag_u.fill_(9)                  # (stale marks of an earlier call must not survive)
+    m.flag_i.fill_(9)
+    bu, bi, by = (torch.from_numpy(a).to(dev) for a in (iu, ii, y))
+    cb = svi.CooBatch(m, bu, bi, by, seg_cap=cap)
+    bad, overflow = cb.read_sizes()
+    assert not bad and not overflow
+    for w, rows_of, cols_of, nrows, flag in (("u", bu, bi, nU, m.flag_u), ("i", bi, bu, nI, m.flag_i)):
+        want = svi.BatchSide(rows_of, cols_of, by, seg_cap=cap)
+        got = cb.side(w)
+        nseg, nmulti, present = cb.host[w]
+        assert (nseg, nmulti, present) == (want.nseg, want.nmulti, want.nrows), (case, w)
+        assert np.array_equal(got.idx.cpu().numpy(), want.idx.cpu().numpy())
+        assert np.array_equal(got.y.cpu().numpy(), want.y.cpu().numpy())
+        assert np.array_equal(got.segs[:nseg].cpu().numpy(), want.segs.cpu().numpy())
+        assert int(got.nseg_dev.cpu()[0]) == nseg and int(got.nmulti_dev.cpu()[0]) == nmulti
+        wrsp = want.row_seg_ptr.cpu().numpy()
+        wrows = want.rows.cpu().numpy()
+        f = np.zeros(nrows, np.uint8)
+        f[wrows] = np.where(wrsp[1:] - wrsp[:-1] > 1, 2, 1)
+        assert np.array_equal(flag.cpu().numpy(), f)
+        ml = want.multi_local.cpu().numpy()
+        wm = np.stack([wrsp[ml], wrsp[ml + 1] - wrsp[ml], wrows[ml]], axis=1) if ml.size else np.zeros((0, 3), np.int64)
+        assert np.array_equal(got.multi[:nmulti].cpu().numpy(), wm)
+        assert got.short_rows == want.short_rows
+    if nnz > 0:                         # ids past the tables / "negative" (>= 2^63 as size_t): flagged, never gathered
+        for bad_u, bad_i in ((nU, 0), (-1, 0), (0, nI + 5)):
+            iu2, ii2 = iu.copy(), ii.copy()
+            iu2[nnz // 2] = bad_u if bad_u else iu2[nnz // 2]
+            ii2[nnz // 3] = bad_i if bad_i else ii2[nnz // 3]
+            cb2 = svi.CooBatch(m, torch.from_numpy(iu2).to(dev), torch.from_numpy(ii2).to(dev), by, seg_cap=cap)
+            assert cb2.read_sizes()[0]
+
+
 @pytest.mark.parametrize("case", ["ragged", "hubs", "empty-rows", "no-nonzeros"])
 def test_batch_workspace_equals_the_tensor_library_structures(any_backend, case):
     """svi.BatchWorkspace (hpf_hip_svi_batch_prepare: everything on the device, one call, nothing read back) builds

@@ -58,6 +58,31 @@ with warnings.catch_warnings():
               "between the first and the last device operation of a call: %.1f ms"
               % (name, len(batches), per, n.mean() / 1e6, 1e3 * np.median(t_call), 1e3 * min(t_call), 1e3 * max(t_call),
                  1e3 * np.median(t_dev)))
+if os.environ.get("HPF_TIMING") == "1":       # device-synchronised phases, per call, next to the call's triplet count
+    from hpfrec_amd import svi
+    svi.PF_TIMINGS.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for kind, batches in (("users", user_batches), ("items", item_batches)):
+            for b in batches:
+                m.partial_fit(b, batch_type=kind)
+    ph = svi.PF_TIMINGS
+    sizes = [b.shape[0] for b in user_batches + item_batches]
+    print("phases per call [ms] (device-synchronised after each; triplets | " + " | ".join(ph) + "):")
+    for j, nn in enumerate(sizes):
+        print("  %s %9d | " % ("user" if j < len(user_batches) else "item", nn) + " | ".join("%6.2f" % (1e3 * ph[p_][j]) for p_ in ph))
+if os.environ.get("PF_PROFILE") == "1":       # where the host spends an item call (cProfile over a second pass of them)
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pr.enable()
+        for b in item_batches:
+            m.partial_fit(b, batch_type="items")
+        torch.cuda.synchronize()
+        pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(14)
 st = m._state
 print("state traffic after the first calls: h2d %.2f GB, d2h %.2f GB" % (st.stats["h2d_bytes"] / 1e9, st.stats["d2h_bytes"] / 1e9))
 th = st.rows("Theta", [0, nU - 1])
