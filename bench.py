@@ -244,6 +244,175 @@ def cpu_baseline(nU, nI, k, nnz_full, sample_users=200_000, iters=4, device=None
     return out
 
 
+def _svi_epoch_bytes(nU, nI, nnz, k, per=65536):
+    """Algorithmic bytes of one stochastic epoch at users_per_batch = items_per_batch = per (mean of a user and an item
+    epoch; fp32 values, int32 ids, every gather counted once, no cache credit -- the convention of SURVEY.md section 8d
+    applied to the reference's statements PXI:277-377): per batch of B rows with n nonzeros touching R rows of the other
+    side, the two sweeps n*(8 + 8k); the reference's whole-table statements (PXI:300,318,322 / 352,370,374) -- the batch
+    side's rates, means and shapes of ALL its rows, 12k per row, and the other side's means, 8k per row; E rows and
+    accumulators of the touched rows (B + R)*16k.  Summed over an epoch: sum n = nnz, sum B = the side's rows."""
+    nb_u, nb_i = -(-nU // per), -(-nI // per)
+    R_u, R_i = min(nI, nnz // nb_u), min(nU, nnz // nb_i)       # (upper bounds on the other side's rows per batch)
+    b_user = nnz * (8 + 8 * k) + nb_u * (nU * 12 * k + nI * 8 * k + R_u * 16 * k) + nU * 16 * k
+    b_item = nnz * (8 + 8 * k) + nb_i * (nI * 12 * k + nU * 8 * k + R_i * 16 * k) + nI * 16 * k
+    return (b_user + b_item) / 2.0, nb_u, nb_i
+
+
+def other_workloads(device, host_triplets, nU, nI, with_oracle=True):
+    """The other single-GPU configurations of BASELINE.json, measured in the driver's own run AFTER the timed region and
+    the long pass (never inside them; `value` does not depend on anything here): C5 stochastic epochs (PXI:262-377), C5
+    read literally as HPF.partial_fit calls (PXI:423-473), C2 full batch.  Every entry names the kernel source it ran on."""
+    import warnings
+    import pandas as pd
+    from hpfrec_amd import svi, HPF
+    out = {"kernel_source_sha16": kernel_source_sha16(), "note": "untimed extras: measured after the timed region"}
+    iu_h, ii_h, y_h = host_triplets
+    nnz = int(y_h.shape[0])
+    k5, per = 200, 65536
+    IU, II = iu_h.astype(np.uint64), ii_h.astype(np.uint64)
+    none_f, none_i = np.empty(0, np.float32), np.empty(0, np.uint64)
+
+    def svi_fit(Y, iu, ii, st, n_u, n_i, epochs, upb=per, ipb=per, verbose=0):
+        Theta = np.empty((n_u, k5), np.float32)
+        Beta = np.empty((n_i, k5), np.float32)
+        i, temp, _ = backend.fit_hpf(0.3, 0.3, 1.0, 0.3, 0.3, 1.0, Y, iu, ii, Theta, Beta, epochs, "maxiter", 0, 1e-3, upb, ipb,
+                                     lambda x: 1 / np.sqrt(x + 2), 0, st, "", 123, verbose, 1, 0, 0, none_f, none_i, none_i,
+                                     0, 1, 0)
+        return i, dict(zip(("Gamma_shp", "Gamma_rte", "Lambda_shp", "Lambda_rte", "k_rte", "t_rte"), temp), Theta=Theta,
+                       Beta=Beta)
+
+    # ---- C5: stochastic epochs through fit_hpf, device-synchronised epoch loop (svi.SVI_TIMINGS) -----------------------
+    try:
+        os.environ["HPF_TIMING"] = "1"
+        epochs = 8
+        svi_fit(y_h, IU, II, np.zeros(1, np.uint64), nU, nI, 2)                     # warm: code objects, allocator
+        i_last, fit = svi_fit(y_h, IU, II, np.zeros(1, np.uint64), nU, nI, epochs)
+        loop = dict(svi.SVI_TIMINGS)
+        ms_epoch = loop["seconds"] / loop["epochs"] * 1e3
+        b_epoch, nb_u, nb_i = _svi_epoch_bytes(nU, nI, nnz, k5)
+        finite = bool(np.isfinite(fit["Theta"]).all() and np.isfinite(fit["Beta"]).all() and (fit["Theta"] > 0).all())
+        del fit
+        out["c5_svi"] = {
+            "workload": "C5 stochastic VI: C3 matrix (%d x %d, %d nnz), k=%d, users_per_batch = items_per_batch = %d (%d user / "
+                        "%d item batches per epoch), fit_hpf from host arrays" % (nU, nI, nnz, k5, per, nb_u, nb_i),
+            "epochs_timed": int(loop["epochs"]), "ms_per_epoch": ms_epoch,
+            "ms_per_batch": ms_epoch / ((nb_u + nb_i) / 2.0),
+            "timing": "device-synchronised wall time of the epoch loop alone (no llk check inside: stop_crit='maxiter', "
+                      "verbose=0), %d epochs alternating item / user epochs; reference loop PXI:262-377" % loop["epochs"],
+            "algorithmic_bytes_per_epoch": b_epoch, "frac_of_hbm_peak": b_epoch / (ms_epoch * 1e-3) / HBM_PEAK,
+            "host_seconds_in_the_loop": {"preparing": loop.get("host_prepare_s"), "issuing": loop.get("host_issue_s")},
+            "last_epoch_index": int(i_last), "state_finite": finite}
+    except Exception as exc:   # noqa: BLE001  (the headline line must survive)
+        out["c5_svi"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+    finally:
+        os.environ.pop("HPF_TIMING", None)
+    torch.cuda.empty_cache()
+
+    # ---- C5 parity in this run: 2 epochs on a <= 100k-user slice against the oracle's fit_svi -------------------------
+    if with_oracle and "error" not in out["c5_svi"]:
+        try:
+            from oracle import hpf_oracle as O
+            n_u = 100_000
+            keep = iu_h < n_u
+            Ys, ius, iis, st_ix_u = O.svi_inputs_like_reference(y_h[keep], iu_h[keep], ii_h[keep], n_u, nI)
+            _, got = svi_fit(Ys, ius, iis, st_ix_u, n_u, nI, 2)
+            dev_of = {}
+            for exact in (False, True):
+                st = O.fit_svi(Ys, ius, iis, st_ix_u, n_u, nI, k5, 2, 123, per, per, nthreads=O.max_threads(), exact_colsums=exact)
+                dev_of["float64 column sums" if exact else "as it is"] = max(
+                    float(np.max(np.abs(got[n] - getattr(st, n)) / np.abs(getattr(st, n)))) for n in O.State.names)
+            out["c5_svi"]["parity_in_this_run"] = {
+                "slice": "users < %d of the same matrix (all items): %d nnz, 2 epochs (one item, one user), k=%d, %d-row "
+                         "batches" % (n_u, int(Ys.shape[0]), k5, per),
+                "max_rel_dev_all_eight_arrays_vs_oracle_fit_svi": dev_of,
+                "note": "the oracle restates PXI:262-377 and is bit-exact to the reference's own captures "
+                        "(tests/golden/svi_large.npz); numpy's sequential float32 column sums over 1e5..4e5 rows are the noisy "
+                        "side (SURVEY.md section 7): the second figure replaces them by float64 sums in the oracle"}
+            del got, st
+        except Exception as exc:   # noqa: BLE001
+            out["c5_svi"]["parity_in_this_run"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+
+    # ---- C5 read literally: HPF.partial_fit, 65,536-user and 65,536-item calls on the resident k=200 model ----------
+    try:
+        order = np.argsort(iu_h, kind="stable")
+        U1, I1, Y1 = iu_h[order], ii_h[order], y_h[order]
+        order = np.argsort(ii_h, kind="stable")
+        U2, I2, Y2 = iu_h[order], ii_h[order], y_h[order]
+        del order
+        ptr_u = np.searchsorted(U1, np.arange(0, nU + per, per))
+        ptr_i = np.searchsorted(I2, np.arange(0, nI + per, per))
+
+        def frames(U, I, C, ptr):
+            return [pd.DataFrame({"UserId": U[a:b], "ItemId": I[a:b], "Count": C[a:b]}) for a, b in zip(ptr[:-1], ptr[1:])
+                    if b > a]
+        ub, ib = frames(U1, I1, Y1, ptr_u), frames(U2, I2, Y2, ptr_i)
+        m = HPF(k=k5, reindex=False, keep_data=False, random_seed=7, verbose=False)
+        res = {}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m.partial_fit(ub[0], nusers=nU, nitems=nI)        # uploads the initial state once
+            m.partial_fit(ib[-1], batch_type="items")
+            torch.cuda.synchronize()
+            for name, batches, kind in (("user", ub, "users"), ("item", ib, "items")):
+                t_call = []
+                for b in batches:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    m.partial_fit(b, batch_type=kind)
+                    torch.cuda.synchronize()
+                    t_call.append(time.perf_counter() - t0)
+                n_b = np.array([b.shape[0] for b in batches], dtype=np.float64)
+                full = [t for t, b in zip(t_call, batches) if b[("UserId" if kind == "users" else "ItemId")].nunique() == per]
+                res[name] = {"calls": len(batches), "median_ms_per_call": 1e3 * float(np.median(t_call)),
+                             "median_ms_per_full_%d_row_call" % per: 1e3 * float(np.median(full)) if full else None,
+                             "min_ms": 1e3 * float(min(t_call)), "max_ms": 1e3 * float(max(t_call)),
+                             "triplets_per_call": {"mean": float(n_b.mean()), "min": float(n_b.min()), "max": float(n_b.max())},
+                             "us_per_1000_triplets_over_all_calls": 1e9 * float(np.sum(t_call)) / float(n_b.sum())}
+        th = m._state.rows("Theta", [0, nU - 1])
+        res["state_finite"] = bool(np.isfinite(th).all() and (th > 0).all())
+        res["workload"] = ("C5 read literally: HPF.partial_fit(batch_type=...) on the resident k=%d model of the C3 matrix, every "
+                           "call = ALL interactions of <= %d users (items) as a pandas frame from host memory; wall time per "
+                           "call, device-synchronised; reference PXI:423-473, INIT:856-927" % (k5, per))
+        out["c5_partial_fit"] = res
+        del m, ub, ib, U1, I1, Y1, U2, I2, Y2
+    except Exception as exc:   # noqa: BLE001
+        out["c5_partial_fit"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+    torch.cuda.empty_cache()
+
+    # ---- C2: MovieLens-20M-shaped full batch ---------------------------------------------------------------------------
+    try:
+        n_u, n_i, nnz_t, k2, label2 = WORKLOADS["c2"]
+        iu, ii, y = synth_on_device(n_u, n_i, nnz_t, device)
+        nnz2 = int(iu.shape[0])
+        hy = cavi.Hyper(k2, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
+        Theta = np.empty((n_u, k2), np.float32)
+        Beta = np.empty((n_i, k2), np.float32)
+        init = backend.initialize_parameters(Theta, Beta, 123, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
+        m2 = cavi.FullBatchCavi(HipOps(device), device, iu, ii, y, n_u, n_i, hy)
+        m2.load_state(init[0], init[1], init[2], init[3], init[4], init[5], Theta, Beta)
+        del iu, ii, y
+        for _ in range(10):
+            m2.iterate(True)
+        torch.cuda.synchronize()
+        steps2 = 400
+        t0 = time.perf_counter()
+        for _ in range(steps2):
+            m2.iterate(True)
+        torch.cuda.synchronize()
+        ms2 = (time.perf_counter() - t0) / steps2 * 1e3
+        b2 = nnz2 * (8 + 8 * k2) + n_u * (12 + 20 * k2) + n_i * (4 + 24 * k2)
+        out["c2_full_batch"] = {"workload": label2, "nnz": nnz2, "steps": steps2, "ms_per_step": ms2, "iters_per_s": 1e3 / ms2,
+                                "algorithmic_bytes_per_iteration": b2, "frac_of_hbm_peak": b2 / (ms2 * 1e-3) / HBM_PEAK,
+                                "note": "all six output tables stored; at this size the gathered tables (27 MB + 7 MB of E rows) "
+                                        "stay in L2 / Infinity Cache: every gather is still counted at face value",
+                                "state_finite": bool(torch.isfinite(m2.Theta).all().item())}
+        del m2
+    except Exception as exc:   # noqa: BLE001
+        out["c2_full_batch"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+    torch.cuda.empty_cache()
+    return out
+
+
 class HbmActivitySampler:
     """Memory-controller (UMC) activity of one GPU sampled from the driver while the long confirmation pass runs -- the
     only HBM-side observable of this platform (rocprofv3 on gfx950 has no MALL / DRAM byte counter:
@@ -486,6 +655,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extras (lean-iteration and llk-pass timings); used under rocprofv3 so that "
                          "per-kernel averages cover exactly the warm-up + timed iterations")
+    ap.add_argument("--no-workloads", action="store_true",
+                    help="skip the untimed `workloads` block (C5 stochastic epochs, C5 partial_fit calls, C2) of the N=1 line")
     ap.add_argument("--no-fuse", action="store_true", help="separate sweep and row-finalize launches")
     ap.add_argument("--no-autotune", action="store_true",
                     help="N>1: time the library default only")
@@ -554,7 +725,8 @@ def main():
     hy = cavi.Hyper(k, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
     lu, li, ly, (u0, u1) = cavi.shard_users(iu, ii, y, nU, rank, world)
     host_triplets = None
-    if world == 1 and not args.no_cpu_baseline:      # the CPU baseline times the SAME matrix (host copies: 1 GB at C3)
+    want_workloads = world == 1 and args.workload == "c3" and not args.no_workloads and not args.no_extras
+    if world == 1 and (not args.no_cpu_baseline or want_workloads):   # the CPU baseline times the SAME matrix (host copies: 1 GB at C3)
         host_triplets = (iu.cpu().numpy(), ii.cpu().numpy(), y.cpu().numpy())
     del iu, ii, y
     Theta = np.empty((nU, k), np.float32)
@@ -802,6 +974,22 @@ def main():
         llk_ms = (time.perf_counter() - t1) * 1e3 / 3
         llk_val = float(terms[0] - sub)
 
+    # the same iteration with the two column sums of an iteration in the reference's (numpy's) own order: untimed extra
+    ref_ms = ref_steps = None
+    if world == 1 and not args.no_extras and hasattr(model, "ref_sums") and not model.ref_sums:
+        model.ref_sums = True
+        for _ in range(2):
+            model.iterate(True)
+        fence()
+        ref_steps = max(5, min(args.steps, 20))
+        t3 = time.perf_counter()
+        for _ in range(ref_steps):
+            model.iterate(True)
+        fence()
+        ref_ms = (time.perf_counter() - t3) / ref_steps * 1e3
+        model.ref_sums = False
+        model.iterate(True)
+
     # sanity: the state must be finite after the run (a NaN run would be a meaningless number)
     model.flush_items()   # sharded runs: gather the item tables (each rank finalizes a slice of the items)
     finite = bool(torch.isfinite(model.Beta).all().item() and torch.isfinite(model.Theta).all().item())
@@ -968,6 +1156,22 @@ def main():
             line["llk_pass_ms"] = llk_ms
             line["iters_per_sec_incl_llk_every_10"] = 1e3 / (ms + llk_ms / 10.0)
             line["train_llk_after_run"] = llk_val
+            if world == 1:      # the train-llk pass against the same roofline (nnz*(8+4k) + nU*4k bytes)
+                b_llk = nnz * (8 + 4 * k) + nU * 4 * k
+                line["llk_pass"] = {"ms": llk_ms, "algorithmic_bytes": b_llk, "frac_of_hbm_peak": b_llk / (llk_ms * 1e-3) / HBM_PEAK,
+                                    "kernel": "llk_sweep_kernel (PXI:627-658 over the CSR layout) + the colsum dot"}
+        if ref_ms is not None:
+            line["reference_order_column_sums"] = {
+                "switch": "HPF_COLSUM_ORDER=reference", "ms_per_step": ref_ms, "iters_per_s": 1e3 / ref_ms, "steps": ref_steps,
+                "over_default_ms_per_step": ref_ms / ms,
+                "what": "the same iteration with Theta.sum(axis=0) / Beta.sum(axis=0) formed in numpy's own order (float32, "
+                        "row after row: PXI:236,255) on the device -- the mode that holds 1e-4 against the reference itself at "
+                        "every size and horizon (tests/test_hip_parity.py::test_large_vs_golden)"}
+        if want_workloads:
+            try:
+                line["workloads"] = other_workloads(device, host_triplets, nU, nI, with_oracle=not args.no_cpu_baseline)
+            except Exception as e:   # noqa: BLE001  (the bench line must survive)
+                line["workloads"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(nU, nI, k, nnz, device=device, triplets=host_triplets)

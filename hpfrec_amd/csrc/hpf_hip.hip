@@ -1238,27 +1238,103 @@ __global__ __launch_bounds__(BLOCK) void colsum_kernel(const float *__restrict__
 
 // tab.sum(axis=0) in numpy's OWN order (PXI:236,255: Beta.sum(axis=0), Theta.sum(axis=0) of float32 arrays): numpy adds the
 // rows one after the other in float32 -- out[c] = fl(... fl(fl(a[0][c] + a[1][c]) + a[2][c]) ...), verified against a
-// row-by-row loop -- so one lane per column walking the rows in sequence reproduces the reference's sums BIT FOR BIT.  A chain
-// of nrows dependent adds cannot be spread over the chip: this is the diagnostic mode HPF_COLSUM_ORDER=reference (7 ms per
-// 2e5-row table), which shows that what separates the default path from the reference at 1e5..1e6 rows is this order and
-// nothing else (tests/test_hip_parity.py::test_large_vs_golden); the product sums per-block partials in double, fixed order.
-__global__ __launch_bounds__(WAVE) void colsum_sequential_kernel(const float *__restrict__ tab, int64_t nrows, int ld,
-                                                                 float *__restrict__ cs_out) {
-    constexpr int UNR = 64;            // rows in flight per lane
-    const int c = blockIdx.x * WAVE + threadIdx.x;
-    if (c >= ld) return;
-    const float *col = tab + c;
+// row-by-row loop -- so one lane per column walking the rows in sequence reproduces the reference's sums BIT FOR BIT
+// (HPF_COLSUM_ORDER=reference: the mode in which the HIP path holds 1e-4 against the reference itself at every size and
+// horizon, tests/test_hip_parity.py::test_large_vs_golden; the default sums per-block partials in double, fixed order).
+// A chain of nrows dependent adds cannot be spread over the chip, but it can be FED: fed straight from global memory by the
+// lane that adds (round 5) it ran at the latency of its 64 loads in flight -- 84 cycles per row, 7 ms per 2e5-row table.
+// Here a workgroup owns SEQ_COLS = 16 columns (ld/16 workgroups, each on its own CU): all 8 waves fetch the next tile of
+// SEQ_ROWS rows x 64 bytes into registers while wave 0 walks the current tile out of LDS, stored TRANSPOSED (row index
+// fastest) so that one ds_read_b128 hands a lane four consecutive rows of its column.  Measured: 4.25 ns per row whatever
+// the width (1M x 64: 4.25 ms, 380k x 64: 1.6 ms, 200k x 64: 0.85 ms -- 8x the round-5 kernel; profiles/r06_colsum_sequential.txt)
+// against a floor of 3.3 ns: a DEPENDENT v_add_f32 issues every 8 cycles on this chip, and a sequential float32 sum is
+// nothing but dependent adds.  Rows past the end are stored as +0 (x + 0 = x exactly).
+constexpr int SEQ_COLS = 16, SEQ_ROWS = 512, SEQ_PITCH = SEQ_ROWS + 4;      // (pitch 516: conflict-free transposed stores)
+constexpr int SEQ_THREADS = 512, SEQ_G = 16;       // SEQ_G groups of 4 rows are read while the previous SEQ_G are added
+__global__ __launch_bounds__(SEQ_THREADS) void colsum_sequential_kernel(const float *__restrict__ tab, int64_t nrows, int ld,
+                                                                        float *__restrict__ cs_out) {
+    __shared__ __attribute__((aligned(16))) float tile[2][SEQ_COLS][SEQ_PITCH];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid >> 6;
+    const int c0 = blockIdx.x * SEQ_COLS;
+    // thread t fetches the float4s (row = t / 4 + 128 h, columns c0 + 4*(t % 4) ..), h = 0..3, of a tile
+    constexpr int NH = SEQ_ROWS * 4 / SEQ_THREADS, RSTEP = SEQ_THREADS / 4;
+    const int rq = tid >> 2, cq = tid & 3;
+    const float *src = tab + c0 + 4 * cq;
+    const int64_t ntiles = (nrows + SEQ_ROWS - 1) / SEQ_ROWS;
+    float4 pre[NH];
+    auto fetch = [&](int64_t t) {
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            const int64_t r = t * SEQ_ROWS + rq + RSTEP * h;
+            pre[h] = (r < nrows) ? ld4(reinterpret_cast<const float4 *>(src + (size_t)r * ld)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            const int r = rq + RSTEP * h;
+            tile[buf][4 * cq + 0][r] = pre[h].x;
+            tile[buf][4 * cq + 1][r] = pre[h].y;
+            tile[buf][4 * cq + 2][r] = pre[h].z;
+            tile[buf][4 * cq + 3][r] = pre[h].w;
+        }
+    };
     float s = 0.f;                     // (0 + a[0] is a[0]: the same chain as starting from the first row)
-    int64_t r = 0;
-    for (; r + UNR <= nrows; r += UNR) {
-        float v[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; u++) v[u] = col[(size_t)(r + u) * ld];
-#pragma unroll
-        for (int u = 0; u < UNR; u++) s = __fadd_rn(s, v[u]);
+    if (ntiles > 0) {
+        fetch(0);
+        stage(0);
     }
-    for (; r < nrows; r++) s = __fadd_rn(s, col[(size_t)r * ld]);
-    cs_out[c] = s;
+    __syncthreads();
+    for (int64_t t = 0; t < ntiles; t++) {
+        const int buf = (int)(t & 1);
+        if (t + 1 < ntiles) fetch(t + 1);
+        if (wid == 0 && lane < SEQ_COLS) {
+            const float4 *col = reinterpret_cast<const float4 *>(&tile[buf][lane][0]);
+            // A dependent v_add_f32 issues every 8 cycles (4 to issue + 4 until its result can feed the next): the chain's
+            // own pace is 8 cycles per row, and each add leaves a 4-cycle issue slot free.  Two register sets alternate:
+            // while one is added, the reads of the other are issued INTO those slots -- one ds_read_b128 after every four
+            // adds, pinned with scheduling-group barriers (left to itself the compiler reads 14 groups, adds them, and only
+            // then reads again: the reads' issue slots and the LDS latency on top of the chain, 9.8 cycles per row)
+            float4 A[SEQ_G], B[SEQ_G];
+#pragma unroll
+            for (int g = 0; g < SEQ_G; g++) A[g] = col[g];
+#pragma unroll 1
+            for (int r4 = 0; r4 < SEQ_ROWS / 4; r4 += 2 * SEQ_G) {
+#pragma unroll
+                for (int g = 0; g < SEQ_G; g++) {
+                    B[g] = col[r4 + SEQ_G + g];
+                    s = __fadd_rn(s, A[g].x);
+                    s = __fadd_rn(s, A[g].y);
+                    s = __fadd_rn(s, A[g].z);
+                    s = __fadd_rn(s, A[g].w);
+                }
+#pragma unroll
+                for (int g = 0; g < SEQ_G; g++) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one DS read
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // four VALU
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int nx = (r4 + 2 * SEQ_G < SEQ_ROWS / 4) ? r4 + 2 * SEQ_G : 0;      // (last round: a harmless re-read)
+#pragma unroll
+                for (int g = 0; g < SEQ_G; g++) {
+                    A[g] = col[nx + g];
+                    s = __fadd_rn(s, B[g].x);
+                    s = __fadd_rn(s, B[g].y);
+                    s = __fadd_rn(s, B[g].z);
+                    s = __fadd_rn(s, B[g].w);
+                }
+#pragma unroll
+                for (int g = 0; g < SEQ_G; g++) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (t + 1 < ntiles) stage(buf ^ 1);
+        __syncthreads();
+    }
+    if (wid == 0 && lane < SEQ_COLS) cs_out[c0 + lane] = s;
 }
 
 
@@ -2844,8 +2920,8 @@ int hpf_hip_colsum_f32(const float *tab, int64_t nrows, int ld, float *cs_partia
 }
 
 int hpf_hip_colsum_sequential_f32(const float *tab, int64_t nrows, int ld, float *cs_out, void *stream) {
-    if (!tab || !cs_out || nrows < 0 || ld < 32 || (ld & 31)) return HPF_EINVAL;
-    hipLaunchKernelGGL(colsum_sequential_kernel, dim3((ld + WAVE - 1) / WAVE), dim3(WAVE), 0, (hipStream_t)stream, tab, nrows,
+    if (!tab || !cs_out || nrows < 0 || ld < 32 || (ld & 31) || (reinterpret_cast<uintptr_t>(tab) & 15)) return HPF_EINVAL;
+    hipLaunchKernelGGL(colsum_sequential_kernel, dim3(ld / SEQ_COLS), dim3(SEQ_THREADS), 0, (hipStream_t)stream, tab, nrows,
                        ld, cs_out);
     return last_error();
 }
