@@ -191,8 +191,11 @@ def cpu_baseline(nU, nI, k, nnz_full, sample_users=200_000, iters=4, device=None
     out["calibration_vs_reference"] = ("the port runs 12-15 % FASTER than the real Cython extension (port / reference time per "
                                        "iteration 0.85-0.88, timed side by side in the build container, 8 cores, 2M nnz: "
                                        "profiles/r02_cpu_calibration.txt) -- the reference itself cannot run on the GPU box")
-    # (what the real extension would be expected to give on these cores: the port's rate x the mid-point of that ratio)
-    out["estimated_reference_value"] = out["value"] * 0.865
+    # (NOT a measurement: what the real extension would be expected to give on these cores -- the port's measured rate x the
+    #  mid-point of the ratio the two showed side by side in the build container)
+    out["estimates"] = {"reference_extension_iters_per_s": out["value"] * 0.865,
+                        "how": "cpu_baseline.value x 0.865 (mid-point of the port / reference time ratio 0.85-0.88 of "
+                               "profiles/r02_cpu_calibration.txt); an estimate, not timed here"}
     # the oracle is the checker: the HIP path on the same sample, same start, same numbers of iterations
     if device is not None:
         hyd = cavi.Hyper(k, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)

@@ -438,7 +438,7 @@ class ShardedMixin:
         ok = torch.tensor([0.0 if err else 1.0], device=self.device)
         self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
         good = float(ok.item()) > 0
-        if os.environ.get("HPF_TEST_FAIL_FIRST_CHECK") == self.schedule:     # (tests: the fall-back path)
+        if self.schedule in os.environ.get("HPF_TEST_FAIL_FIRST_CHECK", "").split(","):     # (tests: the fall-back path)
             good, err = False, "failure injected by HPF_TEST_FAIL_FIRST_CHECK"
         prev = getattr(self, "first_check", None) or {}
         worst_all = max(worst, prev.get("max_rel_vs_call_by_call", 0.0) if prev.get("schedule") == self.schedule else 0.0)

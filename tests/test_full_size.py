@@ -250,7 +250,9 @@ def test_c5_subsample_vs_oracle(hip_backend_module):
     PXI:262-377; bit-exact to the reference's own captures in tests/test_oracle.py).  The gate of the stochastic path
     against the REFERENCE at 1e-4 is tests/test_svi_paths.py::test_svi_large_vs_golden_on_gpu (svi_large.npz, 60k x 50k,
     8192-row batches, produced by the real extension); this test is the diagnostic at C5's own k and batch size, where no
-    reference capture fits a fixture: 1e-4 against the port with float64 column sums, 3e-4 against the port as it is."""
+    reference capture fits a fixture: 1e-4 against the port with float64 column sums (measured 8e-6) and, against the port
+    as it is, what it measures (1.5e-4: numpy's sequential float32 column sums over 1.2e5 / 3.8e5 rows, recomputed every
+    batch, are the noisy side) + 20 %, so that a regression cannot hide under the bar."""
     be = hip_backend_module
     nU, nI, k, B = 120_000, 380_000, 200, 65536
     iu, ii, Y = datagen.synthetic_hpf_shaped(nU, nI, 5_800_000, seed=9)
@@ -265,8 +267,10 @@ def test_c5_subsample_vs_oracle(hip_backend_module):
     # as in the full-batch case the reference's own float32 row-by-row column sums (Theta.sum(axis=0) over 1.2e5 rows,
     # Beta.sum(axis=0) over 3.8e5 rows, recomputed every batch) are the noisy side: measured 1.5e-4 against the port as
     # it is, within the 1e-4 bar against the same port with float64 column sums
-    for exact, bar in ((True, 1e-4), (False, 3e-4)):
+    for exact, bar in ((True, 1e-4), (False, 1.8e-4)):
         st = O.fit_svi(Ys, ius, iis, st_ix_u, nU, nI, k, 2, 123, B, B, nthreads=O.max_threads(), exact_colsums=exact)
+        worst = max(_maxrel(got[n], getattr(st, n)) for n in O.State.names)
+        print("C5 subsample vs the oracle %s: %.2e" % ("with float64 column sums" if exact else "as it is", worst))
         for n in O.State.names:
             assert _maxrel(got[n], getattr(st, n)) < bar, (n, exact)
 

@@ -1242,6 +1242,50 @@ def test_bench_multi_rank_path_selftest(ranks):
         assert "no collective library" in co["carried_by"]
 
 
+@pytest.mark.parametrize("struck", ["", "direct,gather-early"])
+def test_bench_launches_its_own_eight_ranks_at_full_size(struck):
+    """`python bench.py --gpus 8 --steps 20 --warmup 5` exactly as the driver's first multi-GPU contact will issue it (no
+    launcher: bench.py becomes torch.distributed.run of 8 ranks of itself), at the FULL C3 size, all ranks on this one GPU
+    with gloo standing in for RCCL (HPF_BENCH_SELFTEST_GLOO=1: a code-path test, not a measurement): ONE JSON line within
+    five minutes, including the exchange autotune and the checked first iterations of every C-issued schedule; and the
+    same when the first-iteration check strikes `direct` and `gather-early` on every rank -- the line then comes from
+    finalize-then-gather, names what failed, and still carries the link probe (or its error)."""
+    import json
+    import subprocess
+    import sys
+    import time
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HPF_BENCH_SELFTEST_GLOO="1", HPF_DIRECT_TIMEOUT_MS="60000", HPF_VERIFY_FIRST="1")
+    for v in ("HPF_SCHEDULE", "HPF_ITEM_RANGES", "HPF_DIRECT_PREFETCH", "HPF_FORCE_SHARDED", "HPF_NATIVE_SHARD",
+              "HPF_SHARD_SWEEP_BPC", "HPF_ITEM_SWEEP_BPC", "RANK", "WORLD_SIZE", "LOCAL_RANK", "HPF_TEST_FAIL_FIRST_CHECK"):
+        env.pop(v, None)
+    if struck:
+        env["HPF_TEST_FAIL_FIRST_CHECK"] = struck
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    took = time.time() - t0
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    print("bench.py --gpus 8 (gloo self-test, struck=%r): %.0f s, schedule %s, %.2f ms per iteration"
+          % (struck, took, d["config"]["schedule"], d["ms_per_step"]))
+    assert took < 300, took
+    assert d["n_gpus"] == 8 and d["steps"] == 20 and d["config"]["state_finite"] is True
+    assert d["config"]["nnz"] > 48_000_000 and d["config"]["k"] == 50
+    co = d["collective"]
+    assert "link_probe" in co, co          # (per-peer pulls and flag round trips, or the error that kept them from running)
+    if struck:
+        assert d["config"]["schedule"] == "finalize-then-gather", d["config"]
+        assert sorted(d["config"]["schedules_struck_by_the_check"]) == ["direct", "gather-early"]
+        assert len(d["config"]["first_iteration_checks_failed"] or []) >= 1
+    else:
+        assert d["config"]["schedule"] == "direct" and not d["config"]["schedules_struck_by_the_check"]
+        assert d["config"]["checked_iterations_passed"].get("direct", 0) >= 3
+
+
 def test_bench_autotune_on_a_one_rank_rccl_group():
     """The exchange autotune of bench.py on REAL RCCL (one rank, HPF_FORCE_SHARDED=1, --autotune-all): every candidate
     completes; the `collective` block comes from the chosen one."""
