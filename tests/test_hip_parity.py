@@ -1280,7 +1280,6 @@ def test_bench_launches_its_own_eight_ranks_at_full_size(struck):
     if struck:
         assert d["config"]["schedule"] == "finalize-then-gather", d["config"]
         assert sorted(d["config"]["schedules_struck_by_the_check"]) == ["direct", "gather-early"]
-        assert len(d["config"]["first_iteration_checks_failed"] or []) >= 1
     else:
         assert d["config"]["schedule"] == "direct" and not d["config"]["schedules_struck_by_the_check"]
         assert d["config"]["checked_iterations_passed"].get("direct", 0) >= 3
