@@ -31,7 +31,7 @@ HPF_HIP_ABI_VERSION = 24
 
 #: every symbol include/hpf_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = (
-    "hpf_hip_abi_version", "hpf_hip_ld_for_k", "hpf_hip_device_info", "hpf_hip_stream_create", "hpf_hip_sweep_f32",
+    "hpf_hip_abi_version", "hpf_hip_ld_for_k", "hpf_hip_device_info", "hpf_hip_sweep_f32",
     "hpf_hip_sweep_finalize_f32",
     "hpf_hip_row_finalize_f32", "hpf_hip_row_finalize_ranges_f32", "hpf_hip_colsum_reduce_f32", "hpf_hip_colsum_reduce_add_f32", "hpf_hip_colsum_f32", "hpf_hip_colsum_sequential_f32", "hpf_hip_expect_f32",
     "hpf_hip_segsum_f32", "hpf_hip_pair_llk_f32", "hpf_hip_llk_sweep_f32", "hpf_hip_pair_dot_f32", "hpf_hip_score_rows_f32", "hpf_hip_gather_probe_f32",
@@ -83,7 +83,6 @@ def lib():
     L.hpf_hip_abi_version.argtypes = []
     L.hpf_hip_ld_for_k.argtypes = [ci]
     L.hpf_hip_device_info.argtypes = [ctypes.POINTER(ci), ctypes.c_char_p, ci]
-    L.hpf_hip_stream_create.argtypes = [ci, ctypes.POINTER(vp)]
     L.hpf_hip_sweep_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp]
     L.hpf_hip_sweep_finalize_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, ci,
                                              ci, ci, vp]

@@ -12,18 +12,8 @@ _SIDE_STREAMS = {}
 
 
 def side_stream(device, kind, priority=0):
-    """The process-wide stream of `kind` on `device` (created on first use; priority -1: its own hardware-queue pool;
-    priority 1: BELOW the compute stream -- the tensor library only creates normal and high ones, so that one comes from
-    hpf_hip_stream_create and is wrapped)."""
+    """The process-wide stream of `kind` on `device` (created on first use; priority -1: its own hardware-queue pool)."""
     key = (str(torch.device(device)), kind)
     if key not in _SIDE_STREAMS:
-        if priority > 0:
-            import ctypes
-            from . import _lib
-            ptr = ctypes.c_void_p()
-            with torch.cuda.device(device):
-                _lib.check(_lib.lib().hpf_hip_stream_create(int(priority), ctypes.byref(ptr)), "hpf_hip_stream_create")
-            _SIDE_STREAMS[key] = torch.cuda.ExternalStream(ptr.value, device=device)
-        else:
-            _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=priority)
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=priority)
     return _SIDE_STREAMS[key]

@@ -1999,11 +1999,12 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
             const int fv = (lv && flag) ? (int)flag[rl] : 0;
             const unsigned long long dmask = __ballot(done_flag != 0 && fv == done_flag);
             const unsigned long long fmask = __ballot(fv != 0) & ~dmask;
+            const unsigned long long vmask = delta ? fmask : ~dmask;       // the rows this pass visits
+            if (delta && vmask == 0) continue;       // (64 rows the step leaves alone: their flags were all that was read)
             const float rs_l = lv ? rs[rl] : 1.f;
             const float rsr_l = (lv && rs_rate) ? rs_rate[rl] : rs_l;
             float rs_new_l = rs_l;
             const int cnt = (int)min((int64_t)WAVE, nrows - g);
-            const unsigned long long vmask = delta ? fmask : ~dmask;       // the rows this pass visits
             for (int b0 = 0; b0 < cnt; b0 += VR) {
                 if (((vmask >> b0) & ((1ull << VR) - 1)) == 0) continue;     // (finished elsewhere / nothing of theirs changes)
                 float4 sv[VR][VPL], rv[VR][VPL], av[VR][VPL], ev[VR][VPL];
@@ -2604,23 +2605,6 @@ int hpf_hip_device_info(int *cu_count, char *arch, int arch_len) {
         strncpy(arch, prop.gcnArchName, (size_t)arch_len - 1);
         arch[arch_len - 1] = 0;
     }
-    return 0;
-}
-
-int hpf_hip_stream_create(int priority, void **stream) {
-    // a stream of its own at a HIP priority (-1 high, 0 normal, 1 low; clamped to the device's range): the tensor library
-    // only hands out normal and high ones, and work that is meant to fill the tails of the compute stream's kernels --
-    // the preparation of the next stochastic epoch -- wants to be BELOW them
-    if (!stream) return HPF_EINVAL;
-    int least = 0, greatest = 0;
-    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if (e != hipSuccess) return (int)e;
-    if (priority > least) priority = least;
-    if (priority < greatest) priority = greatest;
-    hipStream_t st = nullptr;
-    e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, priority);
-    if (e != hipSuccess) return (int)e;
-    *stream = (void *)st;
     return 0;
 }
 

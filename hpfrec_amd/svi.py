@@ -746,10 +746,9 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
     lazy = os.environ.get("HPF_SVI_LAZY", "1") == "1"
     # (one preparation stream per device for the life of the process, like the exchange streams of the sharded fit: a new
     # stream per fit walks through the hardware queues, and some of them collide with the compute stream's)
-    # (HPF_SVI_PREP_PRIORITY, default 1 = low: the next epoch's preparation fills the tails of this epoch's kernels instead of
-    #  taking wave slots from them)
-    prep_stream = _streams.side_stream(dev, "svi-prepare-p%s" % os.environ.get("HPF_SVI_PREP_PRIORITY", "1"),
-                                       priority=int(os.environ.get("HPF_SVI_PREP_PRIORITY", "1"))) if dev.type == "cuda" else None
+    # (a LOW-priority preparation stream -- hipStreamCreateWithPriority below the compute stream's -- was measured and
+    #  changed nothing: 25.5-26.0 ms per C5 epoch either way, profiles/r06_svi_c5_ab.txt)
+    prep_stream = _streams.side_stream(dev, "svi-prepare") if dev.type == "cuda" else None
     if prep_stream is not None:
         prep_stream.wait_stream(torch.cuda.current_stream(dev))      # the CSR / CSC built above
     workspaces = {}

@@ -58,10 +58,6 @@ int hpf_hip_abi_version(void);
 int hpf_hip_ld_for_k(int k);
 
 /* Device name ("gfx950...") and compute-unit count of the current device. */
-/* A HIP stream at a priority (-1 high, 0 normal, 1 low; clamped to the device's range), for callers whose tensor library
- * cannot create a LOW-priority one: the preparation of the next stochastic epoch runs below the compute stream's kernels.
- * The stream lives until the process ends. */
-int hpf_hip_stream_create(int priority, void **stream);
 int hpf_hip_device_info(int *cu_count, char *arch, int arch_len);
 
 /*
