@@ -537,25 +537,54 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
             }
         }
     };
+    // MODE 2 / 3 (the rows of a stochastic batch: 8-50 nonzeros, one or a few rounds of gathers each): a wave's segments are
+    // PIPELINED -- the descriptor of the segment after next is requested while the current segment is swept (wave-uniform:
+    // scalar registers) and, MODE 2 (the other side's rows: 8-12 nonzeros at C5), so are the first 64 ids / counts of the next
+    // segment: a row costs the latency of its gathers, not of the chain descriptor -> ids -> gathers.  (MODE 3 requests the
+    // next row's shape instead; with the ids as well it would hold 131 registers: three waves per SIMD instead of four.)
+    // (the same for the plain sweep's short-row launch -- the item-side ranges of an 8-rank sharded iteration, ~16 nonzeros per
+    //  row -- changed nothing: 0.580 vs 0.581 ms per rank-0-of-8 iteration, profiles/r06_shard_probe_pipelined.txt)
+    constexpr bool PIPE = (MODE == 2 || MODE == 3);
     RowRequest rq_next;
     hpf_segment sg_cur, sg_next;
     sg_cur.begin = 0, sg_cur.len = 0, sg_cur.row = 0;
     sg_next = sg_cur;
-    if constexpr (MODE == 3) {
+    int c_pre = 0;
+    float y_pre = 0.f;
+    auto request_chunk0 = [&](const hpf_segment &d) {
+        const int l0 = min(WAVE, d.len & HPF_SEG_LEN_MASK);
+        c_pre = 0;
+        y_pre = 0.f;
+        if (lane < l0) {
+            c_pre = stream_load(idx + d.begin + lane);
+            y_pre = stream_load(y + d.begin + lane);
+        }
+    };
+    if constexpr (PIPE) {
         const int64_t sg0 = (int64_t)blockIdx.x * WPB + wid;
         if (sg0 < nseg) {
             sg_cur = segs[sg0];
-            request_row(sg_cur.row, rq_next);
+            if constexpr (MODE == 3) request_row(sg_cur.row, rq_next);
+            if constexpr (MODE == 2) request_chunk0(sg_cur);
             if (sg0 + nwaves < nseg) sg_next = segs[sg0 + nwaves];
         }
     }
 
     for (int64_t sg = (int64_t)blockIdx.x * WPB + wid; sg < nseg; sg += nwaves) {
-        const hpf_segment sgm = (MODE == 3) ? sg_cur : segs[sg];
+        const hpf_segment sgm = PIPE ? sg_cur : segs[sg];
         const int len = sgm.len & HPF_SEG_LEN_MASK;
         const float4 *selfp = reinterpret_cast<const float4 *>(tab_self + (size_t)sgm.row * LD);
         float4 rv[VPL], acc[VPL];
         float en3[(MODE == 3) ? NC : 1];
+        const int c_first = c_pre;
+        const float y_first = y_pre;
+        if constexpr (MODE == 2) {
+            if (sg + nwaves < nseg) {
+                sg_cur = sg_next;
+                request_chunk0(sg_cur);
+                if (sg + 2 * nwaves < nseg) sg_next = segs[sg + 2 * nwaves];
+            }
+        }
         if constexpr (MODE == 3) {
             // PROLOGUE: this row's E row from the operands requested one segment ago; then the next segment's are requested
             const RowRequest rq = rq_next;
@@ -630,7 +659,10 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
             const int n = min(WAVE, len - base);
             int myc = 0;
             float myy = 0.f;
-            if (lane < n) {
+            if (MODE == 2 && base == 0) {       // (requested one segment ago)
+                myc = c_first;
+                myy = y_first;
+            } else if (lane < n) {
                 myc = stream_load(ip + base + lane);
                 myy = stream_load(yp + base + lane);
             }
