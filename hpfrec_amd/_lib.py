@@ -33,7 +33,7 @@ HPF_HIP_ABI_VERSION = 24
 SYMBOLS = (
     "hpf_hip_abi_version", "hpf_hip_ld_for_k", "hpf_hip_device_info", "hpf_hip_sweep_f32",
     "hpf_hip_sweep_finalize_f32",
-    "hpf_hip_row_finalize_f32", "hpf_hip_row_finalize_ranges_f32", "hpf_hip_colsum_reduce_f32", "hpf_hip_colsum_reduce_add_f32", "hpf_hip_colsum_f32", "hpf_hip_colsum_sequential_f32", "hpf_hip_expect_f32",
+    "hpf_hip_row_finalize_f32", "hpf_hip_row_finalize_ranges_f32", "hpf_hip_colsum_reduce_f32", "hpf_hip_colsum_f32", "hpf_hip_colsum_sequential_f32", "hpf_hip_expect_f32",
     "hpf_hip_segsum_f32", "hpf_hip_pair_llk_f32", "hpf_hip_llk_sweep_f32", "hpf_hip_pair_dot_f32", "hpf_hip_score_rows_f32", "hpf_hip_gather_probe_f32",
     "hpf_hip_svi_shape_rows_f32", "hpf_hip_svi_refresh_f32", "hpf_hip_svi_rate_rows_f32", "hpf_hip_svi_side_f32", "hpf_hip_sweep_svi_f32", "hpf_hip_sweep_svi_batch_f32", "hpf_hip_mt19937_words", "hpf_hip_uniform_rows_f32", "hpf_hip_svi_batch_prepare", "hpf_hip_svi_prep_scratch_words", "hpf_hip_svi_batch_sizeof", "hpf_hip_svi_epoch_prepare", "hpf_hip_svi_epoch_scratch_words", "hpf_hip_svi_epoch_sizeof", "hpf_hip_svi_coo_sizeof", "hpf_hip_svi_coo_narrow", "hpf_hip_svi_coo_prepare", "hpf_hip_segsum_desc_f32", "hpf_hip_fold_in_f32",
     "hpf_hip_item_shape_rows_f32", "hpf_hip_item_apply_rows_f32", "hpf_hip_gather_payload_ld", "hpf_hip_rccl_open", "hpf_hip_rccl_unique_id", "hpf_hip_rccl_comm_init", "hpf_hip_rccl_comm_count",
@@ -137,10 +137,9 @@ def lib():
     L.hpf_hip_svi_shape_rows_f32.argtypes = [vp, i64, vp, vp, vp, cf, cf, cf, ci, ci, ci, vp]
     L.hpf_hip_svi_refresh_f32.argtypes = [i64, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, ci, ci, ci, ci, ci, vp]
     L.hpf_hip_svi_side_f32.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, cf, cf, cf, ci, ci, ci, ci,
-                                       ci, vp, vp, vp, ci, ci, vp]
+                                       ci, vp, vp, vp, ci, vp]
     L.hpf_hip_sweep_svi_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, cf, cf, cf,
-                                        ci, ci, ci, ci, ci, vp, vp]
-    L.hpf_hip_colsum_reduce_add_f32.argtypes = [vp, ci, vp, vp, ci, vp]
+                                        ci, ci, ci, ci, vp, vp]
     L.hpf_hip_sweep_svi_batch_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, vp, vp,
                                               cf, cf, cf, cf, cf, cf, cf, ci, ci, ci, ci, vp, vp]
     L.hpf_hip_svi_rate_rows_f32.argtypes = [vp, i64, vp, vp, vp, vp, cf, cf, cf, cf, ci, ci, ci, vp]

@@ -281,7 +281,6 @@ struct FinalizeArgs {  // the row-finalize operands when it is fused into the sw
     // rate_top / rate_rs[row] + rate_cs[c], else the stored table rte_in[row][c] (may be the table `rte` points at)
     const float *rate_rs, *rate_cs, *rte_in;
     float rate_top;
-    int delta;        // MODE 2: the column-sum partials hold the CHANGE of the finished rows' means (new - old), not the means
 };
 
 // MODE: 0 = plain sweep; 1 = row finalize fused as EPILOGUE of whole-row segments; 2 = the OTHER side of a stochastic step
@@ -402,12 +401,6 @@ __attribute__((amdgpu_waves_per_eu(HPF_SWEEP_WAVES_PER_EU, (MODE != 0) ? HPF_FUS
         for (int t = 0; t < NC; t++) {
             fsum += fc[t];
             csacc[t] += fc[t];
-        }
-        if (fa.delta) {       // ... minus what the row's mean was before the step (its old shape over its old rate)
-            float fo[NC];
-            div_columns<NC>(so, ro, vld, fo);
-#pragma unroll
-            for (int t = 0; t < NC; t++) csacc[t] -= fo[t];
         }
         if (fa.e_new) {
             double ev[NC];
@@ -1388,8 +1381,7 @@ __global__ __launch_bounds__(SEQ_THREADS) void colsum_sequential_kernel(const fl
 __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float *__restrict__ cs_partial, int nblk,
                                                              float *__restrict__ cs_out, int ld,
                                                              const hpf_p2p::Peers *__restrict__ peers, int which,
-                                                             uint32_t epoch, uint32_t then_wait_kinds, int then_wait_self,
-                                                             const float *__restrict__ base = nullptr) {
+                                                             uint32_t epoch, uint32_t then_wait_kinds, int then_wait_self) {
     __shared__ double red[16][4];
     const int c0 = blockIdx.x * 4;          // (ld is a multiple of 4: grid = ld / 4)
     const float *col = cs_partial + c0;
@@ -1429,7 +1421,6 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float *__rest
         double t = red[0][threadIdx.x];
 #pragma unroll
         for (int q = 1; q < 16; q++) t += red[q][threadIdx.x];
-        if (base) t += (double)base[c];          // (the partials are CHANGES: hpf_hip_colsum_reduce_add_f32)
         float out = (float)t;
         if (peers) {
             const hpf_p2p::Peers pp = *peers;
@@ -1979,11 +1970,7 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                                                          float w_old, float top, float add, float step,
                                                          float step_prev, int rate_mode, int rs_mode, int k,
                                                          const float *__restrict__ rs_rate,
-                                                         float *__restrict__ rs_prev_out, float *e_out, int done_flag,
-                                                         int delta) {
-    // delta != 0 (rate_mode 1 only): the pass visits the FLAGGED rows only and its column-sum partials hold the change of their
-    // means, new - old (old = the row's shape over its rate as loaded): the rows a step does not touch keep their means, so
-    // the side's column sums are the previous ones + the changes -- their shapes and rates need not be read at all.
+                                                         float *__restrict__ rs_prev_out, float *e_out, int done_flag) {
     // done_flag != 0: rows whose flag EQUALS it were finished elsewhere (the sweep's fused epilogue, sweep_kernel MODE 2) --
     // nothing of theirs is read, written or summed here; the other flagged rows (a split row's flag differs) and the
     // unflagged rows are treated as ever.
@@ -2031,19 +2018,17 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
             const int fv = (lv && flag) ? (int)flag[rl] : 0;
             const unsigned long long dmask = __ballot(done_flag != 0 && fv == done_flag);
             const unsigned long long fmask = __ballot(fv != 0) & ~dmask;
-            const unsigned long long vmask = delta ? fmask : ~dmask;       // the rows this pass visits
-            if (delta && vmask == 0) continue;       // (64 rows the step leaves alone: their flags were all that was read)
             const float rs_l = lv ? rs[rl] : 1.f;
             const float rsr_l = (lv && rs_rate) ? rs_rate[rl] : rs_l;
             float rs_new_l = rs_l;
             const int cnt = (int)min((int64_t)WAVE, nrows - g);
             for (int b0 = 0; b0 < cnt; b0 += VR) {
-                if (((vmask >> b0) & ((1ull << VR) - 1)) == 0) continue;     // (finished elsewhere / nothing of theirs changes)
+                if (((dmask >> b0) & ((1ull << VR) - 1)) == ((1ull << VR) - 1)) continue;     // (all of them finished elsewhere)
                 float4 sv[VR][VPL], rv[VR][VPL], av[VR][VPL], ev[VR][VPL];
                 bool fl[VR], live[VR];
 #pragma unroll
                 for (int i = 0; i < VR; i++) {
-                    live[i] = b0 + i < cnt && ((vmask >> (b0 + i)) & 1ull) != 0;
+                    live[i] = b0 + i < cnt && ((dmask >> (b0 + i)) & 1ull) == 0;
                     fl[i] = live[i] && ((fmask >> (b0 + i)) & 1ull) != 0;
                     const size_t o4 = (size_t)(live[i] ? g + b0 + i : 0) * (LD / 4) + lane;
 #pragma unroll
@@ -2077,13 +2062,11 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                         const float e4[4] = {ev[i][v].x, ev[i][v].y, ev[i][v].z, ev[i][v].w};
                         const float c4[4] = {cs4[v].x, cs4[v].y, cs4[v].z, cs4[v].w};
                         float f4[4];
-                        float d4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int e2 = 0; e2 < 4; e2++) {
                             float f = 0.f;
                             if (ok[v][e2]) {
                                 float sx = s4[e2];
-                                if (delta) d4[e2] = s4[e2] / r4[e2];      // the row's mean before the step
                                 if (fl[i]) {
                                     const float fresh = fmaf(e4[e2], a4[e2], prior);
                                     sx = blend_shape(w_new, fresh, w_old, sx);
@@ -2103,10 +2086,10 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                             f4[e2] = f;
                             fsum += f;
                         }
-                        acc4[v].x += f4[0] - d4[0];
-                        acc4[v].y += f4[1] - d4[1];
-                        acc4[v].z += f4[2] - d4[2];
-                        acc4[v].w += f4[3] - d4[3];
+                        acc4[v].x += f4[0];
+                        acc4[v].y += f4[1];
+                        acc4[v].z += f4[2];
+                        acc4[v].w += f4[3];
                         if (fl[i]) reinterpret_cast<float4 *>(shp)[o4 + v * WAVE] = make_float4(s4[0], s4[1], s4[2], s4[3]);
                         if (rte && (rate_mode == 0 || fl[i]))
                             reinterpret_cast<float4 *>(rte)[o4 + v * WAVE] = make_float4(r4[0], r4[1], r4[2], r4[3]);
@@ -2176,7 +2159,6 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
             const int fv = (live && flag) ? (int)flag[r] : 0;
             dn[i] = done_flag != 0 && fv == done_flag;
             fl[i] = fv != 0 && !dn[i];
-            if (delta && !fl[i]) dn[i] = true;          // (an untouched row: nothing of its changes)
             rs_old[i] = live ? rs[r] : 1.f;
             rs_rt[i] = (live && rs_rate) ? rs_rate[r] : rs_old[i];
         }
@@ -2207,10 +2189,9 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                 const int c = lane + WAVE * q;
                 if (c < LD) {
                     const size_t o = (size_t)r * LD + c;
-                    float f = 0.f, s_new = 0.f, rt_new = 1.f, f_old = 0.f;
+                    float f = 0.f, s_new = 0.f, rt_new = 1.f;
                     if (c < k) {
                         float s = sv[i][q];
-                        if (delta) f_old = sv[i][q] / rv[i][q];      // the row's mean before the step
                         if (fl[i]) {
                             const float fresh = fmaf(ev[i][q], av[i][q], prior);
                             s = blend_shape(w_new, fresh, w_old, s);
@@ -2230,7 +2211,7 @@ __global__ __launch_bounds__(BLOCK) void svi_side_kernel(int64_t nrows, const ui
                     }
                     if (fac) fac[o] = f;
                     fsum += f;
-                    csacc[q] += f - f_old;
+                    csacc[q] += f;
                     if (e_out && fl[i] && c < k) {     // (kept for the E row below)
                         sv[i][q] = s_new;
                         rv[i][q] = rt_new;
@@ -2729,7 +2710,7 @@ int hpf_hip_sweep_svi_f32(const hpf_segment *segs, int64_t nseg, const int32_t *
                           const float *tab_other, float *part, float *e_new, float *shp, float *rte, float *fac, float *rs,
                           const float *cs_other, float *cs_partial, float prior, float w_new, float w_old, float top,
                           float add, float step, float step_prev, int k, int ld, int short_rows, int grid_blocks,
-                          int delta_sums, const int64_t *nseg_dev, void *stream) {
+                          const int64_t *nseg_dev, void *stream) {
     if (!segs || !idx || !y || !tab_self || !tab_other || !part || !shp || !rte || !rs || !cs_other || !cs_partial ||
         nseg <= 0 || k <= 0 || ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0 || (e_new && e_new != tab_self))
         return HPF_EINVAL;
@@ -2752,7 +2733,6 @@ int hpf_hip_sweep_svi_f32(const hpf_segment *segs, int64_t nseg, const int32_t *
     fa.w_old = w_old;
     fa.step = step;
     fa.step_prev = step_prev;
-    fa.delta = delta_sums != 0;
     const bool skip = fa.nq4 < ld / 4;
     hipStream_t st = (hipStream_t)stream;
     constexpr int US = (HPF_U >= 8) ? HPF_U / 2 : HPF_U;
@@ -2961,14 +2941,6 @@ int hpf_hip_colsum_reduce_f32(const float *cs_partial, int nblk, float *cs_out, 
     return last_error();
 }
 
-int hpf_hip_colsum_reduce_add_f32(const float *cs_partial, int nblk, const float *base, float *cs_out, int ld, void *stream) {
-    if (!cs_partial || !cs_out || !base || nblk <= 0 || ld < 32 || (ld & 3) || (reinterpret_cast<uintptr_t>(cs_partial) & 15))
-        return HPF_EINVAL;
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(ld / 4), dim3(1024), 0, (hipStream_t)stream,
-                       cs_partial, nblk, cs_out, ld, (const hpf_p2p::Peers *)nullptr, 0, 0u, 0u, -1, base);
-    return last_error();
-}
-
 int hpf_hip_colsum_f32(const float *tab, int64_t nrows, int ld, float *cs_partial, int grid_blocks, void *stream) {
     if (!tab || !cs_partial || nrows <= 0 || grid_blocks <= 0) return HPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -3100,8 +3072,7 @@ int hpf_hip_svi_side_f32(int64_t nrows, const uint8_t *flag, const float *acc, c
                          float *fac, float *rs, const float *cs_other, float *cs_partial, float prior, float w_new,
                          float w_old, float top, float add, float step, float step_prev, int rate_mode, int rs_mode,
                          int k, int ld, int grid_blocks, const float *rs_rate, float *rs_prev_out, float *e_out,
-                         int done_flag, int delta_sums, void *stream) {
-    if (delta_sums && (rate_mode != 1 || rs_mode == 2 || !flag || fac)) return HPF_EINVAL;
+                         int done_flag, void *stream) {
     if (!shp || !rs || !cs_other || !cs_partial || (flag && (!acc || !e)) || nrows <= 0 || k <= 0 ||
         ld != hpf_hip_ld_for_k(k) || grid_blocks <= 0 || (rate_mode != 0 && rate_mode != 1) || rs_mode < 0 ||
         rs_mode > 2 || (rate_mode == 1 && !rte) || (e_out && !flag) || done_flag < 0 || done_flag > 255 ||
@@ -3129,7 +3100,7 @@ int hpf_hip_svi_side_f32(int64_t nrows, const uint8_t *flag, const float *acc, c
 #define CALL(LD)                                                                                                    \
     hipLaunchKernelGGL((svi_side_kernel<LD>), dim3(grid_blocks), dim3(BLOCK), 0, st, nrows, flag, acc, e, shp, rte, \
                        fac, rs, cs_other, cs_partial, prior, w_new, w_old, top, add, step, step_prev, rate_mode,    \
-                       rs_mode, k, rs_rate, rs_prev_out, e_out, done_flag, delta_sums);
+                       rs_mode, k, rs_rate, rs_prev_out, e_out, done_flag);
     HPF_DISPATCH_LD1(ld, CALL)
 #undef CALL
     return last_error();

@@ -177,13 +177,7 @@ class HipOps:
             float(add_rte), k, ld, int(rank), int(world), int(nrows), n, ctypes.addressof(lo), ctypes.addressof(hi),
             cs_partial.shape[0], self._stream()), "hpf_hip_item_apply_rows_f32")
 
-    def colsum_reduce(self, cs_partial, cs_out, ld, base=None):
-        """cs_out = the partial rows summed in double, fixed order; base (optional): + base -- the partials are CHANGES of a
-        side's column sums (hpf_hip_colsum_reduce_add_f32)."""
-        if base is not None:
-            _lib.check(self.L.hpf_hip_colsum_reduce_add_f32(_ptr(cs_partial), cs_partial.shape[0], _ptr(base), _ptr(cs_out),
-                                                            ld, self._stream()), "hpf_hip_colsum_reduce_add_f32")
-            return
+    def colsum_reduce(self, cs_partial, cs_out, ld):
         _lib.check(self.L.hpf_hip_colsum_reduce_f32(_ptr(cs_partial), cs_partial.shape[0], _ptr(cs_out), ld,
                                                     self._stream()), "hpf_hip_colsum_reduce_f32")
 
@@ -361,7 +355,7 @@ class HipOps:
                                                   ld, cs_partial.shape[0], self._stream()), "hpf_hip_svi_refresh_f32")
 
     def svi_side(self, nrows, flag, acc, e, shp, rte, fac, rs, cs_other, cs_partial, prior, w_new, w_old, top, add, step,
-                 step_prev, rate_mode, rs_mode, k, ld, rs_rate=None, rs_prev_out=None, e_out=None, done_flag=0, delta=False):
+                 step_prev, rate_mode, rs_mode, k, ld, rs_rate=None, rs_prev_out=None, e_out=None, done_flag=0):
         """rte / fac None: not stored (rte: rate_mode 0 only); rs_prev_out: the scalar each row's rate was formed with;
         rs_rate: form the rate from these scalars instead of rs (expanding a factored rate); e_out: the flagged rows' new
         E rows (what `expect` would compute from the tables afterwards); done_flag: rows whose flag equals it were finished
@@ -370,12 +364,11 @@ class HipOps:
                                                _ptr(rs), _ptr(cs_other), _ptr(cs_partial), float(prior), float(w_new),
                                                float(w_old), float(top), float(add), float(step), float(step_prev),
                                                int(rate_mode), int(rs_mode), k, ld, cs_partial.shape[0], _ptr(rs_rate),
-                                               _ptr(rs_prev_out), _ptr(e_out), int(done_flag), int(bool(delta)),
-                                               self._stream()),
+                                               _ptr(rs_prev_out), _ptr(e_out), int(done_flag), self._stream()),
                    "hpf_hip_svi_side_f32")
 
     def sweep_svi(self, side, tab_self, tab_other, part, e_new, shp, rte, fac, rs, cs_other, cs_partial, prior, w_new,
-                  w_old, top, add, step, step_prev, k, ld, delta=False):
+                  w_old, top, add, step, step_prev, k, ld):
         """The sweep over a batch grouped by its OTHER side's rows with that side's step fused in (hpf_hip_sweep_svi_f32):
         rows present in one segment are finished by the wavefront that swept them; cs_partial: one row per block."""
         # (8 gathers in flight even for short rows: the epilogue caps the occupancy at 4 waves per SIMD either way, and
@@ -385,8 +378,8 @@ class HipOps:
                                                 _ptr(tab_other), _ptr(part), _ptr(e_new), _ptr(shp), _ptr(rte), _ptr(fac),
                                                 _ptr(rs), _ptr(cs_other), _ptr(cs_partial), float(prior), float(w_new),
                                                 float(w_old), float(top), float(add), float(step), float(step_prev), k, ld,
-                                                short, cs_partial.shape[0], int(bool(delta)),
-                                                _ptr(getattr(side, "nseg_dev", None)), self._stream()), "hpf_hip_sweep_svi_f32")
+                                                short, cs_partial.shape[0], _ptr(getattr(side, "nseg_dev", None)),
+                                                self._stream()), "hpf_hip_sweep_svi_f32")
 
     def sweep_svi_batch(self, side, e_self, tab_other, part, shp, rte_in, rte_out, fac, rs, rs_prev_out, factored, cs_other,
                         cs_partial, prior, w_new, w_old, top, add, step, step_prev, k, ld):

@@ -515,32 +515,24 @@ def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_
     # ... other side: shapes and rates of the touched rows blended towards the step's estimate (the rates with the
     # batch side's NEW column sums), means of every row, scalar rates, column sums
     e_out = O["e"] if e_current else None
-    # The rows of the other side that the batch does NOT touch keep their shapes and rates, hence their means: the side's
-    # column sums after the step are the ones before it + the change of the touched rows' means (new - old, both formed by
-    # the kernel that finishes the row), so the untouched rows' tables are not read at all -- the whole-table pass shrinks to
-    # the split rows.  One float32 rounding per step apart from the reference's recomputation over all rows (PXI:320 / 372);
-    # a side's sums are formed afresh from every row whenever it is the BATCH side.  Lazy epochs only (a stored mean table
-    # is rewritten for every row; partial_fit blends every row's scalar rate, PXI:472-473: both visit every row anyway).
-    delta = fused and lazy and rs_mode == 1 and os.environ.get("HPF_SVI_DELTA_SUMS", "1") == "1"
     if fused:
         blocks, tail = ops.sweep_blocks, m._cs_part.shape[0]
         cs_part = m.fused_cs_part(blocks, tail)
         part = m._part_scratch(s_oth.nseg)
         ops.sweep_svi(s_oth, O["e"], B["e"], part, e_out, O["shp"], O["rte"], None if lazy else O["fac"], O["rs"], cs_batch,
-                      cs_part[:blocks], O["prior"], w_other, step_prev, O["top"], O["add"], step, step_prev, k, ld, delta=delta)
+                      cs_part[:blocks], O["prior"], w_other, step_prev, O["top"], O["add"], step, step_prev, k, ld)
         ops.segsum_desc(part, s_oth.multi, s_oth.nmulti_dev, s_oth.multi_cap, O["acc"], ld)
-        # split rows and (unless the sums are updated by their change) the rows the batch does not touch: their means still
-        # count in the column sums
+        # split rows and the rows the batch does not touch (their means still count in the column sums)
         ops.svi_side(O["n"], O["flag"], O["acc"], O["e"], O["shp"], O["rte"], None if lazy else O["fac"], O["rs"], cs_batch,
                      cs_part[blocks:], O["prior"], w_other, step_prev, O["top"], O["add"], step, step_prev, 1, rs_mode, k, ld,
-                     e_out=e_out, done_flag=1, delta=delta)
+                     e_out=e_out, done_flag=1)
     else:
         cs_part = m._cs_part
         ops.svi_side(O["n"], O["flag"], O["acc"], O["e"], O["shp"], O["rte"], None if lazy else O["fac"], O["rs"], cs_batch,
                      cs_part, O["prior"], w_other, step_prev, O["top"], O["add"], step, step_prev, 1, rs_mode, k, ld,
                      e_out=e_out)
     cs_o = torch.empty(ld, dtype=torch.float32, device=ops.device)
-    ops.colsum_reduce(cs_part, cs_o, ld, base=getattr(m, O["cs"]) if delta else None)
+    ops.colsum_reduce(cs_part, cs_o, ld)
     setattr(m, O["cs"], cs_o)
 
 

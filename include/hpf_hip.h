@@ -265,7 +265,7 @@ int hpf_hip_svi_side_f32(int64_t nrows, const uint8_t *flag, const float *acc, c
                          float *fac, float *rs, const float *cs_other, float *cs_partial, float prior, float w_new,
                          float w_old, float top, float add, float step, float step_prev, int rate_mode, int rs_mode,
                          int k, int ld, int grid_blocks, const float *rs_rate, float *rs_prev_out, float *e_out,
-                         int done_flag, int delta_sums, void *stream);
+                         int done_flag, void *stream);
 /*
  * done_flag (0: none): rows whose flag EQUALS done_flag were finished elsewhere and are skipped entirely -- no load, no
  * store, no share of the column sums.  That elsewhere is the next entry: the OTHER side's pass of a stochastic step fused
@@ -281,21 +281,10 @@ int hpf_hip_svi_side_f32(int64_t nrows, const uint8_t *flag, const float *acc, c
  * shapes, rates, means and E row bit for bit (tests/test_hip_parity.py::test_sweep_svi_op_row_for_row); its scalar rate holds
  * a k-term sum that the two kernels fold in different orders (1e-7).
  */
-/*
- * delta_sums != 0 (both entries; rate_mode 1, rs_mode 0/1, fac == NULL): the rows of the OTHER side that a step does not
- * touch keep their shapes and rates, hence their means -- the side's column sums after the step are the ones before it plus
- * the CHANGE of the touched rows' means.  cs_partial then holds sums of (new mean - old mean) over the rows each call
- * finished (old = the row's shape over its rate as loaded), hpf_hip_svi_side_f32 visits the flagged rows only (the
- * untouched rows' shape and rate tables are not read at all), and hpf_hip_colsum_reduce_add_f32 gives
- * cs_out = float(double(base) + sum of the partials in double) with base = the sums before the step.  The reference
- * recomputes Theta.sum(axis=0) / Beta.sum(axis=0) from the whole table every batch (PXI:320 / 372): the same number up to
- * one float32 rounding per step; a side's sums are formed afresh from all rows whenever it is the BATCH side.
- */
-int hpf_hip_colsum_reduce_add_f32(const float *cs_partial, int nblk, const float *base, float *cs_out, int ld, void *stream);
 int hpf_hip_sweep_svi_f32(const hpf_segment *segs, int64_t nseg, const int32_t *idx, const float *y, const float *tab_self,
                           const float *tab_other, float *part, float *e_new, float *shp, float *rte, float *fac, float *rs,
                           const float *cs_other, float *cs_partial, float prior, float w_new, float w_old, float top,
-                          float add, float step, float step_prev, int k, int ld, int short_rows, int grid_blocks, int delta_sums,
+                          float add, float step, float step_prev, int k, int ld, int short_rows, int grid_blocks,
                           const int64_t *nseg_dev, void *stream);
 int hpf_hip_svi_rate_rows_f32(const int64_t *row_list, int64_t nrows, float *rte, const float *fac, float *rs,
                               const float *cs_other, float top, float add, float step, float step_prev, int mode,

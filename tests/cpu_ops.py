@@ -218,11 +218,8 @@ class CpuOps:
     def unpack_rows(self, src, dst, nrows, k, ld):
         _np(dst)[:nrows, :k] = _np(src).reshape(-1)[: nrows * k].reshape(nrows, k)
 
-    def colsum_reduce(self, cs_partial, cs_out, ld, base=None):
-        t = _np(cs_partial).astype(np.float64).sum(axis=0)
-        if base is not None:
-            t = t + _np(base).astype(np.float64)
-        _np(cs_out)[:] = t.astype(np.float32)
+    def colsum_reduce(self, cs_partial, cs_out, ld):
+        _np(cs_out)[:] = _np(cs_partial).astype(np.float64).sum(axis=0).astype(np.float32)
 
     def colsum_sequential(self, tab, nrows, ld, cs_out):
         _np(cs_out)[:] = _np(tab)[:nrows].sum(axis=0)        # (numpy's own float32 row-after-row order: the reference's)
@@ -526,7 +523,7 @@ class CpuOps:
     sweep_blocks = 1          # (rows of partial column sums the fused sweep writes)
 
     def sweep_svi(self, side, tab_self, tab_other, part, e_new, shp, rte, fac, rs, cs_other, cs_partial, prior, w_new,
-                  w_old, top, add, step, step_prev, k, ld, delta=False):
+                  w_old, top, add, step, step_prev, k, ld):
         """hpf_hip_sweep_svi_f32: the plain sweep, then the flagged-row statements of svi_side (rate_mode 1, rs_mode 1)
         for the rows present in ONE segment, on a compacted copy of their rows (so that only they enter the column sums)."""
         nseg = _live_nseg(side)
@@ -544,11 +541,8 @@ class CpuOps:
         fac_s = torch.zeros_like(sub["shp"])
         ones = torch.ones(rows.shape[0], dtype=torch.uint8)
         e_s = sub["e"].clone() if e_new is not None else None
-        old_mean = (sub["shp"][:, :k].double() / sub["rte"][:, :k].double()).float() if delta else None
         self.svi_side(rows.shape[0], ones, sub["acc"], sub["e"], sub["shp"], sub["rte"], fac_s, sub["rs"], cs_other,
                       cs_partial, prior, w_new, w_old, top, add, step, step_prev, 1, 1, k, ld, e_out=e_s)
-        if delta:        # the partials hold the CHANGE of the finished rows' means
-            _np(cs_partial)[0, :k] = (fac_s[:, :k].double() - old_mean.double()).sum(dim=0).float().numpy()
         shp[rows], rte[rows], rs[rows] = sub["shp"], sub["rte"], sub["rs"]
         if fac is not None:
             fac[rows] = fac_s
@@ -588,32 +582,11 @@ class CpuOps:
             rs_prev_out[rows] = rsp_s
 
     def svi_side(self, nrows, flag, acc, e, shp, rte, fac, rs, cs_other, cs_partial, prior, w_new, w_old, top, add, step,
-                 step_prev, rate_mode, rs_mode, k, ld, rs_rate=None, rs_prev_out=None, e_out=None, done_flag=0, delta=False):
+                 step_prev, rate_mode, rs_mode, k, ld, rs_rate=None, rs_prev_out=None, e_out=None, done_flag=0):
         """hpf_hip_svi_side_f32 = the separate stand-in statements in the reference's order.  rte / fac None: computed
         into scratch tables and dropped; rs_rate / rs_prev_out: the factored-rate plumbing of the lazy epochs; e_out: the
         flagged rows' new E rows (= expect over them afterwards); done_flag: rows whose flag equals it are left out
         altogether (the pass runs on a compacted copy of the others)."""
-        if delta:
-            # only the flagged rows that were not finished elsewhere are visited; the partials hold the change of their means
-            assert flag is not None and rate_mode == 1 and rs_mode != 2 and fac is None and rs_rate is None
-            rows = torch.nonzero((flag[:nrows] != 0) & (flag[:nrows] != done_flag)).reshape(-1) if done_flag else \
-                torch.nonzero(flag[:nrows] != 0).reshape(-1)
-            _np(cs_partial)[:] = 0
-            if rows.shape[0] == 0:
-                return
-            sub = {n: t[rows].clone() for n, t in (("acc", acc), ("e", e), ("shp", shp), ("rte", rte), ("rs", rs))}
-            old_mean = (sub["shp"][:, :k].double() / sub["rte"][:, :k].double()).float()
-            fac_s = torch.zeros_like(sub["shp"])
-            e_s = sub["e"].clone() if e_out is not None else None
-            self.svi_side(rows.shape[0], torch.ones(rows.shape[0], dtype=torch.uint8), sub["acc"], sub["e"], sub["shp"],
-                          sub["rte"], fac_s, sub["rs"], cs_other, cs_partial, prior, w_new, w_old, top, add, step, step_prev,
-                          rate_mode, rs_mode, k, ld, e_out=e_s)
-            _np(cs_partial)[:] = 0
-            _np(cs_partial)[0, :k] = (fac_s[:, :k].double() - old_mean.double()).sum(dim=0).float().numpy()
-            shp[rows], rte[rows], rs[rows] = sub["shp"], sub["rte"], sub["rs"]
-            if e_out is not None:
-                e_out[rows] = e_s
-            return
         if done_flag:
             assert flag is not None and rs_rate is None
             rows = torch.nonzero(flag[:nrows] != done_flag).reshape(-1)

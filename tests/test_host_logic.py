@@ -62,25 +62,21 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     # round 5 entries: the epoch-level batch preparation, the sweep with the other side's stochastic step fused in, the
     # whole-table pass's done_flag
     L.hpf_hip_svi_epoch_prepare.argtypes = [vp, vp]
-    L.hpf_hip_sweep_svi_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp] + [cf] * 7 + [ci] * 5 + [vp, vp]
-    L.hpf_hip_svi_side_f32.argtypes = [i64] + [vp] * 9 + [cf] * 7 + [ci] * 5 + [vp, vp, vp, ci, ci, vp]
+    L.hpf_hip_sweep_svi_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp] + [cf] * 7 + [ci] * 4 + [vp, vp]
+    L.hpf_hip_svi_side_f32.argtypes = [i64] + [vp] * 9 + [cf] * 7 + [ci] * 5 + [vp, vp, vp, ci, vp]
     assert L.hpf_hip_svi_epoch_prepare(None, None) == EINVAL
     desc = ctypes.create_string_buffer(512)
     assert L.hpf_hip_svi_epoch_prepare(ctypes.cast(desc, vp), None) == EINVAL                    # all-null descriptor
     w = (0.3, 1.0, 0.0, 15.3, 0.3, 0.5, 0.5)
-    assert L.hpf_hip_sweep_svi_f32(None, 5, p, p, p, p, p, None, p, p, None, p, p, p, *w, 50, 64, 0, 8, 0, None, None) == EINVAL
-    assert L.hpf_hip_sweep_svi_f32(p, 5, p, p, p, p, p, None, p, p, None, p, p, p, *w, 50, 128, 0, 8, 0, None, None) == EINVAL   # ld
+    assert L.hpf_hip_sweep_svi_f32(None, 5, p, p, p, p, p, None, p, p, None, p, p, p, *w, 50, 64, 0, 8, None, None) == EINVAL
+    assert L.hpf_hip_sweep_svi_f32(p, 5, p, p, p, p, p, None, p, p, None, p, p, p, *w, 50, 128, 0, 8, None, None) == EINVAL   # ld
     q = ctypes.cast(ctypes.create_string_buffer(64), vp)
-    assert L.hpf_hip_sweep_svi_f32(p, 5, p, p, p, p, p, q, p, p, None, p, p, p, *w, 50, 64, 0, 8, 0, None, None) == EINVAL   # e_new must be tab_self
-    side = lambda flag, rs_mode, done, delta=0: L.hpf_hip_svi_side_f32(4, flag, p, p, p, p, None, p, p, p, *w, 1, rs_mode, 50, 64, 2,  # noqa: E731
-                                                                       None, None, None, done, delta, None)
+    assert L.hpf_hip_sweep_svi_f32(p, 5, p, p, p, p, p, q, p, p, None, p, p, p, *w, 50, 64, 0, 8, None, None) == EINVAL   # e_new must be tab_self
+    side = lambda flag, rs_mode, done: L.hpf_hip_svi_side_f32(4, flag, p, p, p, p, None, p, p, p, *w, 1, rs_mode, 50, 64, 2, None,  # noqa: E731
+                                                              None, None, done, None)
     assert side(None, 1, 1) == EINVAL            # done_flag without flags
     assert side(p, 1, 300) == EINVAL
-    assert L.hpf_hip_svi_side_f32(4, p, p, p, p, p, None, p, p, p, *w, 1, 1, 50, 64, 2, p, None, None, 1, 0, None) == EINVAL  # done_flag + rs_rate
-    assert side(p, 2, 1, 1) == EINVAL            # delta column sums with every row's scalar rate blended (every row is visited then)
-    assert side(None, 1, 0, 1) == EINVAL         # delta column sums without flags
-    L.hpf_hip_colsum_reduce_add_f32.argtypes = [vp, ci, vp, vp, ci, vp]
-    assert L.hpf_hip_colsum_reduce_add_f32(p, 4, None, p, 64, None) == EINVAL
+    assert L.hpf_hip_svi_side_f32(4, p, p, p, p, p, None, p, p, p, *w, 1, 1, 50, 64, 2, p, None, None, 1, None) == EINVAL  # done_flag + rs_rate
     # round 6: the sweep with the BATCH side's stochastic step fused in
     L.hpf_hip_sweep_svi_batch_f32.argtypes = [vp, i64] + [vp] * 13 + [cf, vp, vp] + [cf] * 7 + [ci] * 4 + [vp, vp]
     bat = lambda segs, rte_in, rate_rs, rate_cs, ld: L.hpf_hip_sweep_svi_batch_f32(      # noqa: E731

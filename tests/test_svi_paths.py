@@ -363,9 +363,6 @@ def test_lazy_epochs_equal_the_stored_form_bit_for_bit(any_backend, monkeypatch,
     does.  Same float32 statements: all eight arrays and the llk of a verbose fit with a mid-fit check must be EQUAL --
     with alternating epoch types (rates go factored -> table -> factored), user-only and item-only epochs."""
     df, nU, nI = datagen.readme_counts()
-    # (the lazy form's update of the OTHER side's column sums by the change of the touched rows' means is one float32
-    #  rounding per step away from a recomputation over all rows -- test_delta_column_sums_... below: pinned off here)
-    monkeypatch.setenv("HPF_SVI_DELTA_SUMS", "0")
     out = {}
     for lazy in ("1", "0"):
         monkeypatch.setenv("HPF_SVI_LAZY", lazy)
@@ -378,32 +375,6 @@ def test_lazy_epochs_equal_the_stored_form_bit_for_bit(any_backend, monkeypatch,
         out[lazy]["llk"] = np.float64(m.train_llk)
     for n in out["1"]:
         assert np.array_equal(out["1"][n], out["0"][n]), n
-
-
-@pytest.mark.parametrize("kw", [dict(users_per_batch=20, items_per_batch=25), dict(users_per_batch=30),
-                                dict(items_per_batch=40)])
-def test_delta_column_sums_equal_the_recomputed_ones_to_rounding(any_backend, monkeypatch, kw):
-    """Lazy epochs update the OTHER side's column sums by the change of the touched rows' means (hpf_hip_sweep_svi_f32 /
-    hpf_hip_svi_side_f32 with delta_sums, hpf_hip_colsum_reduce_add_f32: the rows a batch does not touch are not read);
-    HPF_SVI_DELTA_SUMS=0 recomputes them from every row each batch as the reference's statements do (PXI:320 / 372).  The
-    two differ by one float32 rounding of the sums per step: the fits agree to summation noise -- all epoch kinds, rows cut
-    into several segments on both sides, epochs of 3-5 batches so that the changes accumulate."""
-    df, nU, nI = datagen.readme_counts()
-    from hpfrec_amd import layout
-    monkeypatch.setattr(layout, "SEG_CAP", 8)
-    out = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("HPF_SVI_DELTA_SUMS", mode)
-        m = HPF(k=12, maxiter=6, random_seed=7, ncores=1, reindex=False, verbose=True, check_every=3,
-                stop_crit="maxiter", **kw)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            m.fit(df.copy())
-        out[mode] = {n: np.array(getattr(m, n)) for n in NAMES}
-        out[mode]["llk"] = np.float64(m.train_llk)
-    for n in out["1"]:
-        assert np.isfinite(out["1"][n]).all()
-        assert _maxrel(out["1"][n], out["0"][n]) < 2e-5, (n, _maxrel(out["1"][n], out["0"][n]))
 
 
 @pytest.mark.parametrize("case,batch_frac", [("ragged", 3), ("hubs", 4), ("empty-rows", 2), ("ragged", 70), ("hubs", 1)])
