@@ -41,7 +41,7 @@ for mode, label in (("sweep_kernel<64, 1, 3", "batch-side sweep (MODE 3)"), ("sw
     tot_b = tot_t = 0.0
     for i in range(n - 22, n):
         rd, wb = 2.0 * f[i] * 1024 / 1e9, w[i] * 1024 / 1e9
-        print("   %6.2f | %5.2f | %7.1f | %.2f" % (rd, wb, t[i], (rd + wb) / t[i] * 1e-3))
+        print("   %6.2f | %5.2f | %7.1f | %.2f" % (rd, wb, t[i], (rd + wb) / t[i] * 1e3))
         tot_b += rd + wb
         tot_t += t[i]
-    print("   total %.1f GB in %.2f ms = %.2f TB/s" % (tot_b, tot_t / 1e3, tot_b / tot_t * 1e-3))
+    print("   total %.1f GB in %.2f ms = %.2f TB/s" % (tot_b, tot_t / 1e3, tot_b / tot_t * 1e3))
