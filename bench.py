@@ -319,19 +319,29 @@ def other_workloads(device, host_triplets, nU, nI, with_oracle=True):
             keep = iu_h < n_u
             Ys, ius, iis, st_ix_u = O.svi_inputs_like_reference(y_h[keep], iu_h[keep], ii_h[keep], n_u, nI)
             _, got = svi_fit(Ys, ius, iis, st_ix_u, n_u, nI, 2)
+            # (the same fit with every column sum of the steps in numpy's own order on the device: HPF_COLSUM_ORDER=reference)
+            os.environ["HPF_COLSUM_ORDER"] = "reference"
+            try:
+                _, got_ref = svi_fit(Ys, ius, iis, st_ix_u, n_u, nI, 2)
+            finally:
+                os.environ.pop("HPF_COLSUM_ORDER", None)
             dev_of = {}
             for exact in (False, True):
                 st = O.fit_svi(Ys, ius, iis, st_ix_u, n_u, nI, k5, 2, 123, per, per, nthreads=O.max_threads(), exact_colsums=exact)
                 dev_of["float64 column sums" if exact else "as it is"] = max(
                     float(np.max(np.abs(got[n] - getattr(st, n)) / np.abs(getattr(st, n)))) for n in O.State.names)
+                if not exact:
+                    dev_of["as it is, with HPF_COLSUM_ORDER=reference on the device"] = max(
+                        float(np.max(np.abs(got_ref[n] - getattr(st, n)) / np.abs(getattr(st, n)))) for n in O.State.names)
             out["c5_svi"]["parity_in_this_run"] = {
                 "slice": "users < %d of the same matrix (all items): %d nnz, 2 epochs (one item, one user), k=%d, %d-row "
                          "batches" % (n_u, int(Ys.shape[0]), k5, per),
                 "max_rel_dev_all_eight_arrays_vs_oracle_fit_svi": dev_of,
                 "note": "the oracle restates PXI:262-377 and is bit-exact to the reference's own captures "
                         "(tests/golden/svi_large.npz); numpy's sequential float32 column sums over 1e5..4e5 rows are the noisy "
-                        "side (SURVEY.md section 7): the second figure replaces them by float64 sums in the oracle"}
-            del got, st
+                        "side (SURVEY.md section 7): the last figure replaces them by float64 sums in the oracle, the middle one "
+                        "forms them in numpy's own order on the device (the reference's arithmetic, matched as it is)"}
+            del got, got_ref, st
         except Exception as exc:   # noqa: BLE001
             out["c5_svi"]["parity_in_this_run"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
 

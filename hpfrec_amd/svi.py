@@ -25,6 +25,14 @@ PF_TIMINGS = {}       # HPF_TIMING=1: {phase: [seconds per partial_fit_device ca
 SVI_TIMINGS = {}      # HPF_TIMING=1: {"epochs": n, "seconds": wall time of the last fit's epoch loop}
 
 
+def _reference_sums():
+    """HPF_COLSUM_ORDER=reference: every Theta.sum(axis=0) / Beta.sum(axis=0) of a stochastic step (PXI:300,320 / 352,372;
+    443-470) is formed in numpy's own order from the STORED mean table (hpf_hip_colsum_sequential_f32), as in the full-batch
+    driver (cavi.py): the mode that holds the stochastic path against the reference itself without the summation-order noise
+    of 1e5..1e6-row float32 sums.  Implies the stored form of the tables (HPF_SVI_LAZY=0)."""
+    return os.environ.get("HPF_COLSUM_ORDER", "tree") == "reference"
+
+
 class BatchSide:
     """Segments over the rows touched by a batch (same fields the sweep launcher reads from SparseSide)."""
 
@@ -347,8 +355,13 @@ class DeviceModel:
             self.get(n, out=a)
 
     def colsum(self, name):
-        """tab.sum(axis=0) -> [ld] (HIP colsum kernels; PXI:300,320,352,372)."""
+        """tab.sum(axis=0) -> [ld] (HIP colsum kernels; PXI:300,320,352,372).  HPF_COLSUM_ORDER=reference: in numpy's own
+        order (float32, row after row), bit for bit the reference's sum."""
         tab = getattr(self, name)
+        if _reference_sums():
+            out = torch.zeros(self.ld, dtype=torch.float32, device=self.ops.device)
+            self.ops.colsum_sequential(tab, tab.shape[0], self.ld, out)
+            return out
         part = torch.zeros((self.ops.finalize_grid(tab.shape[0]), self.ld), dtype=torch.float32, device=self.ops.device)
         self.ops.colsum(tab, tab.shape[0], self.ld, part)
         out = torch.zeros(self.ld, dtype=torch.float32, device=self.ops.device)
@@ -427,6 +440,8 @@ def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_
     python floats.  lazy (the epochs of fit_hpf_svi): the batch side's rate stays factored and no mean table is
     stored -- DeviceModel.materialize() brings the tables up to date when somebody reads them."""
     ops, k, ld = m.ops, m.k, m.ld
+    ref_sums = _reference_sums()
+    lazy = lazy and not ref_sums          # (the reference-order sums walk the stored mean tables)
     step_prev = float(np.float32(1) - np.float32(step))
     step = float(np.float32(step))
     w_other = float(np.float32(step * float(np.float32(mult))))   # step*multiplier as one float32 scalar (PXI:316)
@@ -510,7 +525,10 @@ def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_
         ops.svi_side(B["n"], B["flag"], B["acc"], B["e"], B["shp"], B["rte"], B["fac"], B["rs"], cs_for_batch,
                      cs_part_b, B["prior"], 1.0, 0.0, B["top"], B["add"], step, step_prev, 0, rs_mode, k, ld, done_flag=done_b)
     cs_batch = torch.empty(ld, dtype=torch.float32, device=ops.device)      # (the reduction writes every column)
-    ops.colsum_reduce(cs_fused if fused_b else m._cs_part, cs_batch, ld)
+    if ref_sums:
+        ops.colsum_sequential(B["fac"], B["n"], ld, cs_batch)
+    else:
+        ops.colsum_reduce(cs_fused if fused_b else m._cs_part, cs_batch, ld)
     setattr(m, B["cs"], cs_batch)
     # ... other side: shapes and rates of the touched rows blended towards the step's estimate (the rates with the
     # batch side's NEW column sums), means of every row, scalar rates, column sums
@@ -532,7 +550,10 @@ def _svi_step(m, hy, su, si, flag_u, flag_i, step, mult, user_batch, all_scalar_
                      cs_part, O["prior"], w_other, step_prev, O["top"], O["add"], step, step_prev, 1, rs_mode, k, ld,
                      e_out=e_out)
     cs_o = torch.empty(ld, dtype=torch.float32, device=ops.device)
-    ops.colsum_reduce(cs_part, cs_o, ld)
+    if ref_sums:
+        ops.colsum_sequential(O["fac"], O["n"], ld, cs_o)
+    else:
+        ops.colsum_reduce(cs_part, cs_o, ld)
     setattr(m, O["cs"], cs_o)
 
 

@@ -146,6 +146,28 @@ def test_svi_large_vs_golden_on_gpu(hip_backend):
           % (w[1][0], w[0], max(v[1] for v in worst.values())))
 
 
+@pytest.mark.gpu
+def test_svi_large_vs_golden_with_reference_order_sums_on_gpu(hip_backend, monkeypatch):
+    """The same fits with HPF_COLSUM_ORDER=reference: every Theta.sum(axis=0) / Beta.sum(axis=0) of the stochastic steps is
+    formed in numpy's own order (float32, row after row: hpf_hip_colsum_sequential_f32 over the stored mean tables) and
+    nothing else changes.  The stochastic path is then held against the REFERENCE ITSELF at 3e-5 instead of 1e-4: as in the
+    full-batch case (test_large_vs_golden), the summation order of those column sums over 5e4..6e4 rows is what separates
+    the default path from the reference."""
+    monkeypatch.setenv("HPF_COLSUM_ORDER", "reference")
+    worst = _svi_large_fits(SVI_LARGE_CASES, bar=3e-5)
+    w = max(worst.items(), key=lambda kv: kv[1][0])
+    print("svi_large with reference-order column sums: worst row deviation %.2e (%s), worst column-sum deviation %.2e"
+          % (w[1][0], w[0], max(v[1] for v in worst.values())))
+
+
+def test_reference_order_sums_in_the_stochastic_path_on_standin(cpu_ops_backend, monkeypatch):
+    """HPF_COLSUM_ORDER=reference through the stochastic drivers on the stand-in ops (statement order, stored tables): the
+    small golden captures hold, and the mode implies the stored form."""
+    monkeypatch.setenv("HPF_COLSUM_ORDER", "reference")
+    _svi_fits()
+    _partial_fit_sequence()
+
+
 def _partial_fit_growing_model():
     """partial_fit with new_users / new_items (INIT:933-963: fresh rows appended from a default_rng stream) on the
     resident state: the appended host rows and the device tables stay in step (shape change -> tables rebuilt), and
