@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""hpf_hip_colsum_sequential_f32 (numpy's own float32 row-after-row column sums, HPF_COLSUM_ORDER=reference) timed over table
+sizes and checked bit for bit against numpy (profiles/r06_colsum_sequential.txt)."""
 import time, numpy as np, torch, sys, os
 sys.path.insert(0, os.getcwd())
 from hpfrec_amd.ops_hip import HipOps

@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""A partial_fit batch's upload two ways, 24 times each: copied into a page-locked buffer of our own + asynchronous DMAs, against
+plain pageable `tensor.to(device)` -- per call the host copy, the .to() calls and the synchronisation apart
+(profiles/r06_partial_fit_upload.txt: why svi.partial_fit_device uploads pageable arrays as they are)."""
 import time, numpy as np, torch
 dev = torch.device("cuda", 0)
 n = 3_100_000
