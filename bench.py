@@ -392,6 +392,39 @@ def other_workloads(device, host_triplets, nU, nI, with_oracle=True):
         out["c5_partial_fit"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
     torch.cuda.empty_cache()
 
+    # ---- C4's per-GPU kernel on ONE GPU: the C3 matrix at k = 100 (the 8-GPU run itself is the driver's scaling bench) ----
+    try:
+        k4 = WORKLOADS["c4"][3]
+        iu = torch.from_numpy(iu_h.astype(np.int64)).to(device)
+        ii = torch.from_numpy(ii_h.astype(np.int64)).to(device)
+        y = torch.from_numpy(y_h).to(device)
+        hy = cavi.Hyper(k4, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
+        Theta = np.empty((nU, k4), np.float32)
+        Beta = np.empty((nI, k4), np.float32)
+        init = backend.initialize_parameters(Theta, Beta, 123, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
+        m4 = cavi.FullBatchCavi(HipOps(device), device, iu, ii, y, nU, nI, hy)
+        m4.load_state(init[0], init[1], init[2], init[3], init[4], init[5], Theta, Beta)
+        del iu, ii, y, init, Theta, Beta
+        for _ in range(5):
+            m4.iterate(True)
+        torch.cuda.synchronize()
+        steps4 = 60
+        t0 = time.perf_counter()
+        for _ in range(steps4):
+            m4.iterate(True)
+        torch.cuda.synchronize()
+        ms4 = (time.perf_counter() - t0) / steps4 * 1e3
+        b4 = nnz * (8 + 8 * k4) + nU * (12 + 20 * k4) + nI * (4 + 24 * k4)
+        out["c4_k100_on_one_gpu"] = {
+            "workload": "the C3 matrix at k=%d (ld=128) on ONE GPU, full batch, all six output tables stored: the kernel of BASELINE "
+                        "config C4 without its sharding (the 8-GPU run is the driver's scaling bench)" % k4,
+            "steps": steps4, "ms_per_step": ms4, "iters_per_s": 1e3 / ms4, "algorithmic_bytes_per_iteration": b4,
+            "frac_of_hbm_peak": b4 / (ms4 * 1e-3) / HBM_PEAK, "state_finite": bool(torch.isfinite(m4.Theta).all().item())}
+        del m4
+    except Exception as exc:   # noqa: BLE001
+        out["c4_k100_on_one_gpu"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+    torch.cuda.empty_cache()
+
     # ---- C2: MovieLens-20M-shaped full batch ---------------------------------------------------------------------------
     try:
         n_u, n_i, nnz_t, k2, label2 = WORKLOADS["c2"]
@@ -669,7 +702,8 @@ def main():
                     help="skip the untimed extras (lean-iteration and llk-pass timings); used under rocprofv3 so that "
                          "per-kernel averages cover exactly the warm-up + timed iterations")
     ap.add_argument("--no-workloads", action="store_true",
-                    help="skip the untimed `workloads` block (C5 stochastic epochs, C5 partial_fit calls, C2) of the N=1 line")
+                    help="skip the untimed `workloads` block (C5 stochastic epochs, C5 partial_fit calls, C4's kernel at k=100, C2) "
+                         "of the N=1 line")
     ap.add_argument("--no-fuse", action="store_true", help="separate sweep and row-finalize launches")
     ap.add_argument("--no-autotune", action="store_true",
                     help="N>1: time the library default only")
