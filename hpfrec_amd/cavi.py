@@ -160,12 +160,12 @@ class FullBatchCavi(ShardedMixin):
         self.csB = torch.zeros(ld, **f32)
         self.csT = torch.zeros(ld, **f32)
         self.niter_done = 0
-        # HPF_COLSUM_ORDER=reference (a diagnostic, single GPU): Theta.sum(axis=0) / Beta.sum(axis=0) in numpy's own order --
+        # HPF_COLSUM_ORDER=reference (single GPU): Theta.sum(axis=0) / Beta.sum(axis=0) in numpy's own order --
         # float32, row after row (PXI:236,255) -- instead of the sweeps' per-block partials summed in double: the reference's
         # sums bit for bit, at the price of a chain of nrows dependent adds per iteration and side
         self.ref_sums = os.environ.get("HPF_COLSUM_ORDER", "tree") == "reference"
         if self.ref_sums and self.dist:
-            raise ValueError("HPF_COLSUM_ORDER=reference is a single-GPU diagnostic mode")
+            raise ValueError("HPF_COLSUM_ORDER=reference is a single-GPU mode")
 
     # ------------------------------------------------------------------------------------
     def _pad(self, host_arr, out):

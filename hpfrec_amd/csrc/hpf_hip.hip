@@ -2,12 +2,14 @@
 //
 // What is replaced (reference: /root/reference/hpfrec/cython_loops.pxi = "PXI"):
 //   sweep_kernel        <- update_phi PXI:551-591 fused with update_G_n_L_sh PXI:613-621; MODE 1 also
-//                          run the row finalizer for whole-row segments (epilogue / prologue)
+//                          runs the row finalizer for whole-row segments (epilogue); MODE 2 / 3: the two sides of a
+//                          stochastic step (PXI:292-325, 344-377, 438-473) fused into the sweeps that form their phi-sums
 //   row_finalize_kernel <- numpy rate/shape statements of fit_hpf PXI:236-259 + the psi/log/exp
 //                          hoisted out of update_phi (PXI:588: they only depend on the row)
 //   llk_sweep_kernel, pair_llk_kernel <- llk_plus_rmse PXI:627-658, sum_prediction PXI:816-825
 //   pair_dot_kernel     <- predict_multiple PXI:803-810;  score_rows_kernel <- HPF.topN's GEMV
 //   svi_*_kernel        <- the numpy statements of an SVI batch / partial_fit PXI:300-325,352-377,443-473
+//   colsum_sequential_kernel <- Theta.sum(axis=0) / Beta.sum(axis=0) in numpy's own order (HPF_COLSUM_ORDER=reference)
 //
 // Design: the reference evaluates, per nonzero and factor,
 //   exp(psi(Gs_uk) - log(Gr_uk) + psi(Ls_ik) - log(Lr_ik)) = eT_uk * eB_ik

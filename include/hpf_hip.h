@@ -178,10 +178,13 @@ int hpf_hip_colsum_reduce_f32(const float *cs_partial, int nblk, float *cs_out, 
 int hpf_hip_colsum_f32(const float *tab, int64_t nrows, int ld, float *cs_partial, int grid_blocks, void *stream);
 
 /* cs_out[c] = tab[0][c] + tab[1][c] + ... in float32, the rows IN SEQUENCE: numpy's own order for Beta.sum(axis=0) /
- * Theta.sum(axis=0) (PXI:236,255), reproduced bit for bit -- one lane per column, a chain of nrows dependent adds.  The
- * diagnostic mode HPF_COLSUM_ORDER=reference of the full-batch driver uses it instead of the partial sums of the sweeps +
- * hpf_hip_colsum_reduce_f32: it shows that this order is what separates the default path from the reference at 1e5..1e6
- * rows (tests/test_hip_parity.py::test_large_vs_golden).  Not for production: 7 ms per 2e5-row table. */
+ * Theta.sum(axis=0) (PXI:236,255; the stochastic steps' PXI:300,320 / 352,372), reproduced bit for bit -- one lane per
+ * column, a chain of nrows dependent adds, fed through LDS by the other waves of the workgroup (16 columns per workgroup):
+ * 4.25 ns per row (a dependent v_add_f32 issues every 8 cycles: 3.3 ns is the floor).  HPF_COLSUM_ORDER=reference makes the
+ * drivers use it instead of the partial sums of the sweeps + hpf_hip_colsum_reduce_f32: the mode for callers who need the
+ * reference's sums -- it is the summation order of these statements that separates the default path from the reference at
+ * 1e5..1e6 rows (tests/test_hip_parity.py::test_large_vs_golden, tests/test_svi_paths.py::test_svi_large_vs_golden_with_
+ * reference_order_sums_on_gpu).  tab must be 16-byte aligned. */
 int hpf_hip_colsum_sequential_f32(const float *tab, int64_t nrows, int ld, float *cs_out, void *stream);
 
 /* e[r] = exp(psi(shp[r]) - log(rte[r])) / rowmax, pads zeroed: the hoisted transcendental part of
