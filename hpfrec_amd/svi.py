@@ -2,16 +2,18 @@
 (/root/reference/hpfrec/cython_loops.pxi:262-377, "PXI"), the Cython partial_fit (PXI:423-473) and the
 single-user fold-in calc_user_factors (PXI:476-520) -- the "next" rows f1/f4 of SURVEY.md section 8.
 
-Division of labour in this round:
-  * O(batch_nnz * k): phi and both shape accumulations -> the same `sweep_kernel` as the full-batch
-    path, run over the batch's rows from both sides (two passes, no atomics, deterministic), plus the
-    row-list forms of `expect_kernel` / `segsum_kernel` (update_phi_csr PXI:666-692 always
-    max-subtracts; our E rows are rescaled per row in every mode);
-  * O((nU+nI) * k) per batch: the reference recomputes whole tables with numpy statements every batch
-    (PXI:300,318,322 ...); here those statements are three HIP row kernels (svi_shape_rows,
-    svi_refresh, svi_rate_rows; include/hpf_hip.h) issued in the reference's order.
-torch is used for index plumbing only (grouping a batch by row, aligning accumulators with row lists).
-No numerics run on the host; shuffles and seeds use numpy's generators so batches are the reference's.
+Division of labour:
+  * index structures of a batch (its rows' segment list, the same nonzeros grouped by the other side, flags of the rows both
+    touch): built on the device, once per EPOCH (EpochWorkspace), per batch (BatchWorkspace) or from the caller's COO
+    triplets (CooBatch, partial_fit) -- csrc/hpf_svi_prep.hip; nothing but a handful of sizes is ever read back;
+  * one stochastic step (_svi_step, the reference's statement order): BOTH sides' statements are fused into the sweeps that
+    form their phi-sums (sweep_kernel MODE 3: the batch side, E row in the prologue, row finished in the epilogue; MODE 2:
+    the other side), a whole-table pass per side covers what the sweeps cannot finish (split rows; for the batch side every
+    row outside the batch, whose rates and means the reference recomputes every batch, PXI:300,318 / 352,370);
+  * the batch side's rate stays FACTORED (row scalar + column sums) and no mean table is stored between checks
+    (DeviceModel.materialize expands them on demand, bit-identically).
+torch is used for device memory, the two radix sorts of a COO batch and stream plumbing.  No numerics run on the host;
+shuffles and seeds use numpy's generators so batches are the reference's.
 """
 import os
 
@@ -34,7 +36,10 @@ def _reference_sums():
 
 
 class BatchSide:
-    """Segments over the rows touched by a batch (same fields the sweep launcher reads from SparseSide)."""
+    """Segments over the rows touched by a batch (same fields the sweep launcher reads from SparseSide), built with
+    tensor-library sorts and host-side sizes.  No driver builds its batches this way any more (epochs: EpochWorkspace /
+    BatchWorkspace; partial_fit: CooBatch -- all on the device, nothing read back): this is the plain construction the tests
+    hold those against, and what the op-level tests feed the sweeps with."""
 
     def __init__(self, rows, cols, y, seg_cap=None, grouped=False):
         """rows/cols: int64 device tensors of a COO batch.  grouped=True: the triplets already come grouped by
@@ -64,16 +69,6 @@ class BatchSide:
         nseg_row = self.row_seg_ptr[1:] - self.row_seg_ptr[:-1]
         self.multi_local = torch.nonzero(nseg_row > 1).reshape(-1)              # rows cut into several segments
         self.nmulti = int(self.multi_local.shape[0])
-
-    @classmethod
-    def from_parts(cls, rows, idx, y, row_seg_ptr, segs, multi_local, nseg, nmulti):
-        """The same object from ready-made pieces (no device work, no host synchronisation)."""
-        self = cls.__new__(cls)
-        self.rows, self.idx, self.y, self.row_seg_ptr, self.segs, self.multi_local = rows, idx, y, row_seg_ptr, segs, multi_local
-        self.nseg, self.nmulti, self.nrows = int(nseg), int(nmulti), int(rows.shape[0])
-        self.short_rows = 1 if (self.nseg > 0 and
-                                                   int(y.shape[0]) / self.nseg < layout.SHORT_ROW_NNZ) else 0
-        return self
 
     def tensors(self):
         return [self.rows, self.idx, self.y, self.row_seg_ptr, self.segs, self.multi_local]
