@@ -156,8 +156,12 @@ class EpochWorkspace:
         seg_cap = layout.SEG_CAP if seg_cap is None else int(seg_cap)
         per = int(min(batch_rows, own.nrows))
         nb = -(-own.nrows // per)
-        deg = own.indptr[1:] - own.indptr[:-1]
-        bound = int(torch.topk(deg, per).values.sum().item()) if per > 0 else 0       # (once per fit)
+        # (the bound costs a top-k and a read-back: once per side and batch size -- fits() and the constructor share it)
+        cache = own.__dict__.setdefault("_epoch_bounds", {})
+        if per not in cache:
+            deg = own.indptr[1:] - own.indptr[:-1]
+            cache[per] = int(torch.topk(deg, per).values.sum().item()) if per > 0 else 0
+        bound = cache[per]
         o_segs_cap = min(oth.nrows, bound) + bound // seg_cap + 1
         b_cap = per + bound // seg_cap + 1
         multi_cap = bound // seg_cap + 2
