@@ -828,8 +828,14 @@ def fit_hpf_svi(hy, Y, ix_u, ix_i, Theta, Beta, Gamma_shp, Gamma_rte, Lambda_shp
         ews = None
         if per_epoch[user_epoch]:
             # (epochs alternate sides: one workspace per side; an SVI over one side only alternates two of them)
-            ews = workspace(user_epoch, i % 2, epoch_level=True)
-            prepare(ews, order)
+            try:
+                ews = workspace(user_epoch, i % 2, epoch_level=True)
+            except torch.cuda.OutOfMemoryError:      # a device smaller than the plan assumed: one batch at a time instead
+                workspaces.pop((bool(user_epoch), i % 2, True), None)
+                torch.cuda.empty_cache()
+                per_epoch[user_epoch], ews = False, None
+            else:
+                prepare(ews, order)
         return dict(user_epoch=user_epoch, order=order, per=per, n_side=own.nrows, ews=ews,
                     nb=nbatches_u if user_epoch else nbatches_i)
 
