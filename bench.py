@@ -664,6 +664,16 @@ def _arm_watchdog(seconds):
     t.start()
 
 
+_T0 = time.monotonic()
+
+
+def phase_log(what):
+    """HPF_BENCH_VERBOSE=1: elapsed seconds + phase on stderr (every rank) -- where a slow run spends its time."""
+    if os.environ.get("HPF_BENCH_VERBOSE") == "1":
+        sys.stderr.write("[bench +%7.1f s, rank %s] %s\n" % (time.monotonic() - _T0, os.environ.get("RANK", "0"), what))
+        sys.stderr.flush()
+
+
 def watchdog_progress():
     if "seconds" in watchdog_state:
         watchdog_state["deadline"] = time.monotonic() + watchdog_state["seconds"]
@@ -718,6 +728,9 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("HPF_BENCH_VERBOSE") == "1" and rank == 0:      # where a slow run IS, every 20 s (stderr)
+        import faulthandler
+        faulthandler.dump_traceback_later(20, repeat=True, file=sys.stderr)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if rank != 0:
         # only rank 0 reports: whatever another rank's libraries leave in stdio at exit (RCCL banners ...) must not
@@ -767,6 +780,7 @@ def main():
     else:
         iu, ii, y = synth_on_device(nU, nI, nnz_target, device, item_power=POWER.get(args.workload, 2.5))
     nnz = int(iu.shape[0])
+    phase_log("matrix generated / broadcast: %d nnz" % nnz)
 
     ops = TimedOps(device)
     hy = cavi.Hyper(k, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
@@ -781,8 +795,13 @@ def main():
     init = backend.initialize_parameters(Theta, Beta, 123, 0.3, 0.3, 1.0, 0.3, 0.3, 1.0)
     s = slice(u0, u1)
 
+    shared = {}
+
     def build_model():
-        m = cavi.FullBatchCavi(ops, device, lu, li, ly, u1 - u0, nI, hy)
+        # (every model of the run is over the same triplets: the sparse layouts -- two sorts, the segment lists -- are built
+        #  once and shared; a candidate of the exchange autotune then costs its tables and its exchange set-up only)
+        m = cavi.FullBatchCavi(ops, device, lu, li, ly, u1 - u0, nI, hy, sides=shared.get("sides"))
+        shared.setdefault("sides", m.sides())
         m.load_state(init[0][s], init[1][s], init[2], init[3], init[4][s], init[5], Theta[s], Beta)
         return m
 
@@ -856,7 +875,9 @@ def main():
 
         # 1. the library default, held
         default_key = "default: " + describe(model)
+        phase_log("autotune: default model described (%s)" % default_key)
         t = agreed(short_run(model))
+        phase_log("autotune: default timed")
         if t is not None:
             times[default_key] = t
         watchdog_progress()
@@ -866,7 +887,9 @@ def main():
             t_ms, err, m = None, None, None
             os.environ.update(env)
             try:
+                phase_log("autotune: building %s" % lab)
                 m = build_model()
+                phase_log("autotune: built")
                 key = describe(m) + ("" if all(v in ("HPF_SCHEDULE", "HPF_ITEM_RANGES", "HPF_DIRECT_PREFETCH") for v in env)
                                      else "/" + ",".join("%s=%s" % kv for kv in sorted(env.items()) if "BPC" in kv[0]))
                 if m.schedule != env["HPF_SCHEDULE"]:
@@ -874,17 +897,23 @@ def main():
                 elif m._scatter_views() is not None and m._plan is None:
                     err = "no C-issued plan (%s)" % (m.native_error or "backend without RCCL")
                 else:
+                    phase_log("autotune: exchange set up")
                     t_ms = short_run(m)
+                    phase_log("autotune: timed")
                     m.flush_items()
             except Exception as exc:   # noqa: BLE001
                 key = lab
                 err = "%s: %s" % (type(exc).__name__, str(exc)[:200])
             t = agreed(t_ms)
-            del m
-            torch.cuda.empty_cache()
+            phase_log("autotune: agreed")
+            del m       # (its blocks stay in the caching allocator: the next candidate's model has the same sizes and takes
+            #              them over -- returning them to the driver and asking again cost tens of seconds per candidate
+            #              when several ranks shared one GPU, HPF_BENCH_VERBOSE=1)
+            phase_log("autotune: candidate released")
             for v in env:
                 os.environ.pop(v, None)
             labels[key] = lab
+            phase_log("autotune: candidate %s done (%s)" % (key, t))
             if t is not None:
                 times[key] = t
                 envs[key] = env
@@ -900,11 +929,11 @@ def main():
         if best is not None and best != default_key:
             model.flush_items()
             del model
-            torch.cuda.empty_cache()
             os.environ.update(envs[best])
             model = build_model()
     del lu, li, ly, init, Theta, Beta
-    torch.cuda.empty_cache()
+    if world == 1:
+        torch.cuda.empty_cache()
 
     if args.no_fuse:
         model.set_fused(False)
@@ -916,6 +945,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    phase_log("model ready")
     model.iterate_many(max(args.warmup, 1), store)   # untimed: code-object load, first touch
     for _ in range(12):     # N>1: the checked first iterations of the C-issued schedule (and of its fall-backs) stay untimed
         if not (sharded and getattr(model, "_plan", None) is not None and model._needs_first_check()):
@@ -935,6 +965,7 @@ def main():
         model.iterate_many(args.steps, store)
     fence()
     dt = time.perf_counter() - t0
+    phase_log("timed region done")
     ops.recording = False
     ev_steps = args.steps
     if not events_in_timed and not args.no_events:
@@ -1037,6 +1068,7 @@ def main():
         model.ref_sums = False
         model.iterate(True)
 
+    phase_log("extras done")
     # sanity: the state must be finite after the run (a NaN run would be a meaningless number)
     model.flush_items()   # sharded runs: gather the item tables (each rank finalizes a slice of the items)
     finite = bool(torch.isfinite(model.Beta).all().item() and torch.isfinite(model.Theta).all().item())
@@ -1053,12 +1085,14 @@ def main():
             links = _p2p.link_probe(device, dist, rank, world)
         except Exception as exc:   # noqa: BLE001
             links = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+        phase_log("link probe done")
         try:
             links["library_collectives"] = library_collective_probe(dist, world, device, nI * k)
         except Exception as exc:   # noqa: BLE001
             links["library_collectives"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
         watchdog_progress()
     if sharded:
+        phase_log("library collectives probed")
         try:
             collective = exchange_report(model, dist, world, device, dt / args.steps * 1e3, store, fence)
             if "ranks" in collective:       # the exchange really spans the job: N ranks, as the carrier itself reports
@@ -1068,6 +1102,7 @@ def main():
         if links is not None:
             collective["link_probe"] = links
 
+    phase_log("exchange report done")
     if rank == 0:
         ms = dt / args.steps * 1e3
         ksum = ops.summary()

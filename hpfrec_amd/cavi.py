@@ -100,8 +100,10 @@ def draw_init_words(ops, mt_state, nU, nI, k):
 class FullBatchCavi(ShardedMixin):
     """Device-resident state + one-iteration step for (a shard of) the HPF model."""
 
-    def __init__(self, ops, device, ix_u, ix_i, y, nU, nI, hyper, seg_cap=None):
-        """ix_u/ix_i/y: COO triplets of THIS rank (user ids local to the shard), torch tensors."""
+    def __init__(self, ops, device, ix_u, ix_i, y, nU, nI, hyper, seg_cap=None, sides=None):
+        """ix_u/ix_i/y: COO triplets of THIS rank (user ids local to the shard), torch tensors.  sides: the (users, items,
+        u_sorted) layouts of another model over the SAME triplets (`model.sides()`), taken over instead of being rebuilt --
+        they are read-only (bench.py builds up to seven models of one matrix in a row; the triplets may then be None)."""
         self.ops = ops
         self.device = torch.device(device)
         self.hy = hyper
@@ -109,8 +111,12 @@ class FullBatchCavi(ShardedMixin):
         self.ld = _lib.ld_for_k(self.k)
         self.nU, self.nI = int(nU), int(nI)
         dev = self.device
-        self.users, self.items, self.u_sorted = layout.build_sides(ix_u.to(dev), ix_i.to(dev), y.to(dev),
-                                                                   self.nU, self.nI, seg_cap)
+        if sides is not None:
+            self.users, self.items, self.u_sorted = sides
+            assert self.users.nrows == self.nU and self.items.nrows == self.nI
+        else:
+            self.users, self.items, self.u_sorted = layout.build_sides(ix_u.to(dev), ix_i.to(dev), y.to(dev),
+                                                                       self.nU, self.nI, seg_cap)
         self.nnz = self.users.nnz
         self.dist = _dist()
         # sweep grid of THIS model (the op set is shared): sharded launches cover short item ranges and want fewer,
@@ -217,6 +223,10 @@ class FullBatchCavi(ShardedMixin):
             self._sync_scatter()
         self.rte_factored = False
         self.refresh_expectations()
+
+    def sides(self):
+        """The sparse layouts of this model's triplets, for another model of the same matrix (constructor's `sides`)."""
+        return self.users, self.items, self.u_sorted
 
     def refresh_expectations(self):
         ops, k, ld = self.ops, self.k, self.ld

@@ -64,10 +64,11 @@ def build_segments(indptr, seg_cap=None):
 
 
 def _indptr(sorted_rows, nrows):
-    counts = torch.bincount(sorted_rows, minlength=nrows)
-    indptr = torch.zeros(nrows + 1, dtype=torch.int64, device=sorted_rows.device)
-    torch.cumsum(counts, 0, out=indptr[1:])
-    return indptr
+    """Row pointers of ids that are SORTED: indptr[r] = how many ids are < r -- one binary search per row.  (A histogram +
+    scan does the same with one atomic add per nonzero; on sorted ids neighbouring threads all hit the same counter, and
+    with several ranks sharing a GPU torch.bincount stalled for minutes in bench.py's exchange autotune.)"""
+    bounds = torch.arange(nrows + 1, dtype=sorted_rows.dtype, device=sorted_rows.device)
+    return torch.searchsorted(sorted_rows.contiguous(), bounds, right=False).to(torch.int64)
 
 
 def ids_to_device(a, dev):
